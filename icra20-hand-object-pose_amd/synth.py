@@ -1,0 +1,341 @@
+"""Seeded synthetic inputs for the hot path.
+
+The reference ships neither meshes, nor the PPF table, nor the hand URDF
+(README.md:49-54 of the reference are download links), so every configuration that
+needs them is run on the stand-ins built here:
+
+* ``ellipsoid_model``  -- the "ellipse" object: semi-axes (0.040, 0.025, 0.020) m, Fibonacci
+  points on the surface, analytic outward normals.
+* ``make_scene``       -- the model under a random SE(3), camera-facing half only, Gaussian noise,
+  hand-like clutter, per-point confidence.
+* ``ppf_key_table``    -- the PPF key set, following the recipe of the reference's
+  ``src/perception/src/app/computePPF.cpp:56-107`` (keys of ordered pairs i<j of the 5 mm model).
+* ``t42_hand``         -- a parametric stand-in for the Yale T42 hand: 4 finger links (boxes sampled
+  at 5 mm), each rotating about its local x axis, with the reference's link names.
+* ``replay_poses``     -- ground truth composed with bounded perturbations (rot <= 30 deg,
+  trans <= 15 mm) so that scoring kernels can be timed independently of the generator.
+
+Everything is numpy + ``np.random.Generator(PCG64(seed))``; all outputs are float32 C-contiguous.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+SEMI_AXES = (0.040, 0.025, 0.020)
+
+
+# --------------------------------------------------------------------------- geometry helpers
+def rot_from_axis_angle(axis, angle):
+    axis = np.asarray(axis, dtype=np.float64)
+    axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + math.sin(angle) * K + (1 - math.cos(angle)) * (K @ K)
+
+
+def random_rotation(rng):
+    """Uniform rotation from a unit quaternion."""
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array(
+        [
+            [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+            [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+            [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+        ]
+    )
+
+
+def se3(R, t):
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    return T
+
+
+def apply(T, xyz):
+    return (xyz.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+
+
+def rotate(T, nrm):
+    return (nrm.astype(np.float64) @ T[:3, :3].T).astype(np.float32)
+
+
+def voxel_thin(xyz, leaf, *others):
+    """Keep the first point of every occupied voxel (input order preserved)."""
+    key = np.floor(xyz.astype(np.float64) / leaf).astype(np.int64)
+    key -= key.min(axis=0)
+    dims = key.max(axis=0) + 1
+    lin = (key[:, 0] * dims[1] + key[:, 1]) * dims[2] + key[:, 2]
+    _, first = np.unique(lin, return_index=True)
+    first.sort()
+    return (xyz[first],) + tuple(o[first] for o in others)
+
+
+# --------------------------------------------------------------------------- object model
+def ellipsoid_model(m: int, semi=SEMI_AXES):
+    """``m`` Fibonacci-sphere points mapped onto the ellipsoid; returns (xyz, normals) float32."""
+    a, b, c = semi
+    i = np.arange(m, dtype=np.float64) + 0.5
+    phi = np.arccos(1 - 2 * i / m)
+    theta = math.pi * (1 + 5**0.5) * i
+    u = np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], axis=1)
+    xyz = u * np.array([a, b, c])
+    n = xyz / np.array([a * a, b * b, c * c])
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    return xyz.astype(np.float32), n.astype(np.float32)
+
+
+def ellipsoid_model_spacing(spacing: float, semi=SEMI_AXES):
+    """Model with approximately ``spacing`` metres between neighbours (5 mm / 1 mm levels)."""
+    a, b, c = semi
+    p = 1.6075
+    area = 4 * math.pi * (((a * b) ** p + (a * c) ** p + (b * c) ** p) / 3) ** (1 / p)
+    m = max(16, int(round(area / (spacing * spacing))))
+    return ellipsoid_model(m, semi)
+
+
+# --------------------------------------------------------------------------- scene
+@dataclass
+class Scene:
+    xyz: np.ndarray  # (N,3) float32, camera frame
+    nrm: np.ndarray  # (N,3) float32, unit, towards the camera
+    conf: np.ndarray  # (N,)  float32
+    gt_pose: np.ndarray  # (4,4) float64 model->camera
+    n_object: int = 0
+
+
+def make_scene(n_points: int, seed: int = 7, semi=SEMI_AXES, noise=0.0005, clutter_frac=0.12,
+               normal_jitter_deg=3.0, high_conf_only=True) -> Scene:
+    """Camera-facing half of the ellipsoid under a random SE(3) + clutter.
+
+    t in [-0.1,0.1]^2 x [0.3,0.5], uniform rotation.  ``n_points`` is the size of the returned cloud;
+    about ``clutter_frac`` of it are hand-like clutter points next to the object.  With
+    ``high_conf_only`` every returned point has confidence >= 0.8 (i.e. the cloud is what the reference
+    calls ``_scene_high_confidence``, PoseEstimator.cpp:41-45); otherwise clutter gets 0.3.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    R = random_rotation(rng)
+    t = np.array([rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), rng.uniform(0.3, 0.5)])
+    T = se3(R, t)
+    n_clutter = int(round(n_points * clutter_frac))
+    n_obj = n_points - n_clutter
+    # over-sample the full surface, keep the visible half, then cut to n_obj
+    dense_xyz, dense_n = ellipsoid_model(int(n_obj * 2.6) + 64, semi)
+    perm = rng.permutation(len(dense_xyz))
+    dense_xyz, dense_n = dense_xyz[perm], dense_n[perm]
+    xyz = apply(T, dense_xyz).astype(np.float64)
+    nrm = rotate(T, dense_n).astype(np.float64)
+    view = xyz / np.linalg.norm(xyz, axis=1, keepdims=True)
+    vis = np.einsum("ij,ij->i", nrm, view) < -0.05
+    xyz, nrm = xyz[vis][:n_obj], nrm[vis][:n_obj]
+    if len(xyz) < n_obj:
+        raise RuntimeError("not enough visible points; raise the over-sampling factor")
+    xyz = xyz + rng.normal(scale=noise, size=xyz.shape)
+    # normal jitter
+    jit = rng.normal(scale=math.radians(normal_jitter_deg), size=nrm.shape)
+    nrm = nrm + np.cross(jit, nrm)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    # clutter: two finger-like slabs touching the object along +-x of the object frame
+    cl = []
+    cn = []
+    for s in (-1.0, 1.0):
+        k = n_clutter // 2 if s < 0 else n_clutter - n_clutter // 2
+        local = np.stack(
+            [np.full(k, s * (semi[0] + 0.004)) + rng.normal(scale=0.0004, size=k),
+             rng.uniform(-0.012, 0.012, size=k), rng.uniform(-0.03, 0.03, size=k)], axis=1)
+        ln = np.tile(np.array([-s, 0.0, 0.0]), (k, 1))
+        cl.append(local)
+        cn.append(ln)
+    cl = apply(T, np.concatenate(cl)).astype(np.float64)
+    cn = rotate(T, np.concatenate(cn)).astype(np.float64)
+    # orient clutter normals towards the camera like flipNormalTowardsViewpoint does
+    flip = np.einsum("ij,ij->i", cn, cl) > 0
+    cn[flip] *= -1
+    all_xyz = np.concatenate([xyz, cl]).astype(np.float32)
+    all_nrm = np.concatenate([nrm, cn]).astype(np.float32)
+    conf = np.concatenate([np.ones(len(xyz)), np.full(len(cl), 0.85 if high_conf_only else 0.3)]).astype(np.float32)
+    # interleave deterministically so clutter is not a suffix
+    order = rng.permutation(len(all_xyz))
+    return Scene(np.ascontiguousarray(all_xyz[order]), np.ascontiguousarray(all_nrm[order]),
+                 np.ascontiguousarray(conf[order]), T, n_obj)
+
+
+# --------------------------------------------------------------------------- PPF key table
+_DIST_DISCRET = 5
+_ANGLE_DISCRET = 10
+
+
+def _closest_bin(value, disc):
+    lower = value - (value % disc)
+    upper = lower + disc
+    return np.where((value - lower) < (upper - value), lower, upper)
+
+
+def ppf_keys_numpy(xyz, nrm):
+    """Keys of all ordered pairs i<j (computePPF.cpp:17-38,91-100), float32 arithmetic as numpy does it.
+
+    Used only to *build* a table for synthetic runs; the table is an input to both the oracle and the
+    product, so it needs to be plausible, not bit-equal to any reference output.
+    """
+    xyz = xyz.astype(np.float32)
+    n = nrm.astype(np.float32)
+    n = n / np.linalg.norm(n, axis=1, keepdims=True).astype(np.float32)
+    m = len(xyz)
+    keys = set()
+    for i in range(m - 1):
+        d = xyz[i + 1:] - xyz[i]  # p2 - p1
+        dist = np.linalg.norm(d, axis=1).astype(np.float32)
+        ok = dist > 0
+        dn = d[ok] / dist[ok, None]
+        k0 = (dist[ok] * np.float32(1000)).astype(np.int64)
+        a1 = np.degrees(np.arccos(np.clip(dn @ n[i], -1, 1).astype(np.float32)).astype(np.float64)).astype(np.int64)
+        a2 = np.degrees(np.arccos(np.clip(np.einsum("ij,ij->i", dn, n[i + 1:][ok]), -1, 1).astype(np.float32)).astype(np.float64)).astype(np.int64)
+        a3 = np.degrees(np.arccos(np.clip(n[i + 1:][ok] @ n[i], -1, 1).astype(np.float32)).astype(np.float64)).astype(np.int64)
+        kk = np.stack([_closest_bin(k0, _DIST_DISCRET), _closest_bin(a1, _ANGLE_DISCRET),
+                       _closest_bin(a2, _ANGLE_DISCRET), _closest_bin(a3, _ANGLE_DISCRET)], axis=1)
+        keys.update(map(tuple, np.unique(kk, axis=0).tolist()))
+    out = np.array(sorted(keys), dtype=np.int32).reshape(-1, 4)
+    return np.ascontiguousarray(out)
+
+
+def ppf_key_table(semi=SEMI_AXES, density=0.005):
+    xyz, nrm = ellipsoid_model_spacing(density, semi)
+    return ppf_keys_numpy(xyz, nrm)
+
+
+# --------------------------------------------------------------------------- replay poses
+def replay_poses(gt_pose, h: int, seed: int = 11, max_rot_deg=30.0, max_trans=0.015):
+    """``h`` row-major 4x4 float32 poses = gt o perturbation (rot <= 30 deg, trans <= 15 mm)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = np.empty((h, 4, 4), dtype=np.float32)
+    for k in range(h):
+        axis = rng.normal(size=3)
+        ang = math.radians(max_rot_deg) * rng.uniform() ** 2  # denser near the truth
+        dR = rot_from_axis_angle(axis, ang)
+        dt = rng.normal(size=3)
+        dt = dt / np.linalg.norm(dt) * max_trans * rng.uniform() ** 2
+        out[k] = (gt_pose @ se3(dR, dt)).astype(np.float32)
+    return out
+
+
+# --------------------------------------------------------------------------- stand-in T42 hand
+FINGER_NAMES = ("finger_1_1", "finger_1_2", "finger_2_1", "finger_2_2")
+PAIR_NAMES = {"finger_1_1": "finger_2_1", "finger_2_1": "finger_1_1", "finger_1_2": "finger_2_2",
+              "finger_2_2": "finger_1_2"}
+
+
+def _box_cloud(lo, hi, spacing):
+    """Points on the surface of an axis-aligned box with outward normals."""
+    lo = np.asarray(lo, dtype=np.float64)
+    hi = np.asarray(hi, dtype=np.float64)
+    pts, nrm = [], []
+    for ax in range(3):
+        o = [a for a in range(3) if a != ax]
+        g0 = np.arange(lo[o[0]], hi[o[0]] + 1e-9, spacing)
+        g1 = np.arange(lo[o[1]], hi[o[1]] + 1e-9, spacing)
+        u, v = np.meshgrid(g0, g1, indexing="ij")
+        for val, sgn in ((lo[ax], -1.0), (hi[ax], 1.0)):
+            p = np.zeros((u.size, 3))
+            p[:, o[0]] = u.ravel()
+            p[:, o[1]] = v.ravel()
+            p[:, ax] = val
+            n = np.zeros((u.size, 3))
+            n[:, ax] = sgn
+            pts.append(p)
+            nrm.append(n)
+    return np.concatenate(pts).astype(np.float32), np.concatenate(nrm).astype(np.float32)
+
+
+@dataclass
+class HandModel:
+    """Kinematic stand-in: names, parents, link->parent transforms and per-link clouds (link frame).
+
+    Mirrors what ``Hand::parseURDF`` leaves behind (Hand.cpp:375-502): ``_clouds``, ``_parent_names``,
+    ``_tf_in_parent``; ``_tf_self`` starts as identity.  In the link frame +y is the inner (grasping)
+    side and the link extends along -z ... +z, matching how objFuncPSO reads ``FingerProperty``
+    (Hand.cpp:24-54,141-152).
+    """
+    parents: dict = field(default_factory=dict)
+    tf_in_parent: dict = field(default_factory=dict)
+    clouds: dict = field(default_factory=dict)  # name -> (xyz, nrm)
+
+
+def t42_hand(spacing=0.005) -> HandModel:
+    h = HandModel()
+    prox = _box_cloud((-0.010, -0.006, 0.0), (0.010, 0.006, 0.060), spacing)
+    dist = _box_cloud((-0.009, -0.005, 0.0), (0.009, 0.005, 0.045), spacing)
+    base = _box_cloud((-0.03, -0.045, -0.05), (0.03, 0.045, 0.0), spacing)
+    h.clouds["base_link"] = base
+    h.parents["base_link"] = "world"
+    h.tf_in_parent["base_link"] = np.eye(4, dtype=np.float32)
+    # finger 1 sits at y=-0.04 with its inner side (+y of the link) facing +y of the hand base,
+    # finger 2 at y=+0.04 mirrored (rotated pi about z) so its inner side faces -y.
+    f1 = se3(np.eye(3), [0.0, -0.040, 0.0])
+    f2 = se3(rot_from_axis_angle([0, 0, 1], math.pi), [0.0, 0.040, 0.0])
+    d = se3(np.eye(3), [0.0, 0.0, 0.062])
+    for name, parent, tf, cloud in (
+        ("finger_1_1", "base_link", f1, prox), ("finger_1_2", "finger_1_1", d, dist),
+        ("finger_2_1", "base_link", f2, prox), ("finger_2_2", "finger_2_1", d, dist),
+    ):
+        h.parents[name] = parent
+        h.tf_in_parent[name] = tf.astype(np.float32)
+        h.clouds[name] = cloud
+    return h
+
+
+def rx(angle):
+    c, s = math.cos(angle), math.sin(angle)
+    T = np.eye(4)
+    T[1, 1], T[1, 2], T[2, 1], T[2, 2] = c, -s, s, c
+    return T
+
+
+def hand_fk(hand: HandModel, angles: dict, name: str):
+    """getTFHandBase (Hand.cpp:505-523): link -> hand-base with self rotations Rx(angle)."""
+    T = np.eye(4)
+    cur = name
+    while cur != "base_link":
+        T = hand.tf_in_parent[cur].astype(np.float64) @ rx(angles.get(cur, 0.0)) @ T
+        cur = hand.parents[cur]
+    return T
+
+
+def make_hand_scene(hand: HandModel, true_angles: dict, n_points: int, seed: int = 5, noise=0.0006,
+                    clutter_frac=0.25):
+    """Scene of the hand region in the hand-base frame: the posed finger links seen from a camera on
+    the -x side (so roughly half of every link is visible), plus background clutter, thinned/padded
+    to ``n_points``.  Returns (xyz, nrm) float32.  Normals point towards the camera."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cam = np.array([-0.6, 0.05, 0.05])
+    pts, nrm = [], []
+    dense = t42_hand(spacing=0.0012)
+    for name in FINGER_NAMES:
+        T = hand_fk(hand, true_angles, name)
+        x, n = dense.clouds[name]
+        xw, nw = apply(T, x).astype(np.float64), rotate(T, n).astype(np.float64)
+        view = xw - cam
+        view /= np.linalg.norm(view, axis=1, keepdims=True)
+        vis = np.einsum("ij,ij->i", nw, view) < -0.1
+        pts.append(xw[vis])
+        nrm.append(nw[vis])
+    pts = np.concatenate(pts)
+    nrm = np.concatenate(nrm)
+    n_cl = int(n_points * clutter_frac)
+    n_f = n_points - n_cl
+    if len(pts) >= n_f:
+        sel = rng.choice(len(pts), size=n_f, replace=False)
+    else:
+        sel = rng.choice(len(pts), size=n_f, replace=True)
+    pts, nrm = pts[sel] + rng.normal(scale=noise, size=(n_f, 3)), nrm[sel]
+    # clutter: a table-like plane far below and random blobs away from the fingers
+    cl = np.stack([rng.uniform(-0.24, -0.11, n_cl), rng.uniform(-0.15, 0.15, n_cl),
+                   rng.uniform(-0.11, -0.09, n_cl)], axis=1)
+    cln = np.tile(np.array([0.0, 0.0, 1.0]), (n_cl, 1))
+    xyz = np.concatenate([pts, cl]).astype(np.float32)
+    nn = np.concatenate([nrm, cln]).astype(np.float32)
+    order = rng.permutation(len(xyz))
+    return np.ascontiguousarray(xyz[order]), np.ascontiguousarray(nn[order])

@@ -1,0 +1,334 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes bindings of the CPU oracle (liboracle.so) and, when it has been
+built in the build container, of the reference's own OpenGR fork (oracle/_ref/libref_s4pcs.so).
+
+Importers: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.  Never the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from contextlib import contextmanager
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "_build", "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libref_s4pcs.so")
+
+fp = C.POINTER(C.c_float)
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+
+def F(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(fp)
+
+
+def I(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ip)
+
+
+def D(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(dp)
+
+
+def soa(a):
+    """(n,3) -> contiguous (3,n) float32 planes."""
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32).T)
+
+
+def build(force=False):
+    """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(
+            os.path.getmtime(os.path.join(HERE, f)) for f in ("hop_oracle.cpp", "hop_oracle.h")):
+        subprocess.check_call(["make", "-C", HERE, "_build/liboracle.so"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+@contextmanager
+def quiet_stdout():
+    """The reference headers print to stdout from C++ (match4pcsBase.hpp:264-265 etc.)."""
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+    try:
+        yield
+    finally:
+        os.dup2(saved, 1)
+        os.close(devnull)
+        os.close(saved)
+
+
+class S4Opts(C.Structure):
+    _fields_ = [("sample_size", C.c_int), ("overlap", C.c_float), ("delta", C.c_float), ("dispersion", C.c_float),
+                ("success_quadrilaterals", C.c_int), ("n_trials", C.c_int), ("random_seed", C.c_uint)]
+
+
+class RefOpts(C.Structure):
+    _fields_ = [("sample_size", C.c_int), ("overlap", C.c_float), ("delta", C.c_float), ("dispersion", C.c_float),
+                ("success_quadrilaterals", C.c_int), ("max_time_seconds", C.c_int),
+                ("max_normal_difference", C.c_float), ("max_color_distance", C.c_float)]
+
+
+class FingerArgs(C.Structure):
+    _fields_ = [
+        ("fp_min", C.c_float * 3), ("fp_max", C.c_float * 3), ("fp_stride_z", C.c_float), ("fp_num_division", C.c_int),
+        ("fp_hist_min_y", fp), ("fo_min", C.c_float * 3), ("fo_max", C.c_float * 3),
+        ("model2handbase", C.c_float * 16), ("finger_out2parent", C.c_float * 16),
+        ("pair_tip1", C.c_float * 4), ("pair_tip2", C.c_float * 4), ("is_palm_side", C.c_int),
+        ("is_right_side", C.c_int), ("gripper_min_dist", C.c_float), ("dist_thres", C.c_float),
+        ("cos_normal_thres", C.c_float), ("check_normal", C.c_int), ("max_outter_pts", C.c_int),
+        ("outter_pt_dist", C.c_float), ("outter_pt_dist_weight", C.c_float),
+        ("model_xyz", fp), ("model_nrm", fp), ("n_model", C.c_int),
+        ("scene_xyz", fp), ("n_scene", C.c_int), ("scene_nrm_lookup", fp), ("n_lookup", C.c_int),
+        ("swivel_xyz", fp), ("n_swivel", C.c_int),
+    ]
+
+
+class PsoSettings(C.Structure):
+    _fields_ = [("n_pop", C.c_int), ("n_gen", C.c_int), ("check_freq", C.c_int), ("c_cog", C.c_double),
+                ("c_soc", C.c_double), ("initial_w", C.c_double), ("w_min", C.c_double), ("w_max", C.c_double),
+                ("err_tol", C.c_double), ("lower_rad", C.c_double), ("upper_rad", C.c_double), ("seed", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            build()
+        L = C.CDLL(ORACLE_SO)
+        L.orc_acosf.restype = C.c_float
+        L.orc_acosf.argtypes = [C.c_float]
+        L.orc_s4pcs_create.restype = C.c_void_p
+        L.orc_s4pcs_create.argtypes = [C.POINTER(S4Opts)]
+        L.orc_s4pcs_destroy.argtypes = [C.c_void_p]
+        L.orc_s4pcs_set_keys.argtypes = [C.c_void_p, ip, C.c_int]
+        L.orc_s4pcs_run.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, fp, fp, C.c_int, C.c_int]
+        L.orc_s4pcs_num_hypos.argtypes = [C.c_void_p]
+        L.orc_s4pcs_get_hypos.argtypes = [C.c_void_p, fp, fp]
+        L.orc_s4pcs_num_bases.argtypes = [C.c_void_p]
+        L.orc_s4pcs_get_base.argtypes = [C.c_void_p, C.c_int, ip, fp, ip]
+        L.orc_s4pcs_get_base_lists.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
+        L.orc_s4pcs_num_sampled_q.argtypes = [C.c_void_p]
+        L.orc_s4pcs_get_state.argtypes = [C.c_void_p, fp, fp, fp, fp, fp, ip]
+        L.orc_s4pcs_verify.restype = C.c_float
+        L.orc_s4pcs_verify.argtypes = [C.c_void_p, fp]
+        L.orc_verify_batch.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_int, C.c_float, C.c_int, ip]
+        L.orc_compute_lcp_batch.argtypes = [fp, fp, C.c_int, fp, fp, C.c_int, fp, C.c_int, C.c_float, C.c_float,
+                                            C.c_int, fp]
+        L.orc_icp_refine_batch.argtypes = [fp, fp, C.c_int, fp, fp, C.c_int, fp, C.c_int, C.c_int, C.c_float,
+                                           C.c_float, C.c_int, ip, ip]
+        L.orc_cluster_poses.restype = C.c_int
+        L.orc_cluster_poses.argtypes = [fp, fp, ip, C.c_int, C.c_float, C.c_float, fp, ip]
+        L.orc_pso_objective.restype = C.c_double
+        L.orc_pso_objective.argtypes = [C.POINTER(FingerArgs), C.c_double]
+        L.orc_pso_objective_batch.argtypes = [C.POINTER(FingerArgs), dp, C.c_int, dp]
+        L.orc_pso_search.argtypes = [C.POINTER(FingerArgs), C.POINTER(PsoSettings), dp, dp]
+        L.orc_finger_property.argtypes = [fp, C.c_int, C.c_int, fp, fp, fp, fp]
+        L.orc_compute_ppf.argtypes = [fp, fp, fp, fp, ip]
+        L.orc_pair_ppf_is_good.argtypes = [fp, fp, fp, fp]
+        L.orc_rigid.argtypes = [fp, fp, fp, fp]
+        L.orc_probe_transform.argtypes = [fp, fp, fp]
+        L.orc_probe_vec.argtypes = [fp, fp, fp]
+        L.orc_probe_quat.argtypes = [fp, fp, fp]
+        _lib = L
+    return _lib
+
+
+_ref = None
+
+
+def ref_available():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        L = C.CDLL(REF_SO)
+        L.ref_create.restype = C.c_void_p
+        L.ref_create.argtypes = [C.POINTER(RefOpts)]
+        L.ref_destroy.argtypes = [C.c_void_p]
+        L.ref_set_ppf_keys.argtypes = [C.c_void_p, ip, C.c_int]
+        L.ref_record_pairs.argtypes = [C.c_void_p, C.c_int]
+        L.ref_run.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, fp, fp, C.c_int, C.c_int]
+        L.ref_num_hypos.argtypes = [C.c_void_p]
+        L.ref_get_hypos.argtypes = [C.c_void_p, fp, fp]
+        L.ref_num_bases.argtypes = [C.c_void_p]
+        L.ref_get_base.argtypes = [C.c_void_p, C.c_int, ip, fp, ip]
+        L.ref_get_base_lists.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
+        L.ref_num_sampled_q.argtypes = [C.c_void_p]
+        L.ref_get_state.argtypes = [C.c_void_p, fp, fp, fp, fp, fp, ip]
+        L.ref_verify.restype = C.c_float
+        L.ref_verify.argtypes = [C.c_void_p, fp]
+        L.ref_compute_ppf.argtypes = [fp, fp, fp, fp, ip]
+        L.ref_pair_ppf_is_good.argtypes = [fp, fp, fp, fp]
+        L.ref_rigid.argtypes = [C.c_void_p, fp, fp, fp, fp]
+        L.ref_probe_transform.argtypes = [fp, fp, fp]
+        L.ref_probe_vec.argtypes = [fp, fp, fp]
+        L.ref_probe_quat.argtypes = [fp, fp, fp]
+        _ref = L
+    return _ref
+
+
+# ------------------------------------------------------------------------------ generator wrappers
+class _GenBase:
+    """Shared read-out logic; `self.L` / `self.h` / prefix differ."""
+
+    def hypos(self):
+        n = self._call("num_hypos")
+        pose = np.zeros((n, 16), np.float32)
+        lcp = np.zeros(n, np.float32)
+        if n:
+            self._call("get_hypos", F(pose), F(lcp))
+        return pose.reshape(n, 4, 4), lcp
+
+    def bases(self):
+        out = []
+        for i in range(self._call("num_bases")):
+            b4 = np.zeros(4, np.int32)
+            inv = np.zeros(2, np.float32)
+            c3 = np.zeros(3, np.int32)
+            self._call("get_base", i, I(b4), F(inv), I(c3))
+            p1 = np.zeros((max(c3[0], 1), 2), np.int32)
+            p2 = np.zeros((max(c3[1], 1), 2), np.int32)
+            q = np.zeros((max(c3[2], 1), 4), np.int32)
+            self._call("get_base_lists", i, I(p1), I(p2), I(q))
+            out.append(dict(base=b4, inv=inv, pairs1=p1[:c3[0]], pairs2=p2[:c3[1]], quads=q[:c3[2]]))
+        return out
+
+
+class OracleS4PCS(_GenBase):
+    def __init__(self, sample_size=100, overlap=0.2, delta=0.003, dispersion=0.5, success_quadrilaterals=10,
+                 n_trials=0, random_seed=5489):
+        self.L = lib()
+        o = S4Opts(sample_size, overlap, delta, dispersion, success_quadrilaterals, n_trials, random_seed)
+        self.h = C.c_void_p(self.L.orc_s4pcs_create(C.byref(o)))
+
+    def _call(self, name, *a):
+        return getattr(self.L, "orc_s4pcs_" + name)(self.h, *a)
+
+    def __del__(self):
+        try:
+            self.L.orc_s4pcs_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_keys(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        self._call("set_keys", I(keys), len(keys))
+
+    def run(self, Pxyz, Pnrm, Pprob, Qxyz, Qnrm, n_calls=1):
+        P, Pn, Q, Qn = soa(Pxyz), soa(Pnrm), soa(Qxyz), soa(Qnrm)
+        pr = np.ascontiguousarray(Pprob, dtype=np.float32)
+        return self._call("run", F(P), F(Pn), F(pr), P.shape[1], F(Q), F(Qn), Q.shape[1], n_calls)
+
+    def state(self):
+        n = self._call("num_sampled_q")
+        q = np.zeros((3, n), np.float32)
+        qn = np.zeros((3, n), np.float32)
+        cp = np.zeros(3, np.float32)
+        cq = np.zeros(3, np.float32)
+        d = np.zeros(1, np.float32)
+        nf = np.zeros(1, np.int32)
+        self._call("get_state", F(q), F(qn), F(cp), F(cq), F(d), I(nf))
+        return dict(Qs=q.T.copy(), Qs_nrm=qn.T.copy(), cP=cp, cQ=cq, diameter=float(d[0]), n_quat_fallback=int(nf[0]))
+
+    def verify(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float32).reshape(16)
+        return float(self._call("verify", F(T)))
+
+
+class RefS4PCS(_GenBase):
+    """The reference's own matcher (build container only)."""
+
+    def __init__(self, sample_size=100, overlap=0.2, delta=0.003, dispersion=0.5, success_quadrilaterals=10,
+                 max_time_seconds=10 ** 9, record_pairs=True):
+        self.L = ref()
+        o = RefOpts(sample_size, overlap, delta, dispersion, success_quadrilaterals, max_time_seconds, -1.0, -1.0)
+        self.h = C.c_void_p(self.L.ref_create(C.byref(o)))
+        self.L.ref_record_pairs(self.h, 1 if record_pairs else 0)
+
+    def _call(self, name, *a):
+        return getattr(self.L, "ref_" + name)(self.h, *a)
+
+    def __del__(self):
+        try:
+            self.L.ref_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_keys(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        self.L.ref_set_ppf_keys(self.h, I(keys), len(keys))
+
+    def run(self, Pxyz, Pnrm, Pprob, Qxyz, Qnrm, n_calls=1):
+        P = np.ascontiguousarray(Pxyz, np.float32)
+        Pn = np.ascontiguousarray(Pnrm, np.float32)
+        Q = np.ascontiguousarray(Qxyz, np.float32)
+        Qn = np.ascontiguousarray(Qnrm, np.float32)
+        pr = np.ascontiguousarray(Pprob, dtype=np.float32)
+        with quiet_stdout():
+            return self._call("run", F(P), F(Pn), F(pr), len(P), F(Q), F(Qn), len(Q), n_calls)
+
+    def state(self):
+        n = self._call("num_sampled_q")
+        q = np.zeros((n, 3), np.float32)
+        qn = np.zeros((n, 3), np.float32)
+        cp = np.zeros(3, np.float32)
+        cq = np.zeros(3, np.float32)
+        d = np.zeros(1, np.float32)
+        nt = np.zeros(1, np.int32)
+        self._call("get_state", F(q), F(qn), F(cp), F(cq), F(d), I(nt))
+        return dict(Qs=q, Qs_nrm=qn, cP=cp, cQ=cq, diameter=float(d[0]), number_of_trials=int(nt[0]))
+
+    def verify(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float32).reshape(16)
+        return float(self._call("verify", F(T)))
+
+
+# ------------------------------------------------------------------------------ scoring wrappers
+def verify_batch(P, Qs, T, delta, use_tree=True):
+    Pp, Qp = soa(P), soa(Qs)
+    T = np.ascontiguousarray(T, np.float32).reshape(-1, 16)
+    out = np.zeros(len(T), np.int32)
+    lib().orc_verify_batch(F(Pp), Pp.shape[1], F(Qp), Qp.shape[1], F(T), len(T), delta, int(use_tree), I(out))
+    return out
+
+
+def compute_lcp_batch(S, Sn, M, Mn, poses, dist=0.001, angle_deg=10.0, use_tree=True):
+    Sp, Snp, Mp, Mnp = soa(S), soa(Sn), soa(M), soa(Mn)
+    T = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    out = np.zeros(len(T), np.float32)
+    lib().orc_compute_lcp_batch(F(Sp), F(Snp), Sp.shape[1], F(Mp), F(Mnp), Mp.shape[1], F(T), len(T), dist,
+                                angle_deg, int(use_tree), F(out))
+    return out
+
+
+def icp_refine_batch(S, Sn, M, Mn, poses, max_iter=10, angle_deg=45.0, max_corr_dist=0.01, use_tree=True):
+    Sp, Snp, Mp, Mnp = soa(S), soa(Sn), soa(M), soa(Mn)
+    T = np.ascontiguousarray(poses, np.float32).reshape(-1, 16).copy()
+    it = np.zeros(len(T), np.int32)
+    cv = np.zeros(len(T), np.int32)
+    lib().orc_icp_refine_batch(F(Sp), F(Snp), Sp.shape[1], F(Mp), F(Mnp), Mp.shape[1], F(T), len(T), max_iter,
+                               angle_deg, max_corr_dist, int(use_tree), I(it), I(cv))
+    return T.reshape(-1, 4, 4), it, cv
+
+
+def cluster_poses(poses, lcp, ids, angle_deg, dist, sym_deg):
+    T = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    lcp = np.ascontiguousarray(lcp, np.float32)
+    ids = np.ascontiguousarray(ids, np.int32)
+    sym = np.ascontiguousarray(sym_deg, np.float32)
+    keep = np.zeros(len(T), np.int32)
+    n = lib().orc_cluster_poses(F(T), F(lcp), I(ids), len(T), angle_deg, dist, F(sym), I(keep))
+    return keep[:n].copy()

@@ -1,0 +1,145 @@
+"""CPU restatement (oracle/) against the golden vectors emitted by the reference's own OpenGR fork
+(tests/golden/*.npz, generator: oracle/gen_golden.py).  No GPU."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+
+def rows(a):
+    return set(map(tuple, np.asarray(a).tolist()))
+
+
+def test_acosf_matches_libm(orc):
+    """The restated fdlibm acosf must equal the libc the oracle would otherwise call (and that the
+    reference called when the golden vectors were made)."""
+    L = orc.lib()
+    libm = C.CDLL("libm.so.6")
+    libm.acosf.restype = C.c_float
+    libm.acosf.argtypes = [C.c_float]
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([
+        rng.uniform(-1, 1, 60000), 1 - 2.0 ** -np.arange(1, 26), -(1 - 2.0 ** -np.arange(1, 26)),
+        [1, -1, 0, 0.5, -0.5, 1.0000001, -1.0000001, 2 ** -27],
+        np.cos(np.radians(np.arange(0, 181, 5))),
+    ]).astype(np.float32)
+    for x in xs:
+        a, b = L.orc_acosf(float(x)), libm.acosf(float(x))
+        assert a == b or (a != a and b != b), (x, a, b)
+
+
+def test_kat_ppf_keys(orc, golden_dir):
+    g = np.load(os.path.join(golden_dir, "kat_pure.npz"))
+    L = orc.lib()
+    k = np.zeros(4, np.int32)
+    for i in range(len(g["ppf_key"])):
+        L.orc_compute_ppf(orc.F(g["ppf_p1"][i].copy()), orc.F(g["ppf_n1"][i].copy()), orc.F(g["ppf_p2"][i].copy()),
+                          orc.F(g["ppf_n2"][i].copy()), orc.I(k))
+        assert np.array_equal(k, g["ppf_key"][i]), i
+    # the NaN -> INT_MIN path must be present in the fixture
+    assert (g["ppf_key"] < -10 ** 9).any()
+
+
+def test_kat_pair_filter(orc, golden_dir):
+    g = np.load(os.path.join(golden_dir, "kat_pure.npz"))
+    L = orc.lib()
+    pts = g["pf_pts"]
+    got = np.array([L.orc_pair_ppf_is_good(*(orc.F(np.ascontiguousarray(pts[k, j])) for j in range(4)))
+                    for k in range(len(pts))], np.int8)
+    assert np.array_equal(got, g["pf_good"])
+    assert 50 < got.sum() < len(got) - 50
+
+
+def test_kat_rigid(orc, golden_dir):
+    g = np.load(os.path.join(golden_dir, "kat_pure.npz"))
+    L = orc.lib()
+    for k in range(len(g["rigid_ok"])):
+        T = np.zeros(16, np.float32)
+        e = np.zeros(1, np.float32)
+        ok = L.orc_rigid(orc.F(np.ascontiguousarray(g["rigid_ref"][k].reshape(9))),
+                         orc.F(np.ascontiguousarray(g["rigid_cand"][k].reshape(9))), orc.F(T), orc.F(e))
+        assert ok == g["rigid_ok"][k]
+        if ok:
+            assert e[0] == g["rigid_rms"][k]            # bit-equal rms
+            assert np.array_equal(T, g["rigid_T"][k])   # bit-equal transform
+
+
+@pytest.mark.parametrize("case", ["case1", "case2", "case3"])
+def test_generator_matches_reference(orc, golden_dir, case):
+    g = np.load(os.path.join(golden_dir, f"s4pcs_{case}.npz"))
+    sample_size, succ, n_calls = (int(v) for v in g["opts"])
+    overlap, delta, disp = (float(v) for v in g["opts_f"])
+    o = orc.OracleS4PCS(sample_size=sample_size, overlap=overlap, delta=delta, dispersion=disp,
+                        success_quadrilaterals=succ)
+    o.set_keys(g["keys"])
+    n = o.run(g["P_xyz"], g["P_nrm"], g["P_conf"], g["Q_xyz"], g["Q_nrm"], n_calls)
+    st = o.state()
+    # L0/L1: sampling, centring, diameter are bit-equal
+    assert np.array_equal(st["Qs"], g["Qs"]) and np.array_equal(st["Qs_nrm"], g["Qs_nrm"])
+    assert np.array_equal(st["cP"], g["cP"]) and np.array_equal(st["cQ"], g["cQ"])
+    assert np.float32(st["diameter"]) == g["diameter"]
+    assert int(g["number_of_trials"]) == 30  # the reference's trial count clamps to 30
+    # L1: per-base trace
+    bases = o.bases()
+    assert len(bases) == int(g["n_bases"])
+    for i, b in enumerate(bases):
+        assert np.array_equal(b["base"], g["base_ids"][i])
+        assert np.array_equal(b["inv"], g["base_inv"][i])
+        assert rows(b["pairs1"]) == rows(g[f"pairs1_{i}"])
+        assert rows(b["pairs2"]) == rows(g[f"pairs2_{i}"])
+        assert rows(b["quads"]) == rows(g[f"quads_{i}"])
+    # hypotheses: same multiset of (lcp, rotation) exactly, translations within 1e-6 m
+    pose, lcp = o.hypos()
+    assert n == len(g["hyp_lcp"]) == len(lcp)
+    flat = pose.reshape(n, 16)
+    rot = flat[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]]
+    order = np.lexsort(tuple(rot[:, ::-1].T) + (-lcp,))
+    pose, lcp = pose[order], lcp[order]
+    assert np.array_equal(lcp, g["hyp_lcp"])
+    assert np.array_equal(pose[:, :3, :3], g["hyp_pose"][:, :3, :3])
+    assert np.abs(pose[:, :3, 3] - g["hyp_pose"][:, :3, 3]).max() < 1e-6
+    # Verify KATs on the state left by the run
+    for T, v in zip(g["verify_T"], g["verify_lcp"]):
+        assert o.verify(T) == v
+    assert st["n_quat_fallback"] == 0  # the JacobiSVD fallback was not exercised here
+
+
+def test_verify_brute_equals_tree(orc, golden_dir):
+    g = np.load(os.path.join(golden_dir, "s4pcs_case1.npz"))
+    P = g["P_xyz"] - g["cP"]  # approximately centred; only used for brute/tree agreement
+    a = orc.verify_batch(P, g["Qs"], g["verify_T"], 0.003, use_tree=True)
+    b = orc.verify_batch(P, g["Qs"], g["verify_T"], 0.003, use_tree=False)
+    assert np.array_equal(a, b)
+    assert a.max() > 0
+
+
+def test_oracle_probes_against_reference_build(orc):
+    """Bit-level probes of the Eigen operation order; only where the reference build exists."""
+    if not orc.ref_available():
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    L, R = orc.lib(), orc.ref()
+    rng = np.random.default_rng(5)
+    for _ in range(3000):
+        a = (rng.normal(size=3) * rng.choice([0.01, 0.1, 1])).astype(np.float32)
+        b = (rng.normal(size=3) * 0.1).astype(np.float32)
+        o1, o2 = np.zeros(9, np.float32), np.zeros(9, np.float32)
+        L.orc_probe_vec(orc.F(a), orc.F(b), orc.F(o1))
+        R.ref_probe_vec(orc.F(a), orc.F(b), orc.F(o2))
+        assert np.array_equal(o1, o2)
+        Rm = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        T = np.eye(4)
+        T[:3, :3] = Rm
+        T[:3, 3] = rng.normal(size=3) * 0.1
+        T = T.astype(np.float32).reshape(16).copy()
+        o1, o2 = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        L.orc_probe_transform(orc.F(T), orc.F(b), orc.F(o1))
+        R.ref_probe_transform(orc.F(T), orc.F(b), orc.F(o2))
+        assert np.array_equal(o1, o2)
+        n = a / np.linalg.norm(a)
+        if n[2] > -0.9999:
+            o1, o2 = np.zeros(7, np.float32), np.zeros(7, np.float32)
+            L.orc_probe_quat(orc.F(n.astype(np.float32)), orc.F(b), orc.F(o1))
+            R.ref_probe_quat(orc.F(n.astype(np.float32)), orc.F(b), orc.F(o2))
+            assert np.array_equal(o1, o2)
