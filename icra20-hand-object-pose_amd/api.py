@@ -1,0 +1,615 @@
+"""ctypes binding of the C-ABI in include/hop.h (libhop.so) and Python mirrors of the reference's host classes.
+
+There is no CPU fallback here: importing works anywhere (so CPU-only tests can check symbols), but every
+compute entry point needs a HIP device and raises ``HopError`` otherwise.
+
+Mirrors (same names / argument meaning as the reference):
+  ``PoseHypo``       include/PoseHypo.h:7-26
+  ``PoseEstimator``  include/PoseEstimator.h:12-49  (setCurScene, runSuper4pcs, clusterPoses, refineByICP, selectBest)
+  ``HandT42``        include/Hand.h:29-92           (getTFHandBase, matchOneComponentPSO)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libhop.so")
+HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "hop.h")
+
+fp = C.POINTER(C.c_float)
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+HOP_MODEL_5MM = 0
+HOP_MODEL_1MM = 1
+TOPK_ROW_FLOATS = 18
+
+
+class HopError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__(f"{where}: status {status} ({_strerror(status)}) {detail}")
+
+
+class S4pcsOpts(C.Structure):
+    _fields_ = [("sample_size", C.c_int), ("overlap", C.c_float), ("delta", C.c_float), ("dispersion", C.c_float),
+                ("success_quadrilaterals", C.c_int), ("max_time_seconds", C.c_int), ("n_trials", C.c_int),
+                ("random_seed", C.c_uint), ("max_normal_difference", C.c_float), ("max_color_distance", C.c_float),
+                ("verify_mode", C.c_int)]
+
+
+class S4pcsStats(C.Structure):
+    _fields_ = [("n_trials_run", C.c_int), ("n_bases", C.c_int), ("n_hypotheses", C.c_int), ("n_pairs", C.c_longlong),
+                ("n_quads", C.c_longlong), ("n_candidates", C.c_longlong), ("n_sampled_q", C.c_int),
+                ("centroid_p", C.c_float * 3), ("centroid_q", C.c_float * 3), ("diameter", C.c_float),
+                ("ms_select", C.c_double), ("ms_device", C.c_double)]
+
+
+class IcpOpts(C.Structure):
+    _fields_ = [("max_iter", C.c_int), ("angle_deg", C.c_float), ("max_corr_dist", C.c_float),
+                ("max_hypotheses", C.c_int), ("nn_mode", C.c_int)]
+
+
+class LcpOpts(C.Structure):
+    _fields_ = [("dist", C.c_float), ("angle_deg", C.c_float), ("nn_mode", C.c_int)]
+
+
+class FingerArgs(C.Structure):
+    _fields_ = [("fp_min", C.c_float * 3), ("fp_max", C.c_float * 3), ("fp_stride_z", C.c_float),
+                ("fp_num_division", C.c_int), ("fp_hist_min_y", fp), ("fo_min", C.c_float * 3), ("fo_max", C.c_float * 3),
+                ("model2handbase", C.c_float * 16), ("finger_out2parent", C.c_float * 16), ("pair_tip1", C.c_float * 4),
+                ("pair_tip2", C.c_float * 4), ("is_palm_side", C.c_int), ("is_right_side", C.c_int),
+                ("gripper_min_dist", C.c_float), ("dist_thres", C.c_float), ("cos_normal_thres", C.c_float),
+                ("check_normal", C.c_int), ("max_outter_pts", C.c_int), ("outter_pt_dist", C.c_float),
+                ("outter_pt_dist_weight", C.c_float), ("model_xyz", fp), ("model_nrm", fp), ("n_model", C.c_int)]
+
+
+class PsoSettings(C.Structure):
+    _fields_ = [("n_pop", C.c_int), ("n_gen", C.c_int), ("check_freq", C.c_int), ("c_cog", C.c_double),
+                ("c_soc", C.c_double), ("initial_w", C.c_double), ("w_min", C.c_double), ("w_max", C.c_double),
+                ("err_tol", C.c_double), ("lower_rad", C.c_double), ("upper_rad", C.c_double), ("seed", C.c_uint64)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("ms_verify", C.c_double), ("ms_gen_other", C.c_double), ("ms_icp_nn", C.c_double),
+                ("ms_icp_solve", C.c_double), ("ms_lcp_fwd", C.c_double), ("ms_lcp_rev", C.c_double),
+                ("ms_pso", C.c_double), ("ms_ppf_matrix", C.c_double), ("n_verify_launches", C.c_longlong),
+                ("n_icp_nn_launches", C.c_longlong), ("n_lcp_launches", C.c_longlong), ("n_pso_launches", C.c_longlong),
+                ("pairs_verify", C.c_longlong), ("pairs_icp", C.c_longlong), ("pairs_lcp", C.c_longlong),
+                ("pairs_pso", C.c_longlong)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/hop.h declares: name -> (restype, argtypes)
+_vp = C.c_void_p
+SIGNATURES = {
+    "hop_abi_version": (C.c_int, []),
+    "hop_strerror": (C.c_char_p, [C.c_int]),
+    "hop_last_error": (C.c_char_p, [_vp]),
+    "hop_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "hop_ctx_destroy": (None, [_vp]),
+    "hop_synchronize": (C.c_int, [_vp]),
+    "hop_set_scene": (C.c_int, [_vp, fp, fp, fp, C.c_int, C.c_float]),
+    "hop_scene_size": (C.c_int, [_vp]),
+    "hop_set_model": (C.c_int, [_vp, C.c_int, fp, fp, C.c_int]),
+    "hop_set_ppf_keys": (C.c_int, [_vp, ip, C.c_int]),
+    "hop_s4pcs_default_opts": (None, [C.POINTER(S4pcsOpts)]),
+    "hop_s4pcs_generate": (C.c_int, [_vp, C.POINTER(S4pcsOpts), fp, fp, C.c_int, ip, C.POINTER(S4pcsStats)]),
+    "hop_s4pcs_num_bases": (C.c_int, [_vp]),
+    "hop_s4pcs_get_base": (C.c_int, [_vp, C.c_int, ip, fp, ip]),
+    "hop_s4pcs_get_sampled_q": (C.c_int, [_vp, fp, fp]),
+    "hop_verify_set_clouds": (C.c_int, [_vp, fp, C.c_int, fp, C.c_int]),
+    "hop_verify_batch": (C.c_int, [_vp, fp, C.c_int, C.c_float, C.c_int, ip]),
+    "hop_hypos_upload": (C.c_int, [_vp, fp, fp, C.c_int]),
+    "hop_hypos_count": (C.c_int, [_vp]),
+    "hop_hypos_download": (C.c_int, [_vp, fp, fp, ip, C.c_int, ip]),
+    "hop_hypos_keep_topk": (C.c_int, [_vp, C.c_int]),
+    "hop_icp_refine": (C.c_int, [_vp, C.POINTER(IcpOpts), ip, ip]),
+    "hop_lcp_select_best": (C.c_int, [_vp, C.POINTER(LcpOpts), fp, fp, ip]),
+    "hop_cluster_poses": (C.c_int, [_vp, C.c_float, C.c_float, fp, C.c_int]),
+    "hop_cluster_poses_host": (C.c_int, [fp, fp, ip, C.c_int, C.c_float, C.c_float, fp, ip, ip]),
+    "hop_topk_pack": (C.c_int, [_vp, C.c_int, C.c_int, fp, ip]),
+    "hop_topk_merge": (C.c_int, [fp, C.c_int, C.c_int, fp, ip]),
+    "hop_hand_set_scene": (C.c_int, [_vp, fp, C.c_int, fp, C.c_int, fp, C.c_int]),
+    "hop_hand_set_finger": (C.c_int, [_vp, C.POINTER(FingerArgs)]),
+    "hop_hand_pso_eval_batch": (C.c_int, [_vp, dp, C.c_int, dp]),
+    "hop_pso_default_settings": (None, [C.POINTER(PsoSettings)]),
+    "hop_hand_pso_search": (C.c_int, [_vp, C.POINTER(PsoSettings), dp, dp]),
+    "hop_timing_reset": (C.c_int, [_vp]),
+    "hop_timing_get": (C.c_int, [_vp, C.POINTER(Timing)]),
+    "hop_timing_enable": (C.c_int, [_vp, C.c_int]),
+}
+
+_lib = None
+
+
+def build_library(force=False):
+    """hipcc cross-compiles gfx950 without a GPU; the .so stays in-tree (icra20-hand-object-pose_amd/lib)."""
+    src = os.path.join(HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", src], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HopError(-2, "load", f"{LIB_PATH} is missing: run __graft_entry__.build() (no CPU fallback exists)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _strerror(status):
+    try:
+        return lib().hop_strerror(status).decode()
+    except Exception:
+        return "?"
+
+
+def F(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(fp)
+
+
+def I(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ip)
+
+
+def D(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(dp)
+
+
+def soa(a):
+    """(n,3) array -> contiguous (3,n) float32 planes (the ABI's cloud layout)."""
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32).T)
+
+
+class Context:
+    """One hop_ctx: a HIP device, its stream and the resident clouds / hypothesis set."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = _vp()
+        rc = self.L.hop_ctx_create(device, C.byref(h))
+        if rc:
+            raise HopError(rc, "hop_ctx_create")
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hop_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, where, ok=()):
+        if rc and rc not in ok:
+            raise HopError(rc, where, self.L.hop_last_error(self.h).decode())
+        return rc
+
+    # ---- clouds
+    def set_scene(self, xyz, nrm, conf=None, high_confidence_thres=0.0):
+        X, Nn = soa(xyz), soa(nrm)
+        cf = None if conf is None else np.ascontiguousarray(conf, dtype=np.float32)
+        self._chk(self.L.hop_set_scene(self.h, F(X), F(Nn), F(cf) if cf is not None else None, X.shape[1],
+                                       high_confidence_thres), "hop_set_scene")
+        return self.L.hop_scene_size(self.h)
+
+    def set_model(self, level, xyz, nrm):
+        X, Nn = soa(xyz), soa(nrm)
+        self._chk(self.L.hop_set_model(self.h, level, F(X), F(Nn), X.shape[1]), "hop_set_model")
+
+    def set_ppf_keys(self, keys):
+        k = np.ascontiguousarray(keys, dtype=np.int32).reshape(-1, 4)
+        self._chk(self.L.hop_set_ppf_keys(self.h, I(k), len(k)), "hop_set_ppf_keys")
+
+    # ---- generator
+    def default_s4pcs_opts(self, **kw):
+        o = S4pcsOpts()
+        self.L.hop_s4pcs_default_opts(C.byref(o))
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+    def s4pcs_generate(self, opts, download=True, cap=None):
+        st = S4pcsStats()
+        n = C.c_int(0)
+        if not download:
+            rc = self.L.hop_s4pcs_generate(self.h, C.byref(opts), None, None, 0, C.byref(n), C.byref(st))
+            self._chk(rc, "hop_s4pcs_generate", ok=(-6,))
+            return None, None, st
+        cap = cap or (1 << 16)
+        while True:
+            pose = np.zeros((cap, 16), np.float32)
+            lcp = np.zeros(cap, np.float32)
+            rc = self.L.hop_s4pcs_generate(self.h, C.byref(opts), F(pose), F(lcp), cap, C.byref(n), C.byref(st))
+            if rc == -4 and n.value > cap:
+                # the set is resident; fetch it with a big enough buffer instead of re-running
+                pose = np.zeros((n.value, 16), np.float32)
+                lcp = np.zeros(n.value, np.float32)
+                ids = np.zeros(n.value, np.int32)
+                m = C.c_int(0)
+                self._chk(self.L.hop_hypos_download(self.h, F(pose), F(lcp), I(ids), n.value, C.byref(m)), "hop_hypos_download")
+                return pose.reshape(-1, 4, 4), lcp, st
+            self._chk(rc, "hop_s4pcs_generate", ok=(-6,))
+            return pose[:n.value].reshape(-1, 4, 4).copy(), lcp[:n.value].copy(), st
+
+    def s4pcs_bases(self):
+        out = []
+        for i in range(self.L.hop_s4pcs_num_bases(self.h)):
+            b4 = np.zeros(4, np.int32)
+            inv = np.zeros(2, np.float32)
+            c3 = np.zeros(3, np.int32)
+            self._chk(self.L.hop_s4pcs_get_base(self.h, i, I(b4), F(inv), I(c3)), "hop_s4pcs_get_base")
+            out.append(dict(base=b4, inv=inv, n_pairs1=int(c3[0]), n_pairs2=int(c3[1]), n_quads=int(c3[2])))
+        return out
+
+    def s4pcs_sampled_q(self, n):
+        x = np.zeros((3, n), np.float32)
+        nn = np.zeros((3, n), np.float32)
+        self._chk(self.L.hop_s4pcs_get_sampled_q(self.h, F(x), F(nn)), "hop_s4pcs_get_sampled_q")
+        return x.T.copy(), nn.T.copy()
+
+    def verify_set_clouds(self, P, Q):
+        Pp, Qp = soa(P), soa(Q)
+        self._chk(self.L.hop_verify_set_clouds(self.h, F(Pp), Pp.shape[1], F(Qp), Qp.shape[1]), "hop_verify_set_clouds")
+
+    def verify_batch(self, T, delta, mode=0):
+        T = np.ascontiguousarray(T, dtype=np.float32).reshape(-1, 16)
+        out = np.zeros(len(T), np.int32)
+        self._chk(self.L.hop_verify_batch(self.h, F(T), len(T), delta, mode, I(out)), "hop_verify_batch")
+        return out
+
+    # ---- resident set
+    def hypos_upload(self, poses, scores=None):
+        T = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 16)
+        s = None if scores is None else np.ascontiguousarray(scores, dtype=np.float32)
+        self._chk(self.L.hop_hypos_upload(self.h, F(T), F(s) if s is not None else None, len(T)), "hop_hypos_upload")
+
+    def hypos_count(self):
+        return self.L.hop_hypos_count(self.h)
+
+    def hypos_download(self):
+        n = self.hypos_count()
+        pose = np.zeros((max(n, 1), 16), np.float32)
+        sc = np.zeros(max(n, 1), np.float32)
+        ids = np.zeros(max(n, 1), np.int32)
+        m = C.c_int(0)
+        self._chk(self.L.hop_hypos_download(self.h, F(pose), F(sc), I(ids), max(n, 1), C.byref(m)), "hop_hypos_download")
+        return pose[:n].reshape(-1, 4, 4), sc[:n], ids[:n]
+
+    def hypos_keep_topk(self, k):
+        self._chk(self.L.hop_hypos_keep_topk(self.h, k), "hop_hypos_keep_topk")
+
+    def icp_refine(self, max_iter=10, angle_deg=45.0, max_corr_dist=0.01, max_hypotheses=0, nn_mode=0, want_stats=False):
+        o = IcpOpts(max_iter, angle_deg, max_corr_dist, max_hypotheses, nn_mode)
+        if want_stats:
+            n = min(self.hypos_count(), max_hypotheses) if max_hypotheses > 0 else self.hypos_count()
+            it = np.zeros(max(n, 1), np.int32)
+            cv = np.zeros(max(n, 1), np.int32)
+            self._chk(self.L.hop_icp_refine(self.h, C.byref(o), I(it), I(cv)), "hop_icp_refine")
+            return it[:n], cv[:n]
+        self._chk(self.L.hop_icp_refine(self.h, C.byref(o), None, None), "hop_icp_refine")
+
+    def lcp_select_best(self, dist=0.001, angle_deg=10.0, nn_mode=0):
+        o = LcpOpts(dist, angle_deg, nn_mode)
+        pose = np.zeros(16, np.float32)
+        sc = C.c_float(0)
+        idx = C.c_int(0)
+        self._chk(self.L.hop_lcp_select_best(self.h, C.byref(o), F(pose), C.byref(sc), C.byref(idx)), "hop_lcp_select_best")
+        return pose.reshape(4, 4), float(sc.value), int(idx.value)
+
+    def cluster_poses(self, angle_deg, dist, sym_deg, assign_id):
+        s = np.ascontiguousarray(sym_deg, dtype=np.float32)
+        self._chk(self.L.hop_cluster_poses(self.h, angle_deg, dist, F(s), int(bool(assign_id))), "hop_cluster_poses")
+
+    def topk_pack(self, k, id_offset=0):
+        rows = np.zeros((k, TOPK_ROW_FLOATS), np.float32)
+        n = C.c_int(0)
+        self._chk(self.L.hop_topk_pack(self.h, k, id_offset, F(rows), C.byref(n)), "hop_topk_pack")
+        return rows, n.value
+
+    # ---- hand
+    def hand_set_scene(self, scene_xyz, lookup_nrm, swivel_xyz):
+        S, Ln, W = soa(scene_xyz), soa(lookup_nrm), soa(swivel_xyz)
+        self._chk(self.L.hop_hand_set_scene(self.h, F(S), S.shape[1], F(Ln), Ln.shape[1], F(W), W.shape[1]), "hop_hand_set_scene")
+
+    def hand_set_finger(self, args: "FingerArgs"):
+        self._chk(self.L.hop_hand_set_finger(self.h, C.byref(args)), "hop_hand_set_finger")
+
+    def hand_pso_eval_batch(self, angles):
+        a = np.ascontiguousarray(angles, dtype=np.float64)
+        out = np.zeros(len(a), np.float64)
+        self._chk(self.L.hop_hand_pso_eval_batch(self.h, D(a), len(a), D(out)), "hop_hand_pso_eval_batch")
+        return out
+
+    def hand_pso_search(self, settings: "PsoSettings"):
+        ang = C.c_double(0)
+        val = C.c_double(0)
+        self._chk(self.L.hop_hand_pso_search(self.h, C.byref(settings), C.byref(ang), C.byref(val)), "hop_hand_pso_search")
+        return float(ang.value), float(val.value)
+
+    # ---- timing
+    def timing_enable(self, on=True):
+        self.L.hop_timing_enable(self.h, int(on))
+
+    def timing_reset(self):
+        self.L.hop_timing_reset(self.h)
+
+    def timing_get(self):
+        t = Timing()
+        self._chk(self.L.hop_timing_get(self.h, C.byref(t)), "hop_timing_get")
+        return t.as_dict()
+
+    def synchronize(self):
+        self._chk(self.L.hop_synchronize(self.h), "hop_synchronize")
+
+
+def topk_merge(tables, k):
+    t = np.ascontiguousarray(tables, dtype=np.float32).reshape(-1, k, TOPK_ROW_FLOATS)
+    out = np.zeros((k, TOPK_ROW_FLOATS), np.float32)
+    n = C.c_int(0)
+    rc = lib().hop_topk_merge(F(t), t.shape[0], k, F(out), C.byref(n))
+    if rc:
+        raise HopError(rc, "hop_topk_merge")
+    return out, n.value
+
+
+def cluster_poses_host(poses, scores, ids, angle_deg, dist, sym_deg):
+    T = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 16)
+    s = np.ascontiguousarray(scores, dtype=np.float32)
+    i = np.ascontiguousarray(ids, dtype=np.int32)
+    sym = np.ascontiguousarray(sym_deg, dtype=np.float32)
+    keep = np.zeros(max(len(T), 1), np.int32)
+    n = C.c_int(0)
+    rc = lib().hop_cluster_poses_host(F(T), F(s), I(i), len(T), angle_deg, dist, F(sym), I(keep), C.byref(n))
+    if rc:
+        raise HopError(rc, "hop_cluster_poses_host")
+    return keep[:n.value].copy()
+
+
+def rows_to_hypos(rows):
+    rows = np.asarray(rows, dtype=np.float32).reshape(-1, TOPK_ROW_FLOATS)
+    score = rows[:, 0].copy()
+    ids = rows[:, 1].copy().view(np.int32)
+    pose = rows[:, 2:].reshape(-1, 4, 4).copy()
+    return pose, score, ids
+
+
+# =============================================================================================== mirrors
+class PoseHypo:
+    """include/PoseHypo.h:7-26"""
+
+    def __init__(self, pose=None, id=-1, lcp_score=0.0):
+        self._pose = np.eye(4, dtype=np.float32) if pose is None else np.asarray(pose, np.float32).reshape(4, 4)
+        self._wrong_ratio = 1.0
+        self._lcp_score = float(lcp_score)
+        self._id = int(id)
+
+
+class PoseEstimator:
+    """Mirror of PoseEstimator<PointT> for the hot-path members (PoseEstimator.h:15-22).
+
+    ``cfg`` is the parsed config_autodataset.yaml (a dict); ``model``/``model001`` are (xyz, normals).
+    """
+
+    def __init__(self, cfg, model, model001, ctx=None, device=0):
+        self.cfg = cfg
+        self.ctx = ctx or Context(device)
+        self.ctx.set_model(HOP_MODEL_5MM, *model)
+        self.ctx.set_model(HOP_MODEL_1MM, *model001)
+        self._pose_hypos = []
+        self.last_stats = None
+
+    def setCurScene(self, object_segment_xyz, object_segment_nrm, confidence):
+        thres = float(self.cfg.get("pose_estimator_high_confidence_thres", 0.8))
+        return self.ctx.set_scene(object_segment_xyz, object_segment_nrm, confidence, thres)
+
+    def runSuper4pcs(self, ppfs, n_trials=0, verify_mode=0):
+        """PoseEstimator.cpp:62-100.  ``ppfs``: (n,4) int key table (the reference passes a std::map whose
+        keys are these rows).  Returns False when no hypothesis is found, as the reference does."""
+        self.ctx.set_ppf_keys(ppfs)
+        c = self.cfg
+        o = self.ctx.default_s4pcs_opts(
+            sample_size=int(c["super4pcs_sample_size"]), overlap=float(c["super4pcs_overlap"]),
+            max_time_seconds=int(c["super4pcs_max_time_seconds"]), delta=float(c["super4pcs_delta"]),
+            dispersion=float(c["super4pcs_dispersion"]), success_quadrilaterals=int(c["super4pcs_success_quadrilaterals"]),
+            max_normal_difference=float(c["super4pcs_max_normal_difference"]),
+            max_color_distance=float(c["super4pcs_max_color_distance"]), n_trials=n_trials, verify_mode=verify_mode)
+        _, _, st = self.ctx.s4pcs_generate(o, download=False)
+        self.last_stats = st
+        return st.n_hypotheses > 0
+
+    def clusterPoses(self, angle_diff, dist_diff, assign_id):
+        name = self.cfg["model_name"]
+        s = self.cfg["object_symmetry"][name]
+        self.ctx.cluster_poses(angle_diff, dist_diff, [s["x"], s["y"], s["z"]], assign_id)
+
+    def refineByICP(self):
+        self.ctx.icp_refine(10, float(self.cfg["icp_angle_thres"]), float(self.cfg["icp_dist_thres"]), max_hypotheses=100)
+
+    def selectBest(self):
+        pose, score, idx = self.ctx.lcp_select_best(float(self.cfg["lcp"]["dist"]), float(self.cfg["lcp"]["normal_angle"]))
+        return PoseHypo(pose, idx, score)
+
+    def hypos(self):
+        pose, sc, ids = self.ctx.hypos_download()
+        return [PoseHypo(pose[i], ids[i], sc[i]) for i in range(len(sc))]
+
+
+def finger_property(xyz, num_division=10):
+    """FingerProperty::FingerProperty (Hand.cpp:182-236): extremes, z stride and per-z-bin min/max (6 x N)."""
+    xyz = np.asarray(xyz, np.float32)
+    mn, mx = xyz.min(axis=0), xyz.max(axis=0)
+    stride = np.float32((mx[2] - mn[2]) / np.float32(num_division))
+    hist = np.empty((6, num_division), np.float32)
+    hist[:3] = np.finfo(np.float32).max
+    hist[3:] = -np.finfo(np.float32).max
+    bins = (np.maximum(xyz[:, 2] - mn[2], np.float32(0)) / stride).astype(np.int32)
+    bins = np.clip(bins, 0, num_division - 1)
+    changed = np.zeros(num_division, bool)
+    for b in range(num_division):
+        sel = xyz[bins == b]
+        if len(sel):
+            hist[:3, b] = sel.min(axis=0)
+            hist[3:, b] = sel.max(axis=0)
+            changed[b] = True
+    for i in range(num_division):
+        if changed[i]:
+            continue
+        for j in range(i + 1, num_division):
+            if changed[j]:
+                hist[:, i] = hist[:, j]
+                changed[i] = True
+                break
+    if not changed[-1]:
+        for i in range(num_division - 2, -1, -1):
+            if changed[i]:
+                hist[:, -1] = hist[:, i]
+                break
+    return dict(min=mn, max=mx, stride_z=stride, hist=hist, num_division=num_division)
+
+
+class HandT42:
+    """Mirror of Hand/HandT42 for the hand-state search (Hand.h:29-92).
+
+    ``hand`` is a kinematic description (hop_amd.synth.HandModel or the equivalent parsed from a URDF):
+    link clouds at 5 mm, parents and link->parent transforms.
+    """
+
+    PAIR = {"finger_1_1": "finger_2_1", "finger_2_1": "finger_1_1", "finger_1_2": "finger_2_2", "finger_2_2": "finger_1_2"}
+
+    def __init__(self, cfg, hand, ctx=None, device=0):
+        self.cfg = cfg
+        self.hand = hand
+        self._ctx = ctx
+        self._device = device
+        self._tf_self = {n: np.eye(4, dtype=np.float32) for n in hand.parents}
+        self._component_status = {n: False for n in hand.parents}
+        self._finger_properties = {n: finger_property(hand.clouds[n][0], 10) for n in hand.parents if "finger" in n}
+        self.gripper_min_dist = 0.0
+        hm = cfg["hand_match"]
+        self._pso = dict(n_pop=int(hm["pso"]["n_pop"]), n_gen=int(hm["pso"]["n_gen"]), check_freq=int(hm["pso"]["check_freq"]),
+                         c_cog=float(hm["pso"]["pso_par_c_cog"]), c_soc=float(hm["pso"]["pso_par_c_soc"]),
+                         initial_w=float(hm["pso"]["pso_par_initial_w"]))
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = Context(self._device)
+        return self._ctx
+
+    def setCurScene(self, scene_removed_noise_xyz, scene_hand_region_nrm, scene_remove_swivel_xyz):
+        """Products of Hand::setCurScene (Hand.cpp:327-332), all in the hand-base frame."""
+        self.ctx.hand_set_scene(scene_removed_noise_xyz, scene_hand_region_nrm, scene_remove_swivel_xyz)
+
+    def getTFHandBase(self, name):
+        """Hand.cpp:505-523 (float matrix products, link -> hand base)."""
+        T = np.eye(4, dtype=np.float32)
+        cur = name
+        while cur != "base_link":
+            T = (self.hand.tf_in_parent[cur].astype(np.float32) @ self._tf_self[cur]).astype(np.float32) @ T
+            T = T.astype(np.float32)
+            cur = self.hand.parents[cur]
+        return T
+
+    def _tip(self, name, use_max_z):
+        p = self._finger_properties[name]
+        return np.array([p["min"][0], p["max"][1], p["max"][2] if use_max_z else p["min"][2], 1.0], np.float32)
+
+    def finger_args(self, model_name, dist_thres):
+        """Fills the ArgPasser fields of Hand::matchOneComponentPSO (Hand.cpp:611-653)."""
+        hm = self.cfg["hand_match"]
+        pair_name = self.PAIR[model_name]
+        a = FingerArgs()
+        if pair_name in ("finger_1_1", "finger_2_1"):
+            pair_out = "finger_1_2" if pair_name == "finger_1_1" else "finger_2_2"
+            tip1 = self.getTFHandBase(pair_out) @ self._tip(pair_out, False)
+            tip2 = self.getTFHandBase(pair_name) @ self._tip(pair_name, False)
+            out_name = "finger_1_2" if model_name == "finger_1_1" else "finger_2_2"
+            fo2p = self.hand.tf_in_parent[out_name].astype(np.float32)
+            fo = self._finger_properties[out_name]
+        else:
+            Tb = self.getTFHandBase(pair_name)
+            tip1 = Tb @ self._tip(pair_name, False)
+            tip2 = Tb @ self._tip(pair_name, True)
+            fo2p = np.eye(4, dtype=np.float32)
+            fo = self._finger_properties[model_name]
+        fpp = self._finger_properties[model_name]
+        for k in range(3):
+            a.fp_min[k], a.fp_max[k] = float(fpp["min"][k]), float(fpp["max"][k])
+            a.fo_min[k], a.fo_max[k] = float(fo["min"][k]), float(fo["max"][k])
+        a.fp_stride_z = float(fpp["stride_z"])
+        a.fp_num_division = fpp["num_division"]
+        hist = np.ascontiguousarray(fpp["hist"][1], np.float32)
+        m2h = np.ascontiguousarray(self.getTFHandBase(model_name), np.float32).reshape(16)
+        xyz, nrm = self.hand.clouds[model_name]
+        X, Nn = soa(xyz), soa(nrm)
+        self._keep = [hist, X, Nn]
+        a.fp_hist_min_y = F(hist)
+        for k in range(16):
+            a.model2handbase[k] = float(m2h[k])
+            a.finger_out2parent[k] = float(fo2p.reshape(16)[k])
+        for k in range(4):
+            a.pair_tip1[k], a.pair_tip2[k] = float(tip1[k]), float(tip2[k])
+        a.is_palm_side = int(model_name in ("finger_1_1", "finger_2_1"))
+        a.is_right_side = int(model_name in ("finger_2_1", "finger_2_2"))
+        a.gripper_min_dist = float(self.gripper_min_dist)
+        a.dist_thres = float(dist_thres)
+        ang = hm["finger1_normal_angle"] if a.is_palm_side else hm["finger2_normal_angle"]
+        a.cos_normal_thres = float(np.float32(math.cos(np.float32(ang) / 180.0 * math.pi)))
+        a.check_normal = int(bool(hm["check_normal"]))
+        a.max_outter_pts = int(hm["max_outter_pts"])
+        a.outter_pt_dist = float(hm["outter_pt_dist"])
+        a.outter_pt_dist_weight = float(hm["outter_pt_dist_weight"])
+        a.model_xyz, a.model_nrm, a.n_model = F(X), F(Nn), X.shape[1]
+        return a
+
+    def pso_settings(self, min_angle, max_angle, seed=0):
+        s = PsoSettings()
+        lib().hop_pso_default_settings(C.byref(s))
+        for k, v in self._pso.items():
+            setattr(s, k, v)
+        s.lower_rad = min_angle * math.pi / 180
+        s.upper_rad = max_angle * math.pi / 180
+        s.seed = seed
+        return s
+
+    def matchOneComponentPSO(self, model_name, min_angle, max_angle, use_normal, dist_thres, normal_angle_thres, least_match):
+        """Hand.cpp:603-672.  ``use_normal`` and ``normal_angle_thres`` are ignored, as in the reference body
+        (thresholds are re-read from the YAML, Hand.cpp:76-83)."""
+        args = self.finger_args(model_name, dist_thres)
+        self.ctx.hand_set_finger(args)
+        angle, objval = self.ctx.hand_pso_search(self.pso_settings(min_angle, max_angle))
+        self.last_objval = objval
+        if -objval <= least_match:
+            self._tf_self[model_name] = np.eye(4, dtype=np.float32)
+            self._component_status[model_name] = False
+            return False
+        a = np.float32(angle)
+        T = np.eye(4, dtype=np.float32)
+        T[1, 1], T[1, 2], T[2, 1], T[2, 2] = np.cos(a), -np.sin(a), np.sin(a), np.cos(a)
+        self._tf_self[model_name] = T
+        self._component_status[model_name] = True
+        self.last_angle = float(a)
+        return True

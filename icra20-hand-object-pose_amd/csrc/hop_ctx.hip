@@ -1,0 +1,1688 @@
+// hop_ctx.hip -- host side of libhop: device memory, streams, the generator's sequential base selection,
+// batching of the per-base kernels, and the C-ABI of include/hop.h.
+//
+// What stays on the host and why
+//   * base selection (MatchBase::SelectRandomTriangle / Match4pcsBase::SelectQuadrilateral,
+//     matchBase.hpp:111-212, match4pcsBase.hpp:107-189) is a sequential, RNG-driven process whose draws
+//     depend on the outcome of the previous draw (probability annealing, std::discrete_distribution
+//     rebuilt per draw).  Its only data-parallel part -- PPF key membership of point pairs -- is computed
+//     once on the GPU as an N x N bit matrix (k_ppf_matrix); the host then only reads bits.
+//   * clusterPoses (PoseEstimator.cpp:106-233) is a greedy pass over a sorted list (host in the reference too).
+//   * the PSO bookkeeping (pso.hpp:146-351) -- a few hundred doubles per generation.
+// Everything that touches clouds runs in the kernels of hop_kernels.hip.
+#include "../../include/hop.h"
+#include "hop_device.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <random>
+#include <string>
+#include <vector>
+
+using namespace hop;
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  template <class T>
+  T* as() const { return static_cast<T*>(p); }
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      e = hipMalloc(&p, bytes);
+      want = bytes;
+    }
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct CloudHost {
+  std::vector<float> x, y, z, nx, ny, nz;
+  int n = 0;
+  void resize(int m) {
+    n = m;
+    x.resize(m), y.resize(m), z.resize(m), nx.resize(m), ny.resize(m), nz.resize(m);
+  }
+};
+struct CloudDevice {
+  DevBuf buf;  // 6 planes
+  int n = 0;
+  const float* plane(int k) const { return buf.as<float>() + (size_t)k * n; }
+};
+
+enum TimeCat { T_VERIFY = 0, T_GEN_OTHER, T_ICP_NN, T_ICP_SOLVE, T_LCP_FWD, T_LCP_REV, T_PSO, T_PPF, T_NCAT };
+
+struct TimedSpan {
+  hipEvent_t a, b;
+  int cat;
+};
+
+struct BaseTraceHost {
+  int ids[4];
+  float inv1, inv2;
+  int n1 = 0, n2 = 0, nq = 0;
+};
+
+}  // namespace
+
+struct hop_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+
+  // scene (= _scene_high_confidence), models
+  CloudHost scene_h;
+  std::vector<float> scene_conf;
+  CloudDevice scene_d;
+  CloudHost model_h[2];
+  CloudDevice model_d[2];
+
+  // PPF key set
+  std::vector<unsigned> key_bitmap;
+  int key_dist_bins = 0;
+  DevBuf key_bitmap_d;
+  bool have_keys = false;
+
+  // generator state of the last run
+  CloudHost gp_h;            // centred P, normals = Point3D normals
+  std::vector<float> gp_prob;
+  CloudHost gq_h;            // sampled centred Q
+  std::vector<float> gq_unit[3];
+  float centroid_p[3] = {0, 0, 0}, centroid_q[3] = {0, 0, 0};
+  float diameter = 0, ratio = 1;
+  CloudDevice gp_d;          // planes: x y z + ppf normals
+  CloudDevice gq_d;          // planes: x y z nx ny nz
+  DevBuf gq_unit_d;          // 3 planes
+  DevBuf ppf_matrix_d;
+  PinnedBuf ppf_matrix_h;
+  int ppf_words = 0;
+  std::vector<BaseTraceHost> trace;
+  bool have_gen_state = false;
+  // verify clouds set explicitly (hop_verify_set_clouds)
+  CloudDevice vp_d, vq_d;
+  std::vector<float> vp_h[3];
+  bool have_verify_clouds = false;
+  // voxel grid over centred P for verify_mode 1
+  DevBuf grid_cell_start_d, grid_pts_d;
+  GridDev grid{};
+  bool grid_valid = false;
+  float grid_delta = 0;
+
+  // batch workspaces of the generator
+  DevBuf bases_d, pairs1_d, pairs2_d, cnt_d, elems_d, queries_d, cands_d, cand_counts_d, counters_d;
+  PinnedBuf bases_h, cnt_h;
+  // resident hypothesis set
+  DevBuf hyp_pose, hyp_score, hyp_id, hyp_key, hyp_inv, tmp_pose, tmp_score, tmp_id, sort_keys_alt, sort_vals, sort_vals_alt, sort_tmp;
+  int n_hyp = 0;
+
+  // scoring workspaces
+  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv;
+
+  // hand
+  CloudDevice hand_scene_d, hand_lookup_d, hand_swivel_d, hand_model_d;
+  int hand_n_scene = 0, hand_n_lookup = 0, hand_n_swivel = 0;
+  hop_finger_args finger{};
+  std::vector<float> finger_hist;
+  DevBuf finger_hist_d, pso_particles_d, pso_match_d, pso_terms_d, pso_sum_d, pso_cnt_d;
+  PinnedBuf pso_particles_h, pso_out_h;
+  bool have_finger = false, have_hand_scene = false;
+
+  // timing
+  bool timing_on = false;
+  std::vector<TimedSpan> spans;
+  std::vector<hipEvent_t> event_pool;
+  hop_timing timing{};
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                        \
+  do {                                                                                           \
+    hipError_t _e = (call);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(_e);                     \
+      return HOP_E_HIP;                                                                          \
+    }                                                                                            \
+  } while (0)
+
+hipEvent_t get_event(hop_ctx* c) {
+  if (!c->event_pool.empty()) {
+    hipEvent_t e = c->event_pool.back();
+    c->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct SpanGuard {
+  hop_ctx* c;
+  int cat;
+  hipEvent_t a{}, b{};
+  SpanGuard(hop_ctx* ctx, int category) : c(ctx), cat(category) {
+    if (c->timing_on) {
+      a = get_event(c);
+      b = get_event(c);
+      (void)hipEventRecord(a, c->stream);
+    }
+  }
+  ~SpanGuard() {
+    if (c->timing_on) {
+      (void)hipEventRecord(b, c->stream);
+      c->spans.push_back({a, b, cat});
+    }
+  }
+};
+void resolve_spans(hop_ctx* c) {
+  if (c->spans.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& s : c->spans) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, s.a, s.b);
+    double* slot = nullptr;
+    switch (s.cat) {
+      case T_VERIFY: slot = &c->timing.ms_verify; break;
+      case T_GEN_OTHER: slot = &c->timing.ms_gen_other; break;
+      case T_ICP_NN: slot = &c->timing.ms_icp_nn; break;
+      case T_ICP_SOLVE: slot = &c->timing.ms_icp_solve; break;
+      case T_LCP_FWD: slot = &c->timing.ms_lcp_fwd; break;
+      case T_LCP_REV: slot = &c->timing.ms_lcp_rev; break;
+      case T_PSO: slot = &c->timing.ms_pso; break;
+      case T_PPF: slot = &c->timing.ms_ppf_matrix; break;
+    }
+    if (slot) *slot += ms;
+    c->event_pool.push_back(s.a);
+    c->event_pool.push_back(s.b);
+  }
+  c->spans.clear();
+}
+
+int upload_cloud(hop_ctx* c, CloudDevice& d, const CloudHost& h) {
+  d.n = h.n;
+  HIPCHK(c, d.buf.ensure(sizeof(float) * 6 * (size_t)std::max(h.n, 1)));
+  if (h.n == 0) return HOP_OK;
+  const std::vector<float>* pl[6] = {&h.x, &h.y, &h.z, &h.nx, &h.ny, &h.nz};
+  for (int k = 0; k < 6; ++k)
+    HIPCHK(c, hipMemcpyAsync(d.buf.as<float>() + (size_t)k * h.n, pl[k]->data(), sizeof(float) * h.n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+// Point3D::set_normal (shared.h:86-88): stored normals are normalised once
+void load_cloud_host(CloudHost& h, const float* xyz, const float* nrm, int n, bool normalise) {
+  h.resize(n);
+  for (int i = 0; i < n; ++i) {
+    h.x[i] = xyz[i], h.y[i] = xyz[n + i], h.z[i] = xyz[2 * (size_t)n + i];
+    V3 nn = v3(nrm[i], nrm[n + i], nrm[2 * (size_t)n + i]);
+    if (normalise) nn = vnormalized(nn);
+    h.nx[i] = nn.x, h.ny[i] = nn.y, h.nz[i] = nn.z;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generator, host part
+// ------------------------------------------------------------------------------------------------
+struct GenHost {
+  hop_ctx* c;
+  hop_s4pcs_opts opt;
+  std::mt19937 randomGenerator_;     // matchBase.hpp:73
+  std::mt19937 point_index_engine_;  // matchBase.hpp:76, seed 0
+  std::vector<float> point_probs_;
+  int n = 0;  // |P|
+  const unsigned long long* M = nullptr;
+  int W = 0;
+  float max_base_diameter_ = -1;
+  std::array<V3, 4> bpos, bnrm;
+
+  GenHost(hop_ctx* ctx, const hop_s4pcs_opts& o) : c(ctx), opt(o), randomGenerator_(o.random_seed), point_index_engine_(0) {}
+
+  bool bit(int i, int j) const { return (M[(size_t)i * W + (j >> 6)] >> (j & 63)) & 1ull; }
+  V3 ppos(int i) const { return v3(c->gp_h.x[i], c->gp_h.y[i], c->gp_h.z[i]); }
+  V3 pnrm(int i) const { return v3(c->gp_h.nx[i], c->gp_h.ny[i], c->gp_h.nz[i]); }
+
+  // UniformDistSampler (sampling.h:67-144): first point of every delta-voxel, open-addressing hash
+  static void uniform_sample(const CloudHost& in, float delta, std::vector<int>& keep) {
+    const uint64_t MAGIC1 = 100000007, MAGIC2 = 161803409, MAGIC3 = 423606823, NO_DATA = 0xffffffffu;
+    const int num_input = in.n;
+    const float scale_ = 1.0f / delta;
+    std::vector<std::array<int, 3>> voxels_(num_input);
+    std::vector<uint64_t> data_(num_input, NO_DATA);
+    keep.clear();
+    for (int i = 0; i < num_input; ++i) {
+      const std::array<int, 3> cell{int(std::floor(in.x[i] * scale_)), int(std::floor(in.y[i] * scale_)), int(std::floor(in.z[i] * scale_))};
+      uint64_t key = (MAGIC1 * (uint64_t)(int64_t)cell[0] + MAGIC2 * (uint64_t)(int64_t)cell[1] + MAGIC3 * (uint64_t)(int64_t)cell[2]) % data_.size();
+      while (true) {
+        if (data_[key] == NO_DATA) {
+          voxels_[key] = cell;
+          break;
+        } else if (voxels_[key] == cell)
+          break;
+        if (++key == data_.size()) key = 0;
+      }
+      if (data_[key] >= (uint64_t)num_input) {
+        keep.push_back(i);
+        data_[key] = keep.size();
+      }
+    }
+  }
+
+  // MatchBase::init (matchBase.hpp:380-462) minus the kd-tree; fills ctx->gp_h / gq_h / centroids / diameter
+  void init_clouds() {
+    const CloudHost& P = c->scene_h;
+    const CloudHost& Q = c->model_h[HOP_MODEL_5MM];
+    std::vector<int> qsel;
+    if (Q.n > opt.sample_size) {
+      uniform_sample(Q, opt.delta, qsel);
+      std::shuffle(qsel.begin(), qsel.end(), randomGenerator_);
+      if ((int)qsel.size() > opt.sample_size) qsel.resize(opt.sample_size);
+    } else {
+      qsel.resize(Q.n);
+      std::iota(qsel.begin(), qsel.end(), 0);
+    }
+    CloudHost& gp = c->gp_h;
+    CloudHost& gq = c->gq_h;
+    gp = P;
+    c->gp_prob = c->scene_conf;
+    gq.resize((int)qsel.size());
+    for (int k = 0; k < gq.n; ++k) {
+      const int i = qsel[k];
+      gq.x[k] = Q.x[i], gq.y[k] = Q.y[i], gq.z[k] = Q.z[i], gq.nx[k] = Q.nx[i], gq.ny[k] = Q.ny[i], gq.nz[k] = Q.nz[i];
+    }
+    auto centre = [](CloudHost& cl, float cen[3]) {
+      V3 s = v3(0, 0, 0);
+      for (int i = 0; i < cl.n; ++i) s = s + v3(cl.x[i], cl.y[i], cl.z[i]);
+      s = s / float(cl.n);
+      for (int i = 0; i < cl.n; ++i) {
+        const V3 p = v3(cl.x[i], cl.y[i], cl.z[i]) - s;
+        cl.x[i] = p.x, cl.y[i] = p.y, cl.z[i] = p.z;
+      }
+      cen[0] = s.x, cen[1] = s.y, cen[2] = s.z;
+    };
+    centre(gp, c->centroid_p);
+    centre(gq, c->centroid_q);
+    // "diameter of P", measured on sampled Q (matchBase.hpp:439-448)
+    float diam = 0.f;
+    for (int i = 0; i < 1000; ++i) {
+      const int at = int(randomGenerator_() % (unsigned long)gq.n);
+      const int bt = int(randomGenerator_() % (unsigned long)gq.n);
+      const float l = vnorm(v3(gq.x[bt], gq.y[bt], gq.z[bt]) - v3(gq.x[at], gq.y[at], gq.z[at]));
+      if (l > diam) diam = l;
+    }
+    c->diameter = diam;
+    max_base_diameter_ = diam;
+    // PairCreationFunctor::synch3DContent (pairCreationFunctor.h:129-161)
+    V3 mn = v3(FLT_MAX, FLT_MAX, FLT_MAX), mx = v3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+    for (int i = 0; i < gq.n; ++i) {
+      mn = v3(std::min(mn.x, gq.x[i]), std::min(mn.y, gq.y[i]), std::min(mn.z, gq.z[i]));
+      mx = v3(std::max(mx.x, gq.x[i]), std::max(mx.y, gq.y[i]), std::max(mx.z, gq.z[i]));
+    }
+    const V3 gcenter = (mn + mx) / 2.f;
+    const V3 diag = mx - mn;
+    c->ratio = (float)((double)std::max(diag.x, std::max(diag.y, diag.z)) + 0.001);
+    for (int k = 0; k < 3; ++k) c->gq_unit[k].resize(gq.n);
+    const V3 half = v3(0.5f, 0.5f, 0.5f);
+    for (int i = 0; i < gq.n; ++i) {
+      const V3 u = (v3(gq.x[i], gq.y[i], gq.z[i]) - gcenter) / c->ratio + half;
+      c->gq_unit[0][i] = u.x, c->gq_unit[1][i] = u.y, c->gq_unit[2][i] = u.z;
+    }
+    n = gp.n;
+    point_probs_ = c->gp_prob;
+  }
+
+  // MatchBase::SelectRandomTriangle, matchBase.hpp:111-212, with key membership read from the bit matrix
+  bool SelectRandomTriangle(int& base1, int& base2, int& base3, std::vector<int>& sample_pool) {
+    base1 = base2 = base3 = -1;
+    std::discrete_distribution<> sampler(point_probs_.begin(), point_probs_.end());
+    const int first_point = sampler(point_index_engine_);
+    point_probs_[first_point] *= opt.dispersion;
+    sample_pool.clear();
+    std::vector<float> probs;
+    const unsigned long long* row = M + (size_t)first_point * W;
+    for (int w = 0; w < W; ++w) {
+      unsigned long long bits = row[w];
+      while (bits) {
+        const int i = w * 64 + __builtin_ctzll(bits);
+        bits &= bits - 1;
+        if (i == first_point || i >= n) continue;
+        sample_pool.push_back(i);
+        probs.push_back(point_probs_[i]);
+      }
+    }
+    if (sample_pool.size() < 3) return false;
+    const float sq_max = max_base_diameter_ * max_base_diameter_;
+    const V3 p0 = ppos(first_point);
+    for (int i = 0; (size_t)i < sample_pool.size() * sample_pool.size() / 4; ++i) {
+      std::discrete_distribution<> sampler1(probs.begin(), probs.end());
+      const int second = sampler1(point_index_engine_);
+      const int third = sampler1(point_index_engine_);
+      if (second == third) continue;
+      if (!bit(sample_pool[second], sample_pool[third])) continue;
+      probs[second] *= opt.dispersion;
+      probs[third] *= opt.dispersion;
+      const V3 u = ppos(sample_pool[second]) - p0;
+      const V3 w = ppos(sample_pool[third]) - p0;
+      const float how_wide = vdot(vnormalized(u), vnormalized(w));
+      if ((double)std::fabs(how_wide) <= std::cos(45 * M_PI / 180.0) && vsqn(u) < sq_max && vsqn(w) < sq_max) {
+        base1 = first_point;
+        base2 = sample_pool[second];
+        base3 = sample_pool[third];
+        break;
+      }
+    }
+    if (base2 == -1 || base3 == -1) return false;
+    // pool for the 4th point; the reference stores the LOOP INDEX here (matchBase.hpp:203) and later
+    // uses it as a point index (match4pcsBase.hpp:159) -- mirrored.
+    std::vector<int> backup;
+    backup.swap(sample_pool);
+    for (int i = 0; i < (int)backup.size(); ++i) {
+      const int id = backup[i];
+      if (id == base2 || id == base3 || id == base1) continue;
+      if (bit(base2, id) && bit(base3, id)) sample_pool.push_back(i);
+    }
+    if (sample_pool.empty()) return false;
+    return base1 != -1 && base2 != -1 && base3 != -1;
+  }
+
+  // Match4pcsBase::distSegmentToSegment, match4pcsBase.hpp:283-354
+  static float distSegmentToSegment(V3 p1, V3 p2, V3 q1, V3 q2, float& invariant1, float& invariant2) {
+    const float kSmall = 0.0001f;
+    const V3 u = p2 - p1, v = q2 - q1, w = p1 - q1;
+    const float a = vdot(u, u), b = vdot(u, v), cc = vdot(v, v), d = vdot(u, w), e = vdot(v, w);
+    const float f = a * cc - b * b;
+    float s1 = 0.0f, s2 = f, t1 = 0.0f, t2 = f;
+    if (f < kSmall) {
+      s1 = 0.0f, s2 = 1.0f, t1 = e, t2 = cc;
+    } else {
+      s1 = (b * e - cc * d);
+      t1 = (a * e - b * d);
+      if (s1 < 0.0f) s1 = 0.0f, t1 = e, t2 = cc;
+      else if (s1 > s2) s1 = s2, t1 = e + b, t2 = cc;
+    }
+    if (t1 < 0.0f) {
+      t1 = 0.0f;
+      if (-d < 0.0f) s1 = 0.0f;
+      else if (-d > a) s1 = s2;
+      else s1 = -d, s2 = a;
+    } else if (t1 > t2) {
+      t1 = t2;
+      if ((-d + b) < 0.0f) s1 = 0;
+      else if ((-d + b) > a) s1 = s2;
+      else s1 = (-d + b), s2 = a;
+    }
+    invariant1 = (std::fabs(s1) < kSmall ? 0.0f : s1 / s2);
+    invariant2 = (std::fabs(t1) < kSmall ? 0.0f : t1 / t2);
+    return vnorm((w + (invariant1 * u)) - (invariant2 * v));
+  }
+
+  // Match4pcsBase::TryQuadrilateral, match4pcsBase.hpp:50-101
+  bool TryQuadrilateral(float& invariant1, float& invariant2, int ids[4]) {
+    float min_distance = FLT_MAX;
+    int best[4] = {-1, -1, -1, -1};
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        if (i == j) continue;
+        int k = 0;
+        while (k == i || k == j) k++;
+        int l = 0;
+        while (l == i || l == j || l == k) l++;
+        float li1, li2;
+        const float sd = distSegmentToSegment(bpos[i], bpos[j], bpos[k], bpos[l], li1, li2);
+        if (sd < min_distance) {
+          min_distance = sd;
+          best[0] = i, best[1] = j, best[2] = k, best[3] = l;
+          invariant1 = li1, invariant2 = li2;
+        }
+      }
+    if (best[0] < 0) return false;
+    const std::array<V3, 4> tp = bpos, tn = bnrm;
+    const int tid[4] = {ids[0], ids[1], ids[2], ids[3]};
+    for (int k = 0; k < 4; ++k) bpos[k] = tp[best[k]], bnrm[k] = tn[best[k]], ids[k] = tid[best[k]];
+    return true;
+  }
+
+  // Match4pcsBase::SelectQuadrilateral, match4pcsBase.hpp:107-189
+  bool SelectQuadrilateral(float& invariant1, float& invariant2, int ids[4]) {
+    const float kBaseTooSmall = 0.2f;
+    int current_trial = 0;
+    std::vector<int> sample_pool;
+    while (current_trial < 1000) {
+      current_trial++;
+      int base1, base2, base3, base4;
+      if (!SelectRandomTriangle(base1, base2, base3, sample_pool)) continue;
+      const V3 b0 = ppos(base1), b1 = ppos(base2), b2 = ppos(base3);
+      const double x1 = b0.x, y1 = b0.y, z1 = b0.z, x2 = b1.x, y2 = b1.y, z2 = b1.z, x3 = b2.x, y3 = b2.y, z3 = b2.z;
+      const float denom = (float)(-x3 * y2 * z1 + x2 * y3 * z1 + x3 * y1 * z2 - x1 * y3 * z2 - x2 * y1 * z3 + x1 * y2 * z3);
+      if (denom != 0) {
+        const float A = (float)((-y2 * z1 + y3 * z1 + y1 * z2 - y3 * z2 - y1 * z3 + y2 * z3) / denom);
+        const float B = (float)((x2 * z1 - x3 * z1 - x1 * z2 + x3 * z2 + x1 * z3 - x2 * z3) / denom);
+        const float C = (float)((-x2 * y1 + x3 * y1 + x1 * y2 - x3 * y2 - x1 * y3 + x2 * y3) / denom);
+        base4 = -1;
+        float best_distance = FLT_MAX;
+        const float too_small = (float)std::pow((double)(max_base_diameter_ * kBaseTooSmall), 2);
+        for (size_t i = 0; i < sample_pool.size(); ++i) {
+          const V3 p = ppos(sample_pool[i]);
+          if (vsqn(p - b0) >= too_small && vsqn(p - b1) >= too_small && vsqn(p - b2) >= too_small) {
+            const float distance = (float)std::fabs((double)((A * p.x + B * p.y) + C * p.z) - 1.0);
+            if (distance < best_distance) {
+              best_distance = distance;
+              base4 = sample_pool[i];
+            }
+          }
+        }
+        if (base4 != -1) {
+          ids[0] = base1, ids[1] = base2, ids[2] = base3, ids[3] = base4;
+          for (int k = 0; k < 4; ++k) bpos[k] = ppos(ids[k]), bnrm[k] = pnrm(ids[k]);
+          if (TryQuadrilateral(invariant1, invariant2, ids)) return true;
+        }
+      }
+    }
+    return false;
+  }
+
+  // per-base constants of the device side of generateCongruents (match4pcsBase.hpp:244-261,
+  // FunctorSuper4pcs.h:163-170, normalset.hpp:205-212)
+  void fill_base(BaseDev& B, float inv1, float inv2) const {
+    for (int k = 0; k < 4; ++k) B.bpos[k][0] = bpos[k].x, B.bpos[k][1] = bpos[k].y, B.bpos[k][2] = bpos[k].z;
+    B.dist1 = vnorm(bpos[0] - bpos[1]);
+    B.dist2 = vnorm(bpos[2] - bpos[3]);
+    B.inv1 = inv1, B.inv2 = inv2;
+    B.e1 = base_edge_features(bpos[0], bnrm[0], bpos[1], bnrm[1]);
+    B.e2 = base_edge_features(bpos[2], bnrm[2], bpos[3], bnrm[3]);
+    const float alpha = vdot(vnormalized(bpos[1] - bpos[0]), vnormalized(bpos[3] - bpos[2]));
+    const float ac = acosf_fdlibm(alpha);
+    const float perimeter = (float)((double)2.f * M_PI * (double)std::atan(ac));
+    unsigned nb = (unsigned)(2 * std::ceil(perimeter * 7.f / 2.f));
+    if (!(nb <= (unsigned)MAX_RING)) nb = alpha == alpha ? (unsigned)MAX_RING : 0u;  // NaN alpha -> no samples
+    const float angleStep = (float)((double)2.f * M_PI / (double)(float)nb);
+    const float sinAlpha = std::sin(ac);
+    B.nb_sample = (int)nb;
+    for (unsigned a = 0; a < nb; ++a) {
+      const float theta = float(a) * angleStep;
+      B.ring[a][0] = sinAlpha * std::cos(theta), B.ring[a][1] = sinAlpha * std::sin(theta), B.ring[a][2] = alpha;
+    }
+  }
+};
+
+NsetGeom make_nset_geom(float eps) {
+  NsetGeom g;
+  g.nepsilon = (float)((double)(1.f / 7.f) + 0.00001);
+  const int depth = (int)(-std::log2(eps));
+  g.eg_size = (int)std::pow(2, depth);
+  g.epsilon = 1.f / g.eg_size;
+  return g;
+}
+
+// voxel grid over a centred cloud, cells of (delta * 1.001): counting sort by cell, built on the host
+// (one pass over N points) and uploaded; used by verify_mode 1.
+int build_verify_grid(hop_ctx* c, const float* x, const float* y, const float* z, int n, float delta) {
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = 0; i < n; ++i) {
+    mn[0] = std::min(mn[0], x[i]), mn[1] = std::min(mn[1], y[i]), mn[2] = std::min(mn[2], z[i]);
+    mx[0] = std::max(mx[0], x[i]), mx[1] = std::max(mx[1], y[i]), mx[2] = std::max(mx[2], z[i]);
+  }
+  const float cell = delta * 1.001f + 1e-9f;
+  GridDev g{};
+  g.ox = mn[0], g.oy = mn[1], g.oz = mn[2];
+  g.inv_cell = 1.0f / cell;
+  g.dx = std::max(1, (int)std::floor((mx[0] - mn[0]) * g.inv_cell) + 1);
+  g.dy = std::max(1, (int)std::floor((mx[1] - mn[1]) * g.inv_cell) + 1);
+  g.dz = std::max(1, (int)std::floor((mx[2] - mn[2]) * g.inv_cell) + 1);
+  const size_t ncell = (size_t)g.dx * g.dy * g.dz;
+  if (ncell > (size_t)1 << 28) return HOP_E_CAPACITY;
+  std::vector<int> start(ncell + 1, 0), cell_of(n);
+  for (int i = 0; i < n; ++i) {
+    int cx = (int)std::floor((x[i] - g.ox) * g.inv_cell), cy = (int)std::floor((y[i] - g.oy) * g.inv_cell),
+        cz = (int)std::floor((z[i] - g.oz) * g.inv_cell);
+    cx = std::min(std::max(cx, 0), g.dx - 1), cy = std::min(std::max(cy, 0), g.dy - 1), cz = std::min(std::max(cz, 0), g.dz - 1);
+    cell_of[i] = (cz * g.dy + cy) * g.dx + cx;
+    start[cell_of[i] + 1]++;
+  }
+  for (size_t k = 0; k < ncell; ++k) start[k + 1] += start[k];
+  std::vector<int> fill(start.begin(), start.end() - 1);
+  std::vector<float4> pts(n);
+  for (int i = 0; i < n; ++i) pts[fill[cell_of[i]]++] = make_float4(x[i], y[i], z[i], 0.f);
+  HIPCHK(c, c->grid_cell_start_d.ensure(sizeof(int) * (ncell + 1)));
+  HIPCHK(c, c->grid_pts_d.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
+  HIPCHK(c, hipMemcpyAsync(c->grid_cell_start_d.p, start.data(), sizeof(int) * (ncell + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->grid_pts_d.p, pts.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  g.cell_start = c->grid_cell_start_d.as<int>();
+  g.pts = c->grid_pts_d.as<float4>();
+  c->grid = g;
+  c->grid_valid = true;
+  c->grid_delta = delta;
+  return HOP_OK;
+}
+
+// sort the resident set by 64-bit keys (ascending) and gather pose/score; ids become 0..n-1
+int sort_resident_by_keys(hop_ctx* c, unsigned long long* keys_d, int n) {
+  if (n <= 0) return HOP_OK;
+  HIPCHK(c, c->sort_keys_alt.ensure(sizeof(unsigned long long) * (size_t)n));
+  HIPCHK(c, c->sort_vals.ensure(sizeof(unsigned) * (size_t)n));
+  HIPCHK(c, c->sort_vals_alt.ensure(sizeof(unsigned) * (size_t)n));
+  launch_iota(c->sort_vals.as<unsigned>(), n, c->stream);
+  size_t tmp_bytes = 0;
+  HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_d, c->sort_keys_alt.as<unsigned long long>(),
+                                               c->sort_vals.as<unsigned>(), c->sort_vals_alt.as<unsigned>(), n, 0, 64, c->stream));
+  HIPCHK(c, c->sort_tmp.ensure(tmp_bytes + 16));
+  HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp_bytes, keys_d, c->sort_keys_alt.as<unsigned long long>(),
+                                               c->sort_vals.as<unsigned>(), c->sort_vals_alt.as<unsigned>(), n, 0, 64, c->stream));
+  HIPCHK(c, c->tmp_pose.ensure(sizeof(float) * 16 * (size_t)n));
+  HIPCHK(c, c->tmp_score.ensure(sizeof(float) * (size_t)n));
+  HIPCHK(c, c->tmp_id.ensure(sizeof(int) * (size_t)n));
+  launch_gather_hypos(c->sort_vals_alt.as<unsigned>(), n, c->hyp_pose.as<float>(), c->hyp_score.as<float>(), c->tmp_pose.as<float>(),
+                      c->tmp_score.as<float>(), c->tmp_id.as<int>(), c->stream);
+  std::swap(c->hyp_pose, c->tmp_pose);
+  std::swap(c->hyp_score, c->tmp_score);
+  std::swap(c->hyp_id, c->tmp_id);
+  return HOP_OK;
+}
+
+int ensure_hyp_capacity(hop_ctx* c, int cap) {
+  HIPCHK(c, c->hyp_pose.ensure(sizeof(float) * 16 * (size_t)cap));
+  HIPCHK(c, c->hyp_score.ensure(sizeof(float) * (size_t)cap));
+  HIPCHK(c, c->hyp_id.ensure(sizeof(int) * (size_t)cap));
+  HIPCHK(c, c->hyp_key.ensure(sizeof(unsigned long long) * (size_t)cap));
+  HIPCHK(c, c->hyp_inv.ensure(sizeof(unsigned) * (size_t)cap));
+  return HOP_OK;
+}
+
+// clusterPoses core (PoseEstimator.cpp:106-233).  Euler angles of every pose are computed once instead of
+// inside the double loop; the comparisons are the reference's.
+void euler_zyx(const float* T, float res[3]) {  // Eigen 3.3 eulerAngles(2,1,0), Geometry/EulerAngles.h:36-108
+  auto R = [&](int r, int cidx) { return T[4 * r + cidx]; };
+  res[0] = std::atan2(R(1, 0), R(0, 0));
+  const float c2 = std::sqrt(R(2, 2) * R(2, 2) + R(2, 1) * R(2, 1));
+  if (res[0] < 0.f) {
+    res[0] += (float)M_PI;
+    res[1] = std::atan2(-R(2, 0), -c2);
+  } else
+    res[1] = std::atan2(-R(2, 0), c2);
+  const float s1 = std::sin(res[0]), c1 = std::cos(res[0]);
+  res[2] = std::atan2(s1 * R(0, 2) - c1 * R(1, 2), c1 * R(1, 1) - s1 * R(0, 1));
+}
+
+int cluster_core(const float* pose16, const float* lcp, const int* ids, int H, float angle_diff, float dist_diff,
+                 const float* sym_deg3, std::vector<int>& keep) {
+  keep.clear();
+  if (H <= 0) return 0;
+  std::vector<int> order(H);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int a, int b) {  // HypoCompare
+    if (lcp[a] > lcp[b]) return true;
+    if (lcp[a] < lcp[b]) return false;
+    return ids[a] < ids[b];
+  });
+  const float radian_thres = (float)((double)(angle_diff / 180.0f) * M_PI);
+  const float sym[3] = {(float)((double)sym_deg3[0] / 180 * M_PI), (float)((double)sym_deg3[1] / 180 * M_PI),
+                        (float)((double)sym_deg3[2] / 180 * M_PI)};
+  std::vector<std::array<float, 3>> eul(H);
+  for (int i = 0; i < H; ++i) euler_zyx(pose16 + 16 * (size_t)i, eul[i].data());
+  keep.push_back(order[0]);
+  for (int oi = 1; oi < H; ++oi) {
+    const int ci = order[oi];
+    const float* cur = pose16 + 16 * (size_t)ci;
+    bool isnew = true;
+    for (int k : keep) {
+      const float* cl = pose16 + 16 * (size_t)k;
+      const V3 t0 = v3(cl[3], cl[7], cl[11]), t1 = v3(cur[3], cur[7], cur[11]);
+      if (vnorm(t0 - t1) >= dist_diff) continue;
+      float roll = std::fabs(eul[k][2] - eul[ci][2]), pitch = std::fabs(eul[k][1] - eul[ci][1]), yaw = std::fabs(eul[k][0] - eul[ci][0]);
+      if (sym[0] == 0) roll = 0;
+      else if (sym[0] > 0) roll = std::min(roll, sym[0] - roll);
+      if (sym[1] == 0) pitch = 0;
+      else if (sym[1] > 0) pitch = std::min(pitch, sym[1] - pitch);
+      if (sym[2] == 0) yaw = 0;
+      else if (sym[2] > 0) yaw = std::min(yaw, sym[2] - yaw);
+      if (pitch <= radian_thres && roll <= radian_thres && yaw <= radian_thres) {
+        isnew = false;
+        break;
+      }
+      // rotationGeodesicDistance (Utils.cpp:29-32): acos((trace(R0*R1)-1)/2.0)
+      float tr[3];
+      for (int d = 0; d < 3; ++d) tr[d] = cl[4 * d + 0] * cur[0 + d] + (cl[4 * d + 1] * cur[4 + d] + cl[4 * d + 2] * cur[8 + d]);
+      const float trace = tr[0] + (tr[1] + tr[2]);
+      const float rot_diff = (float)std::acos(((double)trace - 1) / 2.0);
+      if (rot_diff <= radian_thres) {
+        isnew = false;
+        break;
+      }
+    }
+    if (isnew) keep.push_back(ci);
+  }
+  return (int)keep.size();
+}
+
+}  // namespace
+
+// ==================================================================================================
+extern "C" {
+
+int hop_abi_version(void) { return HOP_ABI_VERSION; }
+
+const char* hop_strerror(int s) {
+  switch (s) {
+    case HOP_OK: return "ok";
+    case HOP_E_INVALID: return "invalid argument";
+    case HOP_E_NO_DEVICE: return "no usable HIP device (libhop has no CPU path)";
+    case HOP_E_HIP: return "HIP runtime error";
+    case HOP_E_CAPACITY: return "capacity exceeded";
+    case HOP_E_STATE: return "call order / missing input";
+    case HOP_E_NO_HYPOTHESIS: return "no hypothesis generated";
+    case HOP_E_ALLOC: return "allocation failed";
+  }
+  return "unknown status";
+}
+
+const char* hop_last_error(const hop_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int hop_ctx_create(int device, hop_ctx** out) {
+  if (!out) return HOP_E_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HOP_E_NO_DEVICE;
+  if (device < 0 || device >= ndev) return HOP_E_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return HOP_E_NO_DEVICE;
+  hop_ctx* c = new (std::nothrow) hop_ctx;
+  if (!c) return HOP_E_ALLOC;
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return HOP_E_HIP;
+  }
+  *out = c;
+  return HOP_OK;
+}
+
+void hop_ctx_destroy(hop_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& s : c->spans) {
+    (void)hipEventDestroy(s.a);
+    (void)hipEventDestroy(s.b);
+  }
+  for (auto e : c->event_pool) (void)hipEventDestroy(e);
+  DevBuf* bufs[] = {&c->scene_d.buf, &c->model_d[0].buf, &c->model_d[1].buf, &c->key_bitmap_d, &c->gp_d.buf, &c->gq_d.buf, &c->gq_unit_d,
+                    &c->ppf_matrix_d, &c->vp_d.buf, &c->vq_d.buf, &c->grid_cell_start_d, &c->grid_pts_d, &c->bases_d, &c->pairs1_d,
+                    &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
+                    &c->hyp_score, &c->hyp_id, &c->hyp_key, &c->hyp_inv, &c->tmp_pose, &c->tmp_score, &c->tmp_id, &c->sort_keys_alt,
+                    &c->sort_vals, &c->sort_vals_alt, &c->sort_tmp, &c->lcp_rev_idx, &c->lcp_rev_d2, &c->lcp_terms, &c->icp_moved,
+                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
+                    &c->hand_swivel_d.buf, &c->hand_model_d.buf, &c->finger_hist_d, &c->pso_particles_d, &c->pso_match_d,
+                    &c->pso_terms_d, &c->pso_sum_d, &c->pso_cnt_d};
+  for (DevBuf* b : bufs) b->release();
+  c->ppf_matrix_h.release(), c->bases_h.release(), c->cnt_h.release(), c->pso_particles_h.release(), c->pso_out_h.release();
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int hop_synchronize(hop_ctx* c) {
+  if (!c) return HOP_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- clouds
+int hop_set_scene(hop_ctx* c, const float* xyz, const float* nrm, const float* conf, int n, float thres) {
+  if (!c || !xyz || !nrm || n < 0) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  CloudHost all;
+  load_cloud_host(all, xyz, nrm, n, true);
+  CloudHost& s = c->scene_h;
+  s.resize(0);
+  c->scene_conf.clear();
+  std::vector<int> keep;
+  for (int i = 0; i < n; ++i) {
+    const float cf = conf ? conf[i] : 1.0f;
+    if (conf && thres > 0 && cf < thres) continue;  // PoseEstimator.cpp:41-45
+    keep.push_back(i);
+  }
+  s.resize((int)keep.size());
+  c->scene_conf.resize(keep.size());
+  for (size_t k = 0; k < keep.size(); ++k) {
+    const int i = keep[k];
+    s.x[k] = all.x[i], s.y[k] = all.y[i], s.z[k] = all.z[i], s.nx[k] = all.nx[i], s.ny[k] = all.ny[i], s.nz[k] = all.nz[i];
+    c->scene_conf[k] = conf ? conf[i] : 1.0f;
+  }
+  // The scoring stages read the raw normals (computeLCP normalises on use; ICP uses them as given):
+  // keep the un-normalised normals on the device copy used by ICP/LCP.
+  CloudHost raw = s;
+  for (size_t k = 0; k < keep.size(); ++k) {
+    const int i = keep[k];
+    raw.nx[k] = nrm[i], raw.ny[k] = nrm[n + i], raw.nz[k] = nrm[2 * (size_t)n + i];
+  }
+  c->have_gen_state = false;
+  c->grid_valid = false;
+  return upload_cloud(c, c->scene_d, raw);
+}
+
+int hop_scene_size(const hop_ctx* c) { return c ? c->scene_h.n : HOP_E_INVALID; }
+
+int hop_set_model(hop_ctx* c, int level, const float* xyz, const float* nrm, int n) {
+  if (!c || !xyz || !nrm || n <= 0 || (level != HOP_MODEL_5MM && level != HOP_MODEL_1MM)) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  load_cloud_host(c->model_h[level], xyz, nrm, n, true);  // generator view: Point3D normals
+  CloudHost raw;
+  load_cloud_host(raw, xyz, nrm, n, false);  // scoring view: as given
+  c->have_gen_state = false;
+  return upload_cloud(c, c->model_d[level], raw);
+}
+
+int hop_set_ppf_keys(hop_ctx* c, const int32_t* keys4, int nkeys) {
+  if (!c || !keys4 || nkeys < 0) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int max_d = 0;
+  for (int i = 0; i < nkeys; ++i) max_d = std::max(max_d, keys4[4 * i]);
+  c->key_dist_bins = max_d / 5 + 1;
+  const size_t nbits = (size_t)c->key_dist_bins * 19 * 19 * 19;
+  c->key_bitmap.assign((nbits + 31) / 32 + 1, 0u);
+  for (int i = 0; i < nkeys; ++i) {
+    const int* k = keys4 + 4 * i;
+    // keys are multiples of 5 / 10 by construction (ppfClosestBin); anything else can never be produced
+    if (k[0] < 0 || k[0] % 5 || k[1] < 0 || k[1] > 180 || k[1] % 10 || k[2] < 0 || k[2] > 180 || k[2] % 10 || k[3] < 0 || k[3] > 180 || k[3] % 10)
+      continue;
+    const size_t bit = (((size_t)(k[0] / 5) * 19 + k[1] / 10) * 19 + k[2] / 10) * 19 + k[3] / 10;
+    c->key_bitmap[bit >> 5] |= 1u << (bit & 31);
+  }
+  HIPCHK(c, c->key_bitmap_d.ensure(sizeof(unsigned) * c->key_bitmap.size()));
+  HIPCHK(c, hipMemcpyAsync(c->key_bitmap_d.p, c->key_bitmap.data(), sizeof(unsigned) * c->key_bitmap.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_keys = true;
+  c->have_gen_state = false;
+  return HOP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- generator
+void hop_s4pcs_default_opts(hop_s4pcs_opts* o) {
+  if (!o) return;
+  o->sample_size = 100, o->overlap = 0.2f, o->delta = 0.003f, o->dispersion = 0.5f;
+  o->success_quadrilaterals = 10, o->max_time_seconds = 1, o->n_trials = 0, o->random_seed = 5489u;
+  o->max_normal_difference = -1.f, o->max_color_distance = -1.f, o->verify_mode = 0;
+}
+
+int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_out, float* lcp_out, int cap, int* n_out,
+                       hop_s4pcs_stats* stats_out) {
+  if (!c || !opts) return HOP_E_INVALID;
+  if (n_out) *n_out = 0;
+  if (opts->max_normal_difference >= 0 || opts->max_color_distance >= 0) return HOP_E_INVALID;
+  if (opts->sample_size <= 0 || opts->sample_size > 4096 || !(opts->delta > 0)) return HOP_E_INVALID;
+  if (c->scene_h.n <= 0 || c->model_h[HOP_MODEL_5MM].n <= 0 || !c->have_keys) return HOP_E_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  const auto t_begin = std::chrono::steady_clock::now();
+  hop_s4pcs_stats st{};
+  c->trace.clear();
+  c->n_hyp = 0;
+
+  GenHost G(c, *opts);
+  G.init_clouds();
+  const int N = c->gp_h.n, NQ = c->gq_h.n;
+  if (N > 65536) return HOP_E_CAPACITY;  // bit matrix N^2/8 bytes
+  st.n_sampled_q = NQ;
+  for (int k = 0; k < 3; ++k) st.centroid_p[k] = c->centroid_p[k], st.centroid_q[k] = c->centroid_q[k];
+  st.diameter = c->diameter;
+
+  // ---- upload generator clouds: P planes x y z + PPF normals (two extra normalisations, matchBase.hpp:53-56)
+  {
+    CloudHost up = c->gp_h;
+    for (int i = 0; i < N; ++i) {
+      V3 nn = vnormalized(vnormalized(v3(up.nx[i], up.ny[i], up.nz[i])));
+      up.nx[i] = nn.x, up.ny[i] = nn.y, up.nz[i] = nn.z;
+    }
+    int rc = upload_cloud(c, c->gp_d, up);
+    if (rc) return rc;
+    rc = upload_cloud(c, c->gq_d, c->gq_h);
+    if (rc) return rc;
+    HIPCHK(c, c->gq_unit_d.ensure(sizeof(float) * 3 * (size_t)NQ));
+    for (int k = 0; k < 3; ++k)
+      HIPCHK(c, hipMemcpyAsync(c->gq_unit_d.as<float>() + (size_t)k * NQ, c->gq_unit[k].data(), sizeof(float) * NQ, hipMemcpyHostToDevice, c->stream));
+  }
+  c->have_gen_state = true;
+  c->have_verify_clouds = false;
+  c->grid_valid = false;
+
+  // ---- K2: PPF membership matrix
+  const int W = (N + 63) / 64;
+  c->ppf_words = W;
+  const size_t mbytes = sizeof(unsigned long long) * (size_t)N * W;
+  HIPCHK(c, c->ppf_matrix_d.ensure(mbytes));
+  HIPCHK(c, c->ppf_matrix_h.ensure(mbytes));
+  {
+    PpfMatrixArgs a{};
+    a.x = c->gp_d.plane(0), a.y = c->gp_d.plane(1), a.z = c->gp_d.plane(2);
+    a.nx = c->gp_d.plane(3), a.ny = c->gp_d.plane(4), a.nz = c->gp_d.plane(5);
+    a.n = N, a.words = W, a.bitmap = c->key_bitmap_d.as<unsigned>(), a.dist_bins = c->key_dist_bins;
+    a.out = c->ppf_matrix_d.as<unsigned long long>();
+    {
+      SpanGuard sg(c, T_PPF);
+      launch_ppf_matrix(a, c->stream);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->ppf_matrix_h.p, c->ppf_matrix_d.p, mbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  G.M = static_cast<const unsigned long long*>(c->ppf_matrix_h.p);
+  G.W = W;
+
+  if (opts->verify_mode == 1) {
+    const int rc = build_verify_grid(c, c->gp_h.x.data(), c->gp_h.y.data(), c->gp_h.z.data(), N, opts->delta);
+    if (rc) return rc;
+  }
+
+  // ---- batch workspaces
+  const int n_trials = opts->n_trials > 0 ? opts->n_trials : 30;
+  if (n_trials > 16384) return HOP_E_CAPACITY;  // 14 bits of the order key
+  const bool never_stops_early = opts->success_quadrilaterals >= n_trials && opts->max_time_seconds <= 0;
+  const int BATCH = never_stops_early ? 64 : std::min(32, n_trials);
+  const int pair_cap = NQ * (NQ - 1) + 2;
+  const int cand_cap = 1 << 22;
+  const int hyp_cap = 1 << 23;
+  HIPCHK(c, c->bases_d.ensure(sizeof(BaseDev) * (size_t)BATCH));
+  HIPCHK(c, c->bases_h.ensure(sizeof(BaseDev) * (size_t)BATCH * 2));
+  HIPCHK(c, c->pairs1_d.ensure(sizeof(unsigned) * (size_t)BATCH * pair_cap));
+  HIPCHK(c, c->pairs2_d.ensure(sizeof(unsigned) * (size_t)BATCH * pair_cap));
+  HIPCHK(c, c->elems_d.ensure(sizeof(QuadElem) * (size_t)BATCH * pair_cap));
+  HIPCHK(c, c->queries_d.ensure(sizeof(QuadQuery) * (size_t)BATCH * pair_cap));
+  HIPCHK(c, c->cnt_d.ensure(sizeof(int) * 3 * (size_t)n_trials + 64));
+  HIPCHK(c, c->cnt_h.ensure(sizeof(int) * 3 * (size_t)n_trials + 64));
+  HIPCHK(c, c->cands_d.ensure(sizeof(Candidate) * (size_t)cand_cap));
+  HIPCHK(c, c->cand_counts_d.ensure(sizeof(int) * (size_t)cand_cap));
+  HIPCHK(c, c->counters_d.ensure(sizeof(int) * 16));
+  int rc = ensure_hyp_capacity(c, hyp_cap);
+  if (rc) return rc;
+  int* counters = c->counters_d.as<int>();  // [0] cand_count, [1] hyp_count, [2] overflow
+  HIPCHK(c, hipMemsetAsync(counters, 0, sizeof(int) * 16, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->cnt_d.p, 0, sizeof(int) * 3 * (size_t)n_trials, c->stream));
+  int* cnt1_all = c->cnt_d.as<int>();
+  int* cnt2_all = cnt1_all + n_trials;
+  const NsetGeom geom = make_nset_geom(opts->delta / c->ratio);
+  const float* qx = c->gq_d.plane(0);
+  const float* qy = c->gq_d.plane(1);
+  const float* qz = c->gq_d.plane(2);
+
+  std::vector<BaseDev> batch;
+  batch.reserve(BATCH);
+  int batch_first_trace = 0;
+  int flip = 0;
+  double ms_select = 0;
+  hipEvent_t stage_ev[2] = {get_event(c), get_event(c)};
+  bool stage_used[2] = {false, false};
+  int* nquads_all = cnt2_all + n_trials;
+
+  auto flush = [&]() -> int {
+    const int nb = (int)batch.size();
+    if (!nb) return HOP_OK;
+    BaseDev* stage = static_cast<BaseDev*>(c->bases_h.p) + (size_t)flip * BATCH;
+    // this staging half was last read by the H2D copy issued two flushes ago
+    if (stage_used[flip]) HIPCHK(c, hipEventSynchronize(stage_ev[flip]));
+    std::memcpy(stage, batch.data(), sizeof(BaseDev) * nb);
+    HIPCHK(c, hipMemcpyAsync(c->bases_d.p, stage, sizeof(BaseDev) * nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(stage_ev[flip], c->stream));
+    stage_used[flip] = true;
+    flip ^= 1;
+    HIPCHK(c, hipMemsetAsync(counters, 0, sizeof(int), c->stream));  // cand_count
+    int* cnt1 = cnt1_all + batch_first_trace;
+    int* cnt2 = cnt2_all + batch_first_trace;
+    {
+      SpanGuard sg(c, T_GEN_OTHER);
+      PairArgs pa{};
+      pa.bases = c->bases_d.as<BaseDev>();
+      pa.qx = qx, pa.qy = qy, pa.qz = qz, pa.qnx = c->gq_d.plane(3), pa.qny = c->gq_d.plane(4), pa.qnz = c->gq_d.plane(5);
+      pa.nq = NQ, pa.eps = 1.0f * opts->delta;
+      pa.pairs1 = c->pairs1_d.as<unsigned>(), pa.pairs2 = c->pairs2_d.as<unsigned>();
+      pa.cnt1 = cnt1, pa.cnt2 = cnt2, pa.cap = pair_cap, pa.overflow = counters + 2;
+      launch_pairs(pa, nb, c->stream);
+      QuadPrepArgs qp{};
+      qp.bases = pa.bases, qp.qx = qx, qp.qy = qy, qp.qz = qz;
+      qp.ux = c->gq_unit_d.as<float>(), qp.uy = qp.ux + NQ, qp.uz = qp.ux + 2 * (size_t)NQ;
+      qp.pairs1 = pa.pairs1, qp.pairs2 = pa.pairs2, qp.cnt1 = cnt1, qp.cnt2 = cnt2, qp.cap = pair_cap, qp.geom = geom;
+      qp.elems = c->elems_d.as<QuadElem>(), qp.queries = c->queries_d.as<QuadQuery>();
+      launch_quad_prep(qp, nb, 2 * pair_cap, c->stream);
+      QuadArgs qa{};
+      qa.bases = pa.bases, qa.qx = qx, qa.qy = qy, qa.qz = qz, qa.pairs1 = pa.pairs1, qa.pairs2 = pa.pairs2;
+      qa.cnt1 = cnt1, qa.cnt2 = cnt2, qa.cap = pair_cap, qa.geom = geom, qa.elems = qp.elems, qa.queries = qp.queries;
+      qa.dist_thr2 = 1.0f * opts->delta, qa.delta = 1.0f * opts->delta, qa.base_index0 = batch_first_trace;
+      qa.cands = c->cands_d.as<Candidate>(), qa.cand_counts = c->cand_counts_d.as<int>(), qa.cand_count = counters, qa.cand_cap = cand_cap;
+      qa.nquads = nquads_all + batch_first_trace;
+      qa.overflow = counters + 2;
+      launch_quads(qa, nb, 64, c->stream);
+    }
+    VerifyArgs va{};
+    va.px = c->gp_d.plane(0), va.py = c->gp_d.plane(1), va.pz = c->gp_d.plane(2), va.np = N;
+    va.qx = qx, va.qy = qy, va.qz = qz, va.nq = NQ;
+    va.T = reinterpret_cast<const float*>(c->cands_d.p), va.t_stride = sizeof(Candidate) / sizeof(float);
+    va.n_cand_ptr = counters, va.n_cand = 0, va.cand_cap = cand_cap;
+    va.sq_eps = opts->delta * opts->delta, va.counts = c->cand_counts_d.as<int>();
+    {
+      SpanGuard sg(c, T_VERIFY);
+      launch_verify(va, opts->verify_mode, c->grid_valid ? &c->grid : nullptr, 2048, c->stream);
+    }
+    c->timing.n_verify_launches += 1;
+    {
+      SpanGuard sg(c, T_GEN_OTHER);
+      EmitArgs ea{};
+      ea.cands = c->cands_d.as<Candidate>(), ea.cand_counts = c->cand_counts_d.as<int>(), ea.cand_count = counters, ea.cand_cap = cand_cap;
+      for (int k = 0; k < 3; ++k) ea.cp[k] = c->centroid_p[k], ea.cq[k] = c->centroid_q[k];
+      ea.nq = NQ, ea.pose = c->hyp_pose.as<float>(), ea.score = c->hyp_score.as<float>(), ea.key = c->hyp_key.as<unsigned long long>();
+      ea.inv_count = c->hyp_inv.as<unsigned>(), ea.hyp_count = counters + 1, ea.hyp_cap = hyp_cap, ea.cand_total = counters + 3;
+      ea.overflow = counters + 2;
+      launch_emit(ea, 256, c->stream);
+    }
+    batch_first_trace += nb;
+    batch.clear();
+    return HOP_OK;
+  };
+
+  // ---- trial loop (Perform_N_steps, cse.hpp:133-194)
+  int success = 0;
+  int trials_run = 0;
+  int checked_trace = 0;  // trace entries whose success has been read back
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < n_trials; ++i) {
+    trials_run = i + 1;
+    float inv1 = 0, inv2 = 0;
+    int ids[4];
+    const auto ts = std::chrono::steady_clock::now();
+    const bool ok = G.SelectQuadrilateral(inv1, inv2, ids);
+    ms_select += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
+    if (ok) {
+      BaseDev B;
+      G.fill_base(B, inv1, inv2);
+      batch.push_back(B);
+      BaseTraceHost t;
+      for (int k = 0; k < 4; ++k) t.ids[k] = ids[k];
+      t.inv1 = inv1, t.inv2 = inv2;
+      c->trace.push_back(t);
+    }
+    const bool batch_full = (int)batch.size() >= BATCH;
+    if (batch_full || (!never_stops_early && ok)) {
+      // A base "succeeds" (TryOneBase, cse.hpp:201-216) when both pair lists are non-empty and at least one
+      // congruent quadrilateral exists; that is known only on the device.  Without early stop nothing has
+      // to be read back here; otherwise flush and read the counters of the bases submitted so far.
+      rc = flush();
+      if (rc) return rc;
+      if (!never_stops_early) {
+        HIPCHK(c, hipMemcpyAsync(c->cnt_h.p, c->cnt_d.p, sizeof(int) * 3 * (size_t)n_trials, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const int* h1 = static_cast<const int*>(c->cnt_h.p);
+        const int* h2 = h1 + n_trials;
+        const int* hq = h2 + n_trials;
+        for (; checked_trace < (int)c->trace.size(); ++checked_trace)
+          if (h1[checked_trace] > 0 && h2[checked_trace] > 0 && hq[checked_trace] > 0) ++success;
+      }
+    }
+    const float fraction_try = float(i) / float(n_trials);
+    float fraction_time = 0.f;
+    if (opts->max_time_seconds > 0) {
+      const long long secs = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count();
+      fraction_time = float(secs / opts->max_time_seconds);
+    }
+    const float fraction = std::max(fraction_time, fraction_try);
+    if (i > n_trials || fraction >= 0.99f || success >= opts->success_quadrilaterals) break;
+  }
+  rc = flush();
+  if (rc) return rc;
+  st.n_trials_run = trials_run;
+
+  // ---- collect
+  int hc[4] = {0, 0, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(c->cnt_h.p, c->cnt_d.p, sizeof(int) * 3 * (size_t)n_trials, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(hc, counters, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (hc[2]) return HOP_E_CAPACITY;
+  {
+    const int* h1 = static_cast<const int*>(c->cnt_h.p);
+    const int* h2 = h1 + n_trials;
+    const int* hq = h2 + n_trials;
+    for (size_t k = 0; k < c->trace.size(); ++k) {
+      c->trace[k].n1 = h1[k], c->trace[k].n2 = h2[k], c->trace[k].nq = hq[k];
+      st.n_pairs += (long long)h1[k] + h2[k];
+      st.n_quads += hq[k];
+    }
+  }
+  st.n_candidates = hc[3];
+  c->timing.pairs_verify += (long long)hc[3] * NQ * (long long)N;
+  c->event_pool.push_back(stage_ev[0]);
+  c->event_pool.push_back(stage_ev[1]);
+  const int H = std::min(hc[1], hyp_cap);
+  st.n_bases = (int)c->trace.size();
+  st.n_hypotheses = H;
+  c->n_hyp = H;
+  // canonical emission order
+  rc = sort_resident_by_keys(c, c->hyp_key.as<unsigned long long>(), H);
+  if (rc) return rc;
+  if (H > 0 && (poses16_out || lcp_out)) {
+    const int m = std::min(H, cap);
+    if (poses16_out) HIPCHK(c, hipMemcpyAsync(poses16_out, c->hyp_pose.p, sizeof(float) * 16 * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    if (lcp_out) HIPCHK(c, hipMemcpyAsync(lcp_out, c->hyp_score.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  st.ms_select = ms_select;
+  st.ms_device = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  if (n_out) *n_out = H;
+  if (stats_out) *stats_out = st;
+  if (H == 0) return HOP_E_NO_HYPOTHESIS;
+  if ((poses16_out || lcp_out) && cap < H) return HOP_E_CAPACITY;
+  return HOP_OK;
+}
+
+int hop_s4pcs_num_bases(const hop_ctx* c) { return c ? (int)c->trace.size() : HOP_E_INVALID; }
+int hop_s4pcs_get_base(const hop_ctx* c, int i, int* base4, float* inv2, int* counts3) {
+  if (!c || i < 0 || i >= (int)c->trace.size()) return HOP_E_INVALID;
+  const BaseTraceHost& t = c->trace[i];
+  if (base4)
+    for (int k = 0; k < 4; ++k) base4[k] = t.ids[k];
+  if (inv2) inv2[0] = t.inv1, inv2[1] = t.inv2;
+  if (counts3) counts3[0] = t.n1, counts3[1] = t.n2, counts3[2] = t.nq;
+  return HOP_OK;
+}
+int hop_s4pcs_get_sampled_q(const hop_ctx* c, float* xyz, float* nrm) {
+  if (!c || !c->have_gen_state) return HOP_E_STATE;
+  const CloudHost& q = c->gq_h;
+  for (int i = 0; i < q.n; ++i) {
+    if (xyz) xyz[i] = q.x[i], xyz[q.n + i] = q.y[i], xyz[2 * (size_t)q.n + i] = q.z[i];
+    if (nrm) nrm[i] = q.nx[i], nrm[q.n + i] = q.ny[i], nrm[2 * (size_t)q.n + i] = q.nz[i];
+  }
+  return HOP_OK;
+}
+
+int hop_verify_set_clouds(hop_ctx* c, const float* p_xyz, int n_p, const float* q_xyz, int n_q) {
+  if (!c || !p_xyz || !q_xyz || n_p <= 0 || n_q <= 0) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  CloudHost P, Q;
+  std::vector<float> zeros((size_t)3 * std::max(n_p, n_q), 0.f);
+  load_cloud_host(P, p_xyz, zeros.data(), n_p, false);
+  load_cloud_host(Q, q_xyz, zeros.data(), n_q, false);
+  int rc = upload_cloud(c, c->vp_d, P);
+  if (rc) return rc;
+  rc = upload_cloud(c, c->vq_d, Q);
+  if (rc) return rc;
+  c->vp_h[0] = P.x, c->vp_h[1] = P.y, c->vp_h[2] = P.z;
+  c->have_verify_clouds = true;
+  c->grid_valid = false;
+  return HOP_OK;
+}
+
+int hop_verify_batch(hop_ctx* c, const float* T16, int H, float delta, int mode, int* count_out) {
+  if (!c || !T16 || !count_out || H < 0) return HOP_E_INVALID;
+  if (!c->have_verify_clouds && !c->have_gen_state) return HOP_E_STATE;
+  if (H == 0) return HOP_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const CloudDevice& P = c->have_verify_clouds ? c->vp_d : c->gp_d;
+  const CloudDevice& Q = c->have_verify_clouds ? c->vq_d : c->gq_d;
+  if (mode == 1 && (!c->grid_valid || c->grid_delta != delta)) {
+    int rc;
+    if (c->have_verify_clouds) rc = build_verify_grid(c, c->vp_h[0].data(), c->vp_h[1].data(), c->vp_h[2].data(), P.n, delta);
+    else rc = build_verify_grid(c, c->gp_h.x.data(), c->gp_h.y.data(), c->gp_h.z.data(), P.n, delta);
+    if (rc) return rc;
+  }
+  HIPCHK(c, c->tmp_pose.ensure(sizeof(float) * 16 * (size_t)H));
+  HIPCHK(c, c->cand_counts_d.ensure(sizeof(int) * (size_t)H));
+  HIPCHK(c, hipMemcpyAsync(c->tmp_pose.p, T16, sizeof(float) * 16 * (size_t)H, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->cand_counts_d.p, 0, sizeof(int) * (size_t)H, c->stream));
+  VerifyArgs va{};
+  va.px = P.plane(0), va.py = P.plane(1), va.pz = P.plane(2), va.np = P.n;
+  va.qx = Q.plane(0), va.qy = Q.plane(1), va.qz = Q.plane(2), va.nq = Q.n;
+  va.T = c->tmp_pose.as<float>(), va.t_stride = 16, va.n_cand_ptr = nullptr, va.n_cand = H, va.cand_cap = H;
+  va.sq_eps = delta * delta, va.counts = c->cand_counts_d.as<int>();
+  const long long total = (long long)H * Q.n;
+  const int blocks = (int)std::min<long long>(4096, (total + 1023) / 1024);
+  {
+    SpanGuard sg(c, T_VERIFY);
+    launch_verify(va, mode, (mode == 1 && c->grid_valid) ? &c->grid : nullptr, std::max(blocks, 1), c->stream);
+  }
+  c->timing.n_verify_launches += 1;
+  c->timing.pairs_verify += total * (long long)P.n;
+  HIPCHK(c, hipMemcpyAsync(count_out, c->cand_counts_d.p, sizeof(int) * (size_t)H, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- resident set
+int hop_hypos_upload(hop_ctx* c, const float* poses16, const float* scores, int H) {
+  if (!c || !poses16 || H < 0) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure_hyp_capacity(c, std::max(H, 1));
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->hyp_pose.p, poses16, sizeof(float) * 16 * (size_t)H, hipMemcpyHostToDevice, c->stream));
+  if (scores) HIPCHK(c, hipMemcpyAsync(c->hyp_score.p, scores, sizeof(float) * (size_t)H, hipMemcpyHostToDevice, c->stream));
+  else HIPCHK(c, hipMemsetAsync(c->hyp_score.p, 0, sizeof(float) * (size_t)H, c->stream));
+  std::vector<int> ids(H);
+  std::iota(ids.begin(), ids.end(), 0);
+  HIPCHK(c, hipMemcpyAsync(c->hyp_id.p, ids.data(), sizeof(int) * (size_t)H, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->n_hyp = H;
+  return HOP_OK;
+}
+int hop_hypos_count(const hop_ctx* c) { return c ? c->n_hyp : HOP_E_INVALID; }
+int hop_hypos_download(hop_ctx* c, float* poses16_out, float* scores_out, int* ids_out, int cap, int* n_out) {
+  if (!c) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int m = std::min(c->n_hyp, cap);
+  if (n_out) *n_out = c->n_hyp;
+  if (m > 0) {
+    if (poses16_out) HIPCHK(c, hipMemcpyAsync(poses16_out, c->hyp_pose.p, sizeof(float) * 16 * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    if (scores_out) HIPCHK(c, hipMemcpyAsync(scores_out, c->hyp_score.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    if (ids_out) HIPCHK(c, hipMemcpyAsync(ids_out, c->hyp_id.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return cap < c->n_hyp ? HOP_E_CAPACITY : HOP_OK;
+}
+int hop_hypos_keep_topk(hop_ctx* c, int k) {
+  if (!c || k < 0) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int H = c->n_hyp;
+  if (H == 0) return HOP_OK;
+  HIPCHK(c, c->hyp_key.ensure(sizeof(unsigned long long) * (size_t)H));
+  launch_score_keys(c->hyp_score.as<float>(), c->hyp_id.as<int>(), H, c->hyp_key.as<unsigned long long>(), c->stream);
+  const int rc = sort_resident_by_keys(c, c->hyp_key.as<unsigned long long>(), H);
+  if (rc) return rc;
+  c->n_hyp = std::min(H, k);
+  return HOP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- ICP
+int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* converged_out) {
+  if (!c || !o || o->max_iter <= 0) return HOP_E_INVALID;
+  if (c->scene_d.n <= 0 || c->model_d[HOP_MODEL_5MM].n <= 0) return HOP_E_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  int H = c->n_hyp;
+  if (o->max_hypotheses > 0 && H > o->max_hypotheses) {  // PoseEstimator.cpp:241: the rest is dropped
+    H = o->max_hypotheses;
+    c->n_hyp = H;
+  }
+  if (H == 0) return HOP_OK;
+  const CloudDevice& S = c->scene_d;
+  const CloudDevice& Mo = c->model_d[HOP_MODEL_5MM];
+  const int nb = icp_blocks_per_hyp(S.n);
+  // batch so that the moved-source workspace stays below ~1 GiB
+  const size_t per_h = sizeof(float) * 6 * (size_t)S.n;
+  const int HB = (int)std::max<size_t>(1, std::min<size_t>((size_t)H, ((size_t)1 << 30) / per_h));
+  HIPCHK(c, c->icp_moved.ensure(per_h * HB));
+  HIPCHK(c, c->icp_partial.ensure(sizeof(double) * ICP_NACC * (size_t)nb * HB));
+  HIPCHK(c, c->icp_state.ensure(sizeof(IcpState) * (size_t)HB));
+  HIPCHK(c, c->icp_iters.ensure(sizeof(int) * (size_t)H));
+  HIPCHK(c, c->icp_conv.ensure(sizeof(int) * (size_t)H));
+  IcpArgs a{};
+  a.sx = S.plane(0), a.sy = S.plane(1), a.sz = S.plane(2), a.snx = S.plane(3), a.sny = S.plane(4), a.snz = S.plane(5), a.ns = S.n;
+  a.mx = Mo.plane(0), a.my = Mo.plane(1), a.mz = Mo.plane(2), a.mnx = Mo.plane(3), a.mny = Mo.plane(4), a.mnz = Mo.plane(5), a.nm = Mo.n;
+  a.pose = c->hyp_pose.as<float>();
+  a.max_iter = o->max_iter;
+  a.max_d2 = o->max_corr_dist * o->max_corr_dist;
+  a.cos_thr = (float)std::cos((double)(o->angle_deg / 180.0f) * M_PI);
+  a.moved = c->icp_moved.as<float>(), a.partial = c->icp_partial.as<double>(), a.state = c->icp_state.as<IcpState>();
+  for (int h0 = 0; h0 < H; h0 += HB) {
+    const int hb = std::min(HB, H - h0);
+    a.h0 = h0;
+    launch_icp_init(a.state, hb, c->stream);
+    for (int it = 0; it < o->max_iter; ++it) {
+      a.iter = it;
+      {
+        SpanGuard sg(c, T_ICP_NN);
+        launch_icp_nn(a, hb, c->stream);
+      }
+      {
+        SpanGuard sg(c, T_ICP_SOLVE);
+        launch_icp_solve(a, hb, c->stream);
+      }
+      c->timing.n_icp_nn_launches += 1;
+    }
+    launch_icp_finish(a, hb, c->icp_iters.as<int>(), c->icp_conv.as<int>(), c->stream);
+  }
+  if (iterations_out) HIPCHK(c, hipMemcpyAsync(iterations_out, c->icp_iters.p, sizeof(int) * (size_t)H, hipMemcpyDeviceToHost, c->stream));
+  if (converged_out) HIPCHK(c, hipMemcpyAsync(converged_out, c->icp_conv.p, sizeof(int) * (size_t)H, hipMemcpyDeviceToHost, c->stream));
+  if (iterations_out || converged_out) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- LCP
+int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_out, float* best_score_out, int* best_index_out) {
+  if (!c || !o || !(o->dist > 0)) return HOP_E_INVALID;
+  if (c->scene_d.n <= 0 || c->model_d[HOP_MODEL_1MM].n <= 0) return HOP_E_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int H = c->n_hyp;
+  if (H == 0) return HOP_E_NO_HYPOTHESIS;
+  const CloudDevice& S = c->scene_d;
+  const CloudDevice& Mo = c->model_d[HOP_MODEL_1MM];
+  const size_t per_h = sizeof(float) * 2 * (size_t)S.n + sizeof(float) * 2 * (size_t)Mo.n;
+  const int HB = (int)std::max<size_t>(1, std::min<size_t>((size_t)H, ((size_t)1 << 30) / per_h));
+  HIPCHK(c, c->lcp_rev_idx.ensure(sizeof(int) * (size_t)Mo.n * HB));
+  HIPCHK(c, c->lcp_rev_d2.ensure(sizeof(float) * (size_t)Mo.n * HB));
+  HIPCHK(c, c->lcp_terms.ensure(sizeof(float) * 2 * (size_t)S.n * HB + 64));
+  LcpArgs a{};
+  a.sx = S.plane(0), a.sy = S.plane(1), a.sz = S.plane(2), a.snx = S.plane(3), a.sny = S.plane(4), a.snz = S.plane(5), a.ns = S.n;
+  a.mx = Mo.plane(0), a.my = Mo.plane(1), a.mz = Mo.plane(2), a.mnx = Mo.plane(3), a.mny = Mo.plane(4), a.mnz = Mo.plane(5), a.nm = Mo.n;
+  a.pose = c->hyp_pose.as<float>();
+  a.dist = o->dist;
+  a.cos_thres = (float)std::cos((double)(o->angle_deg / 180.0f) * M_PI);
+  a.rev_idx = c->lcp_rev_idx.as<int>(), a.rev_d2 = c->lcp_rev_d2.as<float>(), a.terms = c->lcp_terms.as<float>();
+  a.score = c->hyp_score.as<float>();
+  for (int h0 = 0; h0 < H; h0 += HB) {
+    const int hb = std::min(HB, H - h0);
+    a.h0 = h0;
+    {
+      SpanGuard sg(c, T_LCP_REV);
+      launch_lcp_reverse(a, hb, c->stream);
+    }
+    {
+      SpanGuard sg(c, T_LCP_FWD);
+      launch_lcp_forward(a, hb, c->stream);
+    }
+    launch_lcp_sum(a, hb, c->stream);
+    c->timing.n_lcp_launches += 1;
+  }
+  c->timing.pairs_lcp += 2ll * H * (long long)S.n * Mo.n;
+  // arg-max on the host over H floats: first strict maximum in set order (PoseEstimator.cpp:468-496, best_lcp starts at 0)
+  std::vector<float> sc(H);
+  HIPCHK(c, hipMemcpyAsync(sc.data(), c->hyp_score.p, sizeof(float) * (size_t)H, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int best = 0;
+  float best_lcp = 0.f;
+  for (int h = 0; h < H; ++h)
+    if (sc[h] > best_lcp) best_lcp = sc[h], best = h;
+  if (best_index_out) *best_index_out = best;
+  if (best_score_out) *best_score_out = sc[best];
+  if (best_pose16_out) {
+    HIPCHK(c, hipMemcpyAsync(best_pose16_out, c->hyp_pose.as<float>() + 16 * (size_t)best, sizeof(float) * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return HOP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- clustering
+int hop_cluster_poses_host(const float* poses16, const float* scores, const int* ids, int H, float angle_deg, float dist,
+                           const float* sym_deg3, int* keep_out, int* n_keep_out) {
+  if (!poses16 || !scores || !ids || !sym_deg3 || !keep_out || H < 0) return HOP_E_INVALID;
+  std::vector<int> keep;
+  cluster_core(poses16, scores, ids, H, angle_deg, dist, sym_deg3, keep);
+  for (size_t i = 0; i < keep.size(); ++i) keep_out[i] = keep[i];
+  if (n_keep_out) *n_keep_out = (int)keep.size();
+  return HOP_OK;
+}
+
+int hop_cluster_poses(hop_ctx* c, float angle_deg, float dist, const float* sym_deg3, int assign_id) {
+  if (!c || !sym_deg3) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int H = c->n_hyp;
+  if (H == 0) return HOP_OK;
+  std::vector<float> pose((size_t)H * 16), sc(H);
+  std::vector<int> ids(H);
+  int n = 0;
+  int rc = hop_hypos_download(c, pose.data(), sc.data(), ids.data(), H, &n);
+  if (rc) return rc;
+  std::vector<int> keep;
+  cluster_core(pose.data(), sc.data(), ids.data(), H, angle_deg, dist, sym_deg3, keep);
+  std::vector<float> p2(keep.size() * 16), s2(keep.size());
+  std::vector<int> i2(keep.size());
+  for (size_t k = 0; k < keep.size(); ++k) {
+    std::memcpy(&p2[16 * k], &pose[16 * (size_t)keep[k]], sizeof(float) * 16);
+    s2[k] = sc[keep[k]];
+    i2[k] = assign_id ? (int)k : ids[keep[k]];
+  }
+  const int K = (int)keep.size();
+  HIPCHK(c, hipMemcpyAsync(c->hyp_pose.p, p2.data(), sizeof(float) * 16 * (size_t)K, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->hyp_score.p, s2.data(), sizeof(float) * (size_t)K, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->hyp_id.p, i2.data(), sizeof(int) * (size_t)K, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->n_hyp = K;
+  return HOP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- top-k exchange
+int hop_topk_pack(hop_ctx* c, int k, int id_offset, float* rows_out, int* n_rows_out) {
+  if (!c || k <= 0 || !rows_out) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int H = c->n_hyp;
+  std::vector<float> pose((size_t)std::max(H, 1) * 16), sc(std::max(H, 1));
+  std::vector<int> ids(std::max(H, 1));
+  if (H > 0) {
+    int n = 0;
+    const int rc = hop_hypos_download(c, pose.data(), sc.data(), ids.data(), H, &n);
+    if (rc) return rc;
+  }
+  std::vector<int> order(H);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    if (sc[a] > sc[b]) return true;
+    if (sc[a] < sc[b]) return false;
+    return ids[a] < ids[b];
+  });
+  const int m = std::min(k, H);
+  for (int r = 0; r < k; ++r) {
+    float* row = rows_out + (size_t)r * HOP_TOPK_ROW_FLOATS;
+    if (r < m) {
+      const int h = order[r];
+      row[0] = sc[h];
+      const int id = ids[h] + id_offset;
+      std::memcpy(&row[1], &id, 4);
+      std::memcpy(&row[2], &pose[16 * (size_t)h], sizeof(float) * 16);
+    } else {
+      row[0] = -FLT_MAX;
+      const int id = -1;
+      std::memcpy(&row[1], &id, 4);
+      for (int q = 0; q < 16; ++q) row[2 + q] = 0.f;
+    }
+  }
+  if (n_rows_out) *n_rows_out = m;
+  return HOP_OK;
+}
+
+int hop_topk_merge(const float* tables, int n_tables, int k, float* rows_out, int* n_rows_out) {
+  if (!tables || n_tables <= 0 || k <= 0 || !rows_out) return HOP_E_INVALID;
+  std::vector<const float*> rows;
+  for (int t = 0; t < n_tables; ++t)
+    for (int r = 0; r < k; ++r) {
+      const float* row = tables + ((size_t)t * k + r) * HOP_TOPK_ROW_FLOATS;
+      int id;
+      std::memcpy(&id, &row[1], 4);
+      if (id >= 0) rows.push_back(row);
+    }
+  std::stable_sort(rows.begin(), rows.end(), [](const float* a, const float* b) {
+    if (a[0] > b[0]) return true;
+    if (a[0] < b[0]) return false;
+    int ia, ib;
+    std::memcpy(&ia, &a[1], 4);
+    std::memcpy(&ib, &b[1], 4);
+    return ia < ib;
+  });
+  const int m = std::min<int>(k, (int)rows.size());
+  for (int r = 0; r < m; ++r) std::memcpy(rows_out + (size_t)r * HOP_TOPK_ROW_FLOATS, rows[r], sizeof(float) * HOP_TOPK_ROW_FLOATS);
+  for (int r = m; r < k; ++r) {
+    float* row = rows_out + (size_t)r * HOP_TOPK_ROW_FLOATS;
+    row[0] = -FLT_MAX;
+    const int id = -1;
+    std::memcpy(&row[1], &id, 4);
+    for (int q = 0; q < 16; ++q) row[2 + q] = 0.f;
+  }
+  if (n_rows_out) *n_rows_out = m;
+  return HOP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- hand
+int hop_hand_set_scene(hop_ctx* c, const float* scene_xyz, int n_scene, const float* lookup_nrm, int n_lookup, const float* swivel_xyz,
+                       int n_swivel) {
+  if (!c || !scene_xyz || n_scene <= 0 || n_lookup < 0 || n_swivel < 0) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  auto up3 = [&](CloudDevice& d, const float* planes, int n) -> int {
+    CloudHost h;
+    std::vector<float> z((size_t)3 * std::max(n, 1), 0.f);
+    load_cloud_host(h, planes ? planes : z.data(), z.data(), n, false);
+    return upload_cloud(c, d, h);
+  };
+  int rc = up3(c->hand_scene_d, scene_xyz, n_scene);
+  if (rc) return rc;
+  rc = up3(c->hand_lookup_d, lookup_nrm, n_lookup);
+  if (rc) return rc;
+  rc = up3(c->hand_swivel_d, swivel_xyz, n_swivel);
+  if (rc) return rc;
+  c->hand_n_scene = n_scene, c->hand_n_lookup = n_lookup, c->hand_n_swivel = n_swivel;
+  c->have_hand_scene = true;
+  return HOP_OK;
+}
+
+int hop_hand_set_finger(hop_ctx* c, const hop_finger_args* a) {
+  if (!c || !a || !a->model_xyz || !a->model_nrm || a->n_model <= 0 || !a->fp_hist_min_y || a->fp_num_division <= 0) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->finger = *a;
+  c->finger_hist.assign(a->fp_hist_min_y, a->fp_hist_min_y + a->fp_num_division);
+  c->finger.fp_hist_min_y = c->finger_hist.data();
+  CloudHost h;
+  load_cloud_host(h, a->model_xyz, a->model_nrm, a->n_model, false);
+  const int rc = upload_cloud(c, c->hand_model_d, h);
+  if (rc) return rc;
+  c->finger.model_xyz = nullptr, c->finger.model_nrm = nullptr;
+  HIPCHK(c, c->finger_hist_d.ensure(sizeof(float) * a->fp_num_division));
+  HIPCHK(c, hipMemcpyAsync(c->finger_hist_d.p, c->finger_hist.data(), sizeof(float) * a->fp_num_division, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_finger = true;
+  return HOP_OK;
+}
+
+static void mat4_vec4(const M4& T, const float v[4], float out[4]) {
+  for (int i = 0; i < 4; ++i) out[i] = ((T.m[4 * i] * v[0] + T.m[4 * i + 1] * v[1]) + T.m[4 * i + 2] * v[2]) + T.m[4 * i + 3] * v[3];
+}
+
+// objFuncPSO (Hand.cpp:10-178): scalar parts on the host, cloud parts on the device.
+int hop_hand_pso_eval_batch(hop_ctx* c, const double* angles, int n, double* cost_out) {
+  if (!c || !angles || !cost_out || n < 0) return HOP_E_INVALID;
+  if (!c->have_finger || !c->have_hand_scene) return HOP_E_STATE;
+  if (n == 0) return HOP_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const hop_finger_args& a = c->finger;
+  HIPCHK(c, c->pso_particles_h.ensure(sizeof(PsoParticle) * (size_t)n));
+  HIPCHK(c, c->pso_particles_d.ensure(sizeof(PsoParticle) * (size_t)n));
+  HIPCHK(c, c->pso_match_d.ensure(sizeof(int) * (size_t)n));
+  HIPCHK(c, c->pso_sum_d.ensure(sizeof(float) * (size_t)n));
+  HIPCHK(c, c->pso_cnt_d.ensure(sizeof(int) * (size_t)n));
+  HIPCHK(c, c->pso_terms_d.ensure(sizeof(float) * (size_t)n * std::max(c->hand_n_swivel, 1)));
+  HIPCHK(c, c->pso_out_h.ensure((sizeof(int) * 2 + sizeof(float)) * (size_t)n));
+  PsoParticle* P = static_cast<PsoParticle*>(c->pso_particles_h.p);
+  M4 model2handbase, finger_out2parent;
+  std::memcpy(model2handbase.m, a.model2handbase, sizeof(float) * 16);
+  std::memcpy(finger_out2parent.m, a.finger_out2parent, sizeof(float) * 16);
+  std::vector<char> early(n, 0);
+  for (int p = 0; p < n; ++p) {
+    const double X0 = angles[p];
+    M4 tf_self = m4_identity();
+    const float ang = (float)X0;
+    const float cs = std::cos(ang), sn = std::sin(ang);
+    tf_self.m[5] = cs, tf_self.m[6] = -sn, tf_self.m[9] = sn, tf_self.m[10] = cs;
+    const M4 cur = m4_mul(model2handbase, tf_self);
+    float tip1[4], tip2[4];
+    if (a.is_palm_side) {
+      const float t1[4] = {a.fo_min[0], a.fo_max[1], a.fo_min[2], 1};
+      mat4_vec4(m4_mul(cur, finger_out2parent), t1, tip1);
+      const float t2[4] = {a.fp_min[0], a.fp_max[1], a.fp_min[2], 1};
+      mat4_vec4(cur, t2, tip2);
+    } else {
+      const float t1[4] = {a.fp_min[0], a.fp_max[1], a.fp_min[2], 1};
+      mat4_vec4(cur, t1, tip1);
+      const float t2[4] = {a.fp_min[0], a.fp_max[1], a.fp_max[2], 1};
+      mat4_vec4(cur, t2, tip2);
+    }
+    float g1, g2;
+    if (a.is_right_side) g1 = tip1[1] - a.pair_tip1[1], g2 = tip2[1] - a.pair_tip2[1];
+    else g1 = -tip1[1] + a.pair_tip1[1], g2 = -tip2[1] + a.pair_tip2[1];
+    PsoParticle& pp = P[p];
+    std::memset(&pp, 0, sizeof(pp));
+    if (g1 < a.gripper_min_dist || g2 < a.gripper_min_dist) {
+      float score = 0;
+      const float penalty = (float)(1e3 + 1e3 * (double)std::fabs(a.gripper_min_dist - g1));
+      score -= penalty;
+      cost_out[p] = -score;
+      early[p] = 1;
+      pp.skip = 1;
+      continue;
+    }
+    const M4 inv = m4_inverse_affine(cur);
+    for (int k = 0; k < 12; ++k) pp.T[k] = cur.m[k], pp.Tinv[k] = inv.m[k];
+  }
+  HIPCHK(c, hipMemcpyAsync(c->pso_particles_d.p, P, sizeof(PsoParticle) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->pso_match_d.p, 0, sizeof(int) * (size_t)n, c->stream));
+  PsoArgs pa{};
+  pa.particles = c->pso_particles_d.as<PsoParticle>();
+  const CloudDevice& Mo = c->hand_model_d;
+  pa.mx = Mo.plane(0), pa.my = Mo.plane(1), pa.mz = Mo.plane(2), pa.mnx = Mo.plane(3), pa.mny = Mo.plane(4), pa.mnz = Mo.plane(5), pa.nm = Mo.n;
+  pa.sx = c->hand_scene_d.plane(0), pa.sy = c->hand_scene_d.plane(1), pa.sz = c->hand_scene_d.plane(2), pa.ns = c->hand_n_scene;
+  pa.lnx = c->hand_lookup_d.plane(0), pa.lny = c->hand_lookup_d.plane(1), pa.lnz = c->hand_lookup_d.plane(2), pa.n_lookup = c->hand_n_lookup;
+  pa.wx = c->hand_swivel_d.plane(0), pa.wy = c->hand_swivel_d.plane(1), pa.wz = c->hand_swivel_d.plane(2), pa.n_swivel = c->hand_n_swivel;
+  pa.dist_thres = a.dist_thres, pa.cos_normal_thres = a.cos_normal_thres, pa.check_normal = a.check_normal;
+  pa.fp_min_z = a.fp_min[2], pa.fp_stride_z = a.fp_stride_z, pa.fp_num_division = a.fp_num_division;
+  pa.hist_min_y = c->finger_hist_d.as<float>();
+  pa.match_count = c->pso_match_d.as<int>(), pa.outer_terms = c->pso_terms_d.as<float>();
+  pa.outer_sum = c->pso_sum_d.as<float>(), pa.outer_cnt = c->pso_cnt_d.as<int>();
+  {
+    SpanGuard sg(c, T_PSO);
+    launch_pso(pa, n, c->stream);
+  }
+  c->timing.n_pso_launches += 1;
+  c->timing.pairs_pso += (long long)n * Mo.n * c->hand_n_scene;
+  int* h_match = static_cast<int*>(c->pso_out_h.p);
+  int* h_cnt = h_match + n;
+  float* h_sum = reinterpret_cast<float*>(h_cnt + n);
+  HIPCHK(c, hipMemcpyAsync(h_match, c->pso_match_d.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_cnt, c->pso_cnt_d.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_sum, c->pso_sum_d.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int p = 0; p < n; ++p) {
+    if (early[p]) continue;
+    const double X0 = angles[p];
+    float score = 0;
+    // num_match += 1 + X[0] per match, float accumulator (Hand.cpp:99,104,117): replayed exactly
+    float num_match = 0;
+    for (int k = 0; k < h_match[p]; ++k) num_match = (float)((double)num_match + (1 + X0));
+    score += num_match;
+    if (num_match == 0) {
+      score = (float)(-100 + X0);
+      cost_out[p] = -score;
+      continue;
+    }
+    const int num_outer = h_cnt[p];
+    const float avg = h_sum[p] / num_outer;  // 0/0 -> NaN when nothing is outside, as in the reference
+    if (num_outer >= a.max_outter_pts || avg >= 0.005) {
+      const float pen = (float)(1e3 + (double)(a.outter_pt_dist_weight * std::max(avg - a.outter_pt_dist, 0.0f)));
+      score -= pen;
+    } else if (num_outer >= 0 && avg - a.outter_pt_dist > 0) {
+      const float pen = a.outter_pt_dist_weight * std::exp(avg * 1000);
+      score -= pen;
+    }
+    cost_out[p] = -score;
+  }
+  return HOP_OK;
+}
+
+void hop_pso_default_settings(hop_pso_settings* s) {
+  if (!s) return;
+  s->n_pop = 15, s->n_gen = 3, s->check_freq = 10;
+  s->c_cog = 0.1, s->c_soc = 0.9, s->initial_w = 0.0;
+  s->w_min = 0.10, s->w_max = 0.99, s->err_tol = 1e-5;
+  s->lower_rad = 0.0, s->upper_rad = 120.0 * M_PI / 180.0;
+  s->seed = 0;
+}
+
+// optim::pso_int (pso.hpp:146-351): vals_bound, centre particle, inertia method 1, velocity method 1.
+// Random stream: std::mt19937_64(seed) + uniform_real_distribution<double>(0,1) (what Armadillo's C++11
+// backend draws from after arma_rng::set_seed); see DESIGN.md "PSO random stream".
+int hop_hand_pso_search(hop_ctx* c, const hop_pso_settings* s, double* best_angle_out, double* objval_out) {
+  if (!c || !s || s->n_pop <= 0 || s->n_gen < 0) return HOP_E_INVALID;
+  if (!c->have_finger || !c->have_hand_scene) return HOP_E_STATE;
+  std::mt19937_64 eng(s->seed);
+  std::uniform_real_distribution<double> U(0.0, 1.0);
+  const size_t n_pop = (size_t)s->n_pop + 1;
+  const size_t n_gen = (size_t)s->n_gen;
+  const size_t check_freq = s->check_freq > 0 ? (size_t)s->check_freq : n_gen;
+  double par_w = s->initial_w;
+  auto inv_tf = [&](double v) { return v * (s->upper_rad - s->lower_rad) + s->lower_rad; };
+  std::vector<double> P(n_pop), V(n_pop), objfn(n_pop), ang(n_pop);
+  auto eval_all = [&]() -> int {
+    for (size_t i = 0; i < n_pop; ++i) ang[i] = inv_tf(P[i]);
+    const int rc = hop_hand_pso_eval_batch(c, ang.data(), (int)n_pop, objfn.data());
+    if (rc) return rc;
+    for (size_t i = 0; i < n_pop; ++i)
+      if (!std::isfinite(objfn[i])) objfn[i] = std::numeric_limits<double>::max();
+    return HOP_OK;
+  };
+  for (size_t i = 0; i < n_pop; ++i) P[i] = U(eng);
+  auto center = [&]() {
+    double sum = 0;
+    for (size_t i = 0; i + 1 < n_pop; ++i) sum += P[i];
+    P[n_pop - 1] = sum / double(n_pop - 1);
+  };
+  center();
+  int rc = eval_all();
+  if (rc) return rc;
+  std::vector<double> best_vals = objfn, best_vecs = P;
+  size_t gi = std::min_element(objfn.begin(), objfn.end()) - objfn.begin();
+  double cur_best = objfn[gi], best_check = cur_best, gbest = P[gi];
+  size_t iter = 0;
+  double err = 2.0 * s->err_tol;
+  for (size_t i = 0; i < n_pop; ++i) V[i] = U(eng);
+  std::vector<double> r1(n_pop), r2(n_pop);
+  while (err > s->err_tol && iter < n_gen) {
+    iter++;
+    for (size_t i = 0; i < n_pop; ++i) r1[i] = U(eng);
+    for (size_t i = 0; i < n_pop; ++i) r2[i] = U(eng);
+    for (size_t i = 0; i < n_pop; ++i) {
+      V[i] = par_w * V[i] + s->c_cog * r1[i] * (best_vecs[i] - P[i]) + s->c_soc * r2[i] * (gbest - P[i]);
+      P[i] += V[i];
+    }
+    center();
+    for (size_t i = 0; i < n_pop; ++i) P[i] = std::min(std::max(P[i], 0.0), 1.0);
+    rc = eval_all();
+    if (rc) return rc;
+    for (size_t i = 0; i < n_pop; ++i)
+      if (objfn[i] < best_vals[i]) best_vals[i] = objfn[i], best_vecs[i] = P[i];
+    const size_t mi = std::min_element(best_vals.begin(), best_vals.end()) - best_vals.begin();
+    if (best_vals[mi] < cur_best) cur_best = best_vals[mi], gbest = best_vecs[mi];
+    if (iter % check_freq == 0) err = std::fabs(cur_best - best_check) / (1e-20 + std::fabs(best_check));
+    if (cur_best < best_check) best_check = cur_best;
+    par_w = s->w_min + (s->w_max - s->w_min) * double(iter + 1) / double(n_gen);
+  }
+  if (best_angle_out) *best_angle_out = inv_tf(gbest);
+  if (objval_out) *objval_out = (double)(float)best_check;
+  return HOP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- timing
+int hop_timing_enable(hop_ctx* c, int on) {
+  if (!c) return HOP_E_INVALID;
+  c->timing_on = on != 0;
+  return HOP_OK;
+}
+int hop_timing_reset(hop_ctx* c) {
+  if (!c) return HOP_E_INVALID;
+  resolve_spans(c);
+  std::memset(&c->timing, 0, sizeof(c->timing));
+  return HOP_OK;
+}
+int hop_timing_get(hop_ctx* c, hop_timing* out) {
+  if (!c || !out) return HOP_E_INVALID;
+  resolve_spans(c);
+  *out = c->timing;
+  return HOP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+// hop_device.h -- argument blocks and record layouts shared by the kernels (hop_kernels.hip) and the
+// host side of libhop (hop_ctx.hip).  Plain structs, passed to kernels by value.
+#ifndef HOP_DEVICE_H_
+#define HOP_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include "hop_math.h"
+
+namespace hop {
+
+constexpr int NN_TILE = 2048;  // targets per LDS tile (float4 each -> 32 KiB)
+constexpr int NN_CH = 16;      // targets per min-chunk of the scan
+constexpr int PPF_ROWS = 64;   // rows of the PPF matrix handled per block
+constexpr int ICP_NACC = 29;   // 21 (lower triangle of J^T J) + 6 (J^T r) + mse + count
+constexpr int MAX_RING = 64;   // samples on the normal cone (normalset.hpp:208-210; <= 2*ceil(2*pi*atan(pi)*3.5) = 56)
+
+// one base (4 points of P) of the generator, prepared by the host for a batch
+struct BaseDev {
+  float bpos[4][3];  // centred P coordinates of base_3D_[0..3]
+  float dist1, dist2;  // |b0-b1|, |b2-b3| (match4pcsBase.hpp:250-251)
+  float inv1, inv2;    // quadrilateral invariants (TryQuadrilateral)
+  EdgeFeat e1, e2;     // pairPPFisGood features of the two base edges
+  int nb_sample;       // cone samples (normalset.hpp:208-210)
+  float ring[MAX_RING][3];
+};
+
+struct PpfMatrixArgs {
+  const float *x, *y, *z, *nx, *ny, *nz;  // centred P, normals already "PPF-normalised"
+  int n, words;                            // words = ceil(n/64)
+  const unsigned* bitmap;                  // key set as a direct-address bitmap
+  int dist_bins;
+  unsigned long long* out;  // n x words
+};
+
+struct PairArgs {
+  const BaseDev* bases;
+  const float *qx, *qy, *qz, *qnx, *qny, *qnz;  // sampled, centred Q
+  int nq;
+  float eps;  // distance_factor * delta
+  unsigned *pairs1, *pairs2;  // [nbases][cap] packed (a<<16|b)
+  int *cnt1, *cnt2;
+  int cap;
+  int* overflow;
+};
+
+struct QuadElem {  // per first pair
+  short cx, cy, cz, nid;
+  float px, py, pz;
+};
+struct QuadQuery {  // per second pair
+  short cx, cy, cz, pad;
+  float px, py, pz;
+  unsigned mask[11];  // 343 normal bins
+};
+
+struct QuadPrepArgs {
+  const BaseDev* bases;
+  const float *qx, *qy, *qz;  // sampled centred Q (world)
+  const float *ux, *uy, *uz;  // same points in the unit cube (pairCreationFunctor.h:104-108,155-157)
+  const unsigned *pairs1, *pairs2;
+  const int *cnt1, *cnt2;
+  int cap;
+  NsetGeom geom;
+  QuadElem* elems;
+  QuadQuery* queries;
+};
+
+struct Candidate {
+  float T[12];  // centred-frame transform (rows 0..2)
+  float c1[3], c2[3];
+  unsigned long long key;
+};
+
+struct QuadArgs {
+  const BaseDev* bases;
+  const float *qx, *qy, *qz;
+  const unsigned *pairs1, *pairs2;
+  const int *cnt1, *cnt2;
+  int cap;
+  NsetGeom geom;
+  const QuadElem* elems;
+  const QuadQuery* queries;
+  float dist_thr2;  // distance_threshold2 (unsquared delta)
+  float delta;
+  int base_index0;
+  Candidate* cands;
+  int* cand_counts;
+  int* cand_count;
+  int cand_cap;
+  int* nquads;  // per base: congruent quadrilaterals found (before the rigid-fit gate)
+  int* overflow;
+};
+
+struct VerifyArgs {
+  const float *px, *py, *pz;  // centred P
+  int np;
+  const float *qx, *qy, *qz;  // sampled centred Q
+  int nq;
+  const float* T;  // transforms, t_stride floats apart, first 12 floats = rows 0..2
+  int t_stride;
+  const int* n_cand_ptr;  // device counter (or null -> n_cand)
+  int n_cand, cand_cap;
+  float sq_eps;
+  int* counts;
+};
+
+struct GridDev {
+  float ox, oy, oz, inv_cell;
+  int dx, dy, dz;
+  const int* cell_start;  // dx*dy*dz + 1
+  const float4* pts;      // points sorted by cell
+};
+
+struct EmitArgs {
+  const Candidate* cands;
+  const int* cand_counts;
+  const int* cand_count;
+  int cand_cap;
+  float cp[3], cq[3];
+  int nq;
+  float* pose;
+  float* score;
+  unsigned long long* key;
+  unsigned* inv_count;
+  int* hyp_count;
+  int hyp_cap;
+  int* cand_total;  // running sum of candidates over batches
+  int* overflow;
+};
+
+struct LcpArgs {
+  const float *sx, *sy, *sz, *snx, *sny, *snz;
+  int ns;
+  const float *mx, *my, *mz, *mnx, *mny, *mnz;
+  int nm;
+  const float* pose;
+  int h0;
+  float dist, cos_thres;
+  int* rev_idx;
+  float* rev_d2;
+  float* terms;
+  float* score;
+};
+
+struct IcpState {
+  float T_inc[12];
+  float final_tf[16];
+  double mse_prev;
+  int iterations, active, converged, pad;
+};
+
+struct IcpArgs {
+  const float *sx, *sy, *sz, *snx, *sny, *snz;
+  int ns;
+  const float *mx, *my, *mz, *mnx, *mny, *mnz;
+  int nm;
+  float* pose;
+  int h0;
+  int iter, max_iter;
+  float max_d2, cos_thr;
+  float* moved;     // [hb][6][ns]
+  double* partial;  // [hb][blocks][ICP_NACC]
+  IcpState* state;
+};
+
+struct PsoParticle {
+  float T[12];     // cur_model2handbase
+  float Tinv[12];  // its inverse
+  int skip, pad[3];
+};
+
+struct PsoArgs {
+  const PsoParticle* particles;
+  const float *mx, *my, *mz, *mnx, *mny, *mnz;
+  int nm;
+  const float *sx, *sy, *sz;
+  int ns;
+  const float *lnx, *lny, *lnz;
+  int n_lookup;
+  const float *wx, *wy, *wz;
+  int n_swivel;
+  float dist_thres, cos_normal_thres;
+  int check_normal;
+  float fp_min_z, fp_stride_z;
+  int fp_num_division;
+  const float* hist_min_y;
+  int* match_count;
+  float* outer_terms;
+  float* outer_sum;
+  int* outer_cnt;
+};
+
+// launchers (hop_kernels.hip)
+void launch_ppf_matrix(const PpfMatrixArgs& a, hipStream_t s);
+void launch_pairs(const PairArgs& a, int nbases, hipStream_t s);
+void launch_quad_prep(const QuadPrepArgs& a, int nbases, int max_items, hipStream_t s);
+void launch_quads(const QuadArgs& a, int nbases, int blocks_per_base, hipStream_t s);
+void launch_verify(const VerifyArgs& a, int mode, const GridDev* gd, int blocks, hipStream_t s);
+void launch_emit(const EmitArgs& a, int blocks, hipStream_t s);
+void launch_gather_hypos(const unsigned* perm, int n, const float* pose_in, const float* score_in, float* pose_out,
+                         float* score_out, int* id_out, hipStream_t s);
+void launch_iota(unsigned* p, int n, hipStream_t s);
+void launch_score_keys(const float* score, const int* ids, int n, unsigned long long* key, hipStream_t s);
+void launch_lcp_reverse(const LcpArgs& a, int hb, hipStream_t s);
+void launch_lcp_forward(const LcpArgs& a, int hb, hipStream_t s);
+void launch_lcp_sum(const LcpArgs& a, int hb, hipStream_t s);
+int icp_blocks_per_hyp(int ns);
+void launch_icp_init(IcpState* st, int hb, hipStream_t s);
+void launch_icp_nn(const IcpArgs& a, int hb, hipStream_t s);
+void launch_icp_solve(const IcpArgs& a, int hb, hipStream_t s);
+void launch_icp_finish(const IcpArgs& a, int hb, int* iters, int* conv, hipStream_t s);
+void launch_pso(const PsoArgs& a, int n_particles, hipStream_t s);
+void launch_grid_cell_ids(const float* x, const float* y, const float* z, int n, const GridDev& gd, int* cell_of, int* cell_count,
+                          hipStream_t s);
+
+}  // namespace hop
+#endif

@@ -1,0 +1,974 @@
+// hop_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4, wave64).
+//
+// Layout rules used throughout
+//   * clouds live in HBM as SoA planes (x[], y[], z[], nx[], ny[], nz[]): a wave reads 64 consecutive
+//     floats per plane = one 256-B transaction.
+//   * nearest-neighbour scans keep the QUERY points in registers (R per lane) and stream the TARGET
+//     points through an LDS tile as float4{x,y,z,_}; every lane reads the same LDS address per step, which
+//     the LDS serves as a broadcast (no bank conflict), and one ds_read_b128 feeds R*9 VALU ops.
+//   * squared distances use the exact operation order of the CPU code they replace (Eigen's
+//     dx^2+(dy^2+dz^2) for the generator's Verify, FLANN's (dx^2+dy^2)+dz^2 for PCL searches), compiled
+//     with -ffp-contract=off, so inlier counts and nearest indices are bit-reproducible.
+//   * per-hypothesis integer results are reduced with wave ballots + one atomic per (wave, hypothesis).
+#include "hop_device.h"
+
+namespace hop {
+
+// ------------------------------------------------------------------------------------------------
+// brute-force nearest neighbour core
+// ------------------------------------------------------------------------------------------------
+#define HOP_FAR 1.0e15f  // padding coordinate: d^2 ~ 3e30, finite, never the minimum of a real cloud
+
+template <bool FLANN>
+__device__ __forceinline__ float sqdist(const V3& q, const float4& t) {
+  const float dx = q.x - t.x, dy = q.y - t.y, dz = q.z - t.z;
+  if (FLANN) return (dx * dx + dy * dy) + dz * dz;
+  return dx * dx + (dy * dy + dz * dz);
+}
+
+// Scans `tn` targets (multiple of NN_CH) of an LDS tile for R register queries.  Keeps, per query, the
+// smallest squared distance and the index of the FIRST target that attains it (the tie rule of a linear
+// scan).  The per-pair work is sub/mul/add + one v_min; the index is resolved once per tile from the
+// winning NN_CH-chunk, so the hot loop carries no compare/select.
+template <int R, bool FLANN, bool WANT_INDEX>
+__device__ __forceinline__ void nn_scan_tile(const float4* __restrict__ tile, int tn, int tile_base, const V3 (&q)[R],
+                                             float (&best)[R], int (&bidx)[R]) {
+  int chunk_of[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) chunk_of[r] = -1;
+  for (int c = 0; c < tn; c += NN_CH) {
+    float cm[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) cm[r] = 3.0e38f;
+#pragma unroll
+    for (int k = 0; k < NN_CH; ++k) {
+      const float4 t = tile[c + k];
+#pragma unroll
+      for (int r = 0; r < R; ++r) cm[r] = fminf(cm[r], sqdist<FLANN>(q[r], t));
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (cm[r] < best[r]) {
+        best[r] = cm[r];
+        chunk_of[r] = c;
+      }
+  }
+  if (WANT_INDEX) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (chunk_of[r] >= 0) {
+        int found = chunk_of[r];
+        for (int k = NN_CH - 1; k >= 0; --k)  // last write wins -> lowest k with equality
+          if (sqdist<FLANN>(q[r], tile[chunk_of[r] + k]) == best[r]) found = chunk_of[r] + k;
+        bidx[r] = tile_base + found;
+      }
+    }
+  }
+}
+
+// cooperative staging of a tile of raw SoA points into LDS (coalesced plane reads -> float4 writes)
+__device__ __forceinline__ void stage_tile_raw(float4* tile, const float* __restrict__ X, const float* __restrict__ Y,
+                                               const float* __restrict__ Z, int start, int n_total, int tn) {
+  for (int t = threadIdx.x; t < tn; t += blockDim.x) {
+    const int j = start + t;
+    float4 v;
+    if (j < n_total) v = make_float4(X[j], Y[j], Z[j], 0.f);
+    else v = make_float4(HOP_FAR, HOP_FAR, HOP_FAR, 0.f);
+    tile[t] = v;
+  }
+}
+// same, with a rigid transform applied on the way in (batched SE(3) transform fused into the scan)
+__device__ __forceinline__ void stage_tile_tf(float4* tile, const float* __restrict__ X, const float* __restrict__ Y,
+                                              const float* __restrict__ Z, int start, int n_total, int tn,
+                                              const float* T) {
+  for (int t = threadIdx.x; t < tn; t += blockDim.x) {
+    const int j = start + t;
+    float4 v;
+    if (j < n_total) {
+      const V3 p = m4_point(T, v3(X[j], Y[j], Z[j]));
+      v = make_float4(p.x, p.y, p.z, 0.f);
+    } else
+      v = make_float4(HOP_FAR, HOP_FAR, HOP_FAR, 0.f);
+    tile[t] = v;
+  }
+}
+
+__device__ __forceinline__ int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// one atomic per (wave, key) for lanes that vote `flag` on integer `key`
+__device__ __forceinline__ void wave_count_by_key(bool flag, int key, int* __restrict__ counts) {
+  unsigned long long pending = __ballot(flag);
+  while (pending) {
+    const int leader = __ffsll((long long)pending) - 1;
+    const int k = __shfl(key, leader);
+    const unsigned long long same = __ballot(flag && key == k);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&counts[k], __popcll(same));
+    pending &= ~same;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: PPF key membership matrix.  bit (i,j) = key(P[i] -> P[j]) is in the table
+// (gr::computePPF(sampled_P_3D_[i], sampled_P_3D_[j]) + _ppfs.find, matchBase.hpp:131-134,158-159,196-201).
+// One wave owns 64 consecutive columns j (coalesced plane reads, kept in registers) and walks a tile of
+// rows i whose data sits in LDS (broadcast reads); __ballot packs the 64 answers of a row into one word.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ppf_matrix(PpfMatrixArgs a) {
+  __shared__ float rows[PPF_ROWS][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int jb = blockIdx.x * 4 + wave;  // 64-column block
+  const int j = jb * 64 + lane;
+  const int i0 = blockIdx.y * PPF_ROWS;
+  for (int t = threadIdx.x; t < PPF_ROWS; t += blockDim.x) {
+    const int i = i0 + t;
+    if (i < a.n) {
+      rows[t][0] = a.x[i], rows[t][1] = a.y[i], rows[t][2] = a.z[i];
+      rows[t][3] = a.nx[i], rows[t][4] = a.ny[i], rows[t][5] = a.nz[i];
+    }
+  }
+  __syncthreads();
+  if (jb >= a.words) return;
+  V3 pj = v3(0, 0, 0), nj = v3(0, 0, 1);
+  const bool jvalid = j < a.n;
+  if (jvalid) {
+    pj = v3(a.x[j], a.y[j], a.z[j]);
+    nj = v3(a.nx[j], a.ny[j], a.nz[j]);
+  }
+  const int rmax = min(PPF_ROWS, a.n - i0);
+  for (int r = 0; r < rmax; ++r) {
+    const V3 pi = v3(rows[r][0], rows[r][1], rows[r][2]);
+    const V3 ni = v3(rows[r][3], rows[r][4], rows[r][5]);
+    bool member = false;
+    int key[4];
+    if (jvalid && (i0 + r) != j && ppf_key(pi, ni, pj, nj, key)) {
+      // direct-address bitmap: dist bin k0/5 in [0,dmax], angle bins k/10 in [0,18]
+      const int d = key[0] / 5, a1 = key[1] / 10, a2 = key[2] / 10, a3 = key[3] / 10;
+      if (key[0] >= 0 && d < a.dist_bins && (unsigned)a1 < 19u && (unsigned)a2 < 19u && (unsigned)a3 < 19u) {
+        const unsigned bit = ((unsigned)(d * 19 + a1) * 19u + (unsigned)a2) * 19u + (unsigned)a3;
+        member = (a.bitmap[bit >> 5] >> (bit & 31)) & 1u;
+      }
+    }
+    const unsigned long long word = __ballot(member);
+    if (lane == 0) a.out[(size_t)(i0 + r) * a.words + jb] = word;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3a: pair extraction for a batch of bases (FunctorSuper4PCS::ExtractPairs + PairCreationFunctor::process
+// + AdaptivePointFilter, FunctorSuper4pcs.h:79-116, pairCreationFunctor.h:189-214, PointPairFilter.h:88-172)
+// as the brute force the reference's octree accelerator is specified to equal.  One pass serves both
+// base edges: a pair (i>j) is tested against edge (0,1) and edge (2,3).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_append_pair(bool flag, unsigned a, unsigned b, unsigned* list, int* counter, int cap,
+                                                 int* overflow) {
+  const unsigned long long m = __ballot(flag);
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, 2 * __popcll(m));
+  base = __shfl(base, __ffsll((long long)m) - 1);
+  if (flag) {
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    const int pos = base + 2 * rank;
+    if (pos + 1 < cap) {
+      list[pos] = (a << 16) | b;      // (i,j)
+      list[pos + 1] = (b << 16) | a;  // (j,i)
+    } else
+      *overflow = 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pairs(PairArgs a) {
+  const int b = blockIdx.y;
+  const BaseDev& B = a.bases[b];
+  const int n = a.nq;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = (int)(t / n), j = (int)(t % n);
+  bool ok1 = false, ok2 = false;
+  if (i < n && j < i) {
+    const V3 p = v3(a.qx[j], a.qy[j], a.qz[j]), np = v3(a.qnx[j], a.qny[j], a.qnz[j]);
+    const V3 q = v3(a.qx[i], a.qy[i], a.qz[i]), nq = v3(a.qnx[i], a.qny[i], a.qnz[i]);
+    const float distance = vnorm(q - p);
+    const double dd = (double)distance;
+    if (!(fabs(dd - (double)B.dist1) > (double)a.eps)) ok1 = pair_ppf_is_good(p, np, q, nq, B.e1);
+    if (!(fabs(dd - (double)B.dist2) > (double)a.eps)) ok2 = pair_ppf_is_good(p, np, q, nq, B.e2);
+  }
+  unsigned* l1 = a.pairs1 + (size_t)b * a.cap;
+  unsigned* l2 = a.pairs2 + (size_t)b * a.cap;
+  wave_append_pair(ok1, (unsigned)i, (unsigned)j, l1, &a.cnt1[b], a.cap, a.overflow);
+  wave_append_pair(ok2, (unsigned)i, (unsigned)j, l2, &a.cnt2[b], a.cap, a.overflow);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3b: congruent quadrilaterals (FunctorSuper4PCS::FindCongruentQuadrilaterals, FunctorSuper4pcs.h:131-293)
+// with the IndexedNormalSet lookups (normalset.hpp:111-253) expressed as a predicate on
+// (first pair, second pair): the query cell lies in the element's 1-ring, the element's normal bin is one
+// of the bins painted by the query cone, and the world-space invariant points are close.
+//   prep: per first pair  -> cell, normal bin, world invariant point
+//         per second pair -> cell, 343-bit painted-bin mask, world query point
+//   main: the n1 x n2 predicate matrix, fused with the 3-point rigid fit (ComputeRigidTransformation) and
+//         the rms<delta gate of TryCongruentSet (cse.hpp:273-291); survivors become Verify candidates.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_quad_prep(QuadPrepArgs a) {
+  const int b = blockIdx.y;
+  const BaseDev& B = a.bases[b];
+  const int n1 = min(a.cnt1[b], a.cap), n2 = min(a.cnt2[b], a.cap);
+  const NsetGeom g = a.geom;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n1 + n2; t += gridDim.x * blockDim.x) {
+    if (t < n1) {
+      const unsigned pr = a.pairs1[(size_t)b * a.cap + t];
+      const int i0 = pr >> 16, i1 = pr & 0xffff;
+      const V3 u1 = v3(a.ux[i0], a.uy[i0], a.uz[i0]), u2 = v3(a.ux[i1], a.uy[i1], a.uz[i1]);
+      const V3 nrm = vnormalized(u2 - u1);
+      const V3 pos = u1 + B.inv1 * (u2 - u1);
+      QuadElem e;
+      e.cx = (short)(int)(pos.x / g.epsilon), e.cy = (short)(int)(pos.y / g.epsilon), e.cz = (short)(int)(pos.z / g.epsilon);
+      e.nid = (short)nset_index_normal(g, nrm);
+      const V3 w1 = v3(a.qx[i0], a.qy[i0], a.qz[i0]), w2 = v3(a.qx[i1], a.qy[i1], a.qz[i1]);
+      const V3 ip = w1 + (w2 - w1) * B.inv1;
+      e.px = ip.x, e.py = ip.y, e.pz = ip.z;
+      a.elems[(size_t)b * a.cap + t] = e;
+    } else {
+      const int s = t - n1;
+      const unsigned pr = a.pairs2[(size_t)b * a.cap + s];
+      const int i0 = pr >> 16, i1 = pr & 0xffff;
+      const V3 u1 = v3(a.ux[i0], a.uy[i0], a.uz[i0]), u2 = v3(a.ux[i1], a.uy[i1], a.uz[i1]);
+      const V3 query = u1 + B.inv2 * (u2 - u1);
+      const V3 queryn = vnormalized(u2 - u1);
+      QuadQuery q;
+      q.cx = (short)(int)(query.x / g.epsilon), q.cy = (short)(int)(query.y / g.epsilon), q.cz = (short)(int)(query.z / g.epsilon);
+      q.pad = 0;
+      const V3 w1 = v3(a.qx[i0], a.qy[i0], a.qz[i0]), w2 = v3(a.qx[i1], a.qy[i1], a.qz[i1]);
+      const V3 qq = w1 + B.inv2 * (w2 - w1);
+      q.px = qq.x, q.py = qq.y, q.pz = qq.z;
+      // Quaternion::setFromTwoVectors((0,0,1), queryn) then q * ringvec (Geometry/Quaternion.h:578-612,471-481)
+      const V3 v1 = vnormalized(queryn);
+      float c = v1.z;  // v1.dot((0,0,1)) = x*0 + (y*0 + z*1)
+      c = v1.x * 0.f + (v1.y * 0.f + v1.z * 1.f);
+      V3 qv;
+      float qw;
+      if (c < -1.f + 1e-5f) {
+        // Eigen falls back to a JacobiSVD null vector here; analytic stand-in (DESIGN.md "known deviations")
+        c = fmaxf(c, -1.f);
+        V3 axis = vnormalized(v3(-v1.y, v1.x, 0.f));
+        if (vsqn(axis) == 0.f) axis = v3(1.f, 0.f, 0.f);
+        const float w2q = (1.f + c) * 0.5f;
+        qw = sqrtf(w2q);
+        qv = axis * sqrtf(1.f - w2q);
+      } else {
+        const V3 axis = vcross(v3(0.f, 0.f, 1.f), v1);
+        const float s2 = sqrtf((1.f + c) * 2.f);
+        const float invs = 1.f / s2;
+        qv = axis * invs;
+        qw = s2 * 0.5f;
+      }
+      for (int w = 0; w < 11; ++w) q.mask[w] = 0u;
+      for (int k = 0; k < B.nb_sample; ++k) {
+        const V3 rv = v3(B.ring[k][0], B.ring[k][1], B.ring[k][2]);
+        V3 uv = vcross(qv, rv);
+        uv = uv + uv;
+        const V3 rot = (rv + qw * uv) + vcross(qv, uv);
+        const int id = nset_index_normal(g, vnormalized(rot));
+        if (id >= 0 && id < 343) q.mask[id >> 5] |= 1u << (id & 31);
+      }
+      a.queries[(size_t)b * a.cap + s] = q;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_quads(QuadArgs a) {
+  const int b = blockIdx.y;
+  const BaseDev& B = a.bases[b];
+  const int n1 = min(a.cnt1[b], a.cap), n2 = min(a.cnt2[b], a.cap);
+  const long long total = (long long)n1 * n2;
+  const int eg = a.geom.eg_size;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    // consecutive lanes walk consecutive first pairs for one second pair: the query is wave-uniform most of
+    // the time (scalar loads), the elements are read coalesced.
+    const int id2 = (int)(t / n1), id1 = (int)(t % n1);
+    const QuadElem e = a.elems[(size_t)b * a.cap + id1];
+    const QuadQuery& q = a.queries[(size_t)b * a.cap + id2];
+    const int dx = e.cx - q.cx, dy = e.cy - q.cy, dz = e.cz - q.cz;
+    bool ok = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+    ok = ok && e.cx >= 0 && e.cx < eg && e.cy >= 0 && e.cy < eg && e.cz >= 0 && e.cz < eg;
+    ok = ok && q.cx >= 0 && q.cx < eg && q.cy >= 0 && q.cy < eg && q.cz >= 0 && q.cz < eg;
+    ok = ok && e.nid >= 0 && e.nid < 343 && ((q.mask[e.nid >> 5] >> (e.nid & 31)) & 1u);
+    if (ok) {
+      const V3 d = v3(q.px, q.py, q.pz) - v3(e.px, e.py, e.pz);
+      ok = vsqn(d) <= a.dist_thr2;  // squared norm vs the UNSQUARED threshold (FunctorSuper4pcs.h:277)
+    }
+    {
+      const unsigned long long m = __ballot(ok);
+      if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&a.nquads[b], __popcll(m));
+    }
+    if (!ok) continue;
+    const unsigned p1 = a.pairs1[(size_t)b * a.cap + id1], p2 = a.pairs2[(size_t)b * a.cap + id2];
+    const int qa = p1 >> 16, qb = p1 & 0xffff, qc = p2 >> 16;
+    // TryCongruentSet (cse.hpp:229-291): only the first three points enter the fit
+    V3 ref[3], cand[3];
+    for (int k = 0; k < 3; ++k) ref[k] = v3(B.bpos[k][0], B.bpos[k][1], B.bpos[k][2]);
+    cand[0] = v3(a.qx[qa], a.qy[qa], a.qz[qa]);
+    cand[1] = v3(a.qx[qb], a.qy[qb], a.qz[qb]);
+    cand[2] = v3(a.qx[qc], a.qy[qc], a.qz[qc]);
+    const V3 c1 = ((ref[0] + ref[1]) + ref[2]) / 3.f;
+    const V3 c2 = ((cand[0] + cand[1]) + cand[2]) / 3.f;
+    float T[16], rms;
+    const bool fit = rigid_3pt(ref, cand, c1, c2, T, &rms);
+    if (!(fit && rms >= 0.f && rms < a.delta)) continue;
+    const int slot = atomicAdd(a.cand_count, 1);
+    if (slot >= a.cand_cap) {
+      *a.overflow = 1;
+      continue;
+    }
+    Candidate cd;
+    for (int k = 0; k < 12; ++k) cd.T[k] = T[k];
+    cd.c1[0] = c1.x, cd.c1[1] = c1.y, cd.c1[2] = c1.z;
+    cd.c2[0] = c2.x, cd.c2[1] = c2.y, cd.c2[2] = c2.z;
+    // canonical order key: base trial, then first pair in (i,j,flip) order, then second pair
+    const unsigned long long k1 = ((unsigned long long)max(qa, qb) << 12 | (unsigned long long)min(qa, qb)) << 1 | (qa < qb ? 1u : 0u);
+    const int qd = p2 & 0xffff;
+    const unsigned long long k2 = ((unsigned long long)max(qc, qd) << 12 | (unsigned long long)min(qc, qd)) << 1 | (qc < qd ? 1u : 0u);
+    cd.key = ((unsigned long long)(a.base_index0 + b) << 50) | (k1 << 25) | k2;
+    a.cands[slot] = cd;
+    a.cand_counts[slot] = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: Verify (CongruentSetExplorationBase::Verify, cse.hpp:346-435), brute force.
+// query g = (candidate c, sample s): T_c * Qs[s]; targets: all of P (centred), streamed through LDS.
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void k_verify_brute(VerifyArgs a) {
+  __shared__ float4 tile[NN_TILE];
+  const int n_cand = a.n_cand_ptr ? min(*a.n_cand_ptr, a.cand_cap) : a.n_cand;
+  const long long total = (long long)n_cand * a.nq;
+  const int QB = 256 * R;
+  const long long nchunks = (total + QB - 1) / QB;
+  for (long long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    V3 q[R];
+    float best[R];
+    int cidx[R], dummy[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const long long g = chunk * QB + (long long)r * 256 + threadIdx.x;
+      best[r] = 3.0e38f;
+      if (g < total) {
+        const int c = (int)(g / a.nq), s = (int)(g % a.nq);
+        cidx[r] = c;
+        const float* T = a.T + (size_t)c * a.t_stride;
+        q[r] = m4_point(T, v3(a.qx[s], a.qy[s], a.qz[s]));
+      } else {
+        cidx[r] = -1;
+        q[r] = v3(-HOP_FAR, -HOP_FAR, -HOP_FAR);
+      }
+    }
+    for (int start = 0; start < a.np; start += NN_TILE) {
+      const int tn = min(NN_TILE, round_up(a.np - start, NN_CH));
+      __syncthreads();
+      stage_tile_raw(tile, a.px, a.py, a.pz, start, a.np, tn);
+      __syncthreads();
+      nn_scan_tile<R, false, false>(tile, tn, start, q, best, dummy);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) wave_count_by_key(cidx[r] >= 0 && best[r] <= a.sq_eps, cidx[r], a.counts);
+  }
+}
+template __global__ void k_verify_brute<4>(VerifyArgs);
+template __global__ void k_verify_brute<8>(VerifyArgs);
+
+// Verify on a voxel grid over P (cell >= delta): a transformed sample can only have an inlier partner in
+// the 27 cells around its own.  Same arithmetic for the distance test, hence identical counts.
+__global__ __launch_bounds__(256) void k_verify_grid(VerifyArgs a, GridDev gd) {
+  const int n_cand = a.n_cand_ptr ? min(*a.n_cand_ptr, a.cand_cap) : a.n_cand;
+  const long long total = (long long)n_cand * a.nq;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ((total + 63) / 64) * 64;
+       g += (long long)gridDim.x * blockDim.x) {
+    bool hit = false;
+    int c = -1;
+    if (g < total) {
+      c = (int)(g / a.nq);
+      const int s = (int)(g % a.nq);
+      const float* T = a.T + (size_t)c * a.t_stride;
+      const V3 q = m4_point(T, v3(a.qx[s], a.qy[s], a.qz[s]));
+      const float fx = (q.x - gd.ox) * gd.inv_cell, fy = (q.y - gd.oy) * gd.inv_cell, fz = (q.z - gd.oz) * gd.inv_cell;
+      // cells outside [-1, dim] cannot have partners
+      if (fx >= -1.f && fy >= -1.f && fz >= -1.f && fx < (float)(gd.dx + 1) && fy < (float)(gd.dy + 1) && fz < (float)(gd.dz + 1)) {
+        const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+        for (int z = max(cz - 1, 0); z <= min(cz + 1, gd.dz - 1) && !hit; ++z)
+          for (int y = max(cy - 1, 0); y <= min(cy + 1, gd.dy - 1) && !hit; ++y) {
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gd.dx - 1);
+            if (x0 > x1) continue;
+            const int row = (z * gd.dy + y) * gd.dx;
+            const int beg = gd.cell_start[row + x0], end = gd.cell_start[row + x1 + 1];  // x-adjacent cells are contiguous
+            for (int k = beg; k < end; ++k) {
+              const float4 t = gd.pts[k];
+              const float dx = q.x - t.x, dy = q.y - t.y, dz = q.z - t.z;
+              if (dx * dx + (dy * dy + dz * dz) <= a.sq_eps) {
+                hit = true;
+                break;
+              }
+            }
+          }
+      }
+    }
+    wave_count_by_key(hit, c, a.counts);
+  }
+}
+
+// K3c: candidates with at least one inlier become hypotheses (cse.hpp:313-333): the translation is
+// re-expressed for the un-centred clouds, t = c1 + centroid_P - R (c2 + centroid_Q).
+__global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
+  const int n_cand = min(*a.cand_count, a.cand_cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.cand_total, n_cand);
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cand; c += gridDim.x * blockDim.x) {
+    const int cnt = a.cand_counts[c];
+    if (cnt <= 0) continue;
+    const int slot = atomicAdd(a.hyp_count, 1);
+    if (slot >= a.hyp_cap) {
+      *a.overflow = 1;
+      continue;
+    }
+    const Candidate& cd = a.cands[c];
+    const V3 u = v3(cd.c2[0], cd.c2[1], cd.c2[2]) + v3(a.cq[0], a.cq[1], a.cq[2]);
+    const float* R = cd.T;
+    const V3 ru = v3(R[0] * u.x + (R[1] * u.y + R[2] * u.z), R[4] * u.x + (R[5] * u.y + R[6] * u.z), R[8] * u.x + (R[9] * u.y + R[10] * u.z));
+    const V3 t = (v3(cd.c1[0], cd.c1[1], cd.c1[2]) + v3(a.cp[0], a.cp[1], a.cp[2])) - ru;
+    float* P = a.pose + (size_t)slot * 16;
+    P[0] = R[0], P[1] = R[1], P[2] = R[2], P[3] = t.x;
+    P[4] = R[4], P[5] = R[5], P[6] = R[6], P[7] = t.y;
+    P[8] = R[8], P[9] = R[9], P[10] = R[10], P[11] = t.z;
+    P[12] = 0.f, P[13] = 0.f, P[14] = 0.f, P[15] = 1.f;
+    a.score[slot] = (float)((unsigned)cnt) / (float)a.nq;
+    a.key[slot] = cd.key;
+    a.inv_count[slot] = (unsigned)(a.nq - cnt);
+  }
+}
+
+// gather of the sorted hypothesis set
+__global__ void k_gather_hypos(const unsigned* __restrict__ perm, int n, const float* __restrict__ pose_in,
+                               const float* __restrict__ score_in, float* __restrict__ pose_out, float* __restrict__ score_out,
+                               int* __restrict__ id_out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 16) return;
+  const int h = t >> 4, k = t & 15;
+  const unsigned src = perm[h];
+  pose_out[t] = pose_in[(size_t)src * 16 + k];
+  if (k == 0) {
+    score_out[h] = score_in[src];
+    id_out[h] = h;
+  }
+}
+__global__ void k_iota(unsigned* p, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) p[t] = (unsigned)t;
+}
+__global__ void k_score_keys(const float* __restrict__ score, const int* __restrict__ ids, int n, unsigned long long* __restrict__ key) {
+  // descending score, then ascending id, as one ascending 64-bit key (scores are finite and >= 0 here;
+  // negative scores are ordered correctly by the sign-flip trick)
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  unsigned u = __float_as_uint(score[t]);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending float order
+  key[t] = ((unsigned long long)(~u) << 32) | (unsigned)ids[t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4': computeLCP (Utils::computeLCP, Utils.cpp:372-444; flags true, weights 1) for hypotheses
+// [h0, h0+hb).  Pass 1 (k_lcp_reverse): nearest scene point of every transformed model point.
+// Pass 2 (k_lcp_forward): nearest transformed model point of every scene point, both score terms.
+// Pass 3 (k_lcp_sum): the reference adds the terms into one float in scene order; one lane per
+// hypothesis repeats exactly that, so scores are bit-equal to the CPU.
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void k_lcp_reverse(LcpArgs a) {
+  __shared__ float4 tile[NN_TILE];
+  const int h = a.h0 + blockIdx.y;
+  const float* T = a.pose + (size_t)h * 16;
+  V3 q[R];
+  float best[R];
+  int bidx[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int j = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    best[r] = 3.0e38f;
+    bidx[r] = -1;
+    q[r] = j < a.nm ? m4_point(T, v3(a.mx[j], a.my[j], a.mz[j])) : v3(-HOP_FAR, -HOP_FAR, -HOP_FAR);
+  }
+  for (int start = 0; start < a.ns; start += NN_TILE) {
+    const int tn = min(NN_TILE, round_up(a.ns - start, NN_CH));
+    __syncthreads();
+    stage_tile_raw(tile, a.sx, a.sy, a.sz, start, a.ns, tn);
+    __syncthreads();
+    nn_scan_tile<R, true, true>(tile, tn, start, q, best, bidx);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int j = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    if (j < a.nm) {
+      a.rev_idx[(size_t)blockIdx.y * a.nm + j] = bidx[r];
+      a.rev_d2[(size_t)blockIdx.y * a.nm + j] = best[r];
+    }
+  }
+}
+template __global__ void k_lcp_reverse<4>(LcpArgs);
+
+__device__ __forceinline__ float lcp_term(V3 n1, V3 n2, float d2, float dist_thres, float cos_thres) {
+  n1 = vnormalized(n1);
+  n2 = vnormalized(n2);
+  const float d = vdot(n1, n2);
+  if (d > cos_thres) return d * (1 - sqrtf(d2) / dist_thres) * 1.0f;
+  return -1.f;  // "no contribution" marker (real terms are >= 0: d>cos>0 and d2<dist^2)
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_lcp_forward(LcpArgs a) {
+  __shared__ float4 tile[NN_TILE];
+  const int h = a.h0 + blockIdx.y;
+  const float* T = a.pose + (size_t)h * 16;
+  V3 q[R];
+  float best[R];
+  int bidx[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    best[r] = 3.0e38f;
+    bidx[r] = -1;
+    q[r] = i < a.ns ? v3(a.sx[i], a.sy[i], a.sz[i]) : v3(-HOP_FAR, -HOP_FAR, -HOP_FAR);
+  }
+  for (int start = 0; start < a.nm; start += NN_TILE) {
+    const int tn = min(NN_TILE, round_up(a.nm - start, NN_CH));
+    __syncthreads();
+    stage_tile_tf(tile, a.mx, a.my, a.mz, start, a.nm, tn, T);
+    __syncthreads();
+    nn_scan_tile<R, true, true>(tile, tn, start, q, best, bidx);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    if (i >= a.ns) continue;
+    float f = -1.f, g = -1.f;
+    if (bidx[r] >= 0 && best[r] < a.dist * a.dist) {
+      const int j = bidx[r];
+      const V3 ns = v3(a.snx[i], a.sny[i], a.snz[i]);
+      const V3 nmod = m4_dir(T, v3(a.mnx[j], a.mny[j], a.mnz[j]));
+      f = lcp_term(ns, nmod, best[r], a.dist, a.cos_thres);
+      const int ri = a.rev_idx[(size_t)blockIdx.y * a.nm + j];
+      if (ri >= 0) {
+        const float rd2 = a.rev_d2[(size_t)blockIdx.y * a.nm + j];
+        g = lcp_term(nmod, v3(a.snx[ri], a.sny[ri], a.snz[ri]), rd2, a.dist, a.cos_thres);
+      }
+    }
+    a.terms[((size_t)blockIdx.y * a.ns + i) * 2 + 0] = f;
+    a.terms[((size_t)blockIdx.y * a.ns + i) * 2 + 1] = g;
+  }
+}
+template __global__ void k_lcp_forward<4>(LcpArgs);
+
+__global__ __launch_bounds__(64) void k_lcp_sum(LcpArgs a, int hb) {
+  const int hl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hl >= hb) return;
+  const float4* t = reinterpret_cast<const float4*>(a.terms + (size_t)hl * a.ns * 2);
+  float cp = 0.f;
+  const int n4 = (a.ns * 2) / 4;
+  for (int k = 0; k < n4; ++k) {
+    const float4 v = t[k];
+    if (v.x >= 0.f) cp += v.x;
+    if (v.y >= 0.f) cp += v.y;
+    if (v.z >= 0.f) cp += v.z;
+    if (v.w >= 0.f) cp += v.w;
+  }
+  for (int k = n4 * 4; k < a.ns * 2; ++k) {
+    const float v = a.terms[(size_t)hl * a.ns * 2 + k];
+    if (v >= 0.f) cp += v;
+  }
+  a.score[a.h0 + hl] = cp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: batched point-to-plane ICP (Utils::runICP, Utils.cpp:188-229, pcl::IterativeClosestPoint as
+// configured there -- restated).  One iteration = k_icp_nn (move the source by the last
+// increment, find correspondences, accumulate the 6x6 normal equations in double) + k_icp_solve.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  return v;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_icp_nn(IcpArgs a) {
+  __shared__ float4 tile[NN_TILE];
+  __shared__ double red[4][ICP_NACC];
+  const int hl = blockIdx.y, h = a.h0 + hl;
+  IcpState& st = a.state[hl];
+  if (!st.active) return;
+  const float* pose = a.pose + (size_t)h * 16;
+  float Tinc[12];
+  for (int k = 0; k < 12; ++k) Tinc[k] = st.T_inc[k];
+  V3 q[R], qn[R];
+  float best[R];
+  int bidx[R];
+  const bool first = a.iter == 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    best[r] = 3.0e38f;
+    bidx[r] = -1;
+    if (i < a.ns) {
+      V3 p, n;
+      if (first) {
+        p = v3(a.sx[i], a.sy[i], a.sz[i]);
+        n = v3(a.snx[i], a.sny[i], a.snz[i]);
+      } else {
+        const size_t o = (size_t)hl * a.ns * 6 + i;
+        p = v3(a.moved[o], a.moved[o + a.ns], a.moved[o + 2 * (size_t)a.ns]);
+        n = v3(a.moved[o + 3 * (size_t)a.ns], a.moved[o + 4 * (size_t)a.ns], a.moved[o + 5 * (size_t)a.ns]);
+        p = m4_point(Tinc, p);
+        n = m4_dir(Tinc, n);
+      }
+      const size_t o = (size_t)hl * a.ns * 6 + i;
+      a.moved[o] = p.x, a.moved[o + a.ns] = p.y, a.moved[o + 2 * (size_t)a.ns] = p.z;
+      a.moved[o + 3 * (size_t)a.ns] = n.x, a.moved[o + 4 * (size_t)a.ns] = n.y, a.moved[o + 5 * (size_t)a.ns] = n.z;
+      q[r] = p, qn[r] = n;
+    } else {
+      q[r] = v3(-HOP_FAR, -HOP_FAR, -HOP_FAR);
+      qn[r] = v3(0, 0, 0);
+    }
+  }
+  for (int start = 0; start < a.nm; start += NN_TILE) {
+    const int tn = min(NN_TILE, round_up(a.nm - start, NN_CH));
+    __syncthreads();
+    stage_tile_tf(tile, a.mx, a.my, a.mz, start, a.nm, tn, pose);
+    __syncthreads();
+    nn_scan_tile<R, true, true>(tile, tn, start, q, best, bidx);
+  }
+  double acc[ICP_NACC];
+#pragma unroll
+  for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    if (i >= a.ns || bidx[r] < 0 || !(best[r] <= a.max_d2)) continue;
+    const int j = bidx[r];
+    const V3 nt = m4_dir(pose, v3(a.mnx[j], a.mny[j], a.mnz[j]));
+    if (!(vdot(qn[r], nt) >= a.cos_thr)) continue;
+    const V3 tq = m4_point(pose, v3(a.mx[j], a.my[j], a.mz[j]));
+    const V3 c = vcross(q[r], nt);
+    const double J[6] = {c.x, c.y, c.z, nt.x, nt.y, nt.z};
+    const double res = (double)vdot(q[r] - tq, nt);
+    int k = 0;
+    for (int u = 0; u < 6; ++u)
+      for (int v = 0; v <= u; ++v) acc[k++] += J[u] * J[v];
+    for (int u = 0; u < 6; ++u) acc[21 + u] -= J[u] * res;
+    acc[27] += (double)best[r];
+    acc[28] += 1.0;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < ICP_NACC; ++k) {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < ICP_NACC) {
+    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NACC + threadIdx.x] = s;
+  }
+}
+template __global__ void k_icp_nn<4>(IcpArgs);
+
+__device__ bool chol6(double A[6][6], const double b[6], double x[6]) {
+  double L[6][6];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) L[i][j] = 0.0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = A[i][j];
+      for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+      if (i == j) {
+        if (!(s > 1e-300)) return false;
+        L[i][i] = sqrt(s);
+      } else
+        L[i][j] = s / L[j][j];
+    }
+  double y[6];
+  for (int i = 0; i < 6; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+    y[i] = s / L[i][i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double s = y[i];
+    for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k];
+    x[i] = s / L[i][i];
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(64) void k_icp_solve(IcpArgs a, int hb, int nblocks) {
+  const int hl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hl >= hb) return;
+  IcpState& st = a.state[hl];
+  if (!st.active) return;
+  double acc[ICP_NACC];
+  for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
+  for (int blk = 0; blk < nblocks; ++blk)
+    for (int k = 0; k < ICP_NACC; ++k) acc[k] += a.partial[((size_t)hl * nblocks + blk) * ICP_NACC + k];
+  const int cnt = (int)acc[28];
+  if (cnt < 3) {  // not converged: caller substitutes identity (Utils.cpp:218-225)
+    st.active = 0;
+    st.converged = 0;
+    return;
+  }
+  double A[6][6], b[6], x[6];
+  int k = 0;
+  for (int u = 0; u < 6; ++u)
+    for (int v = 0; v <= u; ++v) {
+      A[u][v] = acc[k];
+      A[v][u] = acc[k];
+      ++k;
+    }
+  for (int u = 0; u < 6; ++u) b[u] = acc[21 + u];
+  double tr = 0;
+  for (int u = 0; u < 6; ++u) tr += A[u][u];
+  for (int u = 0; u < 6; ++u) A[u][u] += 1e-9 * tr + 1e-30;
+  if (!chol6(A, b, x)) {
+    st.active = 0;
+    st.converged = 0;
+    return;
+  }
+  const double th = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  double Rm[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  if (th > 1e-12) {
+    const double kx = x[0] / th, ky = x[1] / th, kz = x[2] / th, s = sin(th), c = cos(th), v = 1 - c;
+    Rm[0][0] = c + kx * kx * v, Rm[0][1] = kx * ky * v - kz * s, Rm[0][2] = kx * kz * v + ky * s;
+    Rm[1][0] = ky * kx * v + kz * s, Rm[1][1] = c + ky * ky * v, Rm[1][2] = ky * kz * v - kx * s;
+    Rm[2][0] = kz * kx * v - ky * s, Rm[2][1] = kz * ky * v + kx * s, Rm[2][2] = c + kz * kz * v;
+  }
+  M4 T = m4_identity();
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T.m[4 * i + j] = (float)Rm[i][j];
+    T.m[4 * i + 3] = (float)x[3 + i];
+  }
+  for (int i = 0; i < 12; ++i) st.T_inc[i] = T.m[i];
+  M4 F;
+  for (int i = 0; i < 16; ++i) F.m[i] = st.final_tf[i];
+  F = m4_mul(T, F);
+  for (int i = 0; i < 16; ++i) st.final_tf[i] = F.m[i];
+  st.iterations += 1;
+  const double mse = acc[27] / cnt;
+  bool stop = false;
+  if (st.iterations >= a.max_iter) stop = true;
+  else if (fabs(mse - st.mse_prev) < 1e-6) stop = true;
+  else if (fabs(mse - st.mse_prev) / st.mse_prev < 1e-10) stop = true;
+  st.mse_prev = mse;
+  if (stop) {
+    st.active = 0;
+    st.converged = 1;
+  }
+}
+
+// pose <- T_icp^-1 * pose (PoseEstimator.cpp:267), identity if not converged
+__global__ void k_icp_finish(IcpArgs a, int hb, int* iters_out, int* conv_out) {
+  const int hl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hl >= hb) return;
+  const IcpState& st = a.state[hl];
+  M4 F = m4_identity();
+  if (st.converged)
+    for (int i = 0; i < 16; ++i) F.m[i] = st.final_tf[i];
+  M4 P;
+  float* pose = a.pose + (size_t)(a.h0 + hl) * 16;
+  for (int i = 0; i < 16; ++i) P.m[i] = pose[i];
+  const M4 out = m4_mul(m4_inverse_affine(F), P);
+  for (int i = 0; i < 16; ++i) pose[i] = out.m[i];
+  if (iters_out) iters_out[a.h0 + hl] = st.iterations;
+  if (conv_out) conv_out[a.h0 + hl] = st.converged;
+}
+
+__global__ void k_icp_init(IcpState* st, int hb) {
+  const int hl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hl >= hb) return;
+  IcpState s;
+  for (int i = 0; i < 12; ++i) s.T_inc[i] = (i % 5 == 0) ? 1.f : 0.f;
+  for (int i = 0; i < 16; ++i) s.final_tf[i] = (i % 5 == 0) ? 1.f : 0.f;
+  s.mse_prev = 1.7976931348623157e308;
+  s.iterations = 0;
+  s.active = 1;
+  s.converged = 0;
+  st[hl] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: hand-state objective, data-parallel part of objFuncPSO (Hand.cpp:67-152) for a batch of particles.
+//   k_pso_match : per (particle, finger point) nearest scene point + the match test -> match count
+//   k_pso_outer : per (particle, scene point) outer-side distance term (or -1)
+//   k_pso_outer_sum : sequential float sum per particle, in scene order, as the reference does
+// The host finishes the scalar part of the objective (gripper gap, penalties), hop_host.cpp.
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void k_pso_match(PsoArgs a) {
+  __shared__ float4 tile[NN_TILE];
+  const int p = blockIdx.y;
+  const PsoParticle& pp = a.particles[p];
+  if (pp.skip) return;
+  V3 q[R], qn[R];
+  float best[R];
+  int bidx[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int j = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    best[r] = 3.0e38f;
+    bidx[r] = -1;
+    if (j < a.nm) {
+      q[r] = m4_point(pp.T, v3(a.mx[j], a.my[j], a.mz[j]));
+      qn[r] = m4_dir(pp.T, v3(a.mnx[j], a.mny[j], a.mnz[j]));
+    } else {
+      q[r] = v3(-HOP_FAR, -HOP_FAR, -HOP_FAR);
+      qn[r] = v3(0, 0, 0);
+    }
+  }
+  for (int start = 0; start < a.ns; start += NN_TILE) {
+    const int tn = min(NN_TILE, round_up(a.ns - start, NN_CH));
+    __syncthreads();
+    stage_tile_raw(tile, a.sx, a.sy, a.sz, start, a.ns, tn);
+    __syncthreads();
+    nn_scan_tile<R, true, true>(tile, tn, start, q, best, bidx);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int j = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    bool match = false;
+    if (j < a.nm && bidx[r] >= 0 && best[r] <= a.dist_thres * a.dist_thres) {
+      if (!a.check_normal) match = true;
+      else {
+        // Hand.cpp:91: normal fetched from the UNFILTERED cloud with the filtered cloud's index
+        V3 nn = v3(0, 0, 0);
+        if (bidx[r] < a.n_lookup) nn = v3(a.lnx[bidx[r]], a.lny[bidx[r]], a.lnz[bidx[r]]);
+        if (nn.x == 0.f && nn.y == 0.f && nn.z == 0.f) match = true;
+        else if (isfinite(nn.x) && isfinite(nn.y) && isfinite(nn.z)) match = vdot(qn[r], nn) >= a.cos_normal_thres;
+      }
+    }
+    const unsigned long long m = __ballot(match);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.match_count[p], __popcll(m));
+  }
+}
+template __global__ void k_pso_match<2>(PsoArgs);
+
+__global__ __launch_bounds__(256) void k_pso_outer(PsoArgs a) {
+  const int p = blockIdx.y;
+  const PsoParticle& pp = a.particles[p];
+  if (pp.skip) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_swivel; i += gridDim.x * blockDim.x) {
+    const V3 pt = m4_point(pp.Tinv, v3(a.wx[i], a.wy[i], a.wz[i]));
+    int bin = (int)(fmaxf(pt.z - a.fp_min_z, 0.0f) / a.fp_stride_z);  // FingerProperty::getBinAlongZ, Hand.cpp:244-250
+    bin = max(bin, 0);
+    bin = min(bin, a.fp_num_division - 1);
+    const float lim = a.hist_min_y[bin];
+    a.outer_terms[(size_t)p * a.n_swivel + i] = (pt.y >= lim) ? -1.f : fabsf(pt.y - lim);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_pso_outer_sum(PsoArgs a, int n_particles) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_particles) return;
+  if (a.particles[p].skip) return;
+  float sum = 0.f;
+  int cnt = 0;
+  const float* t = a.outer_terms + (size_t)p * a.n_swivel;
+  for (int i = 0; i < a.n_swivel; ++i) {
+    const float v = t[i];
+    if (v >= 0.f) {
+      sum += v;
+      ++cnt;
+    }
+  }
+  a.outer_sum[p] = sum;
+  a.outer_cnt[p] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// voxel-grid construction over a fixed cloud (counting sort by cell): count, scan on host, fill.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_grid_cell_ids(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
+                                GridDev gd, int* __restrict__ cell_of, int* __restrict__ cell_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int cx = (int)floorf((x[i] - gd.ox) * gd.inv_cell), cy = (int)floorf((y[i] - gd.oy) * gd.inv_cell),
+      cz = (int)floorf((z[i] - gd.oz) * gd.inv_cell);
+  cx = min(max(cx, 0), gd.dx - 1), cy = min(max(cy, 0), gd.dy - 1), cz = min(max(cz, 0), gd.dz - 1);
+  const int c = (cz * gd.dy + cy) * gd.dx + cx;
+  cell_of[i] = c;
+  atomicAdd(&cell_count[c], 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-callable launchers
+// ------------------------------------------------------------------------------------------------
+void launch_ppf_matrix(const PpfMatrixArgs& a, hipStream_t s) {
+  dim3 grid((a.words + 3) / 4, (a.n + PPF_ROWS - 1) / PPF_ROWS);
+  hipLaunchKernelGGL(k_ppf_matrix, grid, dim3(256), 0, s, a);
+}
+void launch_pairs(const PairArgs& a, int nbases, hipStream_t s) {
+  const long long total = (long long)a.nq * a.nq;
+  dim3 grid((unsigned)((total + 255) / 256), nbases);
+  hipLaunchKernelGGL(k_pairs, grid, dim3(256), 0, s, a);
+}
+void launch_quad_prep(const QuadPrepArgs& a, int nbases, int max_items, hipStream_t s) {
+  dim3 grid(max(1, min(64, (max_items + 255) / 256)), nbases);
+  hipLaunchKernelGGL(k_quad_prep, grid, dim3(256), 0, s, a);
+}
+void launch_quads(const QuadArgs& a, int nbases, int blocks_per_base, hipStream_t s) {
+  dim3 grid(blocks_per_base, nbases);
+  hipLaunchKernelGGL(k_quads, grid, dim3(256), 0, s, a);
+}
+void launch_verify(const VerifyArgs& a, int mode, const GridDev* gd, int blocks, hipStream_t s) {
+  if (mode == 1 && gd) hipLaunchKernelGGL(k_verify_grid, dim3(blocks), dim3(256), 0, s, a, *gd);
+  else hipLaunchKernelGGL(k_verify_brute<4>, dim3(blocks), dim3(256), 0, s, a);
+}
+void launch_emit(const EmitArgs& a, int blocks, hipStream_t s) { hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, s, a); }
+void launch_gather_hypos(const unsigned* perm, int n, const float* pose_in, const float* score_in, float* pose_out,
+                         float* score_out, int* id_out, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_gather_hypos, dim3((n * 16 + 255) / 256), dim3(256), 0, s, perm, n, pose_in, score_in, pose_out, score_out, id_out);
+}
+void launch_iota(unsigned* p, int n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, s, p, n);
+}
+void launch_score_keys(const float* score, const int* ids, int n, unsigned long long* key, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_score_keys, dim3((n + 255) / 256), dim3(256), 0, s, score, ids, n, key);
+}
+void launch_lcp_reverse(const LcpArgs& a, int hb, hipStream_t s) {
+  const int R = 4;
+  hipLaunchKernelGGL(k_lcp_reverse<4>, dim3((a.nm + 256 * R - 1) / (256 * R), hb), dim3(256), 0, s, a);
+}
+void launch_lcp_forward(const LcpArgs& a, int hb, hipStream_t s) {
+  const int R = 4;
+  hipLaunchKernelGGL(k_lcp_forward<4>, dim3((a.ns + 256 * R - 1) / (256 * R), hb), dim3(256), 0, s, a);
+}
+void launch_lcp_sum(const LcpArgs& a, int hb, hipStream_t s) {
+  hipLaunchKernelGGL(k_lcp_sum, dim3((hb + 63) / 64), dim3(64), 0, s, a, hb);
+}
+int icp_blocks_per_hyp(int ns) { return (ns + 256 * 4 - 1) / (256 * 4); }
+void launch_icp_init(IcpState* st, int hb, hipStream_t s) { hipLaunchKernelGGL(k_icp_init, dim3((hb + 63) / 64), dim3(64), 0, s, st, hb); }
+void launch_icp_nn(const IcpArgs& a, int hb, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_nn<4>, dim3(icp_blocks_per_hyp(a.ns), hb), dim3(256), 0, s, a);
+}
+void launch_icp_solve(const IcpArgs& a, int hb, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_solve, dim3((hb + 63) / 64), dim3(64), 0, s, a, hb, icp_blocks_per_hyp(a.ns));
+}
+void launch_icp_finish(const IcpArgs& a, int hb, int* iters, int* conv, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_finish, dim3((hb + 63) / 64), dim3(64), 0, s, a, hb, iters, conv);
+}
+void launch_pso(const PsoArgs& a, int n_particles, hipStream_t s) {
+  const int R = 2;
+  hipLaunchKernelGGL(k_pso_match<2>, dim3((a.nm + 256 * R - 1) / (256 * R), n_particles), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_pso_outer, dim3(max(1, min(32, (a.n_swivel + 255) / 256)), n_particles), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_pso_outer_sum, dim3((n_particles + 63) / 64), dim3(64), 0, s, a, n_particles);
+}
+void launch_grid_cell_ids(const float* x, const float* y, const float* z, int n, const GridDev& gd, int* cell_of, int* cell_count,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(k_grid_cell_ids, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, gd, cell_of, cell_count);
+}
+
+}  // namespace hop

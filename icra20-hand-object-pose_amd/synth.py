@@ -147,7 +147,8 @@ def make_scene(n_points: int, seed: int = 7, semi=SEMI_AXES, noise=0.0005, clutt
         local = np.stack(
             [np.full(k, s * (semi[0] + 0.004)) + rng.normal(scale=0.0004, size=k),
              rng.uniform(-0.012, 0.012, size=k), rng.uniform(-0.03, 0.03, size=k)], axis=1)
-        ln = np.tile(np.array([-s, 0.0, 0.0]), (k, 1))
+        # what the camera sees of a finger is its top, not the contact face: normals tangent to the object there
+        ln = np.tile(np.array([0.0, 0.0, 1.0]), (k, 1))
         cl.append(local)
         cn.append(ln)
     cl = apply(T, np.concatenate(cl)).astype(np.float64)
@@ -265,18 +266,22 @@ class HandModel:
 
 
 def t42_hand(spacing=0.005) -> HandModel:
+    """Stand-in T42: two fingers of two links.  Link frame as the reference uses it (Hand.cpp:24-54):
+    the link extends towards -z (tip at min z), +y is the inner (grasping) side, the joint axis is x.
+    Hand-base frame: fingers extend towards -x, finger 1 sits at y=-0.04 (inner side +y), finger 2 at
+    y=+0.04 (inner side -y), as the crops of main_realdata_auto.cpp:80-93 assume."""
     h = HandModel()
-    prox = _box_cloud((-0.010, -0.006, 0.0), (0.010, 0.006, 0.060), spacing)
-    dist = _box_cloud((-0.009, -0.005, 0.0), (0.009, 0.005, 0.045), spacing)
-    base = _box_cloud((-0.03, -0.045, -0.05), (0.03, 0.045, 0.0), spacing)
+    prox = _box_cloud((-0.010, -0.006, -0.060), (0.010, 0.006, 0.0), spacing)
+    dist = _box_cloud((-0.009, -0.005, -0.045), (0.009, 0.005, 0.0), spacing)
+    base = _box_cloud((-0.06, -0.05, -0.02), (0.0, 0.05, 0.02), spacing)
     h.clouds["base_link"] = base
     h.parents["base_link"] = "world"
     h.tf_in_parent["base_link"] = np.eye(4, dtype=np.float32)
-    # finger 1 sits at y=-0.04 with its inner side (+y of the link) facing +y of the hand base,
-    # finger 2 at y=+0.04 mirrored (rotated pi about z) so its inner side faces -y.
-    f1 = se3(np.eye(3), [0.0, -0.040, 0.0])
-    f2 = se3(rot_from_axis_angle([0, 0, 1], math.pi), [0.0, 0.040, 0.0])
-    d = se3(np.eye(3), [0.0, 0.0, 0.062])
+    R1 = np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]], dtype=np.float64)   # link x,y,z -> hand base
+    R2 = np.array([[0, 0, 1], [0, -1, 0], [1, 0, 0]], dtype=np.float64)
+    f1 = se3(R1, [-0.070, -0.040, 0.0])
+    f2 = se3(R2, [-0.070, 0.040, 0.0])
+    d = se3(np.eye(3), [0.0, 0.0, -0.062])
     for name, parent, tf, cloud in (
         ("finger_1_1", "base_link", f1, prox), ("finger_1_2", "finger_1_1", d, dist),
         ("finger_2_1", "base_link", f2, prox), ("finger_2_2", "finger_2_1", d, dist),
@@ -304,38 +309,46 @@ def hand_fk(hand: HandModel, angles: dict, name: str):
     return T
 
 
-def make_hand_scene(hand: HandModel, true_angles: dict, n_points: int, seed: int = 5, noise=0.0006,
-                    clutter_frac=0.25):
-    """Scene of the hand region in the hand-base frame: the posed finger links seen from a camera on
-    the -x side (so roughly half of every link is visible), plus background clutter, thinned/padded
-    to ``n_points``.  Returns (xyz, nrm) float32.  Normals point towards the camera."""
+def make_hand_scene(hand: HandModel, true_angles: dict, n_points: int, seed: int = 5, noise=0.0004,
+                    object_frac=0.2):
+    """Hand-region scene in the hand-base frame: the posed finger links seen from a camera above the hand
+    (+z side), plus a grasped-object blob between the finger tips; resampled to ``n_points``.
+    Returns (xyz, nrm) float32, normals towards the camera.  ``scene_remove_swivel`` of the reference is
+    the subset with x < -0.1 (Hand.cpp:316-320)."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    cam = np.array([-0.6, 0.05, 0.05])
+    cam = np.array([-0.12, 0.0, 0.45])
     pts, nrm = [], []
-    dense = t42_hand(spacing=0.0012)
+    dense = t42_hand(spacing=0.0011)
     for name in FINGER_NAMES:
         T = hand_fk(hand, true_angles, name)
         x, n = dense.clouds[name]
         xw, nw = apply(T, x).astype(np.float64), rotate(T, n).astype(np.float64)
         view = xw - cam
         view /= np.linalg.norm(view, axis=1, keepdims=True)
-        vis = np.einsum("ij,ij->i", nw, view) < -0.1
+        vis = np.einsum("ij,ij->i", nw, view) < -0.15
         pts.append(xw[vis])
         nrm.append(nw[vis])
     pts = np.concatenate(pts)
     nrm = np.concatenate(nrm)
-    n_cl = int(n_points * clutter_frac)
-    n_f = n_points - n_cl
-    if len(pts) >= n_f:
-        sel = rng.choice(len(pts), size=n_f, replace=False)
-    else:
-        sel = rng.choice(len(pts), size=n_f, replace=True)
+    n_obj = int(n_points * object_frac)
+    n_f = n_points - n_obj
+    sel = rng.choice(len(pts), size=n_f, replace=len(pts) < n_f)
     pts, nrm = pts[sel] + rng.normal(scale=noise, size=(n_f, 3)), nrm[sel]
-    # clutter: a table-like plane far below and random blobs away from the fingers
-    cl = np.stack([rng.uniform(-0.24, -0.11, n_cl), rng.uniform(-0.15, 0.15, n_cl),
-                   rng.uniform(-0.11, -0.09, n_cl)], axis=1)
-    cln = np.tile(np.array([0.0, 0.0, 1.0]), (n_cl, 1))
-    xyz = np.concatenate([pts, cl]).astype(np.float32)
-    nn = np.concatenate([nrm, cln]).astype(np.float32)
+    # object: upper half of a small ellipsoid that just fits between the two finger tips
+    tips = []
+    for name in ("finger_1_2", "finger_2_2"):
+        T = hand_fk(hand, true_angles, name)
+        x, _ = hand.clouds[name]
+        tip_local = np.array([[0.0, x[:, 1].max(), x[:, 2].min()]])
+        tips.append(apply(T, tip_local.astype(np.float32))[0].astype(np.float64))
+    gap = abs(tips[1][1] - tips[0][1])
+    centre = 0.5 * (tips[0] + tips[1])
+    semi = (0.020, max(0.5 * gap - 0.001, 0.002), 0.012)
+    ox, on = ellipsoid_model(n_obj * 3 + 16, semi)
+    up = on[:, 2] > 0.1
+    ox, on = ox[up][:n_obj], on[up][:n_obj]
+    ox = ox.astype(np.float64) + np.array([centre[0], centre[1], 0.0])
+    xyz = np.concatenate([pts, ox]).astype(np.float32)
+    nn = np.concatenate([nrm, on.astype(np.float64)]).astype(np.float32)
     order = rng.permutation(len(xyz))
     return np.ascontiguousarray(xyz[order]), np.ascontiguousarray(nn[order])

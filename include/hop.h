@@ -1,0 +1,227 @@
+/* hop.h -- C-ABI of the MI355X-native hot path of wenbowen123/icra20-hand-object-pose.
+ *
+ * One shared library (libhop.so, HIP for gfx950) behind plain-C entry points: no C++ types, no torch
+ * types, caller-owned host buffers in and out.  Every entry point names the reference interface it
+ * replaces (paths relative to the reference root; the reference has no FFI layer of its own -- the
+ * boundary is the set of C++ member functions main_realdata_auto.cpp:99-205 calls).
+ * INTEGRATION.md shows the reference-side shim a maintainer would add.
+ *
+ * Conventions
+ *   - clouds are SoA planes: xyz = [x0..x(n-1) | y0.. | z0..] (3*n floats); normals likewise.
+ *   - poses are row-major 4x4 float (model -> scene).
+ *   - every function returns HOP_OK (0) or a negative hop_status; nothing aborts or throws.
+ *   - one ctx per (host thread, GPU); calls on one ctx are serialised by the caller.
+ *   - the library has no CPU fallback: without a HIP device hop_ctx_create fails with HOP_E_NO_DEVICE.
+ */
+#ifndef HOP_H_
+#define HOP_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HOP_ABI_VERSION 1
+
+typedef enum {
+  HOP_OK = 0,
+  HOP_E_INVALID = -1,     /* bad argument */
+  HOP_E_NO_DEVICE = -2,   /* no usable HIP device */
+  HOP_E_HIP = -3,         /* a HIP runtime call failed (see hop_last_error) */
+  HOP_E_CAPACITY = -4,    /* caller buffer or internal capacity too small */
+  HOP_E_STATE = -5,       /* call order (e.g. generate before set_scene) */
+  HOP_E_NO_HYPOTHESIS = -6, /* generator produced nothing: runSuper4pcs would return false */
+  HOP_E_ALLOC = -7
+} hop_status;
+
+typedef struct hop_ctx hop_ctx;
+
+int hop_abi_version(void);
+const char* hop_strerror(int status);
+/* text of the last HIP error seen by this ctx ("" if none) */
+const char* hop_last_error(const hop_ctx* ctx);
+
+int hop_ctx_create(int device, hop_ctx** out);
+void hop_ctx_destroy(hop_ctx* ctx);
+/* blocks until everything queued on the ctx streams is done */
+int hop_synchronize(hop_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------
+ * Clouds
+ * ---------------------------------------------------------------------------------------------- */
+/* PoseEstimator::setCurScene (src/perception/src/PoseEstimator.cpp:32-46): `xyz/nrm/conf` is the object
+ * segment; points with conf < high_confidence_thres are dropped, the rest is _scene_high_confidence
+ * (P of the generator, source of ICP, scene of computeLCP).  Pass thres <= 0 to keep everything. */
+int hop_set_scene(hop_ctx* ctx, const float* xyz, const float* nrm, const float* conf, int n,
+                  float high_confidence_thres);
+int hop_scene_size(const hop_ctx* ctx);
+
+#define HOP_MODEL_5MM 0 /* `_model`    : Q of the generator, ICP target  (main_realdata_auto.cpp:38)  */
+#define HOP_MODEL_1MM 1 /* `_model001` : computeLCP model                (main_realdata_auto.cpp:37)  */
+/* PoseEstimator ctor (PoseEstimator.cpp:8-23) */
+int hop_set_model(hop_ctx* ctx, int level, const float* xyz, const float* nrm, int n);
+
+/* pcl::Super4PCS::setPPFHash (demos/PCLWrapper/pcl/registration/super4pcs.h:149-152).  Only key
+ * membership is ever used by the reference (matchBase.hpp:134,159,201), so the table is the key set:
+ * nkeys rows of 4 ints (dist mm bin, three angle-degree bins). */
+int hop_set_ppf_keys(hop_ctx* ctx, const int32_t* keys4, int nkeys);
+
+/* ------------------------------------------------------------------------------------------------
+ * Generator: PoseEstimator::runSuper4pcs (PoseEstimator.cpp:62-100) ->
+ * gr::Match4pcsBase::ComputeTransformation (src/OpenGR_4pcs/src/gr/algorithms/
+ * congruentSetExplorationBase.hpp:66-125).  Hypotheses stay resident on the device; they are also
+ * copied out when poses16_out / lcp_out are non-NULL (cap = capacity in hypotheses).
+ * Output order is canonical: base trial, then pair lists in (i desc-major, j) order -- see DESIGN.md.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int sample_size;            /* super4pcs_sample_size            (config_autodataset.yaml:133) */
+  float overlap;              /* super4pcs_overlap                (:134)  */
+  float delta;                /* super4pcs_delta                  (:135)  */
+  float dispersion;           /* super4pcs_dispersion             (:136)  */
+  int success_quadrilaterals; /* super4pcs_success_quadrilaterals (:137)  */
+  int max_time_seconds;       /* super4pcs_max_time_seconds       (:140); <=0 disables the wall-clock cut */
+  int n_trials;               /* base trials; <=0 = the reference's effective 30 (cse.hpp:78,90-100) */
+  unsigned int random_seed;   /* gr MatchBase Options::randomSeed, std::mt19937::default_seed = 5489 */
+  float max_normal_difference; /* must be < 0 (as shipped); other filters are not implemented */
+  float max_color_distance;    /* must be < 0 */
+  int verify_mode;            /* 0 = brute force LDS-tiled, 1 = voxel-grid accelerated (same counts) */
+} hop_s4pcs_opts;
+
+typedef struct {
+  int n_trials_run, n_bases, n_hypotheses;
+  long long n_pairs, n_quads, n_candidates; /* summed over bases */
+  int n_sampled_q;
+  float centroid_p[3], centroid_q[3], diameter;
+  double ms_select, ms_device; /* host base selection / device time (events) */
+} hop_s4pcs_stats;
+
+void hop_s4pcs_default_opts(hop_s4pcs_opts* o);
+int hop_s4pcs_generate(hop_ctx* ctx, const hop_s4pcs_opts* opts, float* poses16_out, float* lcp_out,
+                       int cap, int* n_out, hop_s4pcs_stats* stats_out);
+/* read-back of the per-base trace of the last generate (tests): base ids, invariants, list sizes */
+int hop_s4pcs_num_bases(const hop_ctx* ctx);
+int hop_s4pcs_get_base(const hop_ctx* ctx, int i, int* base4, float* inv2, int* counts3);
+/* sampled, centred Q of the last generate (SoA planes, n = stats.n_sampled_q) */
+int hop_s4pcs_get_sampled_q(const hop_ctx* ctx, float* xyz, float* nrm);
+
+/* CongruentSetExplorationBase::Verify (cse.hpp:346-435) for H transforms given in the centred frame
+ * of the last generate (or of hop_verify_set_clouds).  count_out[h] = inliers among the n_q samples. */
+int hop_verify_set_clouds(hop_ctx* ctx, const float* p_xyz, int n_p, const float* q_xyz, int n_q);
+int hop_verify_batch(hop_ctx* ctx, const float* T16, int H, float delta, int mode, int* count_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Resident hypothesis set (PoseEstimator::_pose_hypos).  The scoring calls below work on it.
+ * ---------------------------------------------------------------------------------------------- */
+/* replace the set by caller poses (ids = 0..H-1, scores as given or 0) */
+int hop_hypos_upload(hop_ctx* ctx, const float* poses16, const float* scores, int H);
+int hop_hypos_count(const hop_ctx* ctx);
+int hop_hypos_download(hop_ctx* ctx, float* poses16_out, float* scores_out, int* ids_out, int cap,
+                       int* n_out);
+/* keep the k best by (score desc, emission order asc) = HypoCompare (PoseEstimator.cpp:110-123);
+ * the survivors are renumbered 0..k-1 in that order. */
+int hop_hypos_keep_topk(hop_ctx* ctx, int k);
+
+/* PoseEstimator::refineByICP (PoseEstimator.cpp:235-275) + Utils::runICP (Utils.cpp:188-229) on the
+ * resident set: source = scene, target = HOP_MODEL_5MM transformed by each pose; pose <- T_icp^-1 * pose.
+ * The reference keeps only the first 100 hypotheses (PoseEstimator.cpp:241): pass max_hypotheses=100
+ * for that, <=0 for "all". */
+typedef struct {
+  int max_iter;        /* 10                       (PoseEstimator.cpp:266) */
+  float angle_deg;     /* icp_angle_thres = 45     (config_autodataset.yaml:127) */
+  float max_corr_dist; /* icp_dist_thres  = 0.01   (:126) */
+  int max_hypotheses;
+  int nn_mode;         /* 0 brute force, 1 grid accelerated */
+} hop_icp_opts;
+int hop_icp_refine(hop_ctx* ctx, const hop_icp_opts* opts, int* iterations_out /*H or NULL*/,
+                   int* converged_out /*H or NULL*/);
+
+/* PoseEstimator::selectBest (PoseEstimator.cpp:465-502) + Utils::computeLCP (Utils.cpp:372-444):
+ * scores every resident pose against HOP_MODEL_1MM, stores the score as its _lcp_score and returns the
+ * arg-max (first maximum in set order, strict '>' as the reference). */
+typedef struct {
+  float dist;      /* lcp.dist = 0.001          (config_autodataset.yaml:116) */
+  float angle_deg; /* lcp.normal_angle = 10     (:117) */
+  int nn_mode;     /* 0 brute force, 1 grid accelerated */
+} hop_lcp_opts;
+int hop_lcp_select_best(hop_ctx* ctx, const hop_lcp_opts* opts, float* best_pose16_out,
+                        float* best_score_out, int* best_index_out);
+
+/* PoseEstimator::clusterPoses(angle_deg, dist, assign_id) (PoseEstimator.cpp:106-233) on the resident
+ * set (host-side greedy pass over the sorted set, as in the reference). sym_deg = object_symmetry x,y,z. */
+int hop_cluster_poses(hop_ctx* ctx, float angle_deg, float dist, const float* sym_deg3, int assign_id);
+/* the same as a pure function on caller arrays; keep_out receives indices of the cluster heads */
+int hop_cluster_poses_host(const float* poses16, const float* scores, const int* ids, int H,
+                           float angle_deg, float dist, const float* sym_deg3, int* keep_out,
+                           int* n_keep_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU exchange: each rank packs its k best rows, ranks all-gather the tables (RCCL through
+ * torch.distributed, see bench.py) and merge them identically.  Row = {score f32, id i32, pose 16 f32}.
+ * ---------------------------------------------------------------------------------------------- */
+#define HOP_TOPK_ROW_FLOATS 18
+int hop_topk_pack(hop_ctx* ctx, int k, int id_offset, float* rows_out /* k*18 floats */, int* n_rows_out);
+/* pure function: merge n_tables tables of k rows each (rows with id < 0 are padding) into the k best */
+int hop_topk_merge(const float* tables, int n_tables, int k, float* rows_out, int* n_rows_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Hand-state search: Hand::matchOneComponentPSO (src/perception/src/Hand.cpp:603-672) ->
+ * optim::pso (include/unconstrained/pso.hpp:146-351) -> objFuncPSO (Hand.cpp:10-178).
+ * ---------------------------------------------------------------------------------------------- */
+/* Hand::setCurScene products (Hand.cpp:327-332): kd-tree cloud (scene_hand_region_removed_noise),
+ * normals of scene_hand_region (indexed with the kd-tree's indices, Hand.cpp:91) and scene_remove_swivel;
+ * all in the hand-base frame. */
+int hop_hand_set_scene(hop_ctx* ctx, const float* scene_xyz, int n_scene, const float* lookup_nrm,
+                       int n_lookup, const float* swivel_xyz, int n_swivel);
+
+typedef struct {
+  float fp_min[3], fp_max[3]; /* FingerProperty of the finger (Hand.cpp:182-236) */
+  float fp_stride_z;
+  int fp_num_division;
+  const float* fp_hist_min_y; /* _hist_alongz row 1 */
+  float fo_min[3], fo_max[3]; /* finger_out_property extremes */
+  float model2handbase[16];   /* getTFHandBase(name) (Hand.cpp:505-523) */
+  float finger_out2parent[16];
+  float pair_tip1[4], pair_tip2[4]; /* Hand.cpp:611-643 */
+  int is_palm_side;                 /* finger_1_1 / finger_2_1 */
+  int is_right_side;                /* finger_2_1 / finger_2_2 */
+  float gripper_min_dist;           /* cfg.gripper_min_dist (main_realdata_auto.cpp:41-45) */
+  float dist_thres;                 /* finger{1,2}_dist_thres */
+  float cos_normal_thres;           /* cos(finger{1,2}_normal_angle) */
+  int check_normal;
+  int max_outter_pts;
+  float outter_pt_dist, outter_pt_dist_weight;
+  const float *model_xyz, *model_nrm; /* finger cloud @5 mm, link frame, SoA */
+  int n_model;
+} hop_finger_args;
+int hop_hand_set_finger(hop_ctx* ctx, const hop_finger_args* args);
+/* objFuncPSO for n angles (radians) at once */
+int hop_hand_pso_eval_batch(hop_ctx* ctx, const double* angles, int n, double* cost_out);
+
+typedef struct {
+  int n_pop, n_gen, check_freq;     /* hand_match.pso.* (config_autodataset.yaml:108-114) */
+  double c_cog, c_soc, initial_w;
+  double w_min, w_max, err_tol;     /* OptimLib defaults 0.10 / 0.99, err_tol 1e-5 (Hand.cpp:594) */
+  double lower_rad, upper_rad;      /* bounds (Hand.cpp:606-609) */
+  uint64_t seed;                    /* arma_rng::set_seed(0) (pso.hpp:152) */
+} hop_pso_settings;
+void hop_pso_default_settings(hop_pso_settings* s);
+/* optim::pso: returns the best angle and the objective value (ArgPasser::objval) */
+int hop_hand_pso_search(hop_ctx* ctx, const hop_pso_settings* s, double* best_angle_out,
+                        double* objval_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement helpers (bench.py): device time in ms of the kernels launched by the last call of the
+ * named stage, measured with HIP events on the ctx stream; and launch counts.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  double ms_verify, ms_gen_other, ms_icp_nn, ms_icp_solve, ms_lcp_fwd, ms_lcp_rev, ms_pso, ms_ppf_matrix;
+  long long n_verify_launches, n_icp_nn_launches, n_lcp_launches, n_pso_launches;
+  long long pairs_verify, pairs_icp, pairs_lcp, pairs_pso; /* algorithmic point-pair evaluations */
+} hop_timing;
+int hop_timing_reset(hop_ctx* ctx);
+int hop_timing_get(hop_ctx* ctx, hop_timing* out);
+int hop_timing_enable(hop_ctx* ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOP_H_ */

@@ -52,33 +52,37 @@ class TracingMatcher : public RefMatcherBase {
   std::vector<BaseTrace> trace;
   bool record_pairs = true;
 
+  // Same call sequence as Match4pcsBase::generateCongruents (match4pcsBase.hpp:207-281), made through the
+  // reference's own member functions, so that the invariants and the two pair lists can be recorded
+  // (the reference keeps them in locals).  Re-deriving the invariants afterwards is NOT possible:
+  // TryQuadrilateral's permutation loop is not closed under relabelling.
   bool generateCongruents(CongruentBaseType& base, Set& quads) override {
-    const bool ok = Base::generateCongruents(base, quads);
-    if (!ok) return false;
+    Scalar invariant1, invariant2;
+    if (!this->SelectQuadrilateral(invariant1, invariant2, base[0], base[1], base[2], base[3])) return false;
+    const auto& b0 = this->base_3D_[0];
+    const auto& b1 = this->base_3D_[1];
+    const auto& b2 = this->base_3D_[2];
+    const auto& b3 = this->base_3D_[3];
+    const Scalar distance1 = (b0.pos() - b1.pos()).norm();
+    const Scalar distance2 = (b2.pos() - b3.pos()).norm();
+    std::vector<std::pair<int, int>> pairs1, pairs2;
+    const Scalar normal_angle1 = (b0.normal() - b1.normal()).norm();
+    const Scalar normal_angle2 = (b2.normal() - b3.normal()).norm();
+    this->fun_.ExtractPairs(distance1, normal_angle1, Base::distance_factor * this->options_.delta, 0, 1, pairs1);
+    this->fun_.ExtractPairs(distance2, normal_angle2, Base::distance_factor * this->options_.delta, 2, 3, pairs2);
+    if (pairs1.size() == 0 || pairs2.size() == 0) return false;
+    if (!this->fun_.FindCongruentQuadrilaterals(invariant1, invariant2, Base::distance_factor * this->options_.delta,
+                                                Base::distance_factor * this->options_.delta, pairs1, pairs2, &quads))
+      return false;
     BaseTrace t;
     t.base = base;
-    for (const auto& q : quads) t.quads.push_back(q);
-    // Re-derive the invariants and pair lists for the (already ordered) base: pure functions of
-    // base_3D_ / sampled_Q_3D_, see match4pcsBase.hpp:50-101,244-261.
-    auto saved = this->base_3D_;
-    int a = base[0], b = base[1], c = base[2], d = base[3];
-    Scalar i1 = 0, i2 = 0;
-    this->TryQuadrilateral(i1, i2, a, b, c, d);
-    this->base_3D_ = saved;
-    t.inv1 = i1;
-    t.inv2 = i2;
+    t.inv1 = invariant1;
+    t.inv2 = invariant2;
     if (record_pairs) {
-      const auto& b0 = this->base_3D_[0];
-      const auto& b1 = this->base_3D_[1];
-      const auto& b2 = this->base_3D_[2];
-      const auto& b3 = this->base_3D_[3];
-      const Scalar d1 = (b0.pos() - b1.pos()).norm();
-      const Scalar d2 = (b2.pos() - b3.pos()).norm();
-      const Scalar na1 = (b0.normal() - b1.normal()).norm();
-      const Scalar na2 = (b2.normal() - b3.normal()).norm();
-      this->fun_.ExtractPairs(d1, na1, Base::distance_factor * this->options_.delta, 0, 1, t.pairs1);
-      this->fun_.ExtractPairs(d2, na2, Base::distance_factor * this->options_.delta, 2, 3, t.pairs2);
+      t.pairs1 = pairs1;
+      t.pairs2 = pairs2;
     }
+    for (const auto& q : quads) t.quads.push_back(q);
     trace.push_back(std::move(t));
     return true;
   }

@@ -1,0 +1,397 @@
+"""GPU parity tests: the HIP path (through the C-ABI, libhop.so) against the CPU oracle and the golden vectors
+emitted by the reference's own code.  Run with `pytest -m gpu` on an MI355X."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api(hop):
+    from hop_amd import api as _api
+    _api.lib()  # raises if libhop.so is missing: no fallback
+    return _api
+
+
+@pytest.fixture(scope="module")
+def ctx(api):
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def synth(hop):
+    return hop.synth
+
+
+def _canon(pose, lcp):
+    flat = pose.reshape(len(pose), 16)
+    rot = flat[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]]
+    order = np.lexsort(tuple(rot[:, ::-1].T) + (-lcp,))
+    return pose[order], lcp[order]
+
+
+def _rot_err_deg(Ra, Rb):
+    c = (np.trace(Ra.T @ Rb) - 1) / 2
+    return math.degrees(math.acos(max(-1.0, min(1.0, float(c)))))
+
+
+# ------------------------------------------------------------------------------------------------ Verify
+@pytest.mark.parametrize("mode", [0, 1])
+def test_verify_matches_reference_golden(ctx, golden_dir, mode):
+    """K4 against Verify values produced by the reference build (exact integer inlier counts)."""
+    g = np.load(os.path.join(golden_dir, "s4pcs_case1.npz"))
+    # centred P exactly as MatchBase::init does it: sequential float sum, then subtract
+    P = g["P_xyz"].astype(np.float32)
+    cen = g["cP"]
+    Pc = (P - cen).astype(np.float32)
+    ctx.verify_set_clouds(Pc, g["Qs"])
+    cnt = ctx.verify_batch(g["verify_T"], 0.003, mode)
+    nq = len(g["Qs"])
+    assert np.array_equal(cnt.astype(np.float32) / np.float32(nq), g["verify_lcp"])
+    assert cnt.max() > 0
+
+
+def test_verify_brute_grid_oracle_agree_large(ctx, orc, synth):
+    """20k-point scene, 100 samples, 512 transforms: brute == grid == oracle (kd-tree), exact counts."""
+    rng = np.random.default_rng(3)
+    sc = synth.make_scene(20000, seed=7)
+    mx, _ = synth.ellipsoid_model(5000)
+    P = (sc.xyz - sc.xyz.mean(axis=0)).astype(np.float32)
+    Qraw = mx[rng.choice(len(mx), 100, replace=False)]
+    cq = Qraw.mean(axis=0)
+    Qs = (Qraw - cq).astype(np.float32)
+    Tg = sc.gt_pose.copy()
+    Tg[:3, 3] = Tg[:3, :3] @ cq + Tg[:3, 3] - sc.xyz.mean(axis=0)   # centred-frame transform
+    T = synth.replay_poses(Tg, 512, seed=5, max_rot_deg=20, max_trans=0.01)
+    ctx.verify_set_clouds(P, Qs)
+    a = ctx.verify_batch(T, 0.003, 0)
+    b = ctx.verify_batch(T, 0.003, 1)
+    assert np.array_equal(a, b)
+    o = orc.verify_batch(P, Qs, T[:96], 0.003, use_tree=True)
+    assert np.array_equal(a[:96], o)
+    assert a.max() > 5
+    # order independence of the scene: a size-independent property of Verify
+    perm = rng.permutation(len(P))
+    ctx.verify_set_clouds(P[perm], Qs)
+    assert np.array_equal(ctx.verify_batch(T, 0.003, 0), a)
+
+
+# ------------------------------------------------------------------------------------------------ generator
+@pytest.mark.parametrize("case", ["case1", "case2"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_generator_matches_reference_golden(ctx, api, orc, golden_dir, case, mode):
+    g = np.load(os.path.join(golden_dir, f"s4pcs_{case}.npz"))
+    sample_size, succ, n_calls = (int(v) for v in g["opts"])
+    assert n_calls == 1
+    overlap, delta, disp = (float(v) for v in g["opts_f"])
+    ctx.set_scene(g["P_xyz"], g["P_nrm"], g["P_conf"], 0.0)
+    ctx.set_model(api.HOP_MODEL_5MM, g["Q_xyz"], g["Q_nrm"])
+    ctx.set_ppf_keys(g["keys"])
+    o = ctx.default_s4pcs_opts(sample_size=sample_size, overlap=overlap, delta=delta, dispersion=disp,
+                               success_quadrilaterals=succ, max_time_seconds=0, n_trials=0, verify_mode=mode)
+    pose, lcp, st = ctx.s4pcs_generate(o)
+    # state
+    assert st.n_sampled_q == len(g["Qs"])
+    qs, qn = ctx.s4pcs_sampled_q(st.n_sampled_q)
+    assert np.array_equal(qs, g["Qs"]) and np.array_equal(qn, g["Qs_nrm"])
+    assert np.array_equal(np.array(st.centroid_p, np.float32), g["cP"])
+    assert np.array_equal(np.array(st.centroid_q, np.float32), g["cQ"])
+    assert np.float32(st.diameter) == g["diameter"]
+    # per-base trace: ids, invariants bit-equal; list sizes equal to the reference's
+    bases = ctx.s4pcs_bases()
+    assert len(bases) == int(g["n_bases"])
+    for i, b in enumerate(bases):
+        assert np.array_equal(b["base"], g["base_ids"][i])
+        assert np.array_equal(b["inv"], g["base_inv"][i])
+        assert b["n_pairs1"] == len(g[f"pairs1_{i}"])
+        assert b["n_pairs2"] == len(g[f"pairs2_{i}"])
+        assert b["n_quads"] == len(g[f"quads_{i}"])
+    # hypotheses: same multiset as the reference (lcp and rotation exact, translation 1e-6 m)
+    assert len(lcp) == len(g["hyp_lcp"])
+    p2, l2 = _canon(pose, lcp)
+    assert np.array_equal(l2, g["hyp_lcp"])
+    assert np.array_equal(p2[:, :3, :3], g["hyp_pose"][:, :3, :3])
+    assert np.abs(p2[:, :3, 3] - g["hyp_pose"][:, :3, 3]).max() < 1e-6
+    # emission order: identical to the oracle's canonical order, element by element
+    oo = orc.OracleS4PCS(sample_size=sample_size, overlap=overlap, delta=delta, dispersion=disp, success_quadrilaterals=succ)
+    oo.set_keys(g["keys"])
+    oo.run(g["P_xyz"], g["P_nrm"], g["P_conf"], g["Q_xyz"], g["Q_nrm"], 1)
+    op, ol = oo.hypos()
+    assert np.array_equal(ol, lcp)
+    assert np.array_equal(op[:, :3, :3], pose[:, :3, :3])
+    assert np.abs(op[:, :3, 3] - pose[:, :3, 3]).max() < 1e-6
+
+
+def test_generator_explicit_trials_matches_oracle(ctx, api, orc, synth):
+    """n_trials as an explicit parameter (beyond the reference's 30-trial clamp), larger scene."""
+    mx, mn = synth.ellipsoid_model_spacing(0.005)
+    keys = synth.ppf_key_table()
+    sc = synth.make_scene(2000, seed=13)
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.0)
+    ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
+    ctx.set_ppf_keys(keys)
+    o = ctx.default_s4pcs_opts(sample_size=80, success_quadrilaterals=1000, max_time_seconds=0, n_trials=48)
+    pose, lcp, st = ctx.s4pcs_generate(o, cap=1 << 18)
+    oo = orc.OracleS4PCS(sample_size=80, success_quadrilaterals=1000, n_trials=48)
+    oo.set_keys(keys)
+    n = oo.run(sc.xyz, sc.nrm, sc.conf, mx, mn, 1)
+    op, ol = oo.hypos()
+    assert st.n_trials_run == 48
+    assert len(lcp) == n
+    assert np.array_equal(ol, lcp)
+    assert np.array_equal(op[:, :3, :3], pose[:, :3, :3])
+    ob = oo.bases()
+    gb = ctx.s4pcs_bases()
+    assert len(ob) == len(gb)
+    for a, b in zip(ob, gb):
+        assert np.array_equal(a["base"], b["base"]) and np.array_equal(a["inv"], b["inv"])
+        assert len(a["pairs1"]) == b["n_pairs1"] and len(a["pairs2"]) == b["n_pairs2"] and len(a["quads"]) == b["n_quads"]
+
+
+# ------------------------------------------------------------------------------------------------ computeLCP
+def _scoring_case(synth, n_scene, n_model, H, seed=7):
+    sc = synth.make_scene(n_scene, seed=seed)
+    mx, mn = synth.ellipsoid_model(n_model)
+    poses = synth.replay_poses(sc.gt_pose, H, seed=11)
+    poses[0] = sc.gt_pose.astype(np.float32)
+    return sc, mx, mn, poses
+
+
+def test_lcp_scores_bit_equal_to_oracle(ctx, api, orc, synth):
+    sc, mx, mn, poses = _scoring_case(synth, 3000, 2500, 48)
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.0)
+    ctx.set_model(api.HOP_MODEL_1MM, mx, mn)
+    ctx.hypos_upload(poses)
+    best_pose, best_score, best_idx = ctx.lcp_select_best(0.001, 10.0)
+    _, scores, _ = ctx.hypos_download()
+    ref = orc.compute_lcp_batch(sc.xyz, sc.nrm, mx, mn, poses, 0.001, 10.0, use_tree=True)
+    assert scores.max() > 10.0, "the ground-truth pose must score"
+    assert np.array_equal(scores, ref), (scores[:6], ref[:6])
+    # selectBest: first strict maximum
+    exp = int(np.flatnonzero(ref == ref.max())[0])
+    assert best_idx == exp and best_score == ref[exp]
+    assert np.array_equal(best_pose, poses[exp])
+
+
+def test_lcp_ragged_and_empty_edge_cases(ctx, api, orc, synth):
+    """Sizes that are not multiples of any tile (1 scene point .. 2049 model points), and a pose far away."""
+    sc, mx, mn, poses = _scoring_case(synth, 777, 2049, 5)
+    far = poses[1].copy()
+    far[:3, 3] += 10.0
+    poses[1] = far
+    for ns in (1, 63, 777):
+        ctx.set_scene(sc.xyz[:ns], sc.nrm[:ns], None, 0.0)
+        ctx.set_model(api.HOP_MODEL_1MM, mx, mn)
+        ctx.hypos_upload(poses)
+        ctx.lcp_select_best(0.002, 15.0)
+        _, scores, _ = ctx.hypos_download()
+        ref = orc.compute_lcp_batch(sc.xyz[:ns], sc.nrm[:ns], mx, mn, poses, 0.002, 15.0, use_tree=False)
+        assert np.array_equal(scores, ref)
+        assert scores[1] == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ ICP
+def test_icp_matches_oracle_and_recovers_pose(ctx, api, orc, synth):
+    sc, mx, mn, poses = _scoring_case(synth, 2500, 1500, 24)
+    # small perturbations so that ICP converges to the truth
+    poses = synth.replay_poses(sc.gt_pose, 24, seed=3, max_rot_deg=6.0, max_trans=0.004)
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.0)
+    ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
+    ctx.hypos_upload(poses)
+    it, cv = ctx.icp_refine(10, 45.0, 0.01, want_stats=True)
+    out, _, _ = ctx.hypos_download()
+    ref, rit, rcv = orc.icp_refine_batch(sc.xyz, sc.nrm, mx, mn, poses, 10, 45.0, 0.01, use_tree=True)
+    assert np.array_equal(it, rit) and np.array_equal(cv, rcv)
+    assert np.abs(out - ref).max() < 2e-5          # float tolerance of the double-precision solve
+    # refined poses are within 1 mm / 1 deg of the ground truth (modulo the ellipsoid's 180 deg symmetries
+    # no symmetry flip can happen from a 6 deg start)
+    gt = sc.gt_pose
+    ok = 0
+    for T in out:
+        if np.linalg.norm(T[:3, 3] - gt[:3, 3]) < 1e-3 and _rot_err_deg(T[:3, :3].astype(np.float64), gt[:3, :3]) < 1.0:
+            ok += 1
+    assert ok >= 20
+
+
+def test_icp_too_few_correspondences_returns_input(ctx, api, orc, synth):
+    sc, mx, mn, poses = _scoring_case(synth, 500, 400, 3)
+    poses[:, :3, 3] += 5.0  # nothing within 1 cm -> not converged -> identity (Utils.cpp:218-225)
+    ctx.set_scene(sc.xyz, sc.nrm, None, 0.0)
+    ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
+    ctx.hypos_upload(poses)
+    it, cv = ctx.icp_refine(10, 45.0, 0.01, want_stats=True)
+    out, _, _ = ctx.hypos_download()
+    assert not cv.any() and not it.any()
+    assert np.abs(out - poses).max() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ resident set
+def test_topk_and_cluster(ctx, api, orc, synth):
+    rng = np.random.default_rng(0)
+    sc, mx, mn, poses = _scoring_case(synth, 300, 300, 400)
+    scores = (rng.integers(0, 20, size=len(poses)) / 20.0).astype(np.float32)  # many ties
+    ctx.hypos_upload(poses, scores)
+    ctx.hypos_keep_topk(150)
+    p, s, ids = ctx.hypos_download()
+    order = np.lexsort((np.arange(len(scores)), -scores))[:150]
+    assert np.array_equal(s, scores[order]) and np.array_equal(p, poses[order])
+    assert np.array_equal(ids, np.arange(150))
+    # clustering: device-resident call == pure host function == oracle
+    ctx.hypos_upload(poses, scores)
+    ctx.cluster_poses(30.0, 0.015, [180, 180, 180], True)
+    pc, scs, idc = ctx.hypos_download()
+    keep = orc.cluster_poses(poses, scores, np.arange(len(poses)), 30.0, 0.015, [180, 180, 180])
+    keep2 = api.cluster_poses_host(poses, scores, np.arange(len(poses)), 30.0, 0.015, [180, 180, 180])
+    assert np.array_equal(keep, keep2)
+    assert np.array_equal(pc, poses[keep]) and np.array_equal(scs, scores[keep])
+    assert np.array_equal(idc, np.arange(len(keep)))
+    rows, n = ctx.topk_pack(8, id_offset=1000)
+    pp, ss, ii = api.rows_to_hypos(rows)
+    assert n == min(8, len(keep)) and (ii[:n] >= 1000).all()
+
+
+# ------------------------------------------------------------------------------------------------ hand
+def _hand_case(synth, api, n_scene=4000):
+    hand = synth.t42_hand()
+    true = {"finger_1_1": math.radians(10), "finger_1_2": math.radians(6), "finger_2_1": math.radians(12), "finger_2_2": math.radians(5)}
+    xyz, nrm = synth.make_hand_scene(hand, true, n_scene, seed=5)
+    return hand, true, xyz, nrm
+
+
+def _cfg():
+    return {"hand_match": {"finger1_min_match": 5, "finger2_min_match": 5, "finger1_dist_thres": 0.005, "finger2_dist_thres": 0.005,
+                           "finger1_normal_angle": 60, "finger2_normal_angle": 60, "check_normal": True, "max_outter_pts": 300,
+                           "outter_pt_dist": 0.002, "outter_pt_dist_weight": 1, "planar_dist_thres": 0.001,
+                           "pso": {"n_pop": 15, "n_gen": 3, "check_freq": 10, "pso_par_c_cog": 0.1, "pso_par_c_soc": 0.9,
+                                   "pso_par_initial_w": 0.0}}}
+
+
+def _oracle_args(orc, a, xyz, nrm, swivel, keep):
+    """Copies a hop FingerArgs into the oracle's struct."""
+    o = orc.FingerArgs()
+    for k in range(3):
+        o.fp_min[k], o.fp_max[k], o.fo_min[k], o.fo_max[k] = a.fp_min[k], a.fp_max[k], a.fo_min[k], a.fo_max[k]
+    o.fp_stride_z, o.fp_num_division, o.fp_hist_min_y = a.fp_stride_z, a.fp_num_division, a.fp_hist_min_y
+    for k in range(16):
+        o.model2handbase[k], o.finger_out2parent[k] = a.model2handbase[k], a.finger_out2parent[k]
+    for k in range(4):
+        o.pair_tip1[k], o.pair_tip2[k] = a.pair_tip1[k], a.pair_tip2[k]
+    for f in ("is_palm_side", "is_right_side", "gripper_min_dist", "dist_thres", "cos_normal_thres", "check_normal",
+              "max_outter_pts", "outter_pt_dist", "outter_pt_dist_weight", "n_model"):
+        setattr(o, f, getattr(a, f))
+    o.model_xyz, o.model_nrm = a.model_xyz, a.model_nrm
+    S, Ln, W = orc.soa(xyz), orc.soa(nrm), orc.soa(swivel)
+    keep.extend([S, Ln, W])
+    o.scene_xyz, o.n_scene = orc.F(S), S.shape[1]
+    o.scene_nrm_lookup, o.n_lookup = orc.F(Ln), Ln.shape[1]
+    o.swivel_xyz, o.n_swivel = orc.F(W), W.shape[1]
+    return o
+
+
+@pytest.mark.parametrize("finger", ["finger_1_1", "finger_2_2"])
+def test_pso_objective_equals_oracle(ctx, api, orc, synth, finger):
+    import ctypes as C
+    hand, true, xyz, nrm = _hand_case(synth, api)
+    swivel = xyz[xyz[:, 0] < -0.1]  # scene_remove_swivel: x in (-0.25,-0.1), Hand.cpp:316-320
+    h = api.HandT42(_cfg(), hand, ctx=ctx)
+    h.gripper_min_dist = 0.0144
+    if finger.endswith("_2"):   # the proximal link is already placed when the distal one is searched
+        par = finger[:-1] + "1"
+        a = np.float32(true[par])
+        T = np.eye(4, dtype=np.float32)
+        T[1, 1], T[1, 2], T[2, 1], T[2, 2] = np.cos(a), -np.sin(a), np.sin(a), np.cos(a)
+        h._tf_self[par] = T
+    h.setCurScene(xyz, nrm, swivel)
+    args = h.finger_args(finger, 0.005)
+    ctx.hand_set_finger(args)
+    angles = np.radians(np.linspace(0.0, 120.0 if finger.endswith("_1") else 90.0, 97))
+    got = ctx.hand_pso_eval_batch(angles)
+    keep = []
+    oa = _oracle_args(orc, args, xyz, nrm, swivel, keep)
+    ref = np.zeros(len(angles))
+    orc.lib().orc_pso_objective_batch(C.byref(oa), orc.D(np.ascontiguousarray(angles)), len(angles), orc.D(ref))
+    assert np.array_equal(got, ref), np.abs(got - ref).max()
+    # the objective has a real minimum near the true angle
+    best = angles[np.argmin(ref)]
+    assert abs(best - true[finger]) < math.radians(8.0)
+    assert ref.min() < -5
+
+
+def test_pso_search_equals_oracle(ctx, api, orc, synth):
+    import ctypes as C
+    hand, true, xyz, nrm = _hand_case(synth, api)
+    swivel = xyz[xyz[:, 0] < -0.1]  # scene_remove_swivel: x in (-0.25,-0.1), Hand.cpp:316-320
+    h = api.HandT42(_cfg(), hand, ctx=ctx)
+    h.gripper_min_dist = 0.0144
+    h.setCurScene(xyz, nrm, swivel)
+    ok = h.matchOneComponentPSO("finger_1_1", 0, 120, False, 0.005, 60, 5)
+    assert ok
+    args = h.finger_args("finger_1_1", 0.005)
+    # note: _tf_self[finger_1_1] is now set, but model2handbase of the link itself excludes its own angle?  No:
+    # getTFHandBase includes _tf_self of the link, exactly as the reference does on a second call.
+    h._tf_self["finger_1_1"] = np.eye(4, dtype=np.float32)
+    args = h.finger_args("finger_1_1", 0.005)
+    keep = []
+    oa = _oracle_args(orc, args, xyz, nrm, swivel, keep)
+    s = h.pso_settings(0, 120)
+    os_ = orc.PsoSettings(s.n_pop, s.n_gen, s.check_freq, s.c_cog, s.c_soc, s.initial_w, s.w_min, s.w_max, s.err_tol, s.lower_rad,
+                          s.upper_rad, s.seed)
+    ang = C.c_double(0)
+    val = C.c_double(0)
+    orc.lib().orc_pso_search(C.byref(oa), C.byref(os_), C.byref(ang), C.byref(val))
+    assert h.last_angle == np.float32(ang.value)
+    assert h.last_objval == val.value
+    assert abs(ang.value - true["finger_1_1"]) < math.radians(10.0)
+
+
+# ------------------------------------------------------------------------------------------------ pipeline
+def test_full_chain_pose_within_1mm_1deg_of_oracle(ctx, api, orc, synth):
+    """gen -> cluster(30,15mm) -> ICP(<=100) -> cluster(5,3mm) -> selectBest, as main_realdata_auto.cpp:187-204
+    (minus the two rejectBy* steps, which are 'next' rows): GPU chain vs oracle chain on the same inputs."""
+    mx5, mn5 = synth.ellipsoid_model_spacing(0.005)
+    mx1, mn1 = synth.ellipsoid_model(4000)
+    keys = synth.ppf_key_table()
+    sc = synth.make_scene(1200, seed=7)
+    sym = [180, 180, 180]
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8)
+    ctx.set_model(api.HOP_MODEL_5MM, mx5, mn5)
+    ctx.set_model(api.HOP_MODEL_1MM, mx1, mn1)
+    ctx.set_ppf_keys(keys)
+    o = ctx.default_s4pcs_opts(max_time_seconds=0)
+    pose, lcp, st = ctx.s4pcs_generate(o)
+    ctx.cluster_poses(30.0, 0.015, sym, True)
+    ctx.icp_refine(10, 45.0, 0.01, max_hypotheses=100)
+    ctx.cluster_poses(5.0, 0.003, sym, False)
+    best, score, idx = ctx.lcp_select_best(0.001, 10.0)
+    # oracle chain
+    oo = orc.OracleS4PCS()
+    oo.set_keys(keys)
+    oo.run(sc.xyz, sc.nrm, sc.conf, mx5, mn5, 1)
+    op, ol = oo.hypos()
+    assert np.array_equal(ol, lcp)
+    keep = orc.cluster_poses(op, ol, np.arange(len(ol)), 30.0, 0.015, sym)
+    p1, l1 = op[keep][:100], ol[keep][:100]
+    p2, _, _ = orc.icp_refine_batch(sc.xyz, sc.nrm, mx5, mn5, p1, 10, 45.0, 0.01)
+    keep2 = orc.cluster_poses(p2, l1, np.arange(len(l1)), 5.0, 0.003, sym)
+    p3 = p2[keep2]
+    s3 = orc.compute_lcp_batch(sc.xyz, sc.nrm, mx1, mn1, p3, 0.001, 10.0)
+    ob = p3[int(np.flatnonzero(s3 == s3.max())[0])]
+    assert np.linalg.norm(best[:3, 3] - ob[:3, 3]) < 1e-3
+    assert _rot_err_deg(best[:3, :3].astype(np.float64), ob[:3, :3].astype(np.float64)) < 1.0
+    assert abs(score - s3.max()) <= 1e-4 * s3.max()
+    # and the estimate is a correct pose: the model under `best` lies on the model under the truth
+    a = mx1 @ best[:3, :3].T + best[:3, 3]
+    b = mx1 @ sc.gt_pose[:3, :3].T + sc.gt_pose[:3, 3]
+    from scipy.spatial import cKDTree
+    adi = cKDTree(b).query(a)[0].mean()
+    assert adi < 0.005  # the authors' evaluator threshold (scripts/eval_all.py:77)
+
+
+def test_library_fails_loudly_without_fallback(api):
+    with pytest.raises(api.HopError):
+        api.Context(99)  # no such device: an error code, not a CPU path
