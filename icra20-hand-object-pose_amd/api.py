@@ -254,14 +254,19 @@ class Context:
             self._chk(rc, "hop_s4pcs_generate", ok=(-6,))
             return pose[:n.value].reshape(-1, 4, 4).copy(), lcp[:n.value].copy(), st
 
-    def s4pcs_bases(self):
+    def s4pcs_bases(self, successful_only=True):
+        """Per-base trace of the last generate.  A base is "successful" when generateCongruents would return
+        true (both pair lists and the quadrilateral set non-empty, match4pcsBase.hpp:269-280); the reference
+        only counts / keeps those."""
         out = []
         for i in range(self.L.hop_s4pcs_num_bases(self.h)):
             b4 = np.zeros(4, np.int32)
             inv = np.zeros(2, np.float32)
             c3 = np.zeros(3, np.int32)
             self._chk(self.L.hop_s4pcs_get_base(self.h, i, I(b4), F(inv), I(c3)), "hop_s4pcs_get_base")
-            out.append(dict(base=b4, inv=inv, n_pairs1=int(c3[0]), n_pairs2=int(c3[1]), n_quads=int(c3[2])))
+            ok = c3[0] > 0 and c3[1] > 0 and c3[2] > 0
+            if ok or not successful_only:
+                out.append(dict(base=b4, inv=inv, n_pairs1=int(c3[0]), n_pairs2=int(c3[1]), n_quads=int(c3[2]), success=bool(ok)))
         return out
 
     def s4pcs_sampled_q(self, n):
