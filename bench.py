@@ -177,7 +177,7 @@ def main():
         if world == 1:
             return rows
         t = torch.from_numpy(rows).to(dev)
-        out = torch.empty((world,) + t.shape, dtype=t.dtype, device=dev)
+        out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=dev)
         dist.all_gather_into_tensor(out, t)
         merged, _ = api.topk_merge(out.cpu().numpy(), K)
         return merged

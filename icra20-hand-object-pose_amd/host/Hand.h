@@ -1,0 +1,232 @@
+// Hand.h -- host-side mirror of the reference's Hand / HandT42 for the hand-state search
+// (src/perception/include/Hand.h:29-92; Hand.cpp:182-250 FingerProperty, :505-523 getTFHandBase,
+// :587-600 initPSO, :603-672 matchOneComponentPSO), forwarding to the C-ABI.  The URDF/mesh loading of
+// Hand::parseURDF (Hand.cpp:375-502) is replaced by addComponent() calls with link clouds already at 5 mm.
+#ifndef HOP_HOST_HAND_H_
+#define HOP_HOST_HAND_H_
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "PoseEstimator.h"
+
+struct Mat4 {
+  float m[16];
+  static Mat4 Identity() {
+    Mat4 r;
+    for (int i = 0; i < 16; ++i) r.m[i] = (i % 5 == 0) ? 1.f : 0.f;
+    return r;
+  }
+};
+inline Mat4 operator*(const Mat4& a, const Mat4& b) {
+  Mat4 r;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float s = 0.f;
+      for (int k = 0; k < 4; ++k) s += a.m[4 * i + k] * b.m[4 * k + j];
+      r.m[4 * i + j] = s;
+    }
+  return r;
+}
+inline void mulPoint(const Mat4& T, const float v[4], float out[4]) {
+  for (int i = 0; i < 4; ++i) out[i] = ((T.m[4 * i] * v[0] + T.m[4 * i + 1] * v[1]) + T.m[4 * i + 2] * v[2]) + T.m[4 * i + 3] * v[3];
+}
+
+// FingerProperty (Hand.h:8-21, Hand.cpp:182-250)
+class FingerProperty {
+ public:
+  float _min_x = 0, _min_y = 0, _min_z = 0, _max_x = 0, _max_y = 0, _max_z = 0;
+  float _stride_z = 0;
+  std::vector<float> _hist_alongz;  // 6 x N, row-major
+  int _num_division = 0;
+  FingerProperty() {}
+  FingerProperty(const hop::Cloud& model, int num_division) : _num_division(num_division) {
+    const int n = model.n;
+    const float *x = model.xyz.data(), *y = x + n, *z = y + n;
+    _min_x = _min_y = _min_z = FLT_MAX;
+    _max_x = _max_y = _max_z = -FLT_MAX;
+    for (int i = 0; i < n; ++i) {
+      _min_x = std::min(_min_x, x[i]), _min_y = std::min(_min_y, y[i]), _min_z = std::min(_min_z, z[i]);
+      _max_x = std::max(_max_x, x[i]), _max_y = std::max(_max_y, y[i]), _max_z = std::max(_max_z, z[i]);
+    }
+    _stride_z = (_max_z - _min_z) / num_division;
+    _hist_alongz.assign(6 * (size_t)num_division, 0.f);
+    for (int c = 0; c < num_division; ++c)
+      for (int r = 0; r < 6; ++r) H(r, c) = r < 3 ? FLT_MAX : -FLT_MAX;
+    std::vector<bool> changed(num_division, false);
+    for (int i = 0; i < n; ++i) {
+      const int bin = getBinAlongZ(z[i]);
+      H(0, bin) = std::min(H(0, bin), x[i]), H(1, bin) = std::min(H(1, bin), y[i]), H(2, bin) = std::min(H(2, bin), z[i]);
+      H(3, bin) = std::max(H(3, bin), x[i]), H(4, bin) = std::max(H(4, bin), y[i]), H(5, bin) = std::max(H(5, bin), z[i]);
+      changed[bin] = true;
+    }
+    for (int i = 0; i < num_division; ++i) {
+      if (changed[i]) continue;
+      for (int j = i + 1; j < num_division; ++j)
+        if (changed[j]) {
+          for (int r = 0; r < 6; ++r) H(r, i) = H(r, j);
+          changed[i] = true;
+          break;
+        }
+    }
+    if (!changed[num_division - 1])
+      for (int i = num_division - 2; i >= 0; --i)
+        if (changed[i]) {
+          for (int r = 0; r < 6; ++r) H(r, num_division - 1) = H(r, i);
+          break;
+        }
+  }
+  float& H(int r, int c) { return _hist_alongz[(size_t)r * _num_division + c]; }
+  int getBinAlongZ(float z) const {
+    int bin = (int)(std::max(z - _min_z, 0.0f) / _stride_z);
+    bin = std::max(bin, 0);
+    return std::min(bin, _num_division - 1);
+  }
+};
+
+class Hand {
+ public:
+  Hand(ConfigParser* cfg1, hop_ctx* ctx) : cfg(cfg1), ctx_(ctx) { initPSO(); }
+  virtual ~Hand() {}
+
+  // Hand::addComponent (Hand.cpp:525-534); `cloud` already down-sampled to 5 mm, in the link frame
+  void addComponent(const std::string& name, const std::string& parent_name, const hop::Cloud& cloud, const Mat4& tf_in_parent) {
+    _clouds[name] = cloud;
+    _parent_names[name] = parent_name;
+    _tf_in_parent[name] = tf_in_parent;
+    _tf_self[name] = Mat4::Identity();
+    _component_status[name] = false;
+    if (name.find("finger") != std::string::npos) _finger_properties[name] = FingerProperty(cloud, 10);
+  }
+
+  // products of Hand::setCurScene (Hand.cpp:327-332), hand-base frame
+  void setCurScene(const hop::Cloud& scene_hand_region_removed_noise, const hop::Cloud& scene_hand_region,
+                   const hop::Cloud& scene_remove_swivel) {
+    hop::check(hop_hand_set_scene(ctx_, scene_hand_region_removed_noise.xyz.data(), scene_hand_region_removed_noise.n,
+                                  scene_hand_region.nrm.data(), scene_hand_region.n, scene_remove_swivel.xyz.data(),
+                                  scene_remove_swivel.n),
+               ctx_, "hop_hand_set_scene");
+  }
+
+  // Hand::getTFHandBase (Hand.cpp:505-523)
+  void getTFHandBase(std::string cur_name, Mat4& tf_in_handbase) {
+    tf_in_handbase = Mat4::Identity();
+    while (cur_name != "base_link") {
+      if (_tf_self.find(cur_name) == _tf_self.end()) throw std::runtime_error("cur_name does not exist: " + cur_name);
+      tf_in_handbase = _tf_in_parent[cur_name] * _tf_self[cur_name] * tf_in_handbase;
+      cur_name = _parent_names[cur_name];
+    }
+  }
+
+  void initPSO() {  // Hand.cpp:587-600
+    hop_pso_default_settings(&_pso_settings);
+    _pso_settings.n_pop = cfg->geti("hand_match.pso.n_pop");
+    _pso_settings.n_gen = cfg->geti("hand_match.pso.n_gen");
+    _pso_settings.check_freq = cfg->geti("hand_match.pso.check_freq");
+    _pso_settings.err_tol = 1e-5;
+    _pso_settings.c_cog = cfg->getf("hand_match.pso.pso_par_c_cog");
+    _pso_settings.c_soc = cfg->getf("hand_match.pso.pso_par_c_soc");
+    _pso_settings.initial_w = cfg->getf("hand_match.pso.pso_par_initial_w");
+  }
+
+  // Hand::matchOneComponentPSO (Hand.cpp:603-672).  use_normal / normal_angle_thres are ignored by the
+  // reference body (thresholds come from the YAML, Hand.cpp:76-83); kept for signature compatibility.
+  bool matchOneComponentPSO(std::string model_name, float min_angle, float max_angle, bool /*use_normal*/, float dist_thres,
+                            float /*normal_angle_thres*/, float least_match) {
+    _pso_settings.upper_rad = max_angle * M_PI / 180;
+    _pso_settings.lower_rad = min_angle * M_PI / 180;
+    std::map<std::string, std::string> pair_names{{"finger_1_1", "finger_2_1"}, {"finger_2_1", "finger_1_1"},
+                                                  {"finger_1_2", "finger_2_2"}, {"finger_2_2", "finger_1_2"}};
+    hop_finger_args a;
+    std::memset(&a, 0, sizeof(a));
+    const std::string pair_name = pair_names[model_name];
+    Mat4 pair_in_base;
+    auto tip = [&](const std::string& n, bool max_z, float out[4]) {
+      const FingerProperty& p = _finger_properties[n];
+      out[0] = p._min_x, out[1] = p._max_y, out[2] = max_z ? p._max_z : p._min_z, out[3] = 1.f;
+    };
+    Mat4 finger_out2parent = Mat4::Identity();
+    FingerProperty finger_out_property = _finger_properties[model_name];
+    float t[4];
+    if (pair_name == "finger_1_1" || pair_name == "finger_2_1") {
+      const std::string pair_out = pair_name == "finger_1_1" ? "finger_1_2" : "finger_2_2";
+      tip(pair_out, false, t);
+      getTFHandBase(pair_out, pair_in_base);
+      mulPoint(pair_in_base, t, a.pair_tip1);
+      getTFHandBase(pair_name, pair_in_base);
+      tip(pair_name, false, t);
+      mulPoint(pair_in_base, t, a.pair_tip2);
+      const std::string out_name = model_name == "finger_1_1" ? "finger_1_2" : "finger_2_2";
+      finger_out2parent = _tf_in_parent[out_name];
+      finger_out_property = _finger_properties[out_name];
+    } else {
+      getTFHandBase(pair_name, pair_in_base);
+      tip(pair_name, false, t);
+      mulPoint(pair_in_base, t, a.pair_tip1);
+      tip(pair_name, true, t);
+      mulPoint(pair_in_base, t, a.pair_tip2);
+    }
+    const FingerProperty& fp = _finger_properties[model_name];
+    a.fp_min[0] = fp._min_x, a.fp_min[1] = fp._min_y, a.fp_min[2] = fp._min_z;
+    a.fp_max[0] = fp._max_x, a.fp_max[1] = fp._max_y, a.fp_max[2] = fp._max_z;
+    a.fo_min[0] = finger_out_property._min_x, a.fo_min[1] = finger_out_property._min_y, a.fo_min[2] = finger_out_property._min_z;
+    a.fo_max[0] = finger_out_property._max_x, a.fo_max[1] = finger_out_property._max_y, a.fo_max[2] = finger_out_property._max_z;
+    a.fp_stride_z = fp._stride_z;
+    a.fp_num_division = fp._num_division;
+    a.fp_hist_min_y = fp._hist_alongz.data() + (size_t)1 * fp._num_division;
+    Mat4 model2handbase;
+    getTFHandBase(model_name, model2handbase);
+    std::memcpy(a.model2handbase, model2handbase.m, sizeof(float) * 16);
+    std::memcpy(a.finger_out2parent, finger_out2parent.m, sizeof(float) * 16);
+    a.is_palm_side = (model_name == "finger_1_1" || model_name == "finger_2_1");
+    a.is_right_side = (model_name == "finger_2_1" || model_name == "finger_2_2");
+    a.gripper_min_dist = cfg->gripper_min_dist;
+    a.dist_thres = dist_thres;
+    const float ang = cfg->getf(a.is_palm_side ? "hand_match.finger1_normal_angle" : "hand_match.finger2_normal_angle");
+    a.cos_normal_thres = (float)std::cos(ang / 180.0 * M_PI);
+    a.check_normal = cfg->getb("hand_match.check_normal");
+    a.max_outter_pts = cfg->geti("hand_match.max_outter_pts");
+    a.outter_pt_dist = cfg->getf("hand_match.outter_pt_dist");
+    a.outter_pt_dist_weight = cfg->getf("hand_match.outter_pt_dist_weight");
+    const hop::Cloud& cl = _clouds[model_name];
+    a.model_xyz = cl.xyz.data(), a.model_nrm = cl.nrm.data(), a.n_model = cl.n;
+    hop::check(hop_hand_set_finger(ctx_, &a), ctx_, "hop_hand_set_finger");
+    double angle = 0, objval = 0;
+    hop::check(hop_hand_pso_search(ctx_, &_pso_settings, &angle, &objval), ctx_, "hop_hand_pso_search");
+    if (-objval <= least_match) {
+      std::printf("%s PSO matching failed\n", model_name.c_str());
+      _tf_self[model_name] = Mat4::Identity();
+      _component_status[model_name] = false;
+      return false;
+    }
+    const float af = static_cast<float>(angle);
+    Mat4 R = Mat4::Identity();
+    R.m[5] = std::cos(af), R.m[6] = -std::sin(af), R.m[9] = std::sin(af), R.m[10] = std::cos(af);
+    _tf_self[model_name] = R;
+    _component_status[model_name] = true;
+    _finger_angles[model_name] = af;
+    std::printf("%s PSO final angle=%f, match_score=%f\n", model_name.c_str(), af, -objval);
+    return true;
+  }
+
+  std::map<std::string, hop::Cloud> _clouds;
+  std::map<std::string, std::string> _parent_names;
+  std::map<std::string, Mat4> _tf_in_parent, _tf_self;
+  std::map<std::string, FingerProperty> _finger_properties;
+  std::map<std::string, bool> _component_status;
+  std::map<std::string, float> _finger_angles;
+  ConfigParser* cfg;
+  hop_pso_settings _pso_settings;
+
+ protected:
+  hop_ctx* ctx_;
+};
+
+class HandT42 : public Hand {
+ public:
+  HandT42(ConfigParser* cfg1, hop_ctx* ctx) : Hand(cfg1, ctx) {}
+};
+#endif

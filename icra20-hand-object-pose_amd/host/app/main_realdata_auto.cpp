@@ -1,0 +1,144 @@
+// main_realdata_auto.cpp -- the reference driver's hot-path call order (src/perception/src/app/
+// main_realdata_auto.cpp:99-205) on top of libhop, for one frame whose clouds are given as files.
+//
+//   main_realdata_auto <config_autodataset.yaml> <frame_dir> [out_dir]
+//
+// The reference loads meshes, a Boost PPF archive and a URDF, none of which ship with it; here the frame
+// directory holds the already prepared clouds (what Hand::setCurScene / main :54-181 would produce):
+//   model.bin model001.bin object_segment.bin   clouds (see read_cloud)
+//   ppf_keys.bin                                int32 n, then n*4 int32 keys
+//   hand.txt                                    one line per link: name parent cloud_file 16 floats (row-major)
+//   hand_scene.bin hand_region.bin hand_swivel.bin
+//   cam_side.txt                                1 if cam_in_handbase(1,3) > 0 (main :114), else 0
+// Steps not on the hot path (adjustHandHeight, removeSurroundingPoints..., rejectBy*) are "next" rows.
+#include <cstdint>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include "../Hand.h"
+
+static hop::Cloud read_cloud(const std::string& path) {
+  // int32 n, int32 has_conf, then 3n float xyz planes, 3n float normal planes, [n float conf]
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("cannot open " + path);
+  int32_t n = 0, has_conf = 0;
+  f.read(reinterpret_cast<char*>(&n), 4);
+  f.read(reinterpret_cast<char*>(&has_conf), 4);
+  hop::Cloud c;
+  c.n = n;
+  c.xyz.resize(3 * (size_t)n);
+  c.nrm.resize(3 * (size_t)n);
+  f.read(reinterpret_cast<char*>(c.xyz.data()), sizeof(float) * 3 * (size_t)n);
+  f.read(reinterpret_cast<char*>(c.nrm.data()), sizeof(float) * 3 * (size_t)n);
+  if (has_conf) {
+    c.conf.resize(n);
+    f.read(reinterpret_cast<char*>(c.conf.data()), sizeof(float) * (size_t)n);
+  }
+  if (!f) throw std::runtime_error("short read " + path);
+  return c;
+}
+
+int main(int argc, char** argv) {
+  if (argc == 3 && std::string(argv[1]) == "--dump-config") {  // key=value lines of everything the parser read
+    try {
+      ConfigParser cfg(argv[2]);
+      for (const auto& kv : cfg.all()) std::cout << kv.first << "=" << kv.second << "\n";
+      return 0;
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "error: %s\n", e.what());
+      return 3;
+    }
+  }
+  if (argc < 3) {
+    std::cout << "usage: main_realdata_auto <config.yaml> <frame_dir> [out_dir]\n       main_realdata_auto --dump-config <config.yaml>\n";
+    return 2;
+  }
+  try {
+    const std::string config_dir = argv[1], frame = std::string(argv[2]) + "/", out_dir = argc > 3 ? argv[3] : argv[2];
+    std::cout << "Using config file: " << config_dir << std::endl;
+    ConfigParser cfg(config_dir);
+    std::vector<int32_t> ppfs;
+    {
+      std::ifstream f(frame + "ppf_keys.bin", std::ios::binary);
+      int32_t n = 0;
+      f.read(reinterpret_cast<char*>(&n), 4);
+      ppfs.resize(4 * (size_t)n);
+      f.read(reinterpret_cast<char*>(ppfs.data()), sizeof(int32_t) * 4 * (size_t)n);
+    }
+    const hop::Cloud model = read_cloud(frame + "model.bin"), model001 = read_cloud(frame + "model001.bin");
+    {  // main_realdata_auto.cpp:41-45
+      float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+      for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < model001.n; ++i) {
+          mn[k] = std::min(mn[k], model001.xyz[(size_t)k * model001.n + i]);
+          mx[k] = std::max(mx[k], model001.xyz[(size_t)k * model001.n + i]);
+        }
+      cfg.gripper_min_dist = 0.8 * std::min(std::min(std::abs(mn[0] - mx[0]), std::abs(mn[1] - mx[1])), std::abs(mn[2] - mx[2]));
+    }
+    PoseEstimator est(&cfg, model, model001);
+    HandT42 hand(&cfg, est.ctx());
+    {
+      std::ifstream f(frame + "hand.txt");
+      std::string line;
+      while (std::getline(f, line)) {
+        std::istringstream ss(line);
+        std::string name, parent, file;
+        if (!(ss >> name >> parent >> file)) continue;
+        Mat4 T;
+        for (int i = 0; i < 16; ++i) ss >> T.m[i];
+        hand.addComponent(name, parent, read_cloud(frame + file), T);
+      }
+    }
+    hand.setCurScene(read_cloud(frame + "hand_scene.bin"), read_cloud(frame + "hand_region.bin"), read_cloud(frame + "hand_swivel.bin"));
+    int cam_right = 1;
+    {
+      std::ifstream f(frame + "cam_side.txt");
+      if (f) f >> cam_right;
+    }
+    const float f1_min = cfg.getf("hand_match.finger1_min_match"), f2_min = cfg.getf("hand_match.finger2_min_match");
+    const float f1_d = cfg.getf("hand_match.finger1_dist_thres"), f2_d = cfg.getf("hand_match.finger2_dist_thres");
+    const float f1_a = cfg.getf("hand_match.finger1_normal_angle"), f2_a = cfg.getf("hand_match.finger2_normal_angle");
+    bool match1 = false, match2 = false;
+    if (cam_right) {  // main_realdata_auto.cpp:114-139
+      match1 = hand.matchOneComponentPSO("finger_2_1", 0, 120, false, f1_d, f1_a, f1_min);
+      if (match1) hand.matchOneComponentPSO("finger_2_2", 0, 90, true, f2_d, f2_a, f2_min);
+      match2 = hand.matchOneComponentPSO("finger_1_1", 0, 120, false, f1_d, f1_a, f1_min);
+      if (match2) hand.matchOneComponentPSO("finger_1_2", 0, 90, true, f2_d, f2_a, f2_min);
+    } else {
+      match2 = hand.matchOneComponentPSO("finger_1_1", 0, 120, false, f1_d, f1_a, f1_min);
+      if (match2) hand.matchOneComponentPSO("finger_1_2", 0, 90, true, f2_d, f2_a, f2_min);
+      match1 = hand.matchOneComponentPSO("finger_2_1", 0, 120, false, f1_d, f1_a, f1_min);
+      if (match1) hand.matchOneComponentPSO("finger_2_2", 0, 90, true, f2_d, f2_a, f2_min);
+    }
+    est.setCurScene(read_cloud(frame + "object_segment.bin"));
+    const bool succeed = est.runSuper4pcs(ppfs);
+    PoseHypo best(-1);
+    if (!succeed) {
+      std::printf("No pose found...\n");
+      std::ofstream ff(out_dir + "/model2scene.txt");
+      ff << "1 0 0 0\n0 1 0 0\n0 0 1 0\n0 0 0 1\n";
+      return 1;
+    }
+    est.clusterPoses(30, 0.015, true);
+    est.refineByICP();
+    est.clusterPoses(5, 0.003, false);
+    est.selectBest(best);
+    std::ofstream ff(out_dir + "/model2scene.txt");
+    ff.precision(9);
+    std::cout << "best tf:\n";
+    for (int r = 0; r < 4; ++r) {
+      for (int c = 0; c < 4; ++c) {
+        ff << best._pose[4 * r + c] << (c == 3 ? "\n" : " ");
+        std::cout << best._pose[4 * r + c] << (c == 3 ? "\n" : " ");
+      }
+    }
+    std::ofstream fa(out_dir + "/finger_angles.txt");
+    fa.precision(9);
+    for (auto& kv : hand._finger_angles) fa << kv.first << " " << kv.second << "\n";
+    return 0;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 3;
+  }
+}

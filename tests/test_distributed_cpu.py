@@ -1,0 +1,71 @@
+"""The N>1 path on CPU: two processes, gloo, all-gather of the packed top-k tables and the identical merge
+(bench.py's exchange()).  Tables are built from synthetic rows; no GPU, no kernel."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, k, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import hop_loader
+    hop_loader.load()
+    from hop_amd import api
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(100 + rank)
+    rows = np.zeros((k, api.TOPK_ROW_FLOATS), np.float32)
+    sc = np.sort(rng.integers(0, 50, k))[::-1].astype(np.float32)
+    rows[:, 0] = sc
+    rows[:, 1] = (np.arange(k, dtype=np.int32) + rank * (1 << 24)).view(np.float32)
+    rows[:, 2:] = rng.normal(size=(k, 16))
+    if rank == 1:  # a rank with fewer hypotheses than k pads with id = -1
+        rows[k - 5:, 0] = -np.finfo(np.float32).max
+        rows[k - 5:, 1] = np.array([-1], np.int32).view(np.float32)[0]
+    t = torch.from_numpy(rows)
+    out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype)  # concatenated layout: valid for gloo and nccl
+    dist.all_gather_into_tensor(out, t)
+    merged, n = api.topk_merge(out.numpy(), k)
+    np.save(os.path.join(out_dir, f"merged_{rank}.npy"), merged)
+    np.save(os.path.join(out_dir, f"rows_{rank}.npy"), rows)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_topk_allgather_merge_two_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import hop_loader
+    hop_loader.load()
+    from hop_amd import api
+    api.build_library()
+    k, world = 32, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, k, str(tmp_path)), nprocs=world, join=True)
+    m0 = np.load(tmp_path / "merged_0.npy")
+    m1 = np.load(tmp_path / "merged_1.npy")
+    assert np.array_equal(m0, m1), "every rank must hold the same merged table"
+    rows = np.concatenate([np.load(tmp_path / f"rows_{r}.npy") for r in range(world)])
+    ids = rows[:, 1].copy().view(np.int32)
+    valid = rows[ids >= 0]
+    vid = ids[ids >= 0]
+    order = np.lexsort((vid, -valid[:, 0]))[:k]
+    assert np.array_equal(m0, valid[order])
+    pose, score, mid = api.rows_to_hypos(m0)
+    assert (np.diff(score) <= 0).all()
+    assert set(mid >> 24) == {0, 1}, "both ranks contribute to the global top-k"
