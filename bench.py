@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--hyps", type=int, default=10240)
     ap.add_argument("--particles", type=int, default=200)
     ap.add_argument("--hand-scene", type=int, default=20000)
-    ap.add_argument("--verify-mode", type=int, default=0)
+    ap.add_argument("--verify-mode", type=int, default=1, help="0 brute-force LDS scan, 1 voxel grid (identical counts)")
+    ap.add_argument("--nn-mode", type=int, default=2, help="ICP / computeLCP nearest neighbour: 0 brute force, 1 voxel grid, 2 NN cell lists for ICP (identical results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     return ap.parse_args()
@@ -110,10 +111,10 @@ class Workload:
         t2 = time.perf_counter()
         c.hypos_keep_topk(self.args.hyps)
         h = c.hypos_count()
-        c.icp_refine(10, 45.0, 0.01)
+        c.icp_refine(10, 45.0, 0.01, nn_mode=self.args.nn_mode)
         c.synchronize()
         t3 = time.perf_counter()
-        best, score, idx = c.lcp_select_best(0.001, 10.0)
+        best, score, idx = c.lcp_select_best(0.001, 10.0, self.args.nn_mode)
         t4 = time.perf_counter()
         return dict(h=h, h_gen=st.n_hypotheses, n_cand=st.n_candidates, n_bases=st.n_bases, best=best, score=score,
                     t_pso=t1 - t0, t_gen=t2 - t1, t_icp=t3 - t2, t_lcp=t4 - t3, ms_select=st.ms_select)
@@ -273,7 +274,7 @@ def main():
             "config": {"workload": "C2: ellipse, 2048 Super4PCS base trials + 200-particle hand search, 20k-pt scene / 5k-pt model",
                        "scene_points": N, "model_points": M, "base_trials": args.bases, "sample_size": 100,
                        "hypotheses_scored_per_rank": H, "pso_particles": args.particles, "hand_scene_points": args.hand_scene,
-                       "verify_mode": args.verify_mode, "parallelism": f"hypothesis-parallel x{world}, all-gather top-{K}"},
+                       "verify_mode": args.verify_mode, "nn_mode": args.nn_mode, "parallelism": f"hypothesis-parallel x{world}, all-gather top-{K}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": n_dom,
                          "algorithmic_bytes_per_launch": alg_bytes,

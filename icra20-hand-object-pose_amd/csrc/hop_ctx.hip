@@ -61,6 +61,29 @@ struct DevBuf {
   }
 };
 
+struct GridStore {
+  DevBuf cell_start_d, pts_d;
+  hop::GridDev g{};
+  bool valid = false;
+  float cell = 0;
+  void release() {
+    cell_start_d.release();
+    pts_d.release();
+    valid = false;
+  }
+};
+
+struct CellListStore {
+  DevBuf start_d, pts_d, u2_d, count_d;
+  hop::CellListDev c{};
+  bool valid = false;
+  float cell = 0, max_dist = 0;
+  void release() {
+    start_d.release(), pts_d.release(), u2_d.release(), count_d.release();
+    valid = false;
+  }
+};
+
 struct PinnedBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -146,10 +169,9 @@ struct hop_ctx {
   CloudDevice vp_d, vq_d;
   std::vector<float> vp_h[3];
   bool have_verify_clouds = false;
-  // voxel grid over centred P for verify_mode 1
-  DevBuf grid_cell_start_d, grid_pts_d;
-  GridDev grid{};
-  bool grid_valid = false;
+  // voxel grids: centred P for verify_mode 1; model rest frames and scene for nn_mode 1
+  GridStore verify_grid, model_grid[2], scene_grid;
+  CellListStore model_cells[2];
   float grid_delta = 0;
 
   // batch workspaces of the generator
@@ -556,17 +578,17 @@ NsetGeom make_nset_geom(float eps) {
   return g;
 }
 
-// voxel grid over a centred cloud, cells of (delta * 1.001): counting sort by cell, built on the host
-// (one pass over N points) and uploaded; used by verify_mode 1.
-int build_verify_grid(hop_ctx* c, const float* x, const float* y, const float* z, int n, float delta) {
+// Voxel grid over a fixed cloud (counting sort by cell on the host: one pass over n points, then upload).
+// pts[k].w carries the original index of the point.
+int build_grid(hop_ctx* c, GridStore& gs, const float* x, const float* y, const float* z, int n, float cell) {
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (int i = 0; i < n; ++i) {
     mn[0] = std::min(mn[0], x[i]), mn[1] = std::min(mn[1], y[i]), mn[2] = std::min(mn[2], z[i]);
     mx[0] = std::max(mx[0], x[i]), mx[1] = std::max(mx[1], y[i]), mx[2] = std::max(mx[2], z[i]);
   }
-  const float cell = delta * 1.001f + 1e-9f;
   GridDev g{};
   g.ox = mn[0], g.oy = mn[1], g.oz = mn[2];
+  g.cell = cell;
   g.inv_cell = 1.0f / cell;
   g.dx = std::max(1, (int)std::floor((mx[0] - mn[0]) * g.inv_cell) + 1);
   g.dy = std::max(1, (int)std::floor((mx[1] - mn[1]) * g.inv_cell) + 1);
@@ -583,18 +605,62 @@ int build_verify_grid(hop_ctx* c, const float* x, const float* y, const float* z
   }
   for (size_t k = 0; k < ncell; ++k) start[k + 1] += start[k];
   std::vector<int> fill(start.begin(), start.end() - 1);
-  std::vector<float4> pts(n);
-  for (int i = 0; i < n; ++i) pts[fill[cell_of[i]]++] = make_float4(x[i], y[i], z[i], 0.f);
-  HIPCHK(c, c->grid_cell_start_d.ensure(sizeof(int) * (ncell + 1)));
-  HIPCHK(c, c->grid_pts_d.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
-  HIPCHK(c, hipMemcpyAsync(c->grid_cell_start_d.p, start.data(), sizeof(int) * (ncell + 1), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->grid_pts_d.p, pts.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  std::vector<float4> pts(std::max(n, 1));
+  for (int i = 0; i < n; ++i) {
+    float w;
+    std::memcpy(&w, &i, 4);
+    pts[fill[cell_of[i]]++] = make_float4(x[i], y[i], z[i], w);
+  }
+  HIPCHK(c, gs.cell_start_d.ensure(sizeof(int) * (ncell + 1)));
+  HIPCHK(c, gs.pts_d.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
+  HIPCHK(c, hipMemcpyAsync(gs.cell_start_d.p, start.data(), sizeof(int) * (ncell + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(gs.pts_d.p, pts.data(), sizeof(float4) * (size_t)std::max(n, 1), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  g.cell_start = c->grid_cell_start_d.as<int>();
-  g.pts = c->grid_pts_d.as<float4>();
-  c->grid = g;
-  c->grid_valid = true;
-  c->grid_delta = delta;
+  g.cell_start = gs.cell_start_d.as<int>();
+  g.pts = gs.pts_d.as<float4>();
+  gs.g = g;
+  gs.valid = true;
+  gs.cell = cell;
+  return HOP_OK;
+}
+
+// NN cell lists of a cloud (device-resident planes x,y,z), padded by max_dist: three small kernels and one scan
+int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const CloudDevice& d, float max_dist, float cell) {
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = 0; i < h.n; ++i) {
+    mn[0] = std::min(mn[0], h.x[i]), mn[1] = std::min(mn[1], h.y[i]), mn[2] = std::min(mn[2], h.z[i]);
+    mx[0] = std::max(mx[0], h.x[i]), mx[1] = std::max(mx[1], h.y[i]), mx[2] = std::max(mx[2], h.z[i]);
+  }
+  const float pad = max_dist + 4 * GRID_MARGIN;
+  CellListBuildArgs a{};
+  a.x = d.plane(0), a.y = d.plane(1), a.z = d.plane(2), a.n = h.n;
+  a.ox = mn[0] - pad, a.oy = mn[1] - pad, a.oz = mn[2] - pad, a.cell = cell;
+  a.dx = (int)std::ceil((mx[0] - mn[0] + 2 * pad) / cell) + 1;
+  a.dy = (int)std::ceil((mx[1] - mn[1] + 2 * pad) / cell) + 1;
+  a.dz = (int)std::ceil((mx[2] - mn[2] + 2 * pad) / cell) + 1;
+  a.max_dist = max_dist, a.margin = 4 * GRID_MARGIN;
+  const size_t ncell = (size_t)a.dx * a.dy * a.dz;
+  if (ncell > (size_t)1 << 24) return HOP_E_CAPACITY;
+  HIPCHK(c, cs.u2_d.ensure(sizeof(float) * ncell));
+  HIPCHK(c, cs.count_d.ensure(sizeof(int) * ncell));
+  HIPCHK(c, cs.start_d.ensure(sizeof(int) * (ncell + 1)));
+  a.u2 = cs.u2_d.as<float>(), a.count = cs.count_d.as<int>();
+  launch_cell_list_bounds(a, c->stream);
+  launch_cell_list_count(a, c->stream);
+  std::vector<int> cnt(ncell), start(ncell + 1, 0);
+  HIPCHK(c, hipMemcpyAsync(cnt.data(), cs.count_d.p, sizeof(int) * ncell, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (size_t k = 0; k < ncell; ++k) start[k + 1] = start[k] + cnt[k];
+  const size_t total = (size_t)start[ncell];
+  HIPCHK(c, cs.pts_d.ensure(sizeof(float4) * std::max<size_t>(total, 1)));
+  HIPCHK(c, hipMemcpyAsync(cs.start_d.p, start.data(), sizeof(int) * (ncell + 1), hipMemcpyHostToDevice, c->stream));
+  a.start = cs.start_d.as<int>(), a.pts = cs.pts_d.as<float4>();
+  launch_cell_list_fill(a, c->stream);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  cs.c.ox = a.ox, cs.c.oy = a.oy, cs.c.oz = a.oz, cs.c.cell = cell, cs.c.inv_cell = 1.0f / cell;
+  cs.c.dx = a.dx, cs.c.dy = a.dy, cs.c.dz = a.dz;
+  cs.c.start = cs.start_d.as<int>(), cs.c.pts = cs.pts_d.as<float4>();
+  cs.valid = true, cs.cell = cell, cs.max_dist = max_dist;
   return HOP_OK;
 }
 
@@ -748,7 +814,7 @@ void hop_ctx_destroy(hop_ctx* c) {
   }
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&c->scene_d.buf, &c->model_d[0].buf, &c->model_d[1].buf, &c->key_bitmap_d, &c->gp_d.buf, &c->gq_d.buf, &c->gq_unit_d,
-                    &c->ppf_matrix_d, &c->vp_d.buf, &c->vq_d.buf, &c->grid_cell_start_d, &c->grid_pts_d, &c->bases_d, &c->pairs1_d,
+                    &c->ppf_matrix_d, &c->vp_d.buf, &c->vq_d.buf, &c->bases_d, &c->pairs1_d,
                     &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
                     &c->hyp_score, &c->hyp_id, &c->hyp_key, &c->hyp_inv, &c->tmp_pose, &c->tmp_score, &c->tmp_id, &c->sort_keys_alt,
                     &c->sort_vals, &c->sort_vals_alt, &c->sort_tmp, &c->lcp_rev_idx, &c->lcp_rev_d2, &c->lcp_terms, &c->icp_moved,
@@ -756,6 +822,8 @@ void hop_ctx_destroy(hop_ctx* c) {
                     &c->hand_swivel_d.buf, &c->hand_model_d.buf, &c->finger_hist_d, &c->pso_particles_d, &c->pso_match_d,
                     &c->pso_terms_d, &c->pso_sum_d, &c->pso_cnt_d};
   for (DevBuf* b : bufs) b->release();
+  c->verify_grid.release(), c->model_grid[0].release(), c->model_grid[1].release(), c->scene_grid.release();
+  c->model_cells[0].release(), c->model_cells[1].release();
   c->ppf_matrix_h.release(), c->bases_h.release(), c->cnt_h.release(), c->pso_particles_h.release(), c->pso_out_h.release();
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -797,7 +865,8 @@ int hop_set_scene(hop_ctx* c, const float* xyz, const float* nrm, const float* c
     raw.nx[k] = nrm[i], raw.ny[k] = nrm[n + i], raw.nz[k] = nrm[2 * (size_t)n + i];
   }
   c->have_gen_state = false;
-  c->grid_valid = false;
+  c->verify_grid.valid = false;
+  c->scene_grid.valid = false;
   return upload_cloud(c, c->scene_d, raw);
 }
 
@@ -810,6 +879,8 @@ int hop_set_model(hop_ctx* c, int level, const float* xyz, const float* nrm, int
   CloudHost raw;
   load_cloud_host(raw, xyz, nrm, n, false);  // scoring view: as given
   c->have_gen_state = false;
+  c->model_grid[level].valid = false;
+  c->model_cells[level].valid = false;
   return upload_cloud(c, c->model_d[level], raw);
 }
 
@@ -883,7 +954,7 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
   }
   c->have_gen_state = true;
   c->have_verify_clouds = false;
-  c->grid_valid = false;
+  c->verify_grid.valid = false;
 
   // ---- K2: PPF membership matrix
   const int W = (N + 63) / 64;
@@ -908,8 +979,9 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
   G.W = W;
 
   if (opts->verify_mode == 1) {
-    const int rc = build_verify_grid(c, c->gp_h.x.data(), c->gp_h.y.data(), c->gp_h.z.data(), N, opts->delta);
+    const int rc = build_grid(c, c->verify_grid, c->gp_h.x.data(), c->gp_h.y.data(), c->gp_h.z.data(), N, opts->delta * 1.001f + 1e-9f);
     if (rc) return rc;
+    c->grid_delta = opts->delta;
   }
 
   // ---- batch workspaces
@@ -998,7 +1070,7 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
     va.sq_eps = opts->delta * opts->delta, va.counts = c->cand_counts_d.as<int>();
     {
       SpanGuard sg(c, T_VERIFY);
-      launch_verify(va, opts->verify_mode, c->grid_valid ? &c->grid : nullptr, 2048, c->stream);
+      launch_verify(va, opts->verify_mode, c->verify_grid.valid ? &c->verify_grid.g : nullptr, 2048, c->stream);
     }
     c->timing.n_verify_launches += 1;
     {
@@ -1142,7 +1214,7 @@ int hop_verify_set_clouds(hop_ctx* c, const float* p_xyz, int n_p, const float* 
   if (rc) return rc;
   c->vp_h[0] = P.x, c->vp_h[1] = P.y, c->vp_h[2] = P.z;
   c->have_verify_clouds = true;
-  c->grid_valid = false;
+  c->verify_grid.valid = false;
   return HOP_OK;
 }
 
@@ -1153,11 +1225,13 @@ int hop_verify_batch(hop_ctx* c, const float* T16, int H, float delta, int mode,
   HIPCHK(c, hipSetDevice(c->device));
   const CloudDevice& P = c->have_verify_clouds ? c->vp_d : c->gp_d;
   const CloudDevice& Q = c->have_verify_clouds ? c->vq_d : c->gq_d;
-  if (mode == 1 && (!c->grid_valid || c->grid_delta != delta)) {
+  if (mode == 1 && (!c->verify_grid.valid || c->grid_delta != delta)) {
     int rc;
-    if (c->have_verify_clouds) rc = build_verify_grid(c, c->vp_h[0].data(), c->vp_h[1].data(), c->vp_h[2].data(), P.n, delta);
-    else rc = build_verify_grid(c, c->gp_h.x.data(), c->gp_h.y.data(), c->gp_h.z.data(), P.n, delta);
+    const float cell = delta * 1.001f + 1e-9f;
+    if (c->have_verify_clouds) rc = build_grid(c, c->verify_grid, c->vp_h[0].data(), c->vp_h[1].data(), c->vp_h[2].data(), P.n, cell);
+    else rc = build_grid(c, c->verify_grid, c->gp_h.x.data(), c->gp_h.y.data(), c->gp_h.z.data(), P.n, cell);
     if (rc) return rc;
+    c->grid_delta = delta;
   }
   HIPCHK(c, c->tmp_pose.ensure(sizeof(float) * 16 * (size_t)H));
   HIPCHK(c, c->cand_counts_d.ensure(sizeof(int) * (size_t)H));
@@ -1172,7 +1246,7 @@ int hop_verify_batch(hop_ctx* c, const float* T16, int H, float delta, int mode,
   const int blocks = (int)std::min<long long>(4096, (total + 1023) / 1024);
   {
     SpanGuard sg(c, T_VERIFY);
-    launch_verify(va, mode, (mode == 1 && c->grid_valid) ? &c->grid : nullptr, std::max(blocks, 1), c->stream);
+    launch_verify(va, mode, (mode == 1 && c->verify_grid.valid) ? &c->verify_grid.g : nullptr, std::max(blocks, 1), c->stream);
   }
   c->timing.n_verify_launches += 1;
   c->timing.pairs_verify += total * (long long)P.n;
@@ -1254,6 +1328,26 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
   a.max_d2 = o->max_corr_dist * o->max_corr_dist;
   a.cos_thr = (float)std::cos((double)(o->angle_deg / 180.0f) * M_PI);
   a.moved = c->icp_moved.as<float>(), a.partial = c->icp_partial.as<double>(), a.state = c->icp_state.as<IcpState>();
+  if (o->nn_mode == 1) {
+    // model grid in its rest frame; cells of a third of the gating distance, rings grow until they cover it
+    const float cell = o->max_corr_dist / 3.f + GRID_MARGIN;
+    GridStore& gs = c->model_grid[HOP_MODEL_5MM];
+    if (!gs.valid || gs.cell != cell) {
+      const CloudHost& mh = c->model_h[HOP_MODEL_5MM];
+      const int rc = build_grid(c, gs, mh.x.data(), mh.y.data(), mh.z.data(), mh.n, cell);
+      if (rc) return rc;
+    }
+    a.model_grid = gs.g;
+    a.max_ring = (int)std::ceil((o->max_corr_dist + 2 * GRID_MARGIN) / cell);
+  } else if (o->nn_mode == 2) {
+    const float cell = o->max_corr_dist / 6.f;
+    CellListStore& cs = c->model_cells[HOP_MODEL_5MM];
+    if (!cs.valid || cs.cell != cell || cs.max_dist != o->max_corr_dist) {
+      const int rc = build_cell_lists(c, cs, c->model_h[HOP_MODEL_5MM], c->model_d[HOP_MODEL_5MM], o->max_corr_dist, cell);
+      if (rc) return rc;
+    }
+    a.cells = cs.c;
+  }
   for (int h0 = 0; h0 < H; h0 += HB) {
     const int hb = std::min(HB, H - h0);
     a.h0 = h0;
@@ -1262,7 +1356,9 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
       a.iter = it;
       {
         SpanGuard sg(c, T_ICP_NN);
-        launch_icp_nn(a, hb, c->stream);
+        if (o->nn_mode == 2) launch_icp_nn_cells(a, hb, c->stream);
+        else if (o->nn_mode == 1) launch_icp_nn_grid(a, hb, c->stream);
+        else launch_icp_nn(a, hb, c->stream);
       }
       {
         SpanGuard sg(c, T_ICP_SOLVE);
@@ -1300,16 +1396,38 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
   a.cos_thres = (float)std::cos((double)(o->angle_deg / 180.0f) * M_PI);
   a.rev_idx = c->lcp_rev_idx.as<int>(), a.rev_d2 = c->lcp_rev_d2.as<float>(), a.terms = c->lcp_terms.as<float>();
   a.score = c->hyp_score.as<float>();
+  const bool lcp_grid = o->nn_mode >= 1;
+  if (lcp_grid) {
+    const float cell = o->dist + GRID_MARGIN * 2;
+    GridStore& gm = c->model_grid[HOP_MODEL_1MM];
+    if (!gm.valid || gm.cell != cell) {
+      const CloudHost& mh = c->model_h[HOP_MODEL_1MM];
+      const int rc = build_grid(c, gm, mh.x.data(), mh.y.data(), mh.z.data(), mh.n, cell);
+      if (rc) return rc;
+    }
+    if (!c->scene_grid.valid || c->scene_grid.cell != cell) {
+      const CloudHost& sh = c->scene_h;
+      const int rc = build_grid(c, c->scene_grid, sh.x.data(), sh.y.data(), sh.z.data(), sh.n, cell);
+      if (rc) return rc;
+    }
+    a.model_grid = gm.g;
+    a.scene_grid = c->scene_grid.g;
+  }
   for (int h0 = 0; h0 < H; h0 += HB) {
     const int hb = std::min(HB, H - h0);
     a.h0 = h0;
-    {
-      SpanGuard sg(c, T_LCP_REV);
-      launch_lcp_reverse(a, hb, c->stream);
-    }
-    {
+    if (lcp_grid) {
       SpanGuard sg(c, T_LCP_FWD);
-      launch_lcp_forward(a, hb, c->stream);
+      launch_lcp_grid(a, hb, c->stream);
+    } else {
+      {
+        SpanGuard sg(c, T_LCP_REV);
+        launch_lcp_reverse(a, hb, c->stream);
+      }
+      {
+        SpanGuard sg(c, T_LCP_FWD);
+        launch_lcp_forward(a, hb, c->stream);
+      }
     }
     launch_lcp_sum(a, hb, c->stream);
     c->timing.n_lcp_launches += 1;

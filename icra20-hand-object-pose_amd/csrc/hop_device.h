@@ -12,6 +12,7 @@ constexpr int NN_TILE = 2048;  // targets per LDS tile (float4 each -> 32 KiB)
 constexpr int NN_CH = 16;      // targets per min-chunk of the scan
 constexpr int PPF_ROWS = 64;   // rows of the PPF matrix handled per block
 constexpr int ICP_NACC = 29;   // 21 (lower triangle of J^T J) + 6 (J^T r) + mse + count
+constexpr float GRID_MARGIN = 1.0e-5f;  // metres; bounds | ||T^-1 s - m|| - ||s - T m|| | for rigid float poses
 constexpr int MAX_RING = 64;   // samples on the normal cone (normalset.hpp:208-210; <= 2*ceil(2*pi*atan(pi)*3.5) = 56)
 
 // one base (4 points of P) of the generator, prepared by the host for a batch
@@ -106,9 +107,32 @@ struct VerifyArgs {
 
 struct GridDev {
   float ox, oy, oz, inv_cell;
+  float cell;
   int dx, dy, dz;
   const int* cell_start;  // dx*dy*dz + 1
-  const float4* pts;      // points sorted by cell
+  const float4* pts;      // points sorted by cell; .w carries the original index (int bits)
+};
+
+// "NN cell lists": for every voxel of the target's (padded) bounding box, the points that can be the nearest
+// neighbour of SOME query inside that voxel (and lie within the gating distance).  One lookup + a short
+// contiguous list replaces the ring walk.
+struct CellListDev {
+  float ox, oy, oz, inv_cell, cell;
+  int dx, dy, dz;
+  const int* start;   // dx*dy*dz + 1
+  const float4* pts;  // concatenated lists; .w = original index (int bits)
+};
+
+struct CellListBuildArgs {
+  const float *x, *y, *z;
+  int n;
+  float ox, oy, oz, cell;
+  int dx, dy, dz;
+  float max_dist, margin;
+  float* u2;      // per cell: min over points of the squared farthest-corner distance
+  int* count;     // per cell
+  const int* start;
+  float4* pts;
 };
 
 struct EmitArgs {
@@ -140,6 +164,8 @@ struct LcpArgs {
   float* rev_d2;
   float* terms;
   float* score;
+  GridDev model_grid;  // nn_mode 1: model in its rest frame, cell >= dist + margin
+  GridDev scene_grid;  //            scene, cell >= dist + margin
 };
 
 struct IcpState {
@@ -161,6 +187,9 @@ struct IcpArgs {
   float* moved;     // [hb][6][ns]
   double* partial;  // [hb][blocks][ICP_NACC]
   IcpState* state;
+  GridDev model_grid;  // nn_mode 1: model in its rest frame
+  int max_ring;        // rings needed to cover max_corr_dist
+  CellListDev cells;   // nn_mode 2: NN cell lists of the model in its rest frame
 };
 
 struct PsoParticle {
@@ -204,9 +233,15 @@ void launch_score_keys(const float* score, const int* ids, int n, unsigned long 
 void launch_lcp_reverse(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_forward(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_sum(const LcpArgs& a, int hb, hipStream_t s);
+void launch_lcp_grid(const LcpArgs& a, int hb, hipStream_t s);
 int icp_blocks_per_hyp(int ns);
 void launch_icp_init(IcpState* st, int hb, hipStream_t s);
 void launch_icp_nn(const IcpArgs& a, int hb, hipStream_t s);
+void launch_icp_nn_grid(const IcpArgs& a, int hb, hipStream_t s);
+void launch_icp_nn_cells(const IcpArgs& a, int hb, hipStream_t s);
+void launch_cell_list_bounds(const CellListBuildArgs& a, hipStream_t s);
+void launch_cell_list_count(const CellListBuildArgs& a, hipStream_t s);
+void launch_cell_list_fill(const CellListBuildArgs& a, hipStream_t s);
 void launch_icp_solve(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_finish(const IcpArgs& a, int hb, int* iters, int* conv, hipStream_t s);
 void launch_pso(const PsoArgs& a, int n_particles, hipStream_t s);

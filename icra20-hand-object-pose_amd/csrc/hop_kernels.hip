@@ -586,6 +586,211 @@ __global__ __launch_bounds__(64) void k_lcp_sum(LcpArgs a, int hb) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Exact nearest neighbour on a voxel grid of the TARGET cloud in its own rest frame (nn_mode 1).
+// Candidates come from grid cells; every candidate's squared distance is evaluated with the same float
+// expression as the brute-force scan, and the result is the lexicographic minimum of (d^2, original index),
+// i.e. exactly what a linear scan over the whole cloud returns -- provided the cells visited cover every
+// point that could win.  Coverage argument: the cube of half-width k cells around the query's cell contains
+// the ball of radius k*cell around the query; a query given in another frame (scene point mapped by the
+// inverse pose) moves by less than GRID_MARGIN, so after ring k every unvisited point is farther than
+// k*cell - GRID_MARGIN in the frame where distances are compared.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void nn_update(float d2, int j, float& best, int& bj) {
+  if (d2 < best || (d2 == best && j < bj)) {
+    best = d2;
+    bj = j;
+  }
+}
+
+template <bool TRANSFORM>
+__device__ __forceinline__ void grid_scan_run(const GridDev& g, int row, int x0, int x1, const float* T, V3 q, float& best, int& bj) {
+  const int beg = g.cell_start[row + x0], end = g.cell_start[row + x1 + 1];
+  for (int k = beg; k < end; ++k) {
+    const float4 t = g.pts[k];
+    V3 p = v3(t.x, t.y, t.z);
+    if (TRANSFORM) p = m4_point(T, p);
+    nn_update(sqdist_flann(q, p), __float_as_int(t.w), best, bj);
+  }
+}
+
+// all grid points within one ring (27 cells) of the cell of qg (= the query expressed in the grid's frame)
+template <bool TRANSFORM>
+__device__ __forceinline__ void grid_nn_ring1(const GridDev& g, V3 qg, const float* T, V3 q, float& best, int& bj) {
+  const float fx = (qg.x - g.ox) * g.inv_cell, fy = (qg.y - g.oy) * g.inv_cell, fz = (qg.z - g.oz) * g.inv_cell;
+  if (!(fx >= -1.f && fy >= -1.f && fz >= -1.f && fx < (float)(g.dx + 1) && fy < (float)(g.dy + 1) && fz < (float)(g.dz + 1))) return;
+  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+  const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dx - 1);
+  if (x0 > x1) return;
+  for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); ++z)
+    for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); ++y) grid_scan_run<TRANSFORM>(g, (z * g.dy + y) * g.dx, x0, x1, T, q, best, bj);
+}
+
+// ring-expanding search: exact nearest neighbour if it lies within sqrt(max_d2), otherwise "whatever was
+// seen" (which the caller rejects by distance, exactly as it rejects the true NN).
+template <bool TRANSFORM>
+__device__ __forceinline__ void grid_nn_rings(const GridDev& g, V3 qg, const float* T, V3 q, int max_ring, float max_d2, float& best,
+                                              int& bj) {
+  const float fx = (qg.x - g.ox) * g.inv_cell, fy = (qg.y - g.oy) * g.inv_cell, fz = (qg.z - g.oz) * g.inv_cell;
+  const float lim = (float)max_ring + 1.f;
+  if (!(fx >= -lim && fy >= -lim && fz >= -lim && fx < (float)g.dx + lim && fy < (float)g.dy + lim && fz < (float)g.dz + lim)) return;
+  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+  for (int k = 0; k <= max_ring; ++k) {
+    for (int ddz = -k; ddz <= k; ++ddz) {
+      const int z = cz + ddz;
+      if (z < 0 || z >= g.dz) continue;
+      for (int ddy = -k; ddy <= k; ++ddy) {
+        const int y = cy + ddy;
+        if (y < 0 || y >= g.dy) continue;
+        const int row = (z * g.dy + y) * g.dx;
+        if (ddz == -k || ddz == k || ddy == -k || ddy == k) {
+          const int x0 = max(cx - k, 0), x1 = min(cx + k, g.dx - 1);
+          if (x0 <= x1) grid_scan_run<TRANSFORM>(g, row, x0, x1, T, q, best, bj);
+        } else {
+          const int xa = cx - k, xb = cx + k;
+          if (xa >= 0 && xa < g.dx) grid_scan_run<TRANSFORM>(g, row, xa, xa, T, q, best, bj);
+          if (xb >= 0 && xb < g.dx) grid_scan_run<TRANSFORM>(g, row, xb, xb, T, q, best, bj);
+        }
+      }
+    }
+    if (k >= 1) {
+      const float cov = (float)k * g.cell - GRID_MARGIN;
+      const float cov2 = cov * cov;
+      if (best <= cov2 || cov2 >= max_d2) break;
+    }
+  }
+}
+
+__device__ __forceinline__ void block_pose_and_inverse(const float* pose, float* sT, float* sTi) {
+  if (threadIdx.x == 0) {
+    M4 P;
+    for (int k = 0; k < 16; ++k) P.m[k] = pose[k];
+    const M4 inv = m4_inverse_affine(P);
+    for (int k = 0; k < 12; ++k) sT[k] = P.m[k], sTi[k] = inv.m[k];
+  }
+  __syncthreads();
+}
+
+// computeLCP on grids: forward NN (scene point -> transformed model) through the model's rest-frame grid,
+// reciprocal NN (transformed model point -> scene) through the scene grid; same terms[] as the brute-force pair.
+__global__ __launch_bounds__(256) void k_lcp_grid(LcpArgs a) {
+  __shared__ float sT[12], sTi[12];
+  const int h = a.h0 + blockIdx.y;
+  block_pose_and_inverse(a.pose + (size_t)h * 16, sT, sTi);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.ns) return;
+  const V3 s = v3(a.sx[i], a.sy[i], a.sz[i]);
+  float best = 3.0e38f;
+  int bj = -1;
+  grid_nn_ring1<true>(a.model_grid, m4_point(sTi, s), sT, s, best, bj);
+  float f = -1.f, g = -1.f;
+  if (bj >= 0 && best < a.dist * a.dist) {
+    const V3 nmod = m4_dir(sT, v3(a.mnx[bj], a.mny[bj], a.mnz[bj]));
+    f = lcp_term(v3(a.snx[i], a.sny[i], a.snz[i]), nmod, best, a.dist, a.cos_thres);
+    const V3 pm = m4_point(sT, v3(a.mx[bj], a.my[bj], a.mz[bj]));
+    float rbest = 3.0e38f;
+    int rk = -1;
+    grid_nn_ring1<false>(a.scene_grid, pm, nullptr, pm, rbest, rk);
+    if (rk >= 0) g = lcp_term(nmod, v3(a.snx[rk], a.sny[rk], a.snz[rk]), rbest, a.dist, a.cos_thres);
+  }
+  a.terms[((size_t)blockIdx.y * a.ns + i) * 2 + 0] = f;
+  a.terms[((size_t)blockIdx.y * a.ns + i) * 2 + 1] = g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NN cell lists (nn_mode 2).  For a voxel C and the cloud M:
+//   U(C)    = min_m  maxdist(m, C)          -- every query q in C has its nearest neighbour within U(C)
+//   list(C) = { m : mindist(m, C) <= min(U(C), max_dist) + margin }
+// If the true nearest neighbour m* of q (q in C) is within max_dist it satisfies
+// mindist(m*,C) <= |q-m*| <= U(C), hence m* is in list(C); scanning list(C) with the exact distance expression
+// and the (d^2, index) order therefore reproduces the linear scan.  `margin` absorbs the float error of
+// mapping the query into the cloud's rest frame (GRID_MARGIN) and of the box arithmetic below.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cell_box(const CellListBuildArgs& a, int cidx, float lo[3], float hi[3]) {
+  const int cx = cidx % a.dx, cy = (cidx / a.dx) % a.dy, cz = cidx / (a.dx * a.dy);
+  lo[0] = a.ox + (float)cx * a.cell, lo[1] = a.oy + (float)cy * a.cell, lo[2] = a.oz + (float)cz * a.cell;
+  for (int k = 0; k < 3; ++k) hi[k] = lo[k] + a.cell;
+}
+__device__ __forceinline__ float box_maxdist2(const float lo[3], const float hi[3], float x, float y, float z) {
+  const float dx = fmaxf(fabsf(x - lo[0]), fabsf(x - hi[0])), dy = fmaxf(fabsf(y - lo[1]), fabsf(y - hi[1])),
+              dz = fmaxf(fabsf(z - lo[2]), fabsf(z - hi[2]));
+  return dx * dx + dy * dy + dz * dz;
+}
+__device__ __forceinline__ float box_mindist2(const float lo[3], const float hi[3], float x, float y, float z) {
+  const float dx = fmaxf(fmaxf(lo[0] - x, x - hi[0]), 0.f), dy = fmaxf(fmaxf(lo[1] - y, y - hi[1]), 0.f),
+              dz = fmaxf(fmaxf(lo[2] - z, z - hi[2]), 0.f);
+  return dx * dx + dy * dy + dz * dz;
+}
+
+__global__ __launch_bounds__(256) void k_cell_list_bounds(CellListBuildArgs a) {
+  __shared__ float red[4];
+  const int cidx = blockIdx.x;
+  float lo[3], hi[3];
+  cell_box(a, cidx, lo, hi);
+  float best = 3.0e38f;
+  for (int i = threadIdx.x; i < a.n; i += blockDim.x) best = fminf(best, box_maxdist2(lo, hi, a.x[i], a.y[i], a.z[i]));
+  for (int off = 32; off > 0; off >>= 1) best = fminf(best, __shfl_down(best, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) a.u2[cidx] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+}
+
+__device__ __forceinline__ float cell_list_thr2(const CellListBuildArgs& a, int cidx) {
+  const float u = sqrtf(a.u2[cidx]) * 1.00001f + a.margin;  // rounded up
+  const float t = fminf(u, a.max_dist + a.margin);
+  return t * t * 1.00001f;
+}
+
+__global__ __launch_bounds__(256) void k_cell_list_count(CellListBuildArgs a) {
+  __shared__ int red[4];
+  const int cidx = blockIdx.x;
+  float lo[3], hi[3];
+  cell_box(a, cidx, lo, hi);
+  const float thr2 = cell_list_thr2(a, cidx);
+  int cnt = 0;
+  for (int i0 = 0; i0 < a.n; i0 += blockDim.x) {
+    const int i = i0 + threadIdx.x;
+    const bool in = i < a.n && box_mindist2(lo, hi, a.x[i], a.y[i], a.z[i]) <= thr2;
+    cnt += __popcll(__ballot(in));
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) a.count[cidx] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(64) void k_cell_list_fill(CellListBuildArgs a) {
+  // one wave per cell: ascending point order, ballot compaction
+  const int cidx = blockIdx.x;
+  float lo[3], hi[3];
+  cell_box(a, cidx, lo, hi);
+  const float thr2 = cell_list_thr2(a, cidx);
+  int pos = a.start[cidx];
+  const int lane = threadIdx.x;
+  for (int i0 = 0; i0 < a.n; i0 += 64) {
+    const int i = i0 + lane;
+    float x = 0, y = 0, z = 0;
+    bool in = false;
+    if (i < a.n) {
+      x = a.x[i], y = a.y[i], z = a.z[i];
+      in = box_mindist2(lo, hi, x, y, z) <= thr2;
+    }
+    const unsigned long long m = __ballot(in);
+    if (in) a.pts[pos + __popcll(m & ((1ull << lane) - 1ull))] = make_float4(x, y, z, __int_as_float(i));
+    pos += __popcll(m);
+  }
+}
+
+__device__ __forceinline__ void cells_nn(const CellListDev& c, V3 qg, const float* T, V3 q, float& best, int& bj) {
+  const float fx = (qg.x - c.ox) * c.inv_cell, fy = (qg.y - c.oy) * c.inv_cell, fz = (qg.z - c.oz) * c.inv_cell;
+  if (!(fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)c.dx && fy < (float)c.dy && fz < (float)c.dz)) return;
+  const int cidx = ((int)fz * c.dy + (int)fy) * c.dx + (int)fx;
+  const int beg = c.start[cidx], end = c.start[cidx + 1];
+  for (int k = beg; k < end; ++k) {
+    const float4 t = c.pts[k];
+    nn_update(sqdist_flann(q, m4_point(T, v3(t.x, t.y, t.z))), __float_as_int(t.w), best, bj);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K5: batched point-to-plane ICP (Utils::runICP, Utils.cpp:188-229, pcl::IterativeClosestPoint as
 // configured there -- restated).  One iteration = k_icp_nn (move the source by the last
 // increment, find correspondences, accumulate the 6x6 normal equations in double) + k_icp_solve.
@@ -677,6 +882,170 @@ __global__ __launch_bounds__(256) void k_icp_nn(IcpArgs a) {
   }
 }
 template __global__ void k_icp_nn<4>(IcpArgs);
+
+template <int R>
+__global__ __launch_bounds__(256) void k_icp_nn_grid(IcpArgs a) {
+  __shared__ float sT[12], sTi[12];
+  __shared__ double red[4][ICP_NACC];
+  const int hl = blockIdx.y, h = a.h0 + hl;
+  IcpState& st = a.state[hl];
+  if (!st.active) return;
+  const float* pose = a.pose + (size_t)h * 16;
+  float Tinc[12];
+  for (int k = 0; k < 12; ++k) Tinc[k] = st.T_inc[k];
+  V3 q[R], qn[R];
+  float best[R];
+  int bidx[R];
+  const bool first = a.iter == 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    best[r] = 3.0e38f;
+    bidx[r] = -1;
+    if (i < a.ns) {
+      V3 p, n;
+      if (first) {
+        p = v3(a.sx[i], a.sy[i], a.sz[i]);
+        n = v3(a.snx[i], a.sny[i], a.snz[i]);
+      } else {
+        const size_t o = (size_t)hl * a.ns * 6 + i;
+        p = v3(a.moved[o], a.moved[o + a.ns], a.moved[o + 2 * (size_t)a.ns]);
+        n = v3(a.moved[o + 3 * (size_t)a.ns], a.moved[o + 4 * (size_t)a.ns], a.moved[o + 5 * (size_t)a.ns]);
+        p = m4_point(Tinc, p);
+        n = m4_dir(Tinc, n);
+      }
+      const size_t o = (size_t)hl * a.ns * 6 + i;
+      a.moved[o] = p.x, a.moved[o + a.ns] = p.y, a.moved[o + 2 * (size_t)a.ns] = p.z;
+      a.moved[o + 3 * (size_t)a.ns] = n.x, a.moved[o + 4 * (size_t)a.ns] = n.y, a.moved[o + 5 * (size_t)a.ns] = n.z;
+      q[r] = p, qn[r] = n;
+    } else {
+      q[r] = v3(-HOP_FAR, -HOP_FAR, -HOP_FAR);
+      qn[r] = v3(0, 0, 0);
+    }
+  }
+  block_pose_and_inverse(pose, sT, sTi);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    if (i < a.ns) grid_nn_rings<true>(a.model_grid, m4_point(sTi, q[r]), sT, q[r], a.max_ring, a.max_d2, best[r], bidx[r]);
+  }
+  double acc[ICP_NACC];
+#pragma unroll
+  for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    if (i >= a.ns || bidx[r] < 0 || !(best[r] <= a.max_d2)) continue;
+    const int j = bidx[r];
+    const V3 nt = m4_dir(pose, v3(a.mnx[j], a.mny[j], a.mnz[j]));
+    if (!(vdot(qn[r], nt) >= a.cos_thr)) continue;
+    const V3 tq = m4_point(pose, v3(a.mx[j], a.my[j], a.mz[j]));
+    const V3 c = vcross(q[r], nt);
+    const double J[6] = {c.x, c.y, c.z, nt.x, nt.y, nt.z};
+    const double res = (double)vdot(q[r] - tq, nt);
+    int k = 0;
+    for (int u = 0; u < 6; ++u)
+      for (int v = 0; v <= u; ++v) acc[k++] += J[u] * J[v];
+    for (int u = 0; u < 6; ++u) acc[21 + u] -= J[u] * res;
+    acc[27] += (double)best[r];
+    acc[28] += 1.0;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < ICP_NACC; ++k) {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < ICP_NACC) {
+    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NACC + threadIdx.x] = s;
+  }
+}
+template __global__ void k_icp_nn_grid<4>(IcpArgs);
+
+template <int R>
+__global__ __launch_bounds__(256) void k_icp_nn_cells(IcpArgs a) {
+  __shared__ float sT[12], sTi[12];
+  __shared__ double red[4][ICP_NACC];
+  const int hl = blockIdx.y, h = a.h0 + hl;
+  IcpState& st = a.state[hl];
+  if (!st.active) return;
+  const float* pose = a.pose + (size_t)h * 16;
+  float Tinc[12];
+  for (int k = 0; k < 12; ++k) Tinc[k] = st.T_inc[k];
+  V3 q[R], qn[R];
+  float best[R];
+  int bidx[R];
+  const bool first = a.iter == 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    best[r] = 3.0e38f;
+    bidx[r] = -1;
+    if (i < a.ns) {
+      V3 p, n;
+      if (first) {
+        p = v3(a.sx[i], a.sy[i], a.sz[i]);
+        n = v3(a.snx[i], a.sny[i], a.snz[i]);
+      } else {
+        const size_t o = (size_t)hl * a.ns * 6 + i;
+        p = v3(a.moved[o], a.moved[o + a.ns], a.moved[o + 2 * (size_t)a.ns]);
+        n = v3(a.moved[o + 3 * (size_t)a.ns], a.moved[o + 4 * (size_t)a.ns], a.moved[o + 5 * (size_t)a.ns]);
+        p = m4_point(Tinc, p);
+        n = m4_dir(Tinc, n);
+      }
+      const size_t o = (size_t)hl * a.ns * 6 + i;
+      a.moved[o] = p.x, a.moved[o + a.ns] = p.y, a.moved[o + 2 * (size_t)a.ns] = p.z;
+      a.moved[o + 3 * (size_t)a.ns] = n.x, a.moved[o + 4 * (size_t)a.ns] = n.y, a.moved[o + 5 * (size_t)a.ns] = n.z;
+      q[r] = p, qn[r] = n;
+    } else {
+      q[r] = v3(-HOP_FAR, -HOP_FAR, -HOP_FAR);
+      qn[r] = v3(0, 0, 0);
+    }
+  }
+  block_pose_and_inverse(pose, sT, sTi);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    if (i < a.ns) cells_nn(a.cells, m4_point(sTi, q[r]), sT, q[r], best[r], bidx[r]);
+  }
+  double acc[ICP_NACC];
+#pragma unroll
+  for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    if (i >= a.ns || bidx[r] < 0 || !(best[r] <= a.max_d2)) continue;
+    const int j = bidx[r];
+    const V3 nt = m4_dir(pose, v3(a.mnx[j], a.mny[j], a.mnz[j]));
+    if (!(vdot(qn[r], nt) >= a.cos_thr)) continue;
+    const V3 tq = m4_point(pose, v3(a.mx[j], a.my[j], a.mz[j]));
+    const V3 c = vcross(q[r], nt);
+    const double J[6] = {c.x, c.y, c.z, nt.x, nt.y, nt.z};
+    const double res = (double)vdot(q[r] - tq, nt);
+    int k = 0;
+    for (int u = 0; u < 6; ++u)
+      for (int v = 0; v <= u; ++v) acc[k++] += J[u] * J[v];
+    for (int u = 0; u < 6; ++u) acc[21 + u] -= J[u] * res;
+    acc[27] += (double)best[r];
+    acc[28] += 1.0;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < ICP_NACC; ++k) {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < ICP_NACC) {
+    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NACC + threadIdx.x] = s;
+  }
+}
+template __global__ void k_icp_nn_cells<4>(IcpArgs);
+
+
 
 __device__ bool chol6(double A[6][6], const double b[6], double x[6]) {
   double L[6][6];
@@ -953,6 +1322,24 @@ int icp_blocks_per_hyp(int ns) { return (ns + 256 * 4 - 1) / (256 * 4); }
 void launch_icp_init(IcpState* st, int hb, hipStream_t s) { hipLaunchKernelGGL(k_icp_init, dim3((hb + 63) / 64), dim3(64), 0, s, st, hb); }
 void launch_icp_nn(const IcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_nn<4>, dim3(icp_blocks_per_hyp(a.ns), hb), dim3(256), 0, s, a);
+}
+void launch_icp_nn_grid(const IcpArgs& a, int hb, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_nn_grid<4>, dim3(icp_blocks_per_hyp(a.ns), hb), dim3(256), 0, s, a);
+}
+void launch_icp_nn_cells(const IcpArgs& a, int hb, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_nn_cells<4>, dim3(icp_blocks_per_hyp(a.ns), hb), dim3(256), 0, s, a);
+}
+void launch_cell_list_bounds(const CellListBuildArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_cell_list_bounds, dim3(a.dx * a.dy * a.dz), dim3(256), 0, s, a);
+}
+void launch_cell_list_count(const CellListBuildArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_cell_list_count, dim3(a.dx * a.dy * a.dz), dim3(256), 0, s, a);
+}
+void launch_cell_list_fill(const CellListBuildArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_cell_list_fill, dim3(a.dx * a.dy * a.dz), dim3(64), 0, s, a);
+}
+void launch_lcp_grid(const LcpArgs& a, int hb, hipStream_t s) {
+  hipLaunchKernelGGL(k_lcp_grid, dim3((a.ns + 255) / 256, hb), dim3(256), 0, s, a);
 }
 void launch_icp_solve(const IcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_solve, dim3((hb + 63) / 64), dim3(64), 0, s, a, hb, icp_blocks_per_hyp(a.ns));

@@ -162,12 +162,13 @@ def _scoring_case(synth, n_scene, n_model, H, seed=7):
     return sc, mx, mn, poses
 
 
-def test_lcp_scores_bit_equal_to_oracle(ctx, api, orc, synth):
+@pytest.mark.parametrize("nn_mode", [0, 1])
+def test_lcp_scores_bit_equal_to_oracle(ctx, api, orc, synth, nn_mode):
     sc, mx, mn, poses = _scoring_case(synth, 3000, 2500, 48)
     ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.0)
     ctx.set_model(api.HOP_MODEL_1MM, mx, mn)
     ctx.hypos_upload(poses)
-    best_pose, best_score, best_idx = ctx.lcp_select_best(0.001, 10.0)
+    best_pose, best_score, best_idx = ctx.lcp_select_best(0.001, 10.0, nn_mode)
     _, scores, _ = ctx.hypos_download()
     ref = orc.compute_lcp_batch(sc.xyz, sc.nrm, mx, mn, poses, 0.001, 10.0, use_tree=True)
     assert scores.max() > 10.0, "the ground-truth pose must score"
@@ -178,7 +179,8 @@ def test_lcp_scores_bit_equal_to_oracle(ctx, api, orc, synth):
     assert np.array_equal(best_pose, poses[exp])
 
 
-def test_lcp_ragged_and_empty_edge_cases(ctx, api, orc, synth):
+@pytest.mark.parametrize("nn_mode", [0, 1])
+def test_lcp_ragged_and_empty_edge_cases(ctx, api, orc, synth, nn_mode):
     """Sizes that are not multiples of any tile (1 scene point .. 2049 model points), and a pose far away."""
     sc, mx, mn, poses = _scoring_case(synth, 777, 2049, 5)
     far = poses[1].copy()
@@ -188,7 +190,7 @@ def test_lcp_ragged_and_empty_edge_cases(ctx, api, orc, synth):
         ctx.set_scene(sc.xyz[:ns], sc.nrm[:ns], None, 0.0)
         ctx.set_model(api.HOP_MODEL_1MM, mx, mn)
         ctx.hypos_upload(poses)
-        ctx.lcp_select_best(0.002, 15.0)
+        ctx.lcp_select_best(0.002, 15.0, nn_mode)
         _, scores, _ = ctx.hypos_download()
         ref = orc.compute_lcp_batch(sc.xyz[:ns], sc.nrm[:ns], mx, mn, poses, 0.002, 15.0, use_tree=False)
         assert np.array_equal(scores, ref)
@@ -196,14 +198,15 @@ def test_lcp_ragged_and_empty_edge_cases(ctx, api, orc, synth):
 
 
 # ------------------------------------------------------------------------------------------------ ICP
-def test_icp_matches_oracle_and_recovers_pose(ctx, api, orc, synth):
+@pytest.mark.parametrize("nn_mode", [0, 1, 2])
+def test_icp_matches_oracle_and_recovers_pose(ctx, api, orc, synth, nn_mode):
     sc, mx, mn, poses = _scoring_case(synth, 2500, 1500, 24)
     # small perturbations so that ICP converges to the truth
     poses = synth.replay_poses(sc.gt_pose, 24, seed=3, max_rot_deg=6.0, max_trans=0.004)
     ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.0)
     ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
     ctx.hypos_upload(poses)
-    it, cv = ctx.icp_refine(10, 45.0, 0.01, want_stats=True)
+    it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=nn_mode, want_stats=True)
     out, _, _ = ctx.hypos_download()
     ref, rit, rcv = orc.icp_refine_batch(sc.xyz, sc.nrm, mx, mn, poses, 10, 45.0, 0.01, use_tree=True)
     assert np.array_equal(it, rit) and np.array_equal(cv, rcv)
@@ -218,16 +221,40 @@ def test_icp_matches_oracle_and_recovers_pose(ctx, api, orc, synth):
     assert ok >= 20
 
 
-def test_icp_too_few_correspondences_returns_input(ctx, api, orc, synth):
+@pytest.mark.parametrize("nn_mode", [0, 1, 2])
+def test_icp_too_few_correspondences_returns_input(ctx, api, orc, synth, nn_mode):
     sc, mx, mn, poses = _scoring_case(synth, 500, 400, 3)
     poses[:, :3, 3] += 5.0  # nothing within 1 cm -> not converged -> identity (Utils.cpp:218-225)
     ctx.set_scene(sc.xyz, sc.nrm, None, 0.0)
     ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
     ctx.hypos_upload(poses)
-    it, cv = ctx.icp_refine(10, 45.0, 0.01, want_stats=True)
+    it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=nn_mode, want_stats=True)
     out, _, _ = ctx.hypos_download()
     assert not cv.any() and not it.any()
     assert np.abs(out - poses).max() < 1e-6
+
+
+def test_icp_and_lcp_grid_equal_brute_bitwise_large(ctx, api, synth):
+    """C2-sized clouds, wide perturbations (far points exercise the ring expansion): the grid path must return
+    the very same bits as the brute-force path (same correspondences -> same sums -> same poses / scores)."""
+    sc, mx, mn, _ = _scoring_case(synth, 20000, 5000, 4)
+    poses = synth.replay_poses(sc.gt_pose, 96, seed=21, max_rot_deg=40.0, max_trans=0.02)
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.0)
+    ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
+    ctx.set_model(api.HOP_MODEL_1MM, mx, mn)
+    res = []
+    for mode in (0, 1, 2):
+        ctx.hypos_upload(poses)
+        it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=mode, want_stats=True)
+        p, _, _ = ctx.hypos_download()
+        ctx.lcp_select_best(0.001, 10.0, mode)
+        _, sc_, _ = ctx.hypos_download()
+        res.append((it.copy(), cv.copy(), p.copy(), sc_.copy()))
+    for r in res[1:]:
+        assert np.array_equal(res[0][0], r[0]) and np.array_equal(res[0][1], r[1])
+        assert np.array_equal(res[0][2], r[2])
+        assert np.array_equal(res[0][3], r[3])
+    assert res[0][0].max() >= 4, "some hypotheses must need several iterations"
 
 
 # ------------------------------------------------------------------------------------------------ resident set
