@@ -12,6 +12,7 @@
 // Everything that touches clouds runs in the kernels of hop_kernels.hip.
 #include "../../include/hop.h"
 #include "hop_device.h"
+#include "hop_select.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -103,14 +104,6 @@ struct PinnedBuf {
   }
 };
 
-struct CloudHost {
-  std::vector<float> x, y, z, nx, ny, nz;
-  int n = 0;
-  void resize(int m) {
-    n = m;
-    x.resize(m), y.resize(m), z.resize(m), nx.resize(m), ny.resize(m), nz.resize(m);
-  }
-};
 struct CloudDevice {
   DevBuf buf;  // 6 planes
   int n = 0;
@@ -137,11 +130,9 @@ struct hop_ctx {
   hipStream_t stream = nullptr;
   std::string last_error;
 
-  // scene (= _scene_high_confidence), models
-  CloudHost scene_h;
-  std::vector<float> scene_conf;
+  // host-side clouds and generator state (scene = _scene_high_confidence)
+  GenState gen;
   CloudDevice scene_d;
-  CloudHost model_h[2];
   CloudDevice model_d[2];
 
   // PPF key set
@@ -151,17 +142,12 @@ struct hop_ctx {
   bool have_keys = false;
 
   // generator state of the last run
-  CloudHost gp_h;            // centred P, normals = Point3D normals
-  std::vector<float> gp_prob;
-  CloudHost gq_h;            // sampled centred Q
-  std::vector<float> gq_unit[3];
-  float centroid_p[3] = {0, 0, 0}, centroid_q[3] = {0, 0, 0};
-  float diameter = 0, ratio = 1;
   CloudDevice gp_d;          // planes: x y z + ppf normals
   CloudDevice gq_d;          // planes: x y z nx ny nz
   DevBuf gq_unit_d;          // 3 planes
   DevBuf ppf_matrix_d;
   PinnedBuf ppf_matrix_h;
+  std::vector<unsigned long long> ppf_matrix_cached;
   int ppf_words = 0;
   std::vector<BaseTraceHost> trace;
   bool have_gen_state = false;
@@ -273,301 +259,6 @@ int upload_cloud(hop_ctx* c, CloudDevice& d, const CloudHost& h) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return HOP_OK;
 }
-
-// Point3D::set_normal (shared.h:86-88): stored normals are normalised once
-void load_cloud_host(CloudHost& h, const float* xyz, const float* nrm, int n, bool normalise) {
-  h.resize(n);
-  for (int i = 0; i < n; ++i) {
-    h.x[i] = xyz[i], h.y[i] = xyz[n + i], h.z[i] = xyz[2 * (size_t)n + i];
-    V3 nn = v3(nrm[i], nrm[n + i], nrm[2 * (size_t)n + i]);
-    if (normalise) nn = vnormalized(nn);
-    h.nx[i] = nn.x, h.ny[i] = nn.y, h.nz[i] = nn.z;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// generator, host part
-// ------------------------------------------------------------------------------------------------
-struct GenHost {
-  hop_ctx* c;
-  hop_s4pcs_opts opt;
-  std::mt19937 randomGenerator_;     // matchBase.hpp:73
-  std::mt19937 point_index_engine_;  // matchBase.hpp:76, seed 0
-  std::vector<float> point_probs_;
-  int n = 0;  // |P|
-  const unsigned long long* M = nullptr;
-  int W = 0;
-  float max_base_diameter_ = -1;
-  std::array<V3, 4> bpos, bnrm;
-
-  GenHost(hop_ctx* ctx, const hop_s4pcs_opts& o) : c(ctx), opt(o), randomGenerator_(o.random_seed), point_index_engine_(0) {}
-
-  bool bit(int i, int j) const { return (M[(size_t)i * W + (j >> 6)] >> (j & 63)) & 1ull; }
-  V3 ppos(int i) const { return v3(c->gp_h.x[i], c->gp_h.y[i], c->gp_h.z[i]); }
-  V3 pnrm(int i) const { return v3(c->gp_h.nx[i], c->gp_h.ny[i], c->gp_h.nz[i]); }
-
-  // UniformDistSampler (sampling.h:67-144): first point of every delta-voxel, open-addressing hash
-  static void uniform_sample(const CloudHost& in, float delta, std::vector<int>& keep) {
-    const uint64_t MAGIC1 = 100000007, MAGIC2 = 161803409, MAGIC3 = 423606823, NO_DATA = 0xffffffffu;
-    const int num_input = in.n;
-    const float scale_ = 1.0f / delta;
-    std::vector<std::array<int, 3>> voxels_(num_input);
-    std::vector<uint64_t> data_(num_input, NO_DATA);
-    keep.clear();
-    for (int i = 0; i < num_input; ++i) {
-      const std::array<int, 3> cell{int(std::floor(in.x[i] * scale_)), int(std::floor(in.y[i] * scale_)), int(std::floor(in.z[i] * scale_))};
-      uint64_t key = (MAGIC1 * (uint64_t)(int64_t)cell[0] + MAGIC2 * (uint64_t)(int64_t)cell[1] + MAGIC3 * (uint64_t)(int64_t)cell[2]) % data_.size();
-      while (true) {
-        if (data_[key] == NO_DATA) {
-          voxels_[key] = cell;
-          break;
-        } else if (voxels_[key] == cell)
-          break;
-        if (++key == data_.size()) key = 0;
-      }
-      if (data_[key] >= (uint64_t)num_input) {
-        keep.push_back(i);
-        data_[key] = keep.size();
-      }
-    }
-  }
-
-  // MatchBase::init (matchBase.hpp:380-462) minus the kd-tree; fills ctx->gp_h / gq_h / centroids / diameter
-  void init_clouds() {
-    const CloudHost& P = c->scene_h;
-    const CloudHost& Q = c->model_h[HOP_MODEL_5MM];
-    std::vector<int> qsel;
-    if (Q.n > opt.sample_size) {
-      uniform_sample(Q, opt.delta, qsel);
-      std::shuffle(qsel.begin(), qsel.end(), randomGenerator_);
-      if ((int)qsel.size() > opt.sample_size) qsel.resize(opt.sample_size);
-    } else {
-      qsel.resize(Q.n);
-      std::iota(qsel.begin(), qsel.end(), 0);
-    }
-    CloudHost& gp = c->gp_h;
-    CloudHost& gq = c->gq_h;
-    gp = P;
-    c->gp_prob = c->scene_conf;
-    gq.resize((int)qsel.size());
-    for (int k = 0; k < gq.n; ++k) {
-      const int i = qsel[k];
-      gq.x[k] = Q.x[i], gq.y[k] = Q.y[i], gq.z[k] = Q.z[i], gq.nx[k] = Q.nx[i], gq.ny[k] = Q.ny[i], gq.nz[k] = Q.nz[i];
-    }
-    auto centre = [](CloudHost& cl, float cen[3]) {
-      V3 s = v3(0, 0, 0);
-      for (int i = 0; i < cl.n; ++i) s = s + v3(cl.x[i], cl.y[i], cl.z[i]);
-      s = s / float(cl.n);
-      for (int i = 0; i < cl.n; ++i) {
-        const V3 p = v3(cl.x[i], cl.y[i], cl.z[i]) - s;
-        cl.x[i] = p.x, cl.y[i] = p.y, cl.z[i] = p.z;
-      }
-      cen[0] = s.x, cen[1] = s.y, cen[2] = s.z;
-    };
-    centre(gp, c->centroid_p);
-    centre(gq, c->centroid_q);
-    // "diameter of P", measured on sampled Q (matchBase.hpp:439-448)
-    float diam = 0.f;
-    for (int i = 0; i < 1000; ++i) {
-      const int at = int(randomGenerator_() % (unsigned long)gq.n);
-      const int bt = int(randomGenerator_() % (unsigned long)gq.n);
-      const float l = vnorm(v3(gq.x[bt], gq.y[bt], gq.z[bt]) - v3(gq.x[at], gq.y[at], gq.z[at]));
-      if (l > diam) diam = l;
-    }
-    c->diameter = diam;
-    max_base_diameter_ = diam;
-    // PairCreationFunctor::synch3DContent (pairCreationFunctor.h:129-161)
-    V3 mn = v3(FLT_MAX, FLT_MAX, FLT_MAX), mx = v3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
-    for (int i = 0; i < gq.n; ++i) {
-      mn = v3(std::min(mn.x, gq.x[i]), std::min(mn.y, gq.y[i]), std::min(mn.z, gq.z[i]));
-      mx = v3(std::max(mx.x, gq.x[i]), std::max(mx.y, gq.y[i]), std::max(mx.z, gq.z[i]));
-    }
-    const V3 gcenter = (mn + mx) / 2.f;
-    const V3 diag = mx - mn;
-    c->ratio = (float)((double)std::max(diag.x, std::max(diag.y, diag.z)) + 0.001);
-    for (int k = 0; k < 3; ++k) c->gq_unit[k].resize(gq.n);
-    const V3 half = v3(0.5f, 0.5f, 0.5f);
-    for (int i = 0; i < gq.n; ++i) {
-      const V3 u = (v3(gq.x[i], gq.y[i], gq.z[i]) - gcenter) / c->ratio + half;
-      c->gq_unit[0][i] = u.x, c->gq_unit[1][i] = u.y, c->gq_unit[2][i] = u.z;
-    }
-    n = gp.n;
-    point_probs_ = c->gp_prob;
-  }
-
-  // MatchBase::SelectRandomTriangle, matchBase.hpp:111-212, with key membership read from the bit matrix
-  bool SelectRandomTriangle(int& base1, int& base2, int& base3, std::vector<int>& sample_pool) {
-    base1 = base2 = base3 = -1;
-    std::discrete_distribution<> sampler(point_probs_.begin(), point_probs_.end());
-    const int first_point = sampler(point_index_engine_);
-    point_probs_[first_point] *= opt.dispersion;
-    sample_pool.clear();
-    std::vector<float> probs;
-    const unsigned long long* row = M + (size_t)first_point * W;
-    for (int w = 0; w < W; ++w) {
-      unsigned long long bits = row[w];
-      while (bits) {
-        const int i = w * 64 + __builtin_ctzll(bits);
-        bits &= bits - 1;
-        if (i == first_point || i >= n) continue;
-        sample_pool.push_back(i);
-        probs.push_back(point_probs_[i]);
-      }
-    }
-    if (sample_pool.size() < 3) return false;
-    const float sq_max = max_base_diameter_ * max_base_diameter_;
-    const V3 p0 = ppos(first_point);
-    for (int i = 0; (size_t)i < sample_pool.size() * sample_pool.size() / 4; ++i) {
-      std::discrete_distribution<> sampler1(probs.begin(), probs.end());
-      const int second = sampler1(point_index_engine_);
-      const int third = sampler1(point_index_engine_);
-      if (second == third) continue;
-      if (!bit(sample_pool[second], sample_pool[third])) continue;
-      probs[second] *= opt.dispersion;
-      probs[third] *= opt.dispersion;
-      const V3 u = ppos(sample_pool[second]) - p0;
-      const V3 w = ppos(sample_pool[third]) - p0;
-      const float how_wide = vdot(vnormalized(u), vnormalized(w));
-      if ((double)std::fabs(how_wide) <= std::cos(45 * M_PI / 180.0) && vsqn(u) < sq_max && vsqn(w) < sq_max) {
-        base1 = first_point;
-        base2 = sample_pool[second];
-        base3 = sample_pool[third];
-        break;
-      }
-    }
-    if (base2 == -1 || base3 == -1) return false;
-    // pool for the 4th point; the reference stores the LOOP INDEX here (matchBase.hpp:203) and later
-    // uses it as a point index (match4pcsBase.hpp:159) -- mirrored.
-    std::vector<int> backup;
-    backup.swap(sample_pool);
-    for (int i = 0; i < (int)backup.size(); ++i) {
-      const int id = backup[i];
-      if (id == base2 || id == base3 || id == base1) continue;
-      if (bit(base2, id) && bit(base3, id)) sample_pool.push_back(i);
-    }
-    if (sample_pool.empty()) return false;
-    return base1 != -1 && base2 != -1 && base3 != -1;
-  }
-
-  // Match4pcsBase::distSegmentToSegment, match4pcsBase.hpp:283-354
-  static float distSegmentToSegment(V3 p1, V3 p2, V3 q1, V3 q2, float& invariant1, float& invariant2) {
-    const float kSmall = 0.0001f;
-    const V3 u = p2 - p1, v = q2 - q1, w = p1 - q1;
-    const float a = vdot(u, u), b = vdot(u, v), cc = vdot(v, v), d = vdot(u, w), e = vdot(v, w);
-    const float f = a * cc - b * b;
-    float s1 = 0.0f, s2 = f, t1 = 0.0f, t2 = f;
-    if (f < kSmall) {
-      s1 = 0.0f, s2 = 1.0f, t1 = e, t2 = cc;
-    } else {
-      s1 = (b * e - cc * d);
-      t1 = (a * e - b * d);
-      if (s1 < 0.0f) s1 = 0.0f, t1 = e, t2 = cc;
-      else if (s1 > s2) s1 = s2, t1 = e + b, t2 = cc;
-    }
-    if (t1 < 0.0f) {
-      t1 = 0.0f;
-      if (-d < 0.0f) s1 = 0.0f;
-      else if (-d > a) s1 = s2;
-      else s1 = -d, s2 = a;
-    } else if (t1 > t2) {
-      t1 = t2;
-      if ((-d + b) < 0.0f) s1 = 0;
-      else if ((-d + b) > a) s1 = s2;
-      else s1 = (-d + b), s2 = a;
-    }
-    invariant1 = (std::fabs(s1) < kSmall ? 0.0f : s1 / s2);
-    invariant2 = (std::fabs(t1) < kSmall ? 0.0f : t1 / t2);
-    return vnorm((w + (invariant1 * u)) - (invariant2 * v));
-  }
-
-  // Match4pcsBase::TryQuadrilateral, match4pcsBase.hpp:50-101
-  bool TryQuadrilateral(float& invariant1, float& invariant2, int ids[4]) {
-    float min_distance = FLT_MAX;
-    int best[4] = {-1, -1, -1, -1};
-    for (int i = 0; i < 4; ++i)
-      for (int j = 0; j < 4; ++j) {
-        if (i == j) continue;
-        int k = 0;
-        while (k == i || k == j) k++;
-        int l = 0;
-        while (l == i || l == j || l == k) l++;
-        float li1, li2;
-        const float sd = distSegmentToSegment(bpos[i], bpos[j], bpos[k], bpos[l], li1, li2);
-        if (sd < min_distance) {
-          min_distance = sd;
-          best[0] = i, best[1] = j, best[2] = k, best[3] = l;
-          invariant1 = li1, invariant2 = li2;
-        }
-      }
-    if (best[0] < 0) return false;
-    const std::array<V3, 4> tp = bpos, tn = bnrm;
-    const int tid[4] = {ids[0], ids[1], ids[2], ids[3]};
-    for (int k = 0; k < 4; ++k) bpos[k] = tp[best[k]], bnrm[k] = tn[best[k]], ids[k] = tid[best[k]];
-    return true;
-  }
-
-  // Match4pcsBase::SelectQuadrilateral, match4pcsBase.hpp:107-189
-  bool SelectQuadrilateral(float& invariant1, float& invariant2, int ids[4]) {
-    const float kBaseTooSmall = 0.2f;
-    int current_trial = 0;
-    std::vector<int> sample_pool;
-    while (current_trial < 1000) {
-      current_trial++;
-      int base1, base2, base3, base4;
-      if (!SelectRandomTriangle(base1, base2, base3, sample_pool)) continue;
-      const V3 b0 = ppos(base1), b1 = ppos(base2), b2 = ppos(base3);
-      const double x1 = b0.x, y1 = b0.y, z1 = b0.z, x2 = b1.x, y2 = b1.y, z2 = b1.z, x3 = b2.x, y3 = b2.y, z3 = b2.z;
-      const float denom = (float)(-x3 * y2 * z1 + x2 * y3 * z1 + x3 * y1 * z2 - x1 * y3 * z2 - x2 * y1 * z3 + x1 * y2 * z3);
-      if (denom != 0) {
-        const float A = (float)((-y2 * z1 + y3 * z1 + y1 * z2 - y3 * z2 - y1 * z3 + y2 * z3) / denom);
-        const float B = (float)((x2 * z1 - x3 * z1 - x1 * z2 + x3 * z2 + x1 * z3 - x2 * z3) / denom);
-        const float C = (float)((-x2 * y1 + x3 * y1 + x1 * y2 - x3 * y2 - x1 * y3 + x2 * y3) / denom);
-        base4 = -1;
-        float best_distance = FLT_MAX;
-        const float too_small = (float)std::pow((double)(max_base_diameter_ * kBaseTooSmall), 2);
-        for (size_t i = 0; i < sample_pool.size(); ++i) {
-          const V3 p = ppos(sample_pool[i]);
-          if (vsqn(p - b0) >= too_small && vsqn(p - b1) >= too_small && vsqn(p - b2) >= too_small) {
-            const float distance = (float)std::fabs((double)((A * p.x + B * p.y) + C * p.z) - 1.0);
-            if (distance < best_distance) {
-              best_distance = distance;
-              base4 = sample_pool[i];
-            }
-          }
-        }
-        if (base4 != -1) {
-          ids[0] = base1, ids[1] = base2, ids[2] = base3, ids[3] = base4;
-          for (int k = 0; k < 4; ++k) bpos[k] = ppos(ids[k]), bnrm[k] = pnrm(ids[k]);
-          if (TryQuadrilateral(invariant1, invariant2, ids)) return true;
-        }
-      }
-    }
-    return false;
-  }
-
-  // per-base constants of the device side of generateCongruents (match4pcsBase.hpp:244-261,
-  // FunctorSuper4pcs.h:163-170, normalset.hpp:205-212)
-  void fill_base(BaseDev& B, float inv1, float inv2) const {
-    for (int k = 0; k < 4; ++k) B.bpos[k][0] = bpos[k].x, B.bpos[k][1] = bpos[k].y, B.bpos[k][2] = bpos[k].z;
-    B.dist1 = vnorm(bpos[0] - bpos[1]);
-    B.dist2 = vnorm(bpos[2] - bpos[3]);
-    B.inv1 = inv1, B.inv2 = inv2;
-    B.e1 = base_edge_features(bpos[0], bnrm[0], bpos[1], bnrm[1]);
-    B.e2 = base_edge_features(bpos[2], bnrm[2], bpos[3], bnrm[3]);
-    const float alpha = vdot(vnormalized(bpos[1] - bpos[0]), vnormalized(bpos[3] - bpos[2]));
-    const float ac = acosf_fdlibm(alpha);
-    const float perimeter = (float)((double)2.f * M_PI * (double)std::atan(ac));
-    unsigned nb = (unsigned)(2 * std::ceil(perimeter * 7.f / 2.f));
-    if (!(nb <= (unsigned)MAX_RING)) nb = alpha == alpha ? (unsigned)MAX_RING : 0u;  // NaN alpha -> no samples
-    const float angleStep = (float)((double)2.f * M_PI / (double)(float)nb);
-    const float sinAlpha = std::sin(ac);
-    B.nb_sample = (int)nb;
-    for (unsigned a = 0; a < nb; ++a) {
-      const float theta = float(a) * angleStep;
-      B.ring[a][0] = sinAlpha * std::cos(theta), B.ring[a][1] = sinAlpha * std::sin(theta), B.ring[a][2] = alpha;
-    }
-  }
-};
 
 NsetGeom make_nset_geom(float eps) {
   NsetGeom g;
@@ -841,9 +532,9 @@ int hop_set_scene(hop_ctx* c, const float* xyz, const float* nrm, const float* c
   HIPCHK(c, hipSetDevice(c->device));
   CloudHost all;
   load_cloud_host(all, xyz, nrm, n, true);
-  CloudHost& s = c->scene_h;
+  CloudHost& s = c->gen.scene_h;
   s.resize(0);
-  c->scene_conf.clear();
+  c->gen.scene_conf.clear();
   std::vector<int> keep;
   for (int i = 0; i < n; ++i) {
     const float cf = conf ? conf[i] : 1.0f;
@@ -851,11 +542,11 @@ int hop_set_scene(hop_ctx* c, const float* xyz, const float* nrm, const float* c
     keep.push_back(i);
   }
   s.resize((int)keep.size());
-  c->scene_conf.resize(keep.size());
+  c->gen.scene_conf.resize(keep.size());
   for (size_t k = 0; k < keep.size(); ++k) {
     const int i = keep[k];
     s.x[k] = all.x[i], s.y[k] = all.y[i], s.z[k] = all.z[i], s.nx[k] = all.nx[i], s.ny[k] = all.ny[i], s.nz[k] = all.nz[i];
-    c->scene_conf[k] = conf ? conf[i] : 1.0f;
+    c->gen.scene_conf[k] = conf ? conf[i] : 1.0f;
   }
   // The scoring stages read the raw normals (computeLCP normalises on use; ICP uses them as given):
   // keep the un-normalised normals on the device copy used by ICP/LCP.
@@ -870,12 +561,12 @@ int hop_set_scene(hop_ctx* c, const float* xyz, const float* nrm, const float* c
   return upload_cloud(c, c->scene_d, raw);
 }
 
-int hop_scene_size(const hop_ctx* c) { return c ? c->scene_h.n : HOP_E_INVALID; }
+int hop_scene_size(const hop_ctx* c) { return c ? c->gen.scene_h.n : HOP_E_INVALID; }
 
 int hop_set_model(hop_ctx* c, int level, const float* xyz, const float* nrm, int n) {
   if (!c || !xyz || !nrm || n <= 0 || (level != HOP_MODEL_5MM && level != HOP_MODEL_1MM)) return HOP_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
-  load_cloud_host(c->model_h[level], xyz, nrm, n, true);  // generator view: Point3D normals
+  load_cloud_host(c->gen.model_h[level], xyz, nrm, n, true);  // generator view: Point3D normals
   CloudHost raw;
   load_cloud_host(raw, xyz, nrm, n, false);  // scoring view: as given
   c->have_gen_state = false;
@@ -887,19 +578,7 @@ int hop_set_model(hop_ctx* c, int level, const float* xyz, const float* nrm, int
 int hop_set_ppf_keys(hop_ctx* c, const int32_t* keys4, int nkeys) {
   if (!c || !keys4 || nkeys < 0) return HOP_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
-  int max_d = 0;
-  for (int i = 0; i < nkeys; ++i) max_d = std::max(max_d, keys4[4 * i]);
-  c->key_dist_bins = max_d / 5 + 1;
-  const size_t nbits = (size_t)c->key_dist_bins * 19 * 19 * 19;
-  c->key_bitmap.assign((nbits + 31) / 32 + 1, 0u);
-  for (int i = 0; i < nkeys; ++i) {
-    const int* k = keys4 + 4 * i;
-    // keys are multiples of 5 / 10 by construction (ppfClosestBin); anything else can never be produced
-    if (k[0] < 0 || k[0] % 5 || k[1] < 0 || k[1] > 180 || k[1] % 10 || k[2] < 0 || k[2] > 180 || k[2] % 10 || k[3] < 0 || k[3] > 180 || k[3] % 10)
-      continue;
-    const size_t bit = (((size_t)(k[0] / 5) * 19 + k[1] / 10) * 19 + k[2] / 10) * 19 + k[3] / 10;
-    c->key_bitmap[bit >> 5] |= 1u << (bit & 31);
-  }
+  build_key_bitmap(keys4, nkeys, c->key_bitmap, c->key_dist_bins);
   HIPCHK(c, c->key_bitmap_d.ensure(sizeof(unsigned) * c->key_bitmap.size()));
   HIPCHK(c, hipMemcpyAsync(c->key_bitmap_d.p, c->key_bitmap.data(), sizeof(unsigned) * c->key_bitmap.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -922,35 +601,35 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
   if (n_out) *n_out = 0;
   if (opts->max_normal_difference >= 0 || opts->max_color_distance >= 0) return HOP_E_INVALID;
   if (opts->sample_size <= 0 || opts->sample_size > 4096 || !(opts->delta > 0)) return HOP_E_INVALID;
-  if (c->scene_h.n <= 0 || c->model_h[HOP_MODEL_5MM].n <= 0 || !c->have_keys) return HOP_E_STATE;
+  if (c->gen.scene_h.n <= 0 || c->gen.model_h[HOP_MODEL_5MM].n <= 0 || !c->have_keys) return HOP_E_STATE;
   HIPCHK(c, hipSetDevice(c->device));
   const auto t_begin = std::chrono::steady_clock::now();
   hop_s4pcs_stats st{};
   c->trace.clear();
   c->n_hyp = 0;
 
-  GenHost G(c, *opts);
+  GenHost G(&c->gen, *opts);
   G.init_clouds();
-  const int N = c->gp_h.n, NQ = c->gq_h.n;
+  const int N = c->gen.gp_h.n, NQ = c->gen.gq_h.n;
   if (N > 65536) return HOP_E_CAPACITY;  // bit matrix N^2/8 bytes
   st.n_sampled_q = NQ;
-  for (int k = 0; k < 3; ++k) st.centroid_p[k] = c->centroid_p[k], st.centroid_q[k] = c->centroid_q[k];
-  st.diameter = c->diameter;
+  for (int k = 0; k < 3; ++k) st.centroid_p[k] = c->gen.centroid_p[k], st.centroid_q[k] = c->gen.centroid_q[k];
+  st.diameter = c->gen.diameter;
 
   // ---- upload generator clouds: P planes x y z + PPF normals (two extra normalisations, matchBase.hpp:53-56)
   {
-    CloudHost up = c->gp_h;
+    CloudHost up = c->gen.gp_h;
     for (int i = 0; i < N; ++i) {
       V3 nn = vnormalized(vnormalized(v3(up.nx[i], up.ny[i], up.nz[i])));
       up.nx[i] = nn.x, up.ny[i] = nn.y, up.nz[i] = nn.z;
     }
     int rc = upload_cloud(c, c->gp_d, up);
     if (rc) return rc;
-    rc = upload_cloud(c, c->gq_d, c->gq_h);
+    rc = upload_cloud(c, c->gq_d, c->gen.gq_h);
     if (rc) return rc;
     HIPCHK(c, c->gq_unit_d.ensure(sizeof(float) * 3 * (size_t)NQ));
     for (int k = 0; k < 3; ++k)
-      HIPCHK(c, hipMemcpyAsync(c->gq_unit_d.as<float>() + (size_t)k * NQ, c->gq_unit[k].data(), sizeof(float) * NQ, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->gq_unit_d.as<float>() + (size_t)k * NQ, c->gen.gq_unit[k].data(), sizeof(float) * NQ, hipMemcpyHostToDevice, c->stream));
   }
   c->have_gen_state = true;
   c->have_verify_clouds = false;
@@ -975,11 +654,15 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
     HIPCHK(c, hipMemcpyAsync(c->ppf_matrix_h.p, c->ppf_matrix_d.p, mbytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  G.M = static_cast<const unsigned long long*>(c->ppf_matrix_h.p);
+  // The selection reads matrix rows millions of times: work on a pageable (normally cached) copy; the pinned
+  // staging buffer is only the DMA target.
+  c->ppf_matrix_cached.resize((size_t)N * W);
+  std::memcpy(c->ppf_matrix_cached.data(), c->ppf_matrix_h.p, mbytes);
+  G.M = c->ppf_matrix_cached.data();
   G.W = W;
 
   if (opts->verify_mode == 1) {
-    const int rc = build_grid(c, c->verify_grid, c->gp_h.x.data(), c->gp_h.y.data(), c->gp_h.z.data(), N, opts->delta * 1.001f + 1e-9f);
+    const int rc = build_grid(c, c->verify_grid, c->gen.gp_h.x.data(), c->gen.gp_h.y.data(), c->gen.gp_h.z.data(), N, opts->delta * 1.001f + 1e-9f);
     if (rc) return rc;
     c->grid_delta = opts->delta;
   }
@@ -1010,7 +693,7 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
   HIPCHK(c, hipMemsetAsync(c->cnt_d.p, 0, sizeof(int) * 3 * (size_t)n_trials, c->stream));
   int* cnt1_all = c->cnt_d.as<int>();
   int* cnt2_all = cnt1_all + n_trials;
-  const NsetGeom geom = make_nset_geom(opts->delta / c->ratio);
+  const NsetGeom geom = make_nset_geom(opts->delta / c->gen.ratio);
   const float* qx = c->gq_d.plane(0);
   const float* qy = c->gq_d.plane(1);
   const float* qz = c->gq_d.plane(2);
@@ -1077,7 +760,7 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
       SpanGuard sg(c, T_GEN_OTHER);
       EmitArgs ea{};
       ea.cands = c->cands_d.as<Candidate>(), ea.cand_counts = c->cand_counts_d.as<int>(), ea.cand_count = counters, ea.cand_cap = cand_cap;
-      for (int k = 0; k < 3; ++k) ea.cp[k] = c->centroid_p[k], ea.cq[k] = c->centroid_q[k];
+      for (int k = 0; k < 3; ++k) ea.cp[k] = c->gen.centroid_p[k], ea.cq[k] = c->gen.centroid_q[k];
       ea.nq = NQ, ea.pose = c->hyp_pose.as<float>(), ea.score = c->hyp_score.as<float>(), ea.key = c->hyp_key.as<unsigned long long>();
       ea.inv_count = c->hyp_inv.as<unsigned>(), ea.hyp_count = counters + 1, ea.hyp_cap = hyp_cap, ea.cand_total = counters + 3;
       ea.overflow = counters + 2;
@@ -1173,6 +856,7 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   st.ms_select = ms_select;
+  if (getenv("HOP_PROFILE_SELECT")) G.print_profile();
   st.ms_device = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   if (n_out) *n_out = H;
   if (stats_out) *stats_out = st;
@@ -1193,7 +877,7 @@ int hop_s4pcs_get_base(const hop_ctx* c, int i, int* base4, float* inv2, int* co
 }
 int hop_s4pcs_get_sampled_q(const hop_ctx* c, float* xyz, float* nrm) {
   if (!c || !c->have_gen_state) return HOP_E_STATE;
-  const CloudHost& q = c->gq_h;
+  const CloudHost& q = c->gen.gq_h;
   for (int i = 0; i < q.n; ++i) {
     if (xyz) xyz[i] = q.x[i], xyz[q.n + i] = q.y[i], xyz[2 * (size_t)q.n + i] = q.z[i];
     if (nrm) nrm[i] = q.nx[i], nrm[q.n + i] = q.ny[i], nrm[2 * (size_t)q.n + i] = q.nz[i];
@@ -1229,7 +913,7 @@ int hop_verify_batch(hop_ctx* c, const float* T16, int H, float delta, int mode,
     int rc;
     const float cell = delta * 1.001f + 1e-9f;
     if (c->have_verify_clouds) rc = build_grid(c, c->verify_grid, c->vp_h[0].data(), c->vp_h[1].data(), c->vp_h[2].data(), P.n, cell);
-    else rc = build_grid(c, c->verify_grid, c->gp_h.x.data(), c->gp_h.y.data(), c->gp_h.z.data(), P.n, cell);
+    else rc = build_grid(c, c->verify_grid, c->gen.gp_h.x.data(), c->gen.gp_h.y.data(), c->gen.gp_h.z.data(), P.n, cell);
     if (rc) return rc;
     c->grid_delta = delta;
   }
@@ -1333,7 +1017,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     const float cell = o->max_corr_dist / 3.f + GRID_MARGIN;
     GridStore& gs = c->model_grid[HOP_MODEL_5MM];
     if (!gs.valid || gs.cell != cell) {
-      const CloudHost& mh = c->model_h[HOP_MODEL_5MM];
+      const CloudHost& mh = c->gen.model_h[HOP_MODEL_5MM];
       const int rc = build_grid(c, gs, mh.x.data(), mh.y.data(), mh.z.data(), mh.n, cell);
       if (rc) return rc;
     }
@@ -1343,7 +1027,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     const float cell = o->max_corr_dist / 6.f;
     CellListStore& cs = c->model_cells[HOP_MODEL_5MM];
     if (!cs.valid || cs.cell != cell || cs.max_dist != o->max_corr_dist) {
-      const int rc = build_cell_lists(c, cs, c->model_h[HOP_MODEL_5MM], c->model_d[HOP_MODEL_5MM], o->max_corr_dist, cell);
+      const int rc = build_cell_lists(c, cs, c->gen.model_h[HOP_MODEL_5MM], c->model_d[HOP_MODEL_5MM], o->max_corr_dist, cell);
       if (rc) return rc;
     }
     a.cells = cs.c;
@@ -1401,12 +1085,12 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
     const float cell = o->dist + GRID_MARGIN * 2;
     GridStore& gm = c->model_grid[HOP_MODEL_1MM];
     if (!gm.valid || gm.cell != cell) {
-      const CloudHost& mh = c->model_h[HOP_MODEL_1MM];
+      const CloudHost& mh = c->gen.model_h[HOP_MODEL_1MM];
       const int rc = build_grid(c, gm, mh.x.data(), mh.y.data(), mh.z.data(), mh.n, cell);
       if (rc) return rc;
     }
     if (!c->scene_grid.valid || c->scene_grid.cell != cell) {
-      const CloudHost& sh = c->scene_h;
+      const CloudHost& sh = c->gen.scene_h;
       const int rc = build_grid(c, c->scene_grid, sh.x.data(), sh.y.data(), sh.z.data(), sh.n, cell);
       if (rc) return rc;
     }
