@@ -133,6 +133,8 @@ struct hop_ctx {
   // host-side clouds and generator state (scene = _scene_high_confidence)
   GenState gen;
   CloudDevice scene_d;
+  CloudDevice scene_sorted_d;  // scoring copy in Morton order (grid paths), + permutation back to caller order
+  DevBuf scene_perm_d;
   CloudDevice model_d[2];
 
   // PPF key set
@@ -156,7 +158,8 @@ struct hop_ctx {
   std::vector<float> vp_h[3];
   bool have_verify_clouds = false;
   // voxel grids: centred P for verify_mode 1; model rest frames and scene for nn_mode 1
-  GridStore verify_grid, model_grid[2], scene_grid;
+  GridStore verify_grid, model_grid[2], scene_grid, hand_grid;
+  std::vector<float> hand_scene_h[3];
   CellListStore model_cells[2];
   float grid_delta = 0;
 
@@ -168,7 +171,7 @@ struct hop_ctx {
   int n_hyp = 0;
 
   // scoring workspaces
-  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv;
+  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv, icp_corr_idx, icp_corr_d2;
 
   // hand
   CloudDevice hand_scene_d, hand_lookup_d, hand_swivel_d, hand_model_d;
@@ -352,6 +355,7 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
   cs.c.dx = a.dx, cs.c.dy = a.dy, cs.c.dz = a.dz;
   cs.c.start = cs.start_d.as<int>(), cs.c.pts = cs.pts_d.as<float4>();
   cs.valid = true, cs.cell = cell, cs.max_dist = max_dist;
+  if (getenv("HOP_PROFILE_SELECT")) std::printf("cell lists: %zu cells, %zu entries (%.1f per cell), cell %.4f\n", ncell, total, (double)total / (double)ncell, cell);
   return HOP_OK;
 }
 
@@ -504,16 +508,16 @@ void hop_ctx_destroy(hop_ctx* c) {
     (void)hipEventDestroy(s.b);
   }
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
-  DevBuf* bufs[] = {&c->scene_d.buf, &c->model_d[0].buf, &c->model_d[1].buf, &c->key_bitmap_d, &c->gp_d.buf, &c->gq_d.buf, &c->gq_unit_d,
+  DevBuf* bufs[] = {&c->scene_d.buf, &c->scene_sorted_d.buf, &c->scene_perm_d, &c->model_d[0].buf, &c->model_d[1].buf, &c->key_bitmap_d, &c->gp_d.buf, &c->gq_d.buf, &c->gq_unit_d,
                     &c->ppf_matrix_d, &c->vp_d.buf, &c->vq_d.buf, &c->bases_d, &c->pairs1_d,
                     &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
                     &c->hyp_score, &c->hyp_id, &c->hyp_key, &c->hyp_inv, &c->tmp_pose, &c->tmp_score, &c->tmp_id, &c->sort_keys_alt,
                     &c->sort_vals, &c->sort_vals_alt, &c->sort_tmp, &c->lcp_rev_idx, &c->lcp_rev_d2, &c->lcp_terms, &c->icp_moved,
-                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
+                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->icp_corr_idx, &c->icp_corr_d2, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
                     &c->hand_swivel_d.buf, &c->hand_model_d.buf, &c->finger_hist_d, &c->pso_particles_d, &c->pso_match_d,
                     &c->pso_terms_d, &c->pso_sum_d, &c->pso_cnt_d};
   for (DevBuf* b : bufs) b->release();
-  c->verify_grid.release(), c->model_grid[0].release(), c->model_grid[1].release(), c->scene_grid.release();
+  c->verify_grid.release(), c->model_grid[0].release(), c->model_grid[1].release(), c->scene_grid.release(), c->hand_grid.release();
   c->model_cells[0].release(), c->model_cells[1].release();
   c->ppf_matrix_h.release(), c->bases_h.release(), c->cnt_h.release(), c->pso_particles_h.release(), c->pso_out_h.release();
   (void)hipStreamDestroy(c->stream);
@@ -558,6 +562,42 @@ int hop_set_scene(hop_ctx* c, const float* xyz, const float* nrm, const float* c
   c->have_gen_state = false;
   c->verify_grid.valid = false;
   c->scene_grid.valid = false;
+  {
+    // Morton order of 2 mm voxels for the grid-based scoring kernels
+    const int m = raw.n;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+    for (int i = 0; i < m; ++i) mn[0] = std::min(mn[0], raw.x[i]), mn[1] = std::min(mn[1], raw.y[i]), mn[2] = std::min(mn[2], raw.z[i]);
+    auto part = [](unsigned long long v) {
+      v &= 0x1fffffull;
+      v = (v | v << 32) & 0x1f00000000ffffull;
+      v = (v | v << 16) & 0x1f0000ff0000ffull;
+      v = (v | v << 8) & 0x100f00f00f00f00full;
+      v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+      v = (v | v << 2) & 0x1249249249249249ull;
+      return v;
+    };
+    std::vector<std::pair<unsigned long long, int>> order(m);
+    for (int i = 0; i < m; ++i) {
+      const unsigned long long qx = (unsigned long long)std::max(0.f, (raw.x[i] - mn[0]) * 500.f), qy = (unsigned long long)std::max(0.f, (raw.y[i] - mn[1]) * 500.f),
+                               qz = (unsigned long long)std::max(0.f, (raw.z[i] - mn[2]) * 500.f);
+      order[i] = {part(qx) | part(qy) << 1 | part(qz) << 2, i};
+    }
+    std::sort(order.begin(), order.end());
+    CloudHost sorted;
+    sorted.resize(m);
+    std::vector<int> perm(std::max(m, 1));
+    for (int k = 0; k < m; ++k) {
+      const int i = order[k].second;
+      perm[k] = i;
+      sorted.x[k] = raw.x[i], sorted.y[k] = raw.y[i], sorted.z[k] = raw.z[i];
+      sorted.nx[k] = raw.nx[i], sorted.ny[k] = raw.ny[i], sorted.nz[k] = raw.nz[i];
+    }
+    const int rc = upload_cloud(c, c->scene_sorted_d, sorted);
+    if (rc) return rc;
+    HIPCHK(c, c->scene_perm_d.ensure(sizeof(int) * (size_t)std::max(m, 1)));
+    HIPCHK(c, hipMemcpyAsync(c->scene_perm_d.p, perm.data(), sizeof(int) * (size_t)std::max(m, 1), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   return upload_cloud(c, c->scene_d, raw);
 }
 
@@ -1023,14 +1063,21 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     }
     a.model_grid = gs.g;
     a.max_ring = (int)std::ceil((o->max_corr_dist + 2 * GRID_MARGIN) / cell);
-  } else if (o->nn_mode == 2) {
-    const float cell = o->max_corr_dist / 6.f;
+  } else if (o->nn_mode == 2 || o->nn_mode == 3) {
+    float cell = o->max_corr_dist / 6.f;
+    if (const char* e = getenv("HOP_ICP_CELL_DIV")) cell = o->max_corr_dist / (float)atof(e);
     CellListStore& cs = c->model_cells[HOP_MODEL_5MM];
     if (!cs.valid || cs.cell != cell || cs.max_dist != o->max_corr_dist) {
       const int rc = build_cell_lists(c, cs, c->gen.model_h[HOP_MODEL_5MM], c->model_d[HOP_MODEL_5MM], o->max_corr_dist, cell);
       if (rc) return rc;
     }
     a.cells = cs.c;
+    HIPCHK(c, c->icp_corr_idx.ensure(sizeof(int) * (size_t)S.n * HB));
+    HIPCHK(c, c->icp_corr_d2.ensure(sizeof(float) * (size_t)S.n * HB));
+    a.corr_idx = c->icp_corr_idx.as<int>(), a.corr_d2 = c->icp_corr_d2.as<float>();
+    // these paths walk the scene in Morton order (the per-hypothesis sums are order-insensitive up to f64 rounding)
+    const CloudDevice& Q = c->scene_sorted_d;
+    a.sx = Q.plane(0), a.sy = Q.plane(1), a.sz = Q.plane(2), a.snx = Q.plane(3), a.sny = Q.plane(4), a.snz = Q.plane(5);
   }
   for (int h0 = 0; h0 < H; h0 += HB) {
     const int hb = std::min(HB, H - h0);
@@ -1040,7 +1087,10 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
       a.iter = it;
       {
         SpanGuard sg(c, T_ICP_NN);
-        if (o->nn_mode == 2) launch_icp_nn_cells(a, hb, c->stream);
+        if (o->nn_mode == 2) {
+          launch_icp_corr_cells(a, hb, c->stream);
+          launch_icp_accum(a, hb, c->stream);
+        } else if (o->nn_mode == 3) launch_icp_nn_cells(a, hb, c->stream);
         else if (o->nn_mode == 1) launch_icp_nn_grid(a, hb, c->stream);
         else launch_icp_nn(a, hb, c->stream);
       }
@@ -1096,6 +1146,9 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
     }
     a.model_grid = gm.g;
     a.scene_grid = c->scene_grid.g;
+    const CloudDevice& Q = c->scene_sorted_d;
+    a.qx = Q.plane(0), a.qy = Q.plane(1), a.qz = Q.plane(2), a.qnx = Q.plane(3), a.qny = Q.plane(4), a.qnz = Q.plane(5);
+    a.perm = c->scene_perm_d.as<int>();
   }
   for (int h0 = 0; h0 < H; h0 += HB) {
     const int hb = std::min(HB, H - h0);
@@ -1261,6 +1314,8 @@ int hop_hand_set_scene(hop_ctx* c, const float* scene_xyz, int n_scene, const fl
   rc = up3(c->hand_swivel_d, swivel_xyz, n_swivel);
   if (rc) return rc;
   c->hand_n_scene = n_scene, c->hand_n_lookup = n_lookup, c->hand_n_swivel = n_swivel;
+  for (int k = 0; k < 3; ++k) c->hand_scene_h[k].assign(scene_xyz + (size_t)k * n_scene, scene_xyz + (size_t)(k + 1) * n_scene);
+  c->hand_grid.valid = false;
   c->have_hand_scene = true;
   return HOP_OK;
 }
@@ -1354,6 +1409,17 @@ int hop_hand_pso_eval_batch(hop_ctx* c, const double* angles, int n, double* cos
   pa.dist_thres = a.dist_thres, pa.cos_normal_thres = a.cos_normal_thres, pa.check_normal = a.check_normal;
   pa.fp_min_z = a.fp_min[2], pa.fp_stride_z = a.fp_stride_z, pa.fp_num_division = a.fp_num_division;
   pa.hist_min_y = c->finger_hist_d.as<float>();
+  {
+    const float cell = a.dist_thres / 2.f + GRID_MARGIN;
+    if (!c->hand_grid.valid || c->hand_grid.cell != cell) {
+      const int rc = build_grid(c, c->hand_grid, c->hand_scene_h[0].data(), c->hand_scene_h[1].data(), c->hand_scene_h[2].data(), c->hand_n_scene, cell);
+      if (rc) return rc;
+    }
+    pa.scene_grid = c->hand_grid.g;
+    pa.max_ring = (int)std::ceil((a.dist_thres + 2 * GRID_MARGIN) / cell);
+    pa.use_grid = 1;
+  }
+  pa.n_particles = n;
   pa.match_count = c->pso_match_d.as<int>(), pa.outer_terms = c->pso_terms_d.as<float>();
   pa.outer_sum = c->pso_sum_d.as<float>(), pa.outer_cnt = c->pso_cnt_d.as<int>();
   {

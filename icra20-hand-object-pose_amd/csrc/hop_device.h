@@ -166,6 +166,10 @@ struct LcpArgs {
   float* score;
   GridDev model_grid;  // nn_mode 1: model in its rest frame, cell >= dist + margin
   GridDev scene_grid;  //            scene, cell >= dist + margin
+  // grid path walks the scene in a spatially sorted order (neighbouring lanes touch neighbouring cells);
+  // `perm` maps the sorted position back to the caller's index, where the terms are stored.
+  const float *qx, *qy, *qz, *qnx, *qny, *qnz;
+  const int* perm;
 };
 
 struct IcpState {
@@ -190,6 +194,8 @@ struct IcpArgs {
   GridDev model_grid;  // nn_mode 1: model in its rest frame
   int max_ring;        // rings needed to cover max_corr_dist
   CellListDev cells;   // nn_mode 2: NN cell lists of the model in its rest frame
+  int* corr_idx;       // nn_mode 2: [hb][ns] nearest model index (or -1)
+  float* corr_d2;      //            [hb][ns] its squared distance
 };
 
 struct PsoParticle {
@@ -213,8 +219,12 @@ struct PsoArgs {
   float fp_min_z, fp_stride_z;
   int fp_num_division;
   const float* hist_min_y;
+  GridDev scene_grid;  // hand scene on a voxel grid (cell = dist_thres/2): exact NN within dist_thres by ring search
+  int max_ring;
+  int use_grid;
+  int n_particles;
   int* match_count;
-  float* outer_terms;
+  float* outer_terms;  // [n_swivel][n_particles]
   float* outer_sum;
   int* outer_cnt;
 };
@@ -239,6 +249,8 @@ void launch_icp_init(IcpState* st, int hb, hipStream_t s);
 void launch_icp_nn(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_nn_grid(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_nn_cells(const IcpArgs& a, int hb, hipStream_t s);
+void launch_icp_corr_cells(const IcpArgs& a, int hb, hipStream_t s);
+void launch_icp_accum(const IcpArgs& a, int hb, hipStream_t s);
 void launch_cell_list_bounds(const CellListBuildArgs& a, hipStream_t s);
 void launch_cell_list_count(const CellListBuildArgs& a, hipStream_t s);
 void launch_cell_list_fill(const CellListBuildArgs& a, hipStream_t s);

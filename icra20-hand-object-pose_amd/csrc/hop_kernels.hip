@@ -676,16 +676,17 @@ __global__ __launch_bounds__(256) void k_lcp_grid(LcpArgs a) {
   __shared__ float sT[12], sTi[12];
   const int h = a.h0 + blockIdx.y;
   block_pose_and_inverse(a.pose + (size_t)h * 16, sT, sTi);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.ns) return;
-  const V3 s = v3(a.sx[i], a.sy[i], a.sz[i]);
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.ns) return;
+  const int i = a.perm[k];  // caller's index of this scene point
+  const V3 s = v3(a.qx[k], a.qy[k], a.qz[k]);
   float best = 3.0e38f;
   int bj = -1;
   grid_nn_ring1<true>(a.model_grid, m4_point(sTi, s), sT, s, best, bj);
   float f = -1.f, g = -1.f;
   if (bj >= 0 && best < a.dist * a.dist) {
     const V3 nmod = m4_dir(sT, v3(a.mnx[bj], a.mny[bj], a.mnz[bj]));
-    f = lcp_term(v3(a.snx[i], a.sny[i], a.snz[i]), nmod, best, a.dist, a.cos_thres);
+    f = lcp_term(v3(a.qnx[k], a.qny[k], a.qnz[k]), nmod, best, a.dist, a.cos_thres);
     const V3 pm = m4_point(sT, v3(a.mx[bj], a.my[bj], a.mz[bj]));
     float rbest = 3.0e38f;
     int rk = -1;
@@ -1047,6 +1048,82 @@ template __global__ void k_icp_nn_cells<4>(IcpArgs);
 
 
 
+// nn_mode 2, split form: the correspondence search (few registers, high occupancy, gather bound) and the
+// normal-equation accumulation (29 f64 accumulators per lane, streaming) are separate launches.
+__global__ __launch_bounds__(256) void k_icp_corr_cells(IcpArgs a) {
+  __shared__ float sT[12], sTi[12], sInc[12];
+  const int hl = blockIdx.y, h = a.h0 + hl;
+  const IcpState& st = a.state[hl];
+  if (!st.active) return;
+  if (threadIdx.x < 12) sInc[threadIdx.x] = st.T_inc[threadIdx.x];
+  block_pose_and_inverse(a.pose + (size_t)h * 16, sT, sTi);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.ns) return;
+  const size_t o = (size_t)hl * a.ns * 6 + i;
+  V3 p, n;
+  if (a.iter == 0) {
+    p = v3(a.sx[i], a.sy[i], a.sz[i]);
+    n = v3(a.snx[i], a.sny[i], a.snz[i]);
+  } else {
+    p = m4_point(sInc, v3(a.moved[o], a.moved[o + a.ns], a.moved[o + 2 * (size_t)a.ns]));
+    n = m4_dir(sInc, v3(a.moved[o + 3 * (size_t)a.ns], a.moved[o + 4 * (size_t)a.ns], a.moved[o + 5 * (size_t)a.ns]));
+  }
+  a.moved[o] = p.x, a.moved[o + a.ns] = p.y, a.moved[o + 2 * (size_t)a.ns] = p.z;
+  a.moved[o + 3 * (size_t)a.ns] = n.x, a.moved[o + 4 * (size_t)a.ns] = n.y, a.moved[o + 5 * (size_t)a.ns] = n.z;
+  float best = 3.0e38f;
+  int bj = -1;
+  cells_nn(a.cells, m4_point(sTi, p), sT, p, best, bj);
+  a.corr_idx[(size_t)hl * a.ns + i] = bj;
+  a.corr_d2[(size_t)hl * a.ns + i] = best;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_icp_accum(IcpArgs a) {
+  __shared__ double red[4][ICP_NACC];
+  const int hl = blockIdx.y, h = a.h0 + hl;
+  const IcpState& st = a.state[hl];
+  if (!st.active) return;
+  const float* pose = a.pose + (size_t)h * 16;
+  double acc[ICP_NACC];
+#pragma unroll
+  for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    if (i >= a.ns) continue;
+    const int j = a.corr_idx[(size_t)hl * a.ns + i];
+    const float d2 = a.corr_d2[(size_t)hl * a.ns + i];
+    if (j < 0 || !(d2 <= a.max_d2)) continue;
+    const size_t o = (size_t)hl * a.ns * 6 + i;
+    const V3 q = v3(a.moved[o], a.moved[o + a.ns], a.moved[o + 2 * (size_t)a.ns]);
+    const V3 qn = v3(a.moved[o + 3 * (size_t)a.ns], a.moved[o + 4 * (size_t)a.ns], a.moved[o + 5 * (size_t)a.ns]);
+    const V3 nt = m4_dir(pose, v3(a.mnx[j], a.mny[j], a.mnz[j]));
+    if (!(vdot(qn, nt) >= a.cos_thr)) continue;
+    const V3 tq = m4_point(pose, v3(a.mx[j], a.my[j], a.mz[j]));
+    const V3 c = vcross(q, nt);
+    const double J[6] = {c.x, c.y, c.z, nt.x, nt.y, nt.z};
+    const double res = (double)vdot(q - tq, nt);
+    int k = 0;
+    for (int u = 0; u < 6; ++u)
+      for (int v = 0; v <= u; ++v) acc[k++] += J[u] * J[v];
+    for (int u = 0; u < 6; ++u) acc[21 + u] -= J[u] * res;
+    acc[27] += (double)d2;
+    acc[28] += 1.0;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < ICP_NACC; ++k) {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < ICP_NACC) {
+    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NACC + threadIdx.x] = s;
+  }
+}
+template __global__ void k_icp_accum<4>(IcpArgs);
+
 __device__ bool chol6(double A[6][6], const double b[6], double x[6]) {
   double L[6][6];
   for (int i = 0; i < 6; ++i)
@@ -1197,12 +1274,20 @@ __global__ __launch_bounds__(256) void k_pso_match(PsoArgs a) {
       qn[r] = v3(0, 0, 0);
     }
   }
-  for (int start = 0; start < a.ns; start += NN_TILE) {
-    const int tn = min(NN_TILE, round_up(a.ns - start, NN_CH));
-    __syncthreads();
-    stage_tile_raw(tile, a.sx, a.sy, a.sz, start, a.ns, tn);
-    __syncthreads();
-    nn_scan_tile<R, true, true>(tile, tn, start, q, best, bidx);
+  if (a.use_grid) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int j = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+      if (j < a.nm) grid_nn_rings<false>(a.scene_grid, q[r], nullptr, q[r], a.max_ring, a.dist_thres * a.dist_thres, best[r], bidx[r]);
+    }
+  } else {
+    for (int start = 0; start < a.ns; start += NN_TILE) {
+      const int tn = min(NN_TILE, round_up(a.ns - start, NN_CH));
+      __syncthreads();
+      stage_tile_raw(tile, a.sx, a.sy, a.sz, start, a.ns, tn);
+      __syncthreads();
+      nn_scan_tile<R, true, true>(tile, tn, start, q, best, bidx);
+    }
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -1225,16 +1310,21 @@ __global__ __launch_bounds__(256) void k_pso_match(PsoArgs a) {
 template __global__ void k_pso_match<2>(PsoArgs);
 
 __global__ __launch_bounds__(256) void k_pso_outer(PsoArgs a) {
-  const int p = blockIdx.y;
-  const PsoParticle& pp = a.particles[p];
-  if (pp.skip) return;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_swivel; i += gridDim.x * blockDim.x) {
-    const V3 pt = m4_point(pp.Tinv, v3(a.wx[i], a.wy[i], a.wz[i]));
+  // lanes = particles (each keeps its inverse transform in registers), the block walks a tile of scene points;
+  // terms are stored point-major so that both this kernel and the sequential sum access them coalesced.
+  const int p = blockIdx.y * blockDim.x + threadIdx.x;
+  const bool live = p < a.n_particles && !a.particles[min(p, a.n_particles - 1)].skip;
+  float Ti[12];
+  for (int k = 0; k < 12; ++k) Ti[k] = live ? a.particles[p].Tinv[k] : 0.f;
+  const int per = (a.n_swivel + gridDim.x - 1) / gridDim.x;
+  const int i0 = blockIdx.x * per, i1 = min(a.n_swivel, i0 + per);
+  for (int i = i0; i < i1; ++i) {
+    const V3 pt = m4_point(Ti, v3(a.wx[i], a.wy[i], a.wz[i]));
     int bin = (int)(fmaxf(pt.z - a.fp_min_z, 0.0f) / a.fp_stride_z);  // FingerProperty::getBinAlongZ, Hand.cpp:244-250
     bin = max(bin, 0);
     bin = min(bin, a.fp_num_division - 1);
     const float lim = a.hist_min_y[bin];
-    a.outer_terms[(size_t)p * a.n_swivel + i] = (pt.y >= lim) ? -1.f : fabsf(pt.y - lim);
+    if (live) a.outer_terms[(size_t)i * a.n_particles + p] = (pt.y >= lim) ? -1.f : fabsf(pt.y - lim);
   }
 }
 
@@ -1244,9 +1334,8 @@ __global__ __launch_bounds__(64) void k_pso_outer_sum(PsoArgs a, int n_particles
   if (a.particles[p].skip) return;
   float sum = 0.f;
   int cnt = 0;
-  const float* t = a.outer_terms + (size_t)p * a.n_swivel;
   for (int i = 0; i < a.n_swivel; ++i) {
-    const float v = t[i];
+    const float v = a.outer_terms[(size_t)i * n_particles + p];
     if (v >= 0.f) {
       sum += v;
       ++cnt;
@@ -1329,6 +1418,12 @@ void launch_icp_nn_grid(const IcpArgs& a, int hb, hipStream_t s) {
 void launch_icp_nn_cells(const IcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_nn_cells<4>, dim3(icp_blocks_per_hyp(a.ns), hb), dim3(256), 0, s, a);
 }
+void launch_icp_corr_cells(const IcpArgs& a, int hb, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_corr_cells, dim3((a.ns + 255) / 256, hb), dim3(256), 0, s, a);
+}
+void launch_icp_accum(const IcpArgs& a, int hb, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_accum<4>, dim3(icp_blocks_per_hyp(a.ns), hb), dim3(256), 0, s, a);
+}
 void launch_cell_list_bounds(const CellListBuildArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_cell_list_bounds, dim3(a.dx * a.dy * a.dz), dim3(256), 0, s, a);
 }
@@ -1350,7 +1445,7 @@ void launch_icp_finish(const IcpArgs& a, int hb, int* iters, int* conv, hipStrea
 void launch_pso(const PsoArgs& a, int n_particles, hipStream_t s) {
   const int R = 2;
   hipLaunchKernelGGL(k_pso_match<2>, dim3((a.nm + 256 * R - 1) / (256 * R), n_particles), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_pso_outer, dim3(max(1, min(32, (a.n_swivel + 255) / 256)), n_particles), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_pso_outer, dim3(max(1, min(256, (a.n_swivel + 63) / 64)), (n_particles + 255) / 256), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_pso_outer_sum, dim3((n_particles + 63) / 64), dim3(64), 0, s, a, n_particles);
 }
 void launch_grid_cell_ids(const float* x, const float* y, const float* z, int n, const GridDev& gd, int* cell_of, int* cell_count,

@@ -250,10 +250,15 @@ def test_icp_and_lcp_grid_equal_brute_bitwise_large(ctx, api, synth):
         ctx.lcp_select_best(0.001, 10.0, mode)
         _, sc_, _ = ctx.hypos_download()
         res.append((it.copy(), cv.copy(), p.copy(), sc_.copy()))
-    for r in res[1:]:
-        assert np.array_equal(res[0][0], r[0]) and np.array_equal(res[0][1], r[1])
-        assert np.array_equal(res[0][2], r[2])
-        assert np.array_equal(res[0][3], r[3])
+    # mode 1 walks the scene in the caller's order like mode 0: bit-identical.  Mode 2 walks it in Morton order, so
+    # its f64 normal-equation sums associate differently: same iteration counts, poses equal to float rounding, and
+    # the computeLCP scores (summed in the caller's order in every mode) equal for equal poses.
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+    assert np.array_equal(res[0][0], res[2][0]) and np.array_equal(res[0][1], res[2][1])
+    assert np.abs(res[0][2] - res[2][2]).max() < 2e-6
+    same = np.all(res[0][2] == res[2][2], axis=(1, 2))
+    assert same.mean() > 0.5 and np.array_equal(res[0][3][same], res[2][3][same])
     assert res[0][0].max() >= 4, "some hypotheses must need several iterations"
 
 
