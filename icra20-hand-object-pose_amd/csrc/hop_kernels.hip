@@ -869,6 +869,7 @@ __global__ __launch_bounds__(256) void k_icp_nn(IcpArgs a) {
     for (int u = 0; u < 6; ++u) acc[21 + u] -= J[u] * res;
     acc[27] += (double)best[r];
     acc[28] += 1.0;
+    acc[29] += (double)q[r].x, acc[30] += (double)q[r].y, acc[31] += (double)q[r].z;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -950,6 +951,7 @@ __global__ __launch_bounds__(256) void k_icp_nn_grid(IcpArgs a) {
     for (int u = 0; u < 6; ++u) acc[21 + u] -= J[u] * res;
     acc[27] += (double)best[r];
     acc[28] += 1.0;
+    acc[29] += (double)q[r].x, acc[30] += (double)q[r].y, acc[31] += (double)q[r].z;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -1031,6 +1033,7 @@ __global__ __launch_bounds__(256) void k_icp_nn_cells(IcpArgs a) {
     for (int u = 0; u < 6; ++u) acc[21 + u] -= J[u] * res;
     acc[27] += (double)best[r];
     acc[28] += 1.0;
+    acc[29] += (double)q[r].x, acc[30] += (double)q[r].y, acc[31] += (double)q[r].z;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -1109,6 +1112,7 @@ __global__ __launch_bounds__(256) void k_icp_accum(IcpArgs a) {
     for (int u = 0; u < 6; ++u) acc[21 + u] -= J[u] * res;
     acc[27] += (double)d2;
     acc[28] += 1.0;
+    acc[29] += (double)q.x, acc[30] += (double)q.y, acc[31] += (double)q.z;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -1192,10 +1196,15 @@ __global__ __launch_bounds__(64) void k_icp_solve(IcpArgs a, int hb, int nblocks
     Rm[1][0] = ky * kx * v + kz * s, Rm[1][1] = c + ky * ky * v, Rm[1][2] = ky * kz * v - kx * s;
     Rm[2][0] = kz * kx * v - ky * s, Rm[2][1] = kz * ky * v + kx * s, Rm[2][2] = c + kz * kz * v;
   }
+  // the increment is applied as the exact rotation about the centroid of the matched source points plus the
+  // translation the linear model gives that centroid (see the oracle's run_icp for the reasoning)
+  const double c0 = acc[29] / cnt, c1 = acc[30] / cnt, c2 = acc[31] / cnt;
+  const double tc[3] = {x[3] + (x[1] * c2 - x[2] * c1), x[4] + (x[2] * c0 - x[0] * c2), x[5] + (x[0] * c1 - x[1] * c0)};
+  const double cc[3] = {c0, c1, c2};
   M4 T = m4_identity();
   for (int i = 0; i < 3; ++i) {
     for (int j = 0; j < 3; ++j) T.m[4 * i + j] = (float)Rm[i][j];
-    T.m[4 * i + 3] = (float)x[3 + i];
+    T.m[4 * i + 3] = (float)(cc[i] - (Rm[i][0] * c0 + Rm[i][1] * c1 + Rm[i][2] * c2) + tc[i]);
   }
   for (int i = 0; i < 12; ++i) st.T_inc[i] = T.m[i];
   M4 F;
@@ -1334,7 +1343,22 @@ __global__ __launch_bounds__(64) void k_pso_outer_sum(PsoArgs a, int n_particles
   if (a.particles[p].skip) return;
   float sum = 0.f;
   int cnt = 0;
-  for (int i = 0; i < a.n_swivel; ++i) {
+  // the additions stay in scene order (bit-equal to the CPU loop); the loads are issued 32 at a time so that
+  // their latency overlaps instead of serialising the loop
+  constexpr int U = 32;
+  int i = 0;
+  for (; i + U <= a.n_swivel; i += U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = a.outer_terms[(size_t)(i + u) * n_particles + p];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (v[u] >= 0.f) {
+        sum += v[u];
+        ++cnt;
+      }
+  }
+  for (; i < a.n_swivel; ++i) {
     const float v = a.outer_terms[(size_t)i * n_particles + p];
     if (v >= 0.f) {
       sum += v;

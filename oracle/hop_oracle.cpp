@@ -1139,6 +1139,7 @@ IcpResult run_icp(const Cloud& src, const Cloud& tgt, bool use_tree, int max_ite
     // correspondences
     double A[6][6] = {}, b[6] = {};
     double mse = 0;
+    double cs[3] = {0, 0, 0};  // sum of the matched source points
     int cnt = 0;
     for (size_t i = 0; i < sp.size(); ++i) {
       float d2 = FLT_MAX;
@@ -1150,6 +1151,7 @@ IcpResult run_icp(const Cloud& src, const Cloud& tgt, bool use_tree, int max_ite
       if (!(dot(sn[i], nt) >= cos_thr)) continue;
       ++cnt;
       mse += (double)d2;
+      cs[0] += (double)sp[i].x, cs[1] += (double)sp[i].y, cs[2] += (double)sp[i].z;
       // residual r = (p - q).n ; jacobian wrt (rx,ry,rz,tx,ty,tz) = [p x n, n]
       const V3 p = sp[i], q = tgt.pos[idx];
       const V3 c = cross(p, nt);
@@ -1184,10 +1186,18 @@ IcpResult run_icp(const Cloud& src, const Cloud& tgt, bool use_tree, int max_ite
       Rm[1][0] = ky * kx * v + kz * s, Rm[1][1] = c + ky * ky * v, Rm[1][2] = ky * kz * v - kx * s;
       Rm[2][0] = kz * kx * v - ky * s, Rm[2][1] = kz * ky * v + kx * s, Rm[2][2] = c + kz * kz * v;
     }
+    // (w, t) solve the linearised problem  p' = p + w x p + t.  PCL's estimator (Levenberg-Marquardt on the same
+    // residuals) returns the minimiser of the NON-linear problem; composing the increment as the exact rotation
+    // about the origin plus t is off by O(|w|^2 |p|) (centimetres for an object 0.4 m from the camera).  The
+    // increment is therefore applied as the exact rotation exp(w) about the centroid c of the matched points,
+    // with the translation the linear model assigns to c:  p' = R (p - c) + c + (t + w x c).
+    const double c0 = cs[0] / cnt, c1 = cs[1] / cnt, c2 = cs[2] / cnt;
+    const double tc[3] = {x[3] + (x[1] * c2 - x[2] * c1), x[4] + (x[2] * c0 - x[0] * c2), x[5] + (x[0] * c1 - x[1] * c0)};
+    const double cc[3] = {c0, c1, c2};
     M4 T = identity4();
     for (int i = 0; i < 3; ++i) {
       for (int j = 0; j < 3; ++j) T.m[i][j] = (float)Rm[i][j];
-      T.m[i][3] = (float)x[3 + i];
+      T.m[i][3] = (float)(cc[i] - (Rm[i][0] * c0 + Rm[i][1] * c1 + Rm[i][2] * c2) + tc[i]);
     }
     for (size_t i = 0; i < sp.size(); ++i) {
       sp[i] = pcl_transform_point(T, sp[i]);
