@@ -144,9 +144,100 @@ __attribute__((target("avx2"))) inline int fourth_point_mask_avx2(const float* X
 }
 #endif
 
+#if defined(__x86_64__)
+__attribute__((target("avx512f"))) inline int fourth_point_mask_avx512(const float* X, const float* Y, const float* Z,
+                                                                      const unsigned long long* mask, int nr, const float b[3][3],
+                                                                      float too_small, float A, float B, float C, float* /*dist_tmp*/) {
+  const __m512 vts = _mm512_set1_ps(too_small), vA = _mm512_set1_ps(A), vB = _mm512_set1_ps(B), vC = _mm512_set1_ps(C);
+  const __m512 one = _mm512_set1_ps(1.0f);
+  __m512 bx[3], by[3], bz[3];
+  for (int q = 0; q < 3; ++q) bx[q] = _mm512_set1_ps(b[q][0]), by[q] = _mm512_set1_ps(b[q][1]), bz[q] = _mm512_set1_ps(b[q][2]);
+  // every lane keeps its own running minimum and the index where it first occurred (strict '<'); the overall
+  // first minimum is the smallest index among the lanes that hold the global minimum
+  __m512 vbest = _mm512_set1_ps(FLT_MAX);
+  __m512i vidx = _mm512_set1_epi32(-1);
+  __m512i cur = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+  const __m512i step = _mm512_set1_epi32(16);
+  const int nfull = nr & ~15;
+  const unsigned short* m16 = reinterpret_cast<const unsigned short*>(mask);
+  for (int k = 0; k < nfull; k += 16, cur = _mm512_add_epi32(cur, step)) {
+    __mmask16 ok = m16[k >> 4];
+    if (!ok) continue;
+    const __m512 px = _mm512_loadu_ps(X + k), py = _mm512_loadu_ps(Y + k), pz = _mm512_loadu_ps(Z + k);
+    for (int q = 0; q < 3; ++q) {
+      const __m512 dx = _mm512_sub_ps(px, bx[q]), dy = _mm512_sub_ps(py, by[q]), dz = _mm512_sub_ps(pz, bz[q]);
+      const __m512 d2 = _mm512_add_ps(_mm512_mul_ps(dx, dx), _mm512_add_ps(_mm512_mul_ps(dy, dy), _mm512_mul_ps(dz, dz)));
+      ok = _mm512_mask_cmp_ps_mask(ok, d2, vts, _CMP_GE_OQ);
+    }
+    const __m512 s = _mm512_add_ps(_mm512_add_ps(_mm512_mul_ps(vA, px), _mm512_mul_ps(vB, py)), _mm512_mul_ps(vC, pz));
+    const __m512 dist = _mm512_abs_ps(_mm512_sub_ps(s, one));
+    const __mmask16 better = _mm512_mask_cmp_ps_mask(ok, dist, vbest, _CMP_LT_OQ);  // false for NaN, like the scalar loop
+    vbest = _mm512_mask_mov_ps(vbest, better, dist);
+    vidx = _mm512_mask_mov_epi32(vidx, better, cur);
+  }
+  float lb[16];
+  int li[16];
+  _mm512_storeu_ps(lb, vbest);
+  _mm512_storeu_si512(li, vidx);
+  float best_distance = FLT_MAX;
+  int best = -1;
+  for (int q = 0; q < 16; ++q)
+    if (li[q] >= 0 && (lb[q] < best_distance || (lb[q] == best_distance && li[q] < best))) best_distance = lb[q], best = li[q];
+  for (int r = nfull; r < nr; ++r) {  // tail (< 16 entries), scalar; strict '<' keeps the earlier index on ties
+    if (!((mask[r >> 6] >> (r & 63)) & 1ull)) continue;
+    const float px = X[r], py = Y[r], pz = Z[r];
+    bool ok = true;
+    for (int q = 0; q < 3 && ok; ++q) {
+      const float dx = px - b[q][0], dy = py - b[q][1], dz = pz - b[q][2];
+      ok = (dx * dx + (dy * dy + dz * dz)) >= too_small;
+    }
+    if (!ok) continue;
+    const float distance = std::fabs(((A * px + B * py) + C * pz) - 1.0f);
+    if (distance < best_distance) best_distance = distance, best = r;
+  }
+  return best;
+}
+
+// pool of one matrix row: ids and weights of the set bits in order, first rank and weight sum per 64-bit word.
+// `weights` must be readable up to 64*W entries.
+__attribute__((target("avx512f"))) inline int pool_build_avx512(const unsigned long long* row, int W, const float* weights, int* ids,
+                                                               float* pr, int* wstart, double* bsum) {
+  const __m512i iota = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+  int k = 0;
+  for (int w = 0; w < W; ++w) {
+    const unsigned long long bits = row[w];
+    wstart[w] = k;
+    if (!bits) {
+      bsum[w] = 0.0;
+      continue;
+    }
+    __m512d acc = _mm512_setzero_pd();
+    for (int c = 0; c < 4; ++c) {
+      const __mmask16 m = (__mmask16)(bits >> (16 * c));
+      if (!m) continue;
+      const int base = w * 64 + c * 16;
+      const __m512 p = _mm512_maskz_loadu_ps(m, weights + base);
+      // compress in registers and store whole vectors (the buffers are padded): the memory-destination form of
+      // vpcompressd is microcoded on Zen 4/5
+      _mm512_storeu_si512(ids + k, _mm512_maskz_compress_epi32(m, _mm512_add_epi32(iota, _mm512_set1_epi32(base))));
+      _mm512_storeu_ps(pr + k, _mm512_maskz_compress_ps(m, p));
+      acc = _mm512_add_pd(acc, _mm512_add_pd(_mm512_cvtps_pd(_mm512_castps512_ps256(p)), _mm512_cvtps_pd(_mm256_castpd_ps(_mm512_extractf64x4_pd(_mm512_castps_pd(p), 1)))));
+      k += __builtin_popcount((unsigned)m);
+    }
+    bsum[w] = _mm512_reduce_add_pd(acc);
+  }
+  wstart[W] = k;
+  return k;
+}
+#endif
+
 inline int fourth_point_mask(const float* X, const float* Y, const float* Z, const unsigned long long* mask, int nr, const float b[3][3],
                              float too_small, float A, float B, float C, std::vector<float>& tmp) {
 #if defined(__x86_64__)
+  if (nr >= 64 && __builtin_cpu_supports("avx512f")) {
+    tmp.resize((size_t)nr + 16);
+    return fourth_point_mask_avx512(X, Y, Z, mask, nr, b, too_small, A, B, C, tmp.data());
+  }
   if (nr >= 64 && __builtin_cpu_supports("avx2")) {
     tmp.resize((size_t)nr + 8);
     return fourth_point_mask_avx2(X, Y, Z, mask, nr, b, too_small, A, B, C, tmp.data());
@@ -278,8 +369,8 @@ struct Fenwick {
     return s;
   }
   double total() const { return prefix(n); }
-  // smallest index r (0-based) with prefix(r+1) >= target; n-1 if none
-  int find(double target) const {
+  // smallest index r (0-based) with prefix(r+1) >= target; n-1 if none.  *before = prefix(r).
+  int find(double target, double* before = nullptr) const {
     int pos = 0;
     double acc = 0.0;
     for (int step = top; step > 0; step >>= 1) {
@@ -289,7 +380,12 @@ struct Fenwick {
         acc += t[nxt];
       }
     }
-    return pos < n ? pos : n - 1;
+    if (pos >= n) {
+      pos = n - 1;
+      acc = prefix(pos);
+    }
+    if (before) *before = acc;
+    return pos;
   }
 };
 
@@ -339,7 +435,8 @@ struct GenHost {
   std::vector<double> bsum_;               // per matrix word: sum of the pool weights of that word
   std::vector<int> wstart_;                // per matrix word: rank of its first pool member
   int npool_ = 0, n4_ = 0;
-  bool have_bmi2_ = false;
+  double pool_total_ = 0.0;
+  bool have_bmi2_ = false, have_avx512_ = false;
   // profile (seconds) of the selection phases, for tools/select_bench.cpp
   double t_first = 0, t_pool = 0, t_pairdraw = 0, t_pool4 = 0, t_fourth = 0;
   long long n_tri_calls = 0, n_pair_iters = 0, n_fallbacks = 0, sum_pool = 0, n_same = 0, n_nobit = 0, n_geom = 0;
@@ -462,16 +559,17 @@ struct GenHost {
 
   // index drawn by std::discrete_distribution over the pool weights probs_[0..npool_) (pool order), answered from the
   // per-word block sums; same exactness guard as draw_index.
-  int draw_pool_index() {
-    const double u = std::generate_canonical<double, std::numeric_limits<double>::digits>(point_index_engine_);
-    const double T = fw_blk_.total();
+  int draw_pool_index(double u) {
+    const double T = pool_total_;
     const double target = u * T;
-    int w = fw_blk_.find(target);  // first word whose cumulative block sum reaches the target
-    while (w < W - 1 && wstart_[w + 1] == wstart_[w]) ++w;
-    while (w > 0 && wstart_[w + 1] == wstart_[w]) --w;
+    double lo = 0.0;
+    int w = fw_blk_.find(target, &lo);  // first word whose cumulative block sum reaches the target
+    if (wstart_[w + 1] == wstart_[w]) {  // an empty word can only be hit through rounding: resolve exactly
+      ++n_fallbacks;
+      return exact_discrete_index(probs_.data(), npool_, u);
+    }
     int r = wstart_[w];
     const int rend = wstart_[w + 1];
-    double lo = fw_blk_.prefix(w);
     for (; r < rend - 1; ++r) {
       if (lo + (double)probs_[r] >= target) break;
       lo += (double)probs_[r];
@@ -498,8 +596,10 @@ struct GenHost {
     if (!fw_all_valid_) {
       fw_all_.build(point_probs_.data(), n);
       fw_all_valid_ = true;
+      point_probs_.resize((size_t)W * 64 + 16, 0.f);  // vector loads of whole words stay in bounds (n itself is unchanged)
 #if defined(__x86_64__)
       have_bmi2_ = __builtin_cpu_supports("bmi2");
+      have_avx512_ = __builtin_cpu_supports("avx512f");
 #endif
       bsum_.assign(W, 0.0);
       wstart_.assign(W + 1, 0);
@@ -515,9 +615,15 @@ struct GenHost {
     int npool = 0;
     for (int w = 0; w < W; ++w) npool += __builtin_popcountll(row[w]);
     npool_ = npool;
-    pool_ids_.resize(npool);
-    probs_.resize(npool);
-    {
+    if (pool_ids_.size() < (size_t)n + 64) pool_ids_.resize((size_t)n + 64), probs_.resize((size_t)n + 64);
+    bool built = false;
+#if defined(__x86_64__)
+    if (have_avx512_) {
+      pool_build_avx512(row, W, point_probs_.data(), pool_ids_.data(), probs_.data(), wstart_.data(), bsum_.data());
+      built = true;
+    }
+#endif
+    if (!built) {
       int k = 0;
       int* ids = pool_ids_.data();
       float* pr = probs_.data();
@@ -540,18 +646,49 @@ struct GenHost {
       wstart_[W] = k;
     }
     fw_blk_.build_d(bsum_.data(), W);
+    pool_total_ = fw_blk_.total();
     t_pool += now() - tp, tp = now();
     sum_pool += npool;
     if (npool < 3) return false;
     const float sq_max = max_base_diameter_ * max_base_diameter_;
     const V3 p0 = ppos(first_point);
     const size_t max_it = (size_t)npool * (size_t)npool / 4;
+    // Every iteration consumes exactly two canonical variates (four engine calls), whatever its outcome, so the
+    // variates of the next iteration can be drawn one iteration early and its matrix word prefetched: the key test
+    // bit(p2,p3) is a random access into the N^2/8-byte matrix (a DRAM miss at C2 sizes).  The indices computed
+    // ahead are only reused if the current iteration did not change the weights; the engine ends exactly where the
+    // reference's would (an unused look-ahead pair is rolled back).
+    const std::mt19937 engine_before = point_index_engine_;
+    auto canon = [&]() { return std::generate_canonical<double, std::numeric_limits<double>::digits>(point_index_engine_); };
+    size_t drawn_pairs = 0;
+    double nu0 = 0, nu1 = 0;
+    int ns = -1, nt = -1;
+    bool have_next = false, next_valid = false;
+    size_t used_pairs = 0;
     for (size_t it = 0; it < max_it && it < (size_t)INT_MAX; ++it) {  // the reference's counter is an int
       ++n_pair_iters;
-      const int second = draw_pool_index();
-      const int third = draw_pool_index();
+      int second, third;
+      if (have_next) {
+        if (next_valid) second = ns, third = nt;
+        else second = draw_pool_index(nu0), third = draw_pool_index(nu1);
+      } else {
+        const double u0 = canon(), u1 = canon();
+        ++drawn_pairs;
+        second = draw_pool_index(u0), third = draw_pool_index(u1);
+      }
+      used_pairs = it + 1;
+      // look ahead (only if another iteration can follow)
+      have_next = false;
+      if (it + 1 < max_it) {
+        nu0 = canon(), nu1 = canon();
+        ++drawn_pairs;
+        ns = draw_pool_index(nu0), nt = draw_pool_index(nu1);
+        have_next = true, next_valid = true;
+        if (ns != nt) __builtin_prefetch(&M[(size_t)pool_ids_[ns] * W + (pool_ids_[nt] >> 6)], 0, 1);
+      }
       if (second == third) continue;
       if (!bit(pool_ids_[second], pool_ids_[third])) continue;
+      next_valid = false;  // the weights change below
       for (int r : {second, third}) {
         probs_[r] *= opt.dispersion;
         const int w = pool_ids_[r] >> 6;
@@ -559,6 +696,7 @@ struct GenHost {
         for (int q = wstart_[w]; q < wstart_[w + 1]; ++q) s += (double)probs_[q];
         fw_blk_.add(w, s - bsum_[w]);
         bsum_[w] = s;
+        pool_total_ = fw_blk_.total();
       }
       const V3 u = ppos(pool_ids_[second]) - p0;
       const V3 w = ppos(pool_ids_[third]) - p0;
@@ -569,6 +707,10 @@ struct GenHost {
         base3 = pool_ids_[third];
         break;
       }
+    }
+    if (drawn_pairs != used_pairs) {  // roll the engine back to "used_pairs pairs consumed"
+      point_index_engine_ = engine_before;
+      point_index_engine_.discard(4ull * used_pairs);
     }
     t_pairdraw += now() - tp, tp = now();
     if (base2 == -1 || base3 == -1) return false;
