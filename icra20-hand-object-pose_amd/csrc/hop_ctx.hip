@@ -75,12 +75,12 @@ struct GridStore {
 };
 
 struct CellListStore {
-  DevBuf start_d, pts_d, u2_d, count_d;
+  DevBuf start_d, pts_d, nrm_d, u2_d, count_d;
   hop::CellListDev c{};
   bool valid = false;
   float cell = 0, max_dist = 0;
   void release() {
-    start_d.release(), pts_d.release(), u2_d.release(), count_d.release();
+    start_d.release(), pts_d.release(), nrm_d.release(), u2_d.release(), count_d.release();
     valid = false;
   }
 };
@@ -171,7 +171,7 @@ struct hop_ctx {
   int n_hyp = 0;
 
   // scoring workspaces
-  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv, icp_corr_idx, icp_corr_d2;
+  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv, icp_corr_idx, icp_hist;
 
   // hand
   CloudDevice hand_scene_d, hand_lookup_d, hand_swivel_d, hand_model_d;
@@ -333,6 +333,9 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
   a.dy = (int)std::ceil((mx[1] - mn[1] + 2 * pad) / cell) + 1;
   a.dz = (int)std::ceil((mx[2] - mn[2] + 2 * pad) / cell) + 1;
   a.max_dist = max_dist, a.margin = 4 * GRID_MARGIN;
+  a.nx = d.plane(3), a.ny = d.plane(4), a.nz = d.plane(5);
+  // domination margin: far above the float error of a squared distance <= max_dist^2 between points of magnitude <= 4 m
+  a.dom_eps = 64.f * max_dist * (4.f * 6.0e-8f) + 1.0e-12f;
   const size_t ncell = (size_t)a.dx * a.dy * a.dz;
   if (ncell > (size_t)1 << 24) return HOP_E_CAPACITY;
   HIPCHK(c, cs.u2_d.ensure(sizeof(float) * ncell));
@@ -347,13 +350,15 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
   for (size_t k = 0; k < ncell; ++k) start[k + 1] = start[k] + cnt[k];
   const size_t total = (size_t)start[ncell];
   HIPCHK(c, cs.pts_d.ensure(sizeof(float4) * std::max<size_t>(total, 1)));
+  HIPCHK(c, cs.nrm_d.ensure(sizeof(float4) * std::max<size_t>(total, 1)));
+  a.nrm = cs.nrm_d.as<float4>();
   HIPCHK(c, hipMemcpyAsync(cs.start_d.p, start.data(), sizeof(int) * (ncell + 1), hipMemcpyHostToDevice, c->stream));
   a.start = cs.start_d.as<int>(), a.pts = cs.pts_d.as<float4>();
   launch_cell_list_fill(a, c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   cs.c.ox = a.ox, cs.c.oy = a.oy, cs.c.oz = a.oz, cs.c.cell = cell, cs.c.inv_cell = 1.0f / cell;
   cs.c.dx = a.dx, cs.c.dy = a.dy, cs.c.dz = a.dz;
-  cs.c.start = cs.start_d.as<int>(), cs.c.pts = cs.pts_d.as<float4>();
+  cs.c.start = cs.start_d.as<int>(), cs.c.pts = cs.pts_d.as<float4>(), cs.c.nrm = cs.nrm_d.as<float4>();
   cs.valid = true, cs.cell = cell, cs.max_dist = max_dist;
   if (getenv("HOP_PROFILE_SELECT")) std::printf("cell lists: %zu cells, %zu entries (%.1f per cell), cell %.4f\n", ncell, total, (double)total / (double)ncell, cell);
   return HOP_OK;
@@ -513,7 +518,7 @@ void hop_ctx_destroy(hop_ctx* c) {
                     &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
                     &c->hyp_score, &c->hyp_id, &c->hyp_key, &c->hyp_inv, &c->tmp_pose, &c->tmp_score, &c->tmp_id, &c->sort_keys_alt,
                     &c->sort_vals, &c->sort_vals_alt, &c->sort_tmp, &c->lcp_rev_idx, &c->lcp_rev_d2, &c->lcp_terms, &c->icp_moved,
-                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->icp_corr_idx, &c->icp_corr_d2, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
+                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->icp_corr_idx, &c->icp_hist, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
                     &c->hand_swivel_d.buf, &c->hand_model_d.buf, &c->finger_hist_d, &c->pso_particles_d, &c->pso_match_d,
                     &c->pso_terms_d, &c->pso_sum_d, &c->pso_cnt_d};
   for (DevBuf* b : bufs) b->release();
@@ -1037,10 +1042,12 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
   const CloudDevice& S = c->scene_d;
   const CloudDevice& Mo = c->model_d[HOP_MODEL_5MM];
   const int nb = icp_blocks_per_hyp(S.n);
-  // batch so that the moved-source workspace stays below ~1 GiB
-  const size_t per_h = sizeof(float) * 6 * (size_t)S.n;
-  const int HB = (int)std::max<size_t>(1, std::min<size_t>((size_t)H, ((size_t)1 << 30) / per_h));
-  HIPCHK(c, c->icp_moved.ensure(per_h * HB));
+  // batch so that the per-point workspace (moved source, 24 B/pt; cell-list path: correspondence, 4 B/pt) stays bounded
+  const bool cells = o->nn_mode >= 2;
+  const size_t per_h = cells ? sizeof(int) * (size_t)S.n : sizeof(float) * 6 * (size_t)S.n;
+  const size_t ws_cap = cells ? ((size_t)4 << 30) : ((size_t)1 << 30);
+  const int HB = (int)std::max<size_t>(1, std::min<size_t>((size_t)H, ws_cap / per_h));
+  if (!cells) HIPCHK(c, c->icp_moved.ensure(per_h * HB));
   HIPCHK(c, c->icp_partial.ensure(sizeof(double) * ICP_NACC * (size_t)nb * HB));
   HIPCHK(c, c->icp_state.ensure(sizeof(IcpState) * (size_t)HB));
   HIPCHK(c, c->icp_iters.ensure(sizeof(int) * (size_t)H));
@@ -1064,7 +1071,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     }
     a.model_grid = gs.g;
     a.max_ring = (int)std::ceil((o->max_corr_dist + 2 * GRID_MARGIN) / cell);
-  } else if (o->nn_mode == 2 || o->nn_mode == 3) {
+  } else if (cells) {
     float cell = o->max_corr_dist / 6.f;
     if (const char* e = getenv("HOP_ICP_CELL_DIV")) cell = o->max_corr_dist / (float)atof(e);
     CellListStore& cs = c->model_cells[HOP_MODEL_5MM];
@@ -1074,8 +1081,8 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     }
     a.cells = cs.c;
     HIPCHK(c, c->icp_corr_idx.ensure(sizeof(int) * (size_t)S.n * HB));
-    HIPCHK(c, c->icp_corr_d2.ensure(sizeof(float) * (size_t)S.n * HB));
-    a.corr_idx = c->icp_corr_idx.as<int>(), a.corr_d2 = c->icp_corr_d2.as<float>();
+    HIPCHK(c, c->icp_hist.ensure(sizeof(float) * 12 * (size_t)std::max(o->max_iter, 1) * HB));
+    a.corr_idx = c->icp_corr_idx.as<int>(), a.hist = c->icp_hist.as<float>();
     // these paths walk the scene in Morton order (the per-hypothesis sums are order-insensitive up to f64 rounding)
     const CloudDevice& Q = c->scene_sorted_d;
     a.sx = Q.plane(0), a.sy = Q.plane(1), a.sz = Q.plane(2), a.snx = Q.plane(3), a.sny = Q.plane(4), a.snz = Q.plane(5);
@@ -1088,11 +1095,10 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
       a.iter = it;
       {
         SpanGuard sg(c, T_ICP_NN);
-        if (o->nn_mode == 2) {
+        if (cells) {
           launch_icp_corr_cells(a, hb, c->stream);
           launch_icp_accum(a, hb, c->stream);
-        } else if (o->nn_mode == 3) launch_icp_nn_cells(a, hb, c->stream);
-        else if (o->nn_mode == 1) launch_icp_nn_grid(a, hb, c->stream);
+        } else if (o->nn_mode == 1) launch_icp_nn_grid(a, hb, c->stream);
         else launch_icp_nn(a, hb, c->stream);
       }
       {

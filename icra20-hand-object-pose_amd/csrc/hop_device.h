@@ -121,6 +121,7 @@ struct CellListDev {
   int dx, dy, dz;
   const int* start;   // dx*dy*dz + 1
   const float4* pts;  // concatenated lists; .w = original index (int bits)
+  const float4* nrm;  // normals of the same entries (or null)
 };
 
 struct CellListBuildArgs {
@@ -133,6 +134,9 @@ struct CellListBuildArgs {
   int* count;     // per cell
   const int* start;
   float4* pts;
+  const float *nx, *ny, *nz;  // optional normals of the cloud ...
+  float4* nrm;                // ... copied next to pts (null: none)
+  float dom_eps;              // domination margin on squared distances
 };
 
 struct EmitArgs {
@@ -194,8 +198,8 @@ struct IcpArgs {
   GridDev model_grid;  // nn_mode 1: model in its rest frame
   int max_ring;        // rings needed to cover max_corr_dist
   CellListDev cells;   // nn_mode 2: NN cell lists of the model in its rest frame
-  int* corr_idx;       // nn_mode 2: [hb][ns] nearest model index (or -1)
-  float* corr_d2;      //            [hb][ns] its squared distance
+  int* corr_idx;       // nn_mode 2: [hb][ns] list position of the accepted correspondence (or -1)
+  float* hist;         // nn_mode 2: [hb][max_iter][12] increments solved so far
 };
 
 struct PsoParticle {
@@ -248,7 +252,6 @@ int icp_blocks_per_hyp(int ns);
 void launch_icp_init(IcpState* st, int hb, hipStream_t s);
 void launch_icp_nn(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_nn_grid(const IcpArgs& a, int hb, hipStream_t s);
-void launch_icp_nn_cells(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_corr_cells(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_accum(const IcpArgs& a, int hb, hipStream_t s);
 void launch_cell_list_bounds(const CellListBuildArgs& a, hipStream_t s);

@@ -741,31 +741,27 @@ __device__ __forceinline__ float cell_list_thr2(const CellListBuildArgs& a, int 
   return t * t * 1.00001f;
 }
 
-__global__ __launch_bounds__(256) void k_cell_list_count(CellListBuildArgs a) {
-  __shared__ int red[4];
+// Pruning (second stage of the list construction).  m in list(C) is DOMINATED when some other m' of the list is
+// closer than m to every point of the (margin-expanded) box by more than `dom_eps`:
+//     max_{q in box} ( |q-m'|^2 - |q-m|^2 ) < -dom_eps ,   the left side being linear in q  (maximum at a corner).
+// A dominated point can neither be the nearest neighbour of a query in C nor tie with it (dom_eps is far above the
+// float error of the distance expression at these magnitudes), and domination is a strict partial order, so the
+// surviving (maximal) points still contain the linear scan's answer.  What is left is essentially the set of points
+// whose Voronoi cell meets the voxel: ~5 instead of ~26 at cell = spacing.
+#define CELL_LCAP 1024
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_cell_list_build(CellListBuildArgs a) {
+  __shared__ float4 lp[CELL_LCAP];
+  __shared__ unsigned char keep[CELL_LCAP];
   const int cidx = blockIdx.x;
   float lo[3], hi[3];
   cell_box(a, cidx, lo, hi);
   const float thr2 = cell_list_thr2(a, cidx);
-  int cnt = 0;
-  for (int i0 = 0; i0 < a.n; i0 += blockDim.x) {
-    const int i = i0 + threadIdx.x;
-    const bool in = i < a.n && box_mindist2(lo, hi, a.x[i], a.y[i], a.z[i]) <= thr2;
-    cnt += __popcll(__ballot(in));
-  }
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) a.count[cidx] = red[0] + red[1] + red[2] + red[3];
-}
-
-__global__ __launch_bounds__(64) void k_cell_list_fill(CellListBuildArgs a) {
-  // one wave per cell: ascending point order, ballot compaction
-  const int cidx = blockIdx.x;
-  float lo[3], hi[3];
-  cell_box(a, cidx, lo, hi);
-  const float thr2 = cell_list_thr2(a, cidx);
-  int pos = a.start[cidx];
   const int lane = threadIdx.x;
+  int L = 0;       // candidates staged in LDS (ascending point order)
+  int extra = 0;   // candidates beyond the LDS capacity: kept without the pruning test
+  int pos = WRITE ? a.start[cidx] : 0;
+  // pass 1: U-bound candidates
   for (int i0 = 0; i0 < a.n; i0 += 64) {
     const int i = i0 + lane;
     float x = 0, y = 0, z = 0;
@@ -775,19 +771,111 @@ __global__ __launch_bounds__(64) void k_cell_list_fill(CellListBuildArgs a) {
       in = box_mindist2(lo, hi, x, y, z) <= thr2;
     }
     const unsigned long long m = __ballot(in);
-    if (in) a.pts[pos + __popcll(m & ((1ull << lane) - 1ull))] = make_float4(x, y, z, __int_as_float(i));
-    pos += __popcll(m);
+    const int at = L + __popcll(m & ((1ull << lane) - 1ull));
+    if (in && at < CELL_LCAP) lp[at] = make_float4(x, y, z, __int_as_float(i));
+    L += __popcll(m);
   }
+  if (L > CELL_LCAP) extra = L - CELL_LCAP, L = CELL_LCAP;
+  __syncthreads();
+  // pass 2: domination test in double
+  const double blo[3] = {(double)lo[0] - a.margin, (double)lo[1] - a.margin, (double)lo[2] - a.margin};
+  const double bhi[3] = {(double)hi[0] + a.margin, (double)hi[1] + a.margin, (double)hi[2] + a.margin};
+  for (int u = lane; u < L; u += 64) {
+    const float4 m = lp[u];
+    const double mm = (double)m.x * m.x + (double)m.y * m.y + (double)m.z * m.z;
+    bool dominated = false;
+    for (int v = 0; v < L && !dominated; ++v) {
+      if (v == u) continue;
+      const float4 o = lp[v];
+      const double ex = (double)o.x - m.x, ey = (double)o.y - m.y, ez = (double)o.z - m.z;
+      const double oo = (double)o.x * o.x + (double)o.y * o.y + (double)o.z * o.z;
+      // f(q) = -2 q.e + |o|^2 - |m|^2 ; max over the box takes the corner minimising q.e
+      const double qe = fmin(ex * blo[0], ex * bhi[0]) + fmin(ey * blo[1], ey * bhi[1]) + fmin(ez * blo[2], ez * bhi[2]);
+      dominated = (oo - mm) - 2.0 * qe < -(double)a.dom_eps;
+    }
+    keep[u] = dominated ? 0 : 1;
+  }
+  __syncthreads();
+  // pass 3: count / write the survivors in ascending point order
+  int kept = 0;
+  for (int u0 = 0; u0 < L; u0 += 64) {
+    const int u = u0 + lane;
+    const bool k = u < L && keep[u];
+    const unsigned long long m = __ballot(k);
+    if (WRITE && k) {
+      const int at = pos + kept + __popcll(m & ((1ull << lane) - 1ull));
+      const float4 t = lp[u];
+      a.pts[at] = t;
+      if (a.nrm) {
+        const int i = __float_as_int(t.w);
+        a.nrm[at] = make_float4(a.nx[i], a.ny[i], a.nz[i], 0.f);
+      }
+    }
+    kept += __popcll(m);
+  }
+  if (extra > 0) {  // overflow (not reached at the sizes this build sees): second scan, unpruned tail
+    int seen = 0;
+    for (int i0 = 0; i0 < a.n; i0 += 64) {
+      const int i = i0 + lane;
+      float x = 0, y = 0, z = 0;
+      bool in = false;
+      if (i < a.n) {
+        x = a.x[i], y = a.y[i], z = a.z[i];
+        in = box_mindist2(lo, hi, x, y, z) <= thr2;
+      }
+      const unsigned long long m = __ballot(in);
+      const int ord = seen + __popcll(m & ((1ull << lane) - 1ull));
+      if (WRITE && in && ord >= CELL_LCAP) {
+        const int at = pos + kept + (ord - CELL_LCAP);
+        a.pts[at] = make_float4(x, y, z, __int_as_float(i));
+        if (a.nrm) a.nrm[at] = make_float4(a.nx[i], a.ny[i], a.nz[i], 0.f);
+      }
+      seen += __popcll(m);
+    }
+    kept += extra;
+  }
+  if (!WRITE && lane == 0) a.count[cidx] = kept;
 }
+template __global__ void k_cell_list_build<false>(CellListBuildArgs);
+template __global__ void k_cell_list_build<true>(CellListBuildArgs);
 
-__device__ __forceinline__ void cells_nn(const CellListDev& c, V3 qg, const float* T, V3 q, float& best, int& bj) {
+// Scan of one cell list.  The candidates are ranked by their squared distance to the query IN THE CLOUD'S REST FRAME
+// (qg, 8 flops each); the reference's distance expression -- query against the candidate moved by T, in the query's
+// frame -- is evaluated only for the winner.  The two differ by float rounding of the two transforms (bounded by
+// `tol` below: 2*d*delta + relative 1e-4, delta = a few ulps of the coordinate magnitude), so whenever the runner-up
+// is within tol of the winner the lane falls back to the literal scan (exact expression, (d^2, index) order).
+// Result: list position of the nearest neighbour (or -1) and the exact squared distance.
+__device__ __forceinline__ void cells_nn(const CellListDev& c, V3 qg, const float* T, V3 q, float& best, int& bpos) {
   const float fx = (qg.x - c.ox) * c.inv_cell, fy = (qg.y - c.oy) * c.inv_cell, fz = (qg.z - c.oz) * c.inv_cell;
   if (!(fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)c.dx && fy < (float)c.dy && fz < (float)c.dz)) return;
   const int cidx = ((int)fz * c.dy + (int)fy) * c.dx + (int)fx;
   const int beg = c.start[cidx], end = c.start[cidx + 1];
+  if (beg >= end) return;
+  float b1 = 3.0e38f, b2 = 3.0e38f;
+  int k1 = beg;
   for (int k = beg; k < end; ++k) {
     const float4 t = c.pts[k];
-    nn_update(sqdist_flann(q, m4_point(T, v3(t.x, t.y, t.z))), __float_as_int(t.w), best, bj);
+    const float dx = qg.x - t.x, dy = qg.y - t.y, dz = qg.z - t.z;
+    const float d = dx * dx + dy * dy + dz * dz;
+    b2 = fminf(b2, fmaxf(b1, d));
+    k1 = d < b1 ? k : k1;
+    b1 = fminf(b1, d);
+  }
+  const float mag = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), 0.25f));
+  const float delta = mag * 2.0e-6f;
+  const float tol = 2.f * sqrtf(b1) * delta + 1.0e-4f * b1 + delta * delta;
+  if (b2 - b1 > tol) {
+    const float4 t = c.pts[k1];
+    best = sqdist_flann(q, m4_point(T, v3(t.x, t.y, t.z)));
+    bpos = k1;
+    return;
+  }
+  int bj = 0x7fffffff;
+  for (int k = beg; k < end; ++k) {
+    const float4 t = c.pts[k];
+    const float d2 = sqdist_flann(q, m4_point(T, v3(t.x, t.y, t.z)));
+    const int j = __float_as_int(t.w);
+    if (d2 < best || (d2 == best && j < bj)) best = d2, bj = j, bpos = k;
   }
 }
 
@@ -967,117 +1055,36 @@ __global__ __launch_bounds__(256) void k_icp_nn_grid(IcpArgs a) {
 }
 template __global__ void k_icp_nn_grid<4>(IcpArgs);
 
-template <int R>
-__global__ __launch_bounds__(256) void k_icp_nn_cells(IcpArgs a) {
-  __shared__ float sT[12], sTi[12];
-  __shared__ double red[4][ICP_NACC];
-  const int hl = blockIdx.y, h = a.h0 + hl;
-  IcpState& st = a.state[hl];
-  if (!st.active) return;
-  const float* pose = a.pose + (size_t)h * 16;
-  float Tinc[12];
-  for (int k = 0; k < 12; ++k) Tinc[k] = st.T_inc[k];
-  V3 q[R], qn[R];
-  float best[R];
-  int bidx[R];
-  const bool first = a.iter == 0;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
-    best[r] = 3.0e38f;
-    bidx[r] = -1;
-    if (i < a.ns) {
-      V3 p, n;
-      if (first) {
-        p = v3(a.sx[i], a.sy[i], a.sz[i]);
-        n = v3(a.snx[i], a.sny[i], a.snz[i]);
-      } else {
-        const size_t o = (size_t)hl * a.ns * 6 + i;
-        p = v3(a.moved[o], a.moved[o + a.ns], a.moved[o + 2 * (size_t)a.ns]);
-        n = v3(a.moved[o + 3 * (size_t)a.ns], a.moved[o + 4 * (size_t)a.ns], a.moved[o + 5 * (size_t)a.ns]);
-        p = m4_point(Tinc, p);
-        n = m4_dir(Tinc, n);
-      }
-      const size_t o = (size_t)hl * a.ns * 6 + i;
-      a.moved[o] = p.x, a.moved[o + a.ns] = p.y, a.moved[o + 2 * (size_t)a.ns] = p.z;
-      a.moved[o + 3 * (size_t)a.ns] = n.x, a.moved[o + 4 * (size_t)a.ns] = n.y, a.moved[o + 5 * (size_t)a.ns] = n.z;
-      q[r] = p, qn[r] = n;
-    } else {
-      q[r] = v3(-HOP_FAR, -HOP_FAR, -HOP_FAR);
-      qn[r] = v3(0, 0, 0);
-    }
-  }
-  block_pose_and_inverse(pose, sT, sTi);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
-    if (i < a.ns) cells_nn(a.cells, m4_point(sTi, q[r]), sT, q[r], best[r], bidx[r]);
-  }
-  double acc[ICP_NACC];
-#pragma unroll
-  for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
-    if (i >= a.ns || bidx[r] < 0 || !(best[r] <= a.max_d2)) continue;
-    const int j = bidx[r];
-    const V3 nt = m4_dir(pose, v3(a.mnx[j], a.mny[j], a.mnz[j]));
-    if (!(vdot(qn[r], nt) >= a.cos_thr)) continue;
-    const V3 tq = m4_point(pose, v3(a.mx[j], a.my[j], a.mz[j]));
-    const V3 c = vcross(q[r], nt);
-    const double J[6] = {c.x, c.y, c.z, nt.x, nt.y, nt.z};
-    const double res = (double)vdot(q[r] - tq, nt);
-    int k = 0;
-    for (int u = 0; u < 6; ++u)
-      for (int v = 0; v <= u; ++v) acc[k++] += J[u] * J[v];
-    for (int u = 0; u < 6; ++u) acc[21 + u] -= J[u] * res;
-    acc[27] += (double)best[r];
-    acc[28] += 1.0;
-    acc[29] += (double)q[r].x, acc[30] += (double)q[r].y, acc[31] += (double)q[r].z;
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < ICP_NACC; ++k) {
-    const double s = wave_sum(acc[k]);
-    if (lane == 0) red[wave][k] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < ICP_NACC) {
-    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NACC + threadIdx.x] = s;
+// nn_mode 2: the correspondence search (few registers, high occupancy, gather bound) and the normal-equation
+// accumulation (32 f64 accumulators per lane) are separate launches.  Neither keeps a moved copy of the source:
+// a point's position at iteration k is the chain T_k(...T_1(p0)) of the increments solved so far, re-applied from the
+// per-hypothesis history (same float operations in the same order as moving the stored cloud once per iteration,
+// 33 flops per step instead of 48 B of HBM traffic).  The only per-point state between the two launches is the list
+// position of the correspondence (4 B).
+__device__ __forceinline__ void icp_chain_point(const float* __restrict__ hist, int iter, V3& p) {
+  for (int k = 0; k < iter; ++k) p = m4_point(hist + 12 * k, p);
+}
+__device__ __forceinline__ void icp_chain_point_normal(const float* __restrict__ hist, int iter, V3& p, V3& n) {
+  for (int k = 0; k < iter; ++k) {
+    p = m4_point(hist + 12 * k, p);
+    n = m4_dir(hist + 12 * k, n);
   }
 }
-template __global__ void k_icp_nn_cells<4>(IcpArgs);
 
-
-
-// nn_mode 2, split form: the correspondence search (few registers, high occupancy, gather bound) and the
-// normal-equation accumulation (29 f64 accumulators per lane, streaming) are separate launches.
 __global__ __launch_bounds__(256) void k_icp_corr_cells(IcpArgs a) {
-  __shared__ float sT[12], sTi[12], sInc[12];
+  __shared__ float sT[12], sTi[12];
   const int hl = blockIdx.y, h = a.h0 + hl;
   const IcpState& st = a.state[hl];
   if (!st.active) return;
-  if (threadIdx.x < 12) sInc[threadIdx.x] = st.T_inc[threadIdx.x];
   block_pose_and_inverse(a.pose + (size_t)h * 16, sT, sTi);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.ns) return;
-  const size_t o = (size_t)hl * a.ns * 6 + i;
-  V3 p, n;
-  if (a.iter == 0) {
-    p = v3(a.sx[i], a.sy[i], a.sz[i]);
-    n = v3(a.snx[i], a.sny[i], a.snz[i]);
-  } else {
-    p = m4_point(sInc, v3(a.moved[o], a.moved[o + a.ns], a.moved[o + 2 * (size_t)a.ns]));
-    n = m4_dir(sInc, v3(a.moved[o + 3 * (size_t)a.ns], a.moved[o + 4 * (size_t)a.ns], a.moved[o + 5 * (size_t)a.ns]));
-  }
-  a.moved[o] = p.x, a.moved[o + a.ns] = p.y, a.moved[o + 2 * (size_t)a.ns] = p.z;
-  a.moved[o + 3 * (size_t)a.ns] = n.x, a.moved[o + 4 * (size_t)a.ns] = n.y, a.moved[o + 5 * (size_t)a.ns] = n.z;
+  V3 p = v3(a.sx[i], a.sy[i], a.sz[i]);
+  icp_chain_point(a.hist + (size_t)hl * a.max_iter * 12, a.iter, p);
   float best = 3.0e38f;
-  int bj = -1;
-  cells_nn(a.cells, m4_point(sTi, p), sT, p, best, bj);
-  a.corr_idx[(size_t)hl * a.ns + i] = bj;
-  a.corr_d2[(size_t)hl * a.ns + i] = best;
+  int pos = -1;
+  cells_nn(a.cells, m4_point(sTi, p), sT, p, best, pos);
+  a.corr_idx[(size_t)hl * a.ns + i] = (pos >= 0 && best <= a.max_d2) ? pos : -1;
 }
 
 template <int R>
@@ -1087,6 +1094,7 @@ __global__ __launch_bounds__(256) void k_icp_accum(IcpArgs a) {
   const IcpState& st = a.state[hl];
   if (!st.active) return;
   const float* pose = a.pose + (size_t)h * 16;
+  const float* hist = a.hist + (size_t)hl * a.max_iter * 12;
   double acc[ICP_NACC];
 #pragma unroll
   for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
@@ -1094,15 +1102,15 @@ __global__ __launch_bounds__(256) void k_icp_accum(IcpArgs a) {
   for (int r = 0; r < R; ++r) {
     const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
     if (i >= a.ns) continue;
-    const int j = a.corr_idx[(size_t)hl * a.ns + i];
-    const float d2 = a.corr_d2[(size_t)hl * a.ns + i];
-    if (j < 0 || !(d2 <= a.max_d2)) continue;
-    const size_t o = (size_t)hl * a.ns * 6 + i;
-    const V3 q = v3(a.moved[o], a.moved[o + a.ns], a.moved[o + 2 * (size_t)a.ns]);
-    const V3 qn = v3(a.moved[o + 3 * (size_t)a.ns], a.moved[o + 4 * (size_t)a.ns], a.moved[o + 5 * (size_t)a.ns]);
-    const V3 nt = m4_dir(pose, v3(a.mnx[j], a.mny[j], a.mnz[j]));
+    const int pos = a.corr_idx[(size_t)hl * a.ns + i];
+    if (pos < 0) continue;
+    V3 q = v3(a.sx[i], a.sy[i], a.sz[i]), qn = v3(a.snx[i], a.sny[i], a.snz[i]);
+    icp_chain_point_normal(hist, a.iter, q, qn);
+    const float4 tp = a.cells.pts[pos], tn = a.cells.nrm[pos];
+    const V3 nt = m4_dir(pose, v3(tn.x, tn.y, tn.z));
     if (!(vdot(qn, nt) >= a.cos_thr)) continue;
-    const V3 tq = m4_point(pose, v3(a.mx[j], a.my[j], a.mz[j]));
+    const V3 tq = m4_point(pose, v3(tp.x, tp.y, tp.z));
+    const float d2 = sqdist_flann(q, tq);
     const V3 c = vcross(q, nt);
     const double J[6] = {c.x, c.y, c.z, nt.x, nt.y, nt.z};
     const double res = (double)vdot(q - tq, nt);
@@ -1207,6 +1215,8 @@ __global__ __launch_bounds__(64) void k_icp_solve(IcpArgs a, int hb, int nblocks
     T.m[4 * i + 3] = (float)(cc[i] - (Rm[i][0] * c0 + Rm[i][1] * c1 + Rm[i][2] * c2) + tc[i]);
   }
   for (int i = 0; i < 12; ++i) st.T_inc[i] = T.m[i];
+  if (a.hist)
+    for (int i = 0; i < 12; ++i) a.hist[((size_t)hl * a.max_iter + st.iterations) * 12 + i] = T.m[i];
   M4 F;
   for (int i = 0; i < 16; ++i) F.m[i] = st.final_tf[i];
   F = m4_mul(T, F);
@@ -1439,9 +1449,6 @@ void launch_icp_nn(const IcpArgs& a, int hb, hipStream_t s) {
 void launch_icp_nn_grid(const IcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_nn_grid<4>, dim3(icp_blocks_per_hyp(a.ns), hb), dim3(256), 0, s, a);
 }
-void launch_icp_nn_cells(const IcpArgs& a, int hb, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_nn_cells<4>, dim3(icp_blocks_per_hyp(a.ns), hb), dim3(256), 0, s, a);
-}
 void launch_icp_corr_cells(const IcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_corr_cells, dim3((a.ns + 255) / 256, hb), dim3(256), 0, s, a);
 }
@@ -1452,10 +1459,10 @@ void launch_cell_list_bounds(const CellListBuildArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_cell_list_bounds, dim3(a.dx * a.dy * a.dz), dim3(256), 0, s, a);
 }
 void launch_cell_list_count(const CellListBuildArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_cell_list_count, dim3(a.dx * a.dy * a.dz), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_cell_list_build<false>, dim3(a.dx * a.dy * a.dz), dim3(64), 0, s, a);
 }
 void launch_cell_list_fill(const CellListBuildArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_cell_list_fill, dim3(a.dx * a.dy * a.dz), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_cell_list_build<true>, dim3(a.dx * a.dy * a.dz), dim3(64), 0, s, a);
 }
 void launch_lcp_grid(const LcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_lcp_grid, dim3((a.ns + 255) / 256, hb), dim3(256), 0, s, a);
