@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--hyps", type=int, default=10240)
     ap.add_argument("--particles", type=int, default=200)
     ap.add_argument("--hand-scene", type=int, default=20000)
-    ap.add_argument("--verify-mode", type=int, default=1, help="0 brute-force LDS scan, 1 voxel grid (identical counts)")
+    ap.add_argument("--verify-mode", type=int, default=2, help="0 brute-force LDS scan, 1 voxel grid, 2 EXIST-mode cell lists (identical counts)")
     ap.add_argument("--nn-mode", type=int, default=2, help="ICP / computeLCP nearest neighbour: 0 brute force, 1 voxel grid, 2 NN cell lists for ICP (identical results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)

@@ -15,6 +15,7 @@
 #include "hop_select.h"
 
 #include <hipcub/hipcub.hpp>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <array>
@@ -149,7 +150,11 @@ struct hop_ctx {
   DevBuf gq_unit_d;          // 3 planes
   DevBuf ppf_matrix_d;
   PinnedBuf ppf_matrix_h;
-  std::vector<unsigned long long> ppf_matrix_cached;
+  // pageable copy of the membership matrix for the host selection (2 MiB aligned, transparent huge pages requested:
+  // the selection makes one random access into it per iteration)
+  unsigned long long* ppf_matrix_cached = nullptr;
+  size_t ppf_matrix_cached_bytes = 0;
+  bool ppf_matrix_registered = false;
   int ppf_words = 0;
   std::vector<BaseTraceHost> trace;
   bool have_gen_state = false;
@@ -160,7 +165,7 @@ struct hop_ctx {
   // voxel grids: centred P for verify_mode 1; model rest frames and scene for nn_mode 1
   GridStore verify_grid, model_grid[2], scene_grid, hand_grid;
   std::vector<float> hand_scene_h[3];
-  CellListStore model_cells[2];
+  CellListStore model_cells[2], scene_cells, verify_cells;
   float grid_delta = 0;
 
   // batch workspaces of the generator
@@ -364,6 +369,64 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
   return HOP_OK;
 }
 
+// NN cell lists of a per-frame cloud from its ring grid (cell >= max_dist + margin): two passes of one kernel around a
+// device-side exclusive scan; nothing but the total entry count crosses PCIe.
+int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, const CloudDevice* normals, float max_dist, int sub,
+                           int exist_mode) {
+  const GridDev& g = gs.g;
+  CellListBuildArgs a{};
+  a.margin = 4 * GRID_MARGIN;
+  if (!(g.cell >= max_dist + a.margin) || sub < 1) return HOP_E_STATE;
+  a.cell = g.cell / (float)sub;
+  a.ox = g.ox - g.cell, a.oy = g.oy - g.cell, a.oz = g.oz - g.cell;
+  a.dx = (g.dx + 2) * sub, a.dy = (g.dy + 2) * sub, a.dz = (g.dz + 2) * sub;
+  a.max_dist = max_dist;
+  if (normals) a.n = normals->n, a.nx = normals->plane(3), a.ny = normals->plane(4), a.nz = normals->plane(5);
+  a.dom_eps = 64.f * max_dist * (4.f * 6.0e-8f) + 1.0e-12f;
+  const size_t ncell = (size_t)a.dx * a.dy * a.dz;
+  if (ncell > (size_t)1 << 28) return HOP_E_CAPACITY;
+  HIPCHK(c, cs.count_d.ensure(sizeof(int) * (ncell + 1)));
+  HIPCHK(c, cs.start_d.ensure(sizeof(int) * (ncell + 1)));
+  a.count = cs.count_d.as<int>();
+  HIPCHK(c, hipMemsetAsync(a.count + ncell, 0, sizeof(int), c->stream));
+  launch_cell_list_local(a, g, false, exist_mode, c->stream);
+  size_t tmp_bytes = 0;
+  HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, a.count, cs.start_d.as<int>(), (int)(ncell + 1), c->stream));
+  HIPCHK(c, c->sort_tmp.ensure(tmp_bytes + 16));
+  HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->sort_tmp.p, tmp_bytes, a.count, cs.start_d.as<int>(), (int)(ncell + 1), c->stream));
+  int total = 0;
+  HIPCHK(c, hipMemcpyAsync(&total, cs.start_d.as<int>() + ncell, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, cs.pts_d.ensure(sizeof(float4) * (size_t)std::max(total, 1)));
+  if (normals) HIPCHK(c, cs.nrm_d.ensure(sizeof(float4) * (size_t)std::max(total, 1)));
+  a.start = cs.start_d.as<int>(), a.pts = cs.pts_d.as<float4>(), a.nrm = normals ? cs.nrm_d.as<float4>() : nullptr;
+  launch_cell_list_local(a, g, true, exist_mode, c->stream);
+  cs.c.ox = a.ox, cs.c.oy = a.oy, cs.c.oz = a.oz, cs.c.cell = a.cell, cs.c.inv_cell = 1.0f / a.cell;
+  cs.c.dx = a.dx, cs.c.dy = a.dy, cs.c.dz = a.dz;
+  cs.c.start = cs.start_d.as<int>(), cs.c.pts = cs.pts_d.as<float4>(), cs.c.nrm = normals ? cs.nrm_d.as<float4>() : nullptr;
+  cs.valid = true, cs.cell = a.cell, cs.max_dist = max_dist;
+  if (getenv("HOP_PROFILE_SELECT")) std::printf("local cell lists: %zu cells, %d entries, cell %.5f\n", ncell, total, a.cell);
+  return HOP_OK;
+}
+
+// Verify acceleration structures over P for `delta`: mode 1 the ring grid, mode 2 the EXIST-mode cell lists on top of it
+int ensure_verify_structures(hop_ctx* c, int mode, float delta, const float* x, const float* y, const float* z, int n) {
+  if (mode < 1) return HOP_OK;
+  if (!c->verify_grid.valid || c->grid_delta != delta) {
+    const int rc = build_grid(c, c->verify_grid, x, y, z, n, delta + 8 * GRID_MARGIN);
+    if (rc) return rc;
+    c->grid_delta = delta;
+    c->verify_cells.valid = false;
+  }
+  if (mode >= 2 && (!c->verify_cells.valid || c->verify_cells.max_dist != delta)) {
+    int sub = 3;
+    if (const char* e = getenv("HOP_VERIFY_SUB")) sub = std::max(1, std::min(8, atoi(e)));
+    const int rc = build_cell_lists_local(c, c->verify_cells, c->verify_grid, nullptr, delta, sub, 1);
+    if (rc) return rc;
+  }
+  return HOP_OK;
+}
+
 // sort the resident set by 64-bit keys (ascending) and gather pose/score; ids become 0..n-1
 int sort_resident_by_keys(hop_ctx* c, unsigned long long* keys_d, int n) {
   if (n <= 0) return HOP_OK;
@@ -513,6 +576,8 @@ void hop_ctx_destroy(hop_ctx* c) {
     (void)hipEventDestroy(s.b);
   }
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
+  if (c->ppf_matrix_registered) (void)hipHostUnregister(c->ppf_matrix_cached);
+  std::free(c->ppf_matrix_cached);
   DevBuf* bufs[] = {&c->scene_d.buf, &c->scene_sorted_d.buf, &c->scene_perm_d, &c->model_d[0].buf, &c->model_d[1].buf, &c->key_bitmap_d, &c->gp_d.buf, &c->gq_d.buf, &c->gq_unit_d,
                     &c->ppf_matrix_d, &c->vp_d.buf, &c->vq_d.buf, &c->bases_d, &c->pairs1_d,
                     &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
@@ -523,7 +588,7 @@ void hop_ctx_destroy(hop_ctx* c) {
                     &c->pso_terms_d, &c->pso_sum_d, &c->pso_cnt_d};
   for (DevBuf* b : bufs) b->release();
   c->verify_grid.release(), c->model_grid[0].release(), c->model_grid[1].release(), c->scene_grid.release(), c->hand_grid.release();
-  c->model_cells[0].release(), c->model_cells[1].release();
+  c->model_cells[0].release(), c->model_cells[1].release(), c->scene_cells.release(), c->verify_cells.release();
   c->ppf_matrix_h.release(), c->bases_h.release(), c->cnt_h.release(), c->pso_particles_h.release(), c->pso_out_h.release();
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -567,6 +632,7 @@ int hop_set_scene(hop_ctx* c, const float* xyz, const float* nrm, const float* c
   c->have_gen_state = false;
   c->verify_grid.valid = false;
   c->scene_grid.valid = false;
+  c->scene_cells.valid = false;
   {
     // Morton order of 2 mm voxels for the grid-based scoring kernels
     const int m = raw.n;
@@ -685,7 +751,29 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
   c->ppf_words = W;
   const size_t mbytes = sizeof(unsigned long long) * (size_t)N * W;
   HIPCHK(c, c->ppf_matrix_d.ensure(mbytes));
-  HIPCHK(c, c->ppf_matrix_h.ensure(mbytes));
+  // The selection reads matrix rows millions of times, at random: the host copy lives in ordinary (CPU-cached) memory,
+  // 2 MiB aligned with transparent huge pages requested, registered with the HIP runtime so that the device-to-host DMA
+  // lands in it directly (hipHostMalloc memory is mapped uncached on the CPU side and reads from it are several times
+  // slower).  If registration is refused, a pinned staging buffer plus one memcpy is used instead.
+  if (c->ppf_matrix_cached_bytes < mbytes) {
+    if (c->ppf_matrix_registered) (void)hipHostUnregister(c->ppf_matrix_cached);
+    c->ppf_matrix_registered = false;
+    std::free(c->ppf_matrix_cached);
+    const size_t cap = (mbytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    c->ppf_matrix_cached = static_cast<unsigned long long*>(std::aligned_alloc((size_t)2 << 20, cap));
+    if (!c->ppf_matrix_cached) {
+      c->ppf_matrix_cached_bytes = 0;
+      return HOP_E_ALLOC;
+    }
+    madvise(c->ppf_matrix_cached, cap, MADV_HUGEPAGE);
+    std::memset(c->ppf_matrix_cached, 0, cap);  // touch: the pages exist (as huge pages where granted) before pinning
+    c->ppf_matrix_cached_bytes = cap;
+    if (!getenv("HOP_NO_HOST_REGISTER") && hipHostRegister(c->ppf_matrix_cached, cap, hipHostRegisterDefault) == hipSuccess)
+      c->ppf_matrix_registered = true;
+    else
+      (void)hipGetLastError();
+  }
+  if (!c->ppf_matrix_registered) HIPCHK(c, c->ppf_matrix_h.ensure(mbytes));
   {
     PpfMatrixArgs a{};
     a.x = c->gp_d.plane(0), a.y = c->gp_d.plane(1), a.z = c->gp_d.plane(2);
@@ -696,20 +784,17 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
       SpanGuard sg(c, T_PPF);
       launch_ppf_matrix(a, c->stream);
     }
-    HIPCHK(c, hipMemcpyAsync(c->ppf_matrix_h.p, c->ppf_matrix_d.p, mbytes, hipMemcpyDeviceToHost, c->stream));
+    void* dst = c->ppf_matrix_registered ? (void*)c->ppf_matrix_cached : c->ppf_matrix_h.p;
+    HIPCHK(c, hipMemcpyAsync(dst, c->ppf_matrix_d.p, mbytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->ppf_matrix_registered) std::memcpy(c->ppf_matrix_cached, c->ppf_matrix_h.p, mbytes);
   }
-  // The selection reads matrix rows millions of times: work on a pageable (normally cached) copy; the pinned
-  // staging buffer is only the DMA target.
-  c->ppf_matrix_cached.resize((size_t)N * W);
-  std::memcpy(c->ppf_matrix_cached.data(), c->ppf_matrix_h.p, mbytes);
-  G.M = c->ppf_matrix_cached.data();
+  G.M = c->ppf_matrix_cached;
   G.W = W;
 
-  if (opts->verify_mode == 1) {
-    const int rc = build_grid(c, c->verify_grid, c->gen.gp_h.x.data(), c->gen.gp_h.y.data(), c->gen.gp_h.z.data(), N, opts->delta * 1.001f + 1e-9f);
+  {
+    const int rc = ensure_verify_structures(c, opts->verify_mode, opts->delta, c->gen.gp_h.x.data(), c->gen.gp_h.y.data(), c->gen.gp_h.z.data(), N);
     if (rc) return rc;
-    c->grid_delta = opts->delta;
   }
 
   // ---- batch workspaces
@@ -799,7 +884,8 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
     va.sq_eps = opts->delta * opts->delta, va.counts = c->cand_counts_d.as<int>();
     {
       SpanGuard sg(c, T_VERIFY);
-      launch_verify(va, opts->verify_mode, c->verify_grid.valid ? &c->verify_grid.g : nullptr, 2048, c->stream);
+      if (opts->verify_mode >= 2) launch_verify_cells(va, c->verify_cells.c, 2048, c->stream);
+      else launch_verify(va, opts->verify_mode, c->verify_grid.valid ? &c->verify_grid.g : nullptr, 2048, c->stream);
     }
     c->timing.n_verify_launches += 1;
     {
@@ -955,13 +1041,10 @@ int hop_verify_batch(hop_ctx* c, const float* T16, int H, float delta, int mode,
   HIPCHK(c, hipSetDevice(c->device));
   const CloudDevice& P = c->have_verify_clouds ? c->vp_d : c->gp_d;
   const CloudDevice& Q = c->have_verify_clouds ? c->vq_d : c->gq_d;
-  if (mode == 1 && (!c->verify_grid.valid || c->grid_delta != delta)) {
-    int rc;
-    const float cell = delta * 1.001f + 1e-9f;
-    if (c->have_verify_clouds) rc = build_grid(c, c->verify_grid, c->vp_h[0].data(), c->vp_h[1].data(), c->vp_h[2].data(), P.n, cell);
-    else rc = build_grid(c, c->verify_grid, c->gen.gp_h.x.data(), c->gen.gp_h.y.data(), c->gen.gp_h.z.data(), P.n, cell);
+  {
+    const int rc = c->have_verify_clouds ? ensure_verify_structures(c, mode, delta, c->vp_h[0].data(), c->vp_h[1].data(), c->vp_h[2].data(), P.n)
+                                         : ensure_verify_structures(c, mode, delta, c->gen.gp_h.x.data(), c->gen.gp_h.y.data(), c->gen.gp_h.z.data(), P.n);
     if (rc) return rc;
-    c->grid_delta = delta;
   }
   HIPCHK(c, c->tmp_pose.ensure(sizeof(float) * 16 * (size_t)H));
   HIPCHK(c, c->cand_counts_d.ensure(sizeof(int) * (size_t)H));
@@ -976,7 +1059,8 @@ int hop_verify_batch(hop_ctx* c, const float* T16, int H, float delta, int mode,
   const int blocks = (int)std::min<long long>(4096, (total + 1023) / 1024);
   {
     SpanGuard sg(c, T_VERIFY);
-    launch_verify(va, mode, (mode == 1 && c->verify_grid.valid) ? &c->verify_grid.g : nullptr, std::max(blocks, 1), c->stream);
+    if (mode >= 2) launch_verify_cells(va, c->verify_cells.c, std::max(blocks, 1), c->stream);
+    else launch_verify(va, mode, (mode == 1 && c->verify_grid.valid) ? &c->verify_grid.g : nullptr, std::max(blocks, 1), c->stream);
   }
   c->timing.n_verify_launches += 1;
   c->timing.pairs_verify += total * (long long)P.n;
@@ -1041,7 +1125,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
   if (H == 0) return HOP_OK;
   const CloudDevice& S = c->scene_d;
   const CloudDevice& Mo = c->model_d[HOP_MODEL_5MM];
-  const int nb = icp_blocks_per_hyp(S.n);
+  const int nb = icp_blocks_per_hyp(S.n, o->nn_mode >= 2);
   // batch so that the per-point workspace (moved source, 24 B/pt; cell-list path: correspondence, 4 B/pt) stays bounded
   const bool cells = o->nn_mode >= 2;
   const size_t per_h = cells ? sizeof(int) * (size_t)S.n : sizeof(float) * 6 * (size_t)S.n;
@@ -1103,7 +1187,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
       }
       {
         SpanGuard sg(c, T_ICP_SOLVE);
-        launch_icp_solve(a, hb, c->stream);
+        launch_icp_solve(a, hb, nb, c->stream);
       }
       c->timing.n_icp_nn_launches += 1;
     }
@@ -1125,9 +1209,13 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
   const CloudDevice& S = c->scene_d;
   const CloudDevice& Mo = c->model_d[HOP_MODEL_1MM];
   const size_t per_h = sizeof(float) * 2 * (size_t)S.n + sizeof(float) * 2 * (size_t)Mo.n;
-  const int HB = (int)std::max<size_t>(1, std::min<size_t>((size_t)H, ((size_t)1 << 30) / per_h));
-  HIPCHK(c, c->lcp_rev_idx.ensure(sizeof(int) * (size_t)Mo.n * HB));
-  HIPCHK(c, c->lcp_rev_d2.ensure(sizeof(float) * (size_t)Mo.n * HB));
+  const bool lcp_grid = o->nn_mode >= 1, lcp_cells = o->nn_mode >= 2;
+  const size_t ws_cap = lcp_grid ? ((size_t)4 << 30) : ((size_t)1 << 30);
+  const int HB = (int)std::max<size_t>(1, std::min<size_t>((size_t)H, ws_cap / per_h));
+  if (!lcp_grid) {
+    HIPCHK(c, c->lcp_rev_idx.ensure(sizeof(int) * (size_t)Mo.n * HB));
+    HIPCHK(c, c->lcp_rev_d2.ensure(sizeof(float) * (size_t)Mo.n * HB));
+  }
   HIPCHK(c, c->lcp_terms.ensure(sizeof(float) * 2 * (size_t)S.n * HB + 64));
   LcpArgs a{};
   a.sx = S.plane(0), a.sy = S.plane(1), a.sz = S.plane(2), a.snx = S.plane(3), a.sny = S.plane(4), a.snz = S.plane(5), a.ns = S.n;
@@ -1137,11 +1225,17 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
   a.cos_thres = (float)std::cos((double)(o->angle_deg / 180.0f) * M_PI);
   a.rev_idx = c->lcp_rev_idx.as<int>(), a.rev_d2 = c->lcp_rev_d2.as<float>(), a.terms = c->lcp_terms.as<float>();
   a.score = c->hyp_score.as<float>();
-  const bool lcp_grid = o->nn_mode >= 1;
   if (lcp_grid) {
-    const float cell = o->dist + GRID_MARGIN * 2;
+    const float cell = o->dist + GRID_MARGIN * 8;
     GridStore& gm = c->model_grid[HOP_MODEL_1MM];
-    if (!gm.valid || gm.cell != cell) {
+    if (lcp_cells) {
+      CellListStore& cs = c->model_cells[HOP_MODEL_1MM];
+      if (!cs.valid || cs.cell != o->dist || cs.max_dist != o->dist) {
+        const int rc = build_cell_lists(c, cs, c->gen.model_h[HOP_MODEL_1MM], c->model_d[HOP_MODEL_1MM], o->dist, o->dist);
+        if (rc) return rc;
+      }
+      a.model_cells = cs.c;
+    } else if (!gm.valid || gm.cell != cell) {
       const CloudHost& mh = c->gen.model_h[HOP_MODEL_1MM];
       const int rc = build_grid(c, gm, mh.x.data(), mh.y.data(), mh.z.data(), mh.n, cell);
       if (rc) return rc;
@@ -1153,6 +1247,13 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
     }
     a.model_grid = gm.g;
     a.scene_grid = c->scene_grid.g;
+    if (lcp_cells) {
+      if (!c->scene_cells.valid || c->scene_cells.max_dist != o->dist) {
+        const int rc = build_cell_lists_local(c, c->scene_cells, c->scene_grid, &c->scene_d, o->dist, 1, 0);
+        if (rc) return rc;
+      }
+      a.scene_cells = c->scene_cells.c;
+    }
     const CloudDevice& Q = c->scene_sorted_d;
     a.qx = Q.plane(0), a.qy = Q.plane(1), a.qz = Q.plane(2), a.qnx = Q.plane(3), a.qny = Q.plane(4), a.qnz = Q.plane(5);
     a.perm = c->scene_perm_d.as<int>();
@@ -1162,7 +1263,8 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
     a.h0 = h0;
     if (lcp_grid) {
       SpanGuard sg(c, T_LCP_FWD);
-      launch_lcp_grid(a, hb, c->stream);
+      if (lcp_cells) launch_lcp_cells(a, hb, c->stream);
+      else launch_lcp_grid(a, hb, c->stream);
     } else {
       {
         SpanGuard sg(c, T_LCP_REV);

@@ -12,6 +12,7 @@ constexpr int NN_TILE = 2048;  // targets per LDS tile (float4 each -> 32 KiB)
 constexpr int NN_CH = 16;      // targets per min-chunk of the scan
 constexpr int PPF_ROWS = 64;   // rows of the PPF matrix handled per block
 constexpr int ICP_NACC = 32;   // 21 (lower triangle of J^T J) + 6 (J^T r) + mse + count + 3 (sum of matched source points)
+constexpr int ICP_ACCUM_R = 16;  // points per thread of the accumulation kernel of the cell-list path
 constexpr float GRID_MARGIN = 1.0e-5f;  // metres; bounds | ||T^-1 s - m|| - ||s - T m|| | for rigid float poses
 constexpr int MAX_RING = 64;   // samples on the normal cone (normalset.hpp:208-210; <= 2*ceil(2*pi*atan(pi)*3.5) = 56)
 
@@ -170,6 +171,8 @@ struct LcpArgs {
   float* score;
   GridDev model_grid;  // nn_mode 1: model in its rest frame, cell >= dist + margin
   GridDev scene_grid;  //            scene, cell >= dist + margin
+  CellListDev model_cells;  // nn_mode 2: NN cell lists of the model (rest frame), max_dist = dist
+  CellListDev scene_cells;  //            and of the scene
   // grid path walks the scene in a spatially sorted order (neighbouring lanes touch neighbouring cells);
   // `perm` maps the sorted position back to the caller's index, where the terms are stored.
   const float *qx, *qy, *qz, *qnx, *qny, *qnz;
@@ -248,7 +251,11 @@ void launch_lcp_reverse(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_forward(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_sum(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_grid(const LcpArgs& a, int hb, hipStream_t s);
-int icp_blocks_per_hyp(int ns);
+void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s);
+void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool write, int exist_mode, hipStream_t s);
+void launch_verify_cells(const VerifyArgs& a, const CellListDev& cl, int blocks, hipStream_t s);
+void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s);
+int icp_blocks_per_hyp(int ns, bool cells);
 void launch_icp_init(IcpState* st, int hb, hipStream_t s);
 void launch_icp_nn(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_nn_grid(const IcpArgs& a, int hb, hipStream_t s);
@@ -257,7 +264,7 @@ void launch_icp_accum(const IcpArgs& a, int hb, hipStream_t s);
 void launch_cell_list_bounds(const CellListBuildArgs& a, hipStream_t s);
 void launch_cell_list_count(const CellListBuildArgs& a, hipStream_t s);
 void launch_cell_list_fill(const CellListBuildArgs& a, hipStream_t s);
-void launch_icp_solve(const IcpArgs& a, int hb, hipStream_t s);
+void launch_icp_solve(const IcpArgs& a, int hb, int nblocks, hipStream_t s);
 void launch_icp_finish(const IcpArgs& a, int hb, int* iters, int* conv, hipStream_t s);
 void launch_pso(const PsoArgs& a, int n_particles, hipStream_t s);
 void launch_grid_cell_ids(const float* x, const float* y, const float* z, int n, const GridDev& gd, int* cell_of, int* cell_count,

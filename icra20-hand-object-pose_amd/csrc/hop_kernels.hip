@@ -416,6 +416,38 @@ __global__ __launch_bounds__(256) void k_verify_grid(VerifyArgs a, GridDev gd) {
   }
 }
 
+// Verify on NN cell lists over P built in EXIST mode (verify_mode 2): one cell lookup, then a handful of candidates
+// (one, when every query of the cell is known to hit).  Same distance expression and threshold as the other modes.
+__global__ __launch_bounds__(256) void k_verify_cells(VerifyArgs a, CellListDev cl) {
+  const int n_cand = a.n_cand_ptr ? min(*a.n_cand_ptr, a.cand_cap) : a.n_cand;
+  const long long total = (long long)n_cand * a.nq;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ((total + 63) / 64) * 64;
+       g += (long long)gridDim.x * blockDim.x) {
+    bool hit = false;
+    int c = -1;
+    if (g < total) {
+      c = (int)(g / a.nq);
+      const int s = (int)(g % a.nq);
+      const float* T = a.T + (size_t)c * a.t_stride;
+      const V3 q = m4_point(T, v3(a.qx[s], a.qy[s], a.qz[s]));
+      const float fx = (q.x - cl.ox) * cl.inv_cell, fy = (q.y - cl.oy) * cl.inv_cell, fz = (q.z - cl.oz) * cl.inv_cell;
+      if (fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)cl.dx && fy < (float)cl.dy && fz < (float)cl.dz) {
+        const int cidx = ((int)fz * cl.dy + (int)fy) * cl.dx + (int)fx;
+        const int beg = cl.start[cidx], end = cl.start[cidx + 1];
+        for (int k = beg; k < end; ++k) {
+          const float4 t = cl.pts[k];
+          const float dx = q.x - t.x, dy = q.y - t.y, dz = q.z - t.z;
+          if (dx * dx + (dy * dy + dz * dz) <= a.sq_eps) {
+            hit = true;
+            break;
+          }
+        }
+      }
+    }
+    wave_count_by_key(hit, c, a.counts);
+  }
+}
+
 // K3c: candidates with at least one inlier become hypotheses (cse.hpp:313-333): the translation is
 // re-expressed for the un-centred clouds, t = c1 + centroid_P - R (c2 + centroid_Q).
 __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
@@ -748,6 +780,14 @@ __device__ __forceinline__ float cell_list_thr2(const CellListBuildArgs& a, int 
 // float error of the distance expression at these magnitudes), and domination is a strict partial order, so the
 // surviving (maximal) points still contain the linear scan's answer.  What is left is essentially the set of points
 // whose Voronoi cell meets the voxel: ~5 instead of ~26 at cell = spacing.
+// o dominates m over the box [blo, bhi]:  max_q ( |q-o|^2 - |q-m|^2 ) < -eps ;  f(q) = -2 q.e + |o|^2 - |m|^2 with e = o - m
+__device__ __forceinline__ bool dominates(const float4& o, const float4& m, const double blo[3], const double bhi[3], float eps) {
+  const double ex = (double)o.x - m.x, ey = (double)o.y - m.y, ez = (double)o.z - m.z;
+  const double oo = (double)o.x * o.x + (double)o.y * o.y + (double)o.z * o.z;
+  const double mm = (double)m.x * m.x + (double)m.y * m.y + (double)m.z * m.z;
+  const double qe = fmin(ex * blo[0], ex * bhi[0]) + fmin(ey * blo[1], ey * bhi[1]) + fmin(ez * blo[2], ez * bhi[2]);
+  return (oo - mm) - 2.0 * qe < -(double)eps;
+}
 #define CELL_LCAP 1024
 template <bool WRITE>
 __global__ __launch_bounds__(64) void k_cell_list_build(CellListBuildArgs a) {
@@ -839,6 +879,115 @@ __global__ __launch_bounds__(64) void k_cell_list_build(CellListBuildArgs a) {
 template __global__ void k_cell_list_build<false>(CellListBuildArgs);
 template __global__ void k_cell_list_build<true>(CellListBuildArgs);
 
+// The same lists built from a ring grid of the cloud (ring cell >= max_dist + margin), one thread per list cell: every
+// point with mindist(m, C) <= max_dist + margin lies in the few ring cells that the box of C grown by that radius
+// touches, so those are the only candidates.  The list grid is the ring grid padded by one ring cell on every side
+// (queries up to max_dist outside the cloud's box) and subdivided `sub` times per axis.  Used for per-frame clouds
+// (the scene), where scanning the whole cloud per cell would be far too slow.
+// EXIST mode (Verify only asks "is any point within max_dist"): a cell all of whose queries are within max_dist of one
+// and the same point (U(C) <= max_dist - margin) keeps just that point -- the first candidate then always hits.
+#define LOCAL_LCAP 40
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_cell_list_local(CellListBuildArgs a, GridDev g, int exist_mode) {
+  __shared__ float4 cand[LOCAL_LCAP * 64];  // [slot][lane]: the list candidates of this lane's cell
+  const int lane = threadIdx.x;
+  const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cidx >= a.dx * a.dy * a.dz) return;
+  float lo[3], hi[3];
+  cell_box(a, cidx, lo, hi);
+  const float R = a.max_dist + a.margin + 1.0e-6f;
+  const int x0 = max((int)floorf((lo[0] - R - g.ox) * g.inv_cell), 0), x1 = min((int)floorf((hi[0] + R - g.ox) * g.inv_cell), g.dx - 1);
+  const int y0 = max((int)floorf((lo[1] - R - g.oy) * g.inv_cell), 0), y1 = min((int)floorf((hi[1] + R - g.oy) * g.inv_cell), g.dy - 1);
+  const int z0 = max((int)floorf((lo[2] - R - g.oz) * g.inv_cell), 0), z1 = min((int)floorf((hi[2] + R - g.oz) * g.inv_cell), g.dz - 1);
+  // pass 1: U(C) and the point that realises it
+  float u2 = 3.0e38f;
+  float4 best = make_float4(0, 0, 0, 0);
+  if (x0 <= x1)
+    for (int z = z0; z <= z1; ++z)
+      for (int y = y0; y <= y1; ++y) {
+        const int row = (z * g.dy + y) * g.dx;
+        const int e = g.cell_start[row + x1 + 1];
+        for (int k = g.cell_start[row + x0]; k < e; ++k) {
+          const float4 t = g.pts[k];
+          const float m2 = box_maxdist2(lo, hi, t.x, t.y, t.z);
+          if (m2 < u2) u2 = m2, best = t;
+        }
+      }
+  if (u2 > 1.0e38f) {
+    if (!WRITE) a.count[cidx] = 0;
+    return;
+  }
+  const int pos = WRITE ? a.start[cidx] : 0;
+  const float all_r = a.max_dist - a.margin;
+  if (exist_mode && all_r > 0.f && sqrtf(u2) * 1.00001f <= all_r) {
+    if (WRITE) a.pts[pos] = best;
+    else a.count[cidx] = 1;
+    return;
+  }
+  const float u = sqrtf(u2) * 1.00001f + a.margin;
+  const float th = fminf(u, a.max_dist + a.margin);
+  const float thr2 = th * th * 1.00001f;
+  // pass 2: list candidates (mindist <= threshold) that the point realising U(C) does not dominate -- it removes most
+  // of them -- into this lane's LDS column, in grid order
+  const double blo[3] = {(double)lo[0] - a.margin, (double)lo[1] - a.margin, (double)lo[2] - a.margin};
+  const double bhi[3] = {(double)hi[0] + a.margin, (double)hi[1] + a.margin, (double)hi[2] + a.margin};
+  const int best_id = __float_as_int(best.w);
+  int L = 0;
+  for (int z = z0; z <= z1; ++z)
+    for (int y = y0; y <= y1; ++y) {
+      const int row = (z * g.dy + y) * g.dx;
+      const int e = g.cell_start[row + x1 + 1];
+      for (int k = g.cell_start[row + x0]; k < e; ++k) {
+        const float4 t = g.pts[k];
+        if (!(box_mindist2(lo, hi, t.x, t.y, t.z) <= thr2)) continue;
+        if (__float_as_int(t.w) != best_id && dominates(best, t, blo, bhi, a.dom_eps)) continue;
+        if (L < LOCAL_LCAP) cand[L * 64 + lane] = t;
+        ++L;
+      }
+    }
+  int kept = 0;
+  if (L <= LOCAL_LCAP) {
+    // pass 3: domination among the survivors
+    for (int i = 0; i < L; ++i) {
+      const float4 m = cand[i * 64 + lane];
+      bool dominated = false;
+      for (int j = 0; j < L && !dominated; ++j)
+        if (j != i) dominated = dominates(cand[j * 64 + lane], m, blo, bhi, a.dom_eps);
+      if (dominated) continue;
+      if (WRITE) {
+        a.pts[pos + kept] = m;
+        if (a.nrm) {
+          const int id = __float_as_int(m.w);
+          a.nrm[pos + kept] = make_float4(a.nx[id], a.ny[id], a.nz[id], 0.f);
+        }
+      }
+      ++kept;
+    }
+  } else {  // more survivors than the LDS column holds (not seen at the sizes built here): keep them all
+    for (int z = z0; z <= z1; ++z)
+      for (int y = y0; y <= y1; ++y) {
+        const int row = (z * g.dy + y) * g.dx;
+        const int e = g.cell_start[row + x1 + 1];
+        for (int k = g.cell_start[row + x0]; k < e; ++k) {
+          const float4 t = g.pts[k];
+          if (!(box_mindist2(lo, hi, t.x, t.y, t.z) <= thr2)) continue;
+          if (__float_as_int(t.w) != best_id && dominates(best, t, blo, bhi, a.dom_eps)) continue;
+          if (WRITE) {
+            a.pts[pos + kept] = t;
+            if (a.nrm) {
+              const int id = __float_as_int(t.w);
+              a.nrm[pos + kept] = make_float4(a.nx[id], a.ny[id], a.nz[id], 0.f);
+            }
+          }
+          ++kept;
+        }
+      }
+  }
+  if (!WRITE) a.count[cidx] = kept;
+}
+template __global__ void k_cell_list_local<false>(CellListBuildArgs, GridDev, int);
+template __global__ void k_cell_list_local<true>(CellListBuildArgs, GridDev, int);
+
 // Scan of one cell list.  The candidates are ranked by their squared distance to the query IN THE CLOUD'S REST FRAME
 // (qg, 8 flops each); the reference's distance expression -- query against the candidate moved by T, in the query's
 // frame -- is evaluated only for the winner.  The two differ by float rounding of the two transforms (bounded by
@@ -877,6 +1026,57 @@ __device__ __forceinline__ void cells_nn(const CellListDev& c, V3 qg, const floa
     const int j = __float_as_int(t.w);
     if (d2 < best || (d2 == best && j < bj)) best = d2, bj = j, bpos = k;
   }
+}
+
+// exact scan of a cell list whose entries are already in the query's frame (no transform): the distance expression
+// is the reference's, ties go to the lower original index
+__device__ __forceinline__ void cells_nn_plain(const CellListDev& c, V3 q, float& best, int& bpos) {
+  const float fx = (q.x - c.ox) * c.inv_cell, fy = (q.y - c.oy) * c.inv_cell, fz = (q.z - c.oz) * c.inv_cell;
+  if (!(fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)c.dx && fy < (float)c.dy && fz < (float)c.dz)) return;
+  const int cidx = ((int)fz * c.dy + (int)fy) * c.dx + (int)fx;
+  const int beg = c.start[cidx], end = c.start[cidx + 1];
+  int bj = 0x7fffffff;
+  for (int k = beg; k < end; ++k) {
+    const float4 t = c.pts[k];
+    const float d2 = sqdist_flann(q, v3(t.x, t.y, t.z));
+    const int j = __float_as_int(t.w);
+    if (d2 < best || (d2 == best && j < bj)) best = d2, bj = j, bpos = k;
+  }
+}
+
+// computeLCP on NN cell lists (nn_mode 2): forward NN through the model's lists (rest frame), reciprocal NN through
+// the scene grid.  Blocks are numbered so that all blocks of one hypothesis land on the same XCD (block b runs on XCD
+// b % 8): the scattered 8-byte term stores of one hypothesis then meet in one L2 and leave it as full lines, and the
+// hypothesis' pose / list reads are shared there too.
+__global__ __launch_bounds__(256) void k_lcp_cells(LcpArgs a, int hb, int nb) {
+  __shared__ float sT[12], sTi[12];
+  const int bid = blockIdx.x, r = bid & 7, t = bid >> 3;
+  const int hl = (t / nb) * 8 + r, bx = t % nb;
+  if (hl >= hb) return;
+  const int h = a.h0 + hl;
+  block_pose_and_inverse(a.pose + (size_t)h * 16, sT, sTi);
+  const int k = bx * blockDim.x + threadIdx.x;
+  if (k >= a.ns) return;
+  const int i = a.perm[k];  // caller's index of this scene point
+  const V3 s = v3(a.qx[k], a.qy[k], a.qz[k]);
+  float best = 3.0e38f;
+  int pos = -1;
+  cells_nn(a.model_cells, m4_point(sTi, s), sT, s, best, pos);
+  float f = -1.f, g = -1.f;
+  if (pos >= 0 && best < a.dist * a.dist) {
+    const float4 mp = a.model_cells.pts[pos], mnr = a.model_cells.nrm[pos];
+    const V3 nmod = m4_dir(sT, v3(mnr.x, mnr.y, mnr.z));
+    f = lcp_term(v3(a.qnx[k], a.qny[k], a.qnz[k]), nmod, best, a.dist, a.cos_thres);
+    const V3 pm = m4_point(sT, v3(mp.x, mp.y, mp.z));
+    float rbest = 3.0e38f;
+    int rk = -1;
+    cells_nn_plain(a.scene_cells, pm, rbest, rk);
+    if (rk >= 0) {
+      const float4 sn = a.scene_cells.nrm[rk];
+      g = lcp_term(nmod, v3(sn.x, sn.y, sn.z), rbest, a.dist, a.cos_thres);
+    }
+  }
+  reinterpret_cast<float2*>(a.terms)[(size_t)hl * a.ns + i] = make_float2(f, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1098,7 +1298,6 @@ __global__ __launch_bounds__(256) void k_icp_accum(IcpArgs a) {
   double acc[ICP_NACC];
 #pragma unroll
   for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
-#pragma unroll
   for (int r = 0; r < R; ++r) {
     const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
     if (i >= a.ns) continue;
@@ -1114,10 +1313,18 @@ __global__ __launch_bounds__(256) void k_icp_accum(IcpArgs a) {
     const V3 c = vcross(q, nt);
     const double J[6] = {c.x, c.y, c.z, nt.x, nt.y, nt.z};
     const double res = (double)vdot(q - tq, nt);
+    // J and res are float-valued, so every product below is exact in double and the fused multiply-add rounds
+    // exactly like the separate multiply and add of the reference accumulation
     int k = 0;
+#pragma unroll
     for (int u = 0; u < 6; ++u)
-      for (int v = 0; v <= u; ++v) acc[k++] += J[u] * J[v];
-    for (int u = 0; u < 6; ++u) acc[21 + u] -= J[u] * res;
+#pragma unroll
+      for (int v = 0; v <= u; ++v) {
+        acc[k] = fma(J[u], J[v], acc[k]);
+        ++k;
+      }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) acc[21 + u] = fma(-J[u], res, acc[21 + u]);
     acc[27] += (double)d2;
     acc[28] += 1.0;
     acc[29] += (double)q.x, acc[30] += (double)q.y, acc[31] += (double)q.z;
@@ -1134,7 +1341,7 @@ __global__ __launch_bounds__(256) void k_icp_accum(IcpArgs a) {
     a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NACC + threadIdx.x] = s;
   }
 }
-template __global__ void k_icp_accum<4>(IcpArgs);
+template __global__ void k_icp_accum<ICP_ACCUM_R>(IcpArgs);
 
 __device__ bool chol6(double A[6][6], const double b[6], double x[6]) {
   double L[6][6];
@@ -1414,6 +1621,9 @@ void launch_quads(const QuadArgs& a, int nbases, int blocks_per_base, hipStream_
   dim3 grid(blocks_per_base, nbases);
   hipLaunchKernelGGL(k_quads, grid, dim3(256), 0, s, a);
 }
+void launch_verify_cells(const VerifyArgs& a, const CellListDev& cl, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_verify_cells, dim3(blocks), dim3(256), 0, s, a, cl);
+}
 void launch_verify(const VerifyArgs& a, int mode, const GridDev* gd, int blocks, hipStream_t s) {
   if (mode == 1 && gd) hipLaunchKernelGGL(k_verify_grid, dim3(blocks), dim3(256), 0, s, a, *gd);
   else hipLaunchKernelGGL(k_verify_brute<4>, dim3(blocks), dim3(256), 0, s, a);
@@ -1441,19 +1651,22 @@ void launch_lcp_forward(const LcpArgs& a, int hb, hipStream_t s) {
 void launch_lcp_sum(const LcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_lcp_sum, dim3((hb + 63) / 64), dim3(64), 0, s, a, hb);
 }
-int icp_blocks_per_hyp(int ns) { return (ns + 256 * 4 - 1) / (256 * 4); }
+int icp_blocks_per_hyp(int ns, bool cells) {
+  const int per_block = 256 * (cells ? ICP_ACCUM_R : 4);
+  return (ns + per_block - 1) / per_block;
+}
 void launch_icp_init(IcpState* st, int hb, hipStream_t s) { hipLaunchKernelGGL(k_icp_init, dim3((hb + 63) / 64), dim3(64), 0, s, st, hb); }
 void launch_icp_nn(const IcpArgs& a, int hb, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_nn<4>, dim3(icp_blocks_per_hyp(a.ns), hb), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_icp_nn<4>, dim3(icp_blocks_per_hyp(a.ns, false), hb), dim3(256), 0, s, a);
 }
 void launch_icp_nn_grid(const IcpArgs& a, int hb, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_nn_grid<4>, dim3(icp_blocks_per_hyp(a.ns), hb), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_icp_nn_grid<4>, dim3(icp_blocks_per_hyp(a.ns, false), hb), dim3(256), 0, s, a);
 }
 void launch_icp_corr_cells(const IcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_corr_cells, dim3((a.ns + 255) / 256, hb), dim3(256), 0, s, a);
 }
 void launch_icp_accum(const IcpArgs& a, int hb, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_accum<4>, dim3(icp_blocks_per_hyp(a.ns), hb), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_icp_accum<ICP_ACCUM_R>, dim3(icp_blocks_per_hyp(a.ns, true), hb), dim3(256), 0, s, a);
 }
 void launch_cell_list_bounds(const CellListBuildArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_cell_list_bounds, dim3(a.dx * a.dy * a.dz), dim3(256), 0, s, a);
@@ -1464,11 +1677,20 @@ void launch_cell_list_count(const CellListBuildArgs& a, hipStream_t s) {
 void launch_cell_list_fill(const CellListBuildArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_cell_list_build<true>, dim3(a.dx * a.dy * a.dz), dim3(64), 0, s, a);
 }
+void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool write, int exist_mode, hipStream_t s) {
+  const int n = a.dx * a.dy * a.dz;
+  if (write) hipLaunchKernelGGL(k_cell_list_local<true>, dim3((n + 63) / 64), dim3(64), 0, s, a, g, exist_mode);
+  else hipLaunchKernelGGL(k_cell_list_local<false>, dim3((n + 63) / 64), dim3(64), 0, s, a, g, exist_mode);
+}
+void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s) {
+  const int nb = (a.ns + 255) / 256;
+  hipLaunchKernelGGL(k_lcp_cells, dim3((unsigned)(nb * ((hb + 7) / 8) * 8)), dim3(256), 0, s, a, hb, nb);
+}
 void launch_lcp_grid(const LcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_lcp_grid, dim3((a.ns + 255) / 256, hb), dim3(256), 0, s, a);
 }
-void launch_icp_solve(const IcpArgs& a, int hb, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_solve, dim3((hb + 63) / 64), dim3(64), 0, s, a, hb, icp_blocks_per_hyp(a.ns));
+void launch_icp_solve(const IcpArgs& a, int hb, int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_solve, dim3((hb + 63) / 64), dim3(64), 0, s, a, hb, nblocks);
 }
 void launch_icp_finish(const IcpArgs& a, int hb, int* iters, int* conv, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_finish, dim3((hb + 63) / 64), dim3(64), 0, s, a, hb, iters, conv);

@@ -8,6 +8,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <chrono>
 #include <climits>
 #include <limits>
@@ -229,6 +230,61 @@ __attribute__((target("avx512f"))) inline int pool_build_avx512(const unsigned l
   wstart[W] = k;
   return k;
 }
+// number of leading entries of the non-decreasing array c[0..n) (padded to a multiple of 8 with +inf) that are < target
+__attribute__((target("avx512f"))) inline int count_below_avx512(const double* c, int n, double target) {
+  const __m512d t = _mm512_set1_pd(target);
+  int cnt = 0;
+  for (int k = 0; k < n; k += 8) cnt += __builtin_popcount((unsigned)_mm512_cmp_pd_mask(_mm512_loadu_pd(c + k), t, _CMP_LT_OQ));
+  return cnt;
+}
+// c[from..n) += d   (n padded to a multiple of 8; the padding is +inf and stays +inf)
+__attribute__((target("avx512f"))) inline void suffix_add_avx512(double* c, int from, int n, double d) {
+  const __m512d dv = _mm512_set1_pd(d);
+  int k = from & ~7;
+  const __mmask8 first = (__mmask8)(0xffu << (from & 7));
+  _mm512_storeu_pd(c + k, _mm512_mask_add_pd(_mm512_loadu_pd(c + k), first, _mm512_loadu_pd(c + k), dv));
+  for (k += 8; k < n; k += 8) _mm512_storeu_pd(c + k, _mm512_add_pd(_mm512_loadu_pd(c + k), dv));
+}
+// first j in [0, cnt) with lo + w[0] + ... + w[j] >= target (cnt-1 if none); *lo_out = the cumulative weight before
+// entry j.  Eight entries per step, prefix sums formed in registers, early exit.
+__attribute__((target("avx512f"))) inline int word_scan_avx512(const float* w, int cnt, double lo, double target, double* lo_out) {
+  const __m512i sh1 = _mm512_setr_epi64(0, 0, 1, 2, 3, 4, 5, 6), sh2 = _mm512_setr_epi64(0, 0, 0, 1, 2, 3, 4, 5), sh4 = _mm512_setr_epi64(0, 0, 0, 0, 0, 1, 2, 3);
+  alignas(64) double buf[8][8];
+  __m512d v[8];
+  const int G = (cnt + 7) >> 3;
+  // local prefix sums of all groups first (independent chains), then the short carry chain over the group totals
+  for (int g = 0; g < G; ++g) {
+    const int left = cnt - 8 * g;
+    const __mmask16 m = left >= 8 ? (__mmask16)0xff : (__mmask16)((1u << left) - 1u);
+    __m512d x = _mm512_cvtps_pd(_mm512_castps512_ps256(_mm512_maskz_loadu_ps(m, w + 8 * g)));
+    x = _mm512_mask_add_pd(x, 0xfe, x, _mm512_permutexvar_pd(sh1, x));
+    x = _mm512_mask_add_pd(x, 0xfc, x, _mm512_permutexvar_pd(sh2, x));
+    x = _mm512_mask_add_pd(x, 0xf0, x, _mm512_permutexvar_pd(sh4, x));
+    v[g] = x;
+    _mm512_store_pd(buf[g], x);
+  }
+  const __m512d t = _mm512_set1_pd(target);
+  double carry[8];
+  double c = lo;
+  int below = 0;
+  for (int g = 0; g < G; ++g) {
+    carry[g] = c;
+    const int left = cnt - 8 * g;
+    const __mmask8 m = left >= 8 ? (__mmask8)0xff : (__mmask8)((1u << left) - 1u);
+    below += __builtin_popcount((unsigned)_mm512_mask_cmp_pd_mask(m, _mm512_add_pd(v[g], _mm512_set1_pd(c)), t, _CMP_LT_OQ));
+    c += buf[g][7];
+  }
+  const int j = below > cnt - 1 ? cnt - 1 : below;  // the last member takes whatever is left
+  *lo_out = j > 0 ? buf[(j - 1) >> 3][(j - 1) & 7] + carry[(j - 1) >> 3] : lo;
+  return j;
+}
+// c[from..n) += d for a short array (n a multiple of 8, +inf padding stays +inf)
+__attribute__((target("avx512f"))) inline int count_below_off_avx512(const double* c, int n, double base, double target) {
+  const __m512d t = _mm512_set1_pd(target), b = _mm512_set1_pd(base);
+  int cnt = 0;
+  for (int k = 0; k < n; k += 8) cnt += __builtin_popcount((unsigned)_mm512_cmp_pd_mask(_mm512_add_pd(_mm512_loadu_pd(c + k), b), t, _CMP_LT_OQ));
+  return cnt;
+}
 #endif
 
 inline int fourth_point_mask(const float* X, const float* Y, const float* Z, const unsigned long long* mask, int nr, const float b[3][3],
@@ -433,10 +489,13 @@ struct GenHost {
   std::vector<float> dist4_;
   std::vector<unsigned long long> mask4_;  // 4th-point candidates as a bit mask over pool ranks
   std::vector<double> bsum_;               // per matrix word: sum of the pool weights of that word
+  std::vector<double> c0_, c1_;            // AVX-512 path: running sums of bsum_ over / inside super-blocks of 16 words
+  int nsb_ = 0;
   std::vector<int> wstart_;                // per matrix word: rank of its first pool member
   int npool_ = 0, n4_ = 0;
   double pool_total_ = 0.0;
-  bool have_bmi2_ = false, have_avx512_ = false;
+  bool have_bmi2_ = false, have_avx512_ = false, simd_draw_ = false;
+  int lookahead_ = 2;
   // profile (seconds) of the selection phases, for tools/select_bench.cpp
   double t_first = 0, t_pool = 0, t_pairdraw = 0, t_pool4 = 0, t_fourth = 0;
   long long n_tri_calls = 0, n_pair_iters = 0, n_fallbacks = 0, sum_pool = 0, n_same = 0, n_nobit = 0, n_geom = 0;
@@ -559,30 +618,76 @@ struct GenHost {
 
   // index drawn by std::discrete_distribution over the pool weights probs_[0..npool_) (pool order), answered from the
   // per-word block sums; same exactness guard as draw_index.
-  int draw_pool_index(double u) {
+  struct PoolDraw {
+    int r;          // pool rank
+    double lo, hi;  // cumulative weight before / through rank r when the draw was resolved
+    double u;       // the canonical variate
+  };
+  PoolDraw draw_pool_index(double u) {
     const double T = pool_total_;
     const double target = u * T;
-    double lo = 0.0;
-    int w = fw_blk_.find(target, &lo);  // first word whose cumulative block sum reaches the target
-    if (wstart_[w + 1] == wstart_[w]) {  // an empty word can only be hit through rounding: resolve exactly
-      ++n_fallbacks;
-      return exact_discrete_index(probs_.data(), npool_, u);
+    double lo = 0.0, hi;
+    int r;
+#if defined(__x86_64__)
+    if (simd_draw_) {
+      // first word whose cumulative block sum reaches the target: count of cumulative sums below it (no branches to
+      // mispredict); then the same inside the word on prefix sums formed in registers
+      const int sb = std::min(count_below_avx512(c0_.data(), (int)c0_.size(), target), nsb_ - 1);
+      const double base0 = sb > 0 ? c0_[sb - 1] : 0.0;
+      const int wi = count_below_off_avx512(c1_.data() + 16 * sb, 16, base0, target);
+      const int w = std::min(16 * sb + wi, W - 1);
+      const int rs = wstart_[w], cnt = wstart_[w + 1] - rs;
+      if (cnt == 0) {
+        ++n_fallbacks;
+        return {exact_discrete_index(probs_.data(), npool_, u), 0.0, -1.0, u};
+      }
+      lo = base0 + ((w & 15) > 0 ? c1_[w - 1] : 0.0);
+      r = rs + word_scan_avx512(probs_.data() + rs, cnt, lo, target, &lo);
+      hi = lo + (double)probs_[r];
+    } else
+#endif
+    {
+      const int w = fw_blk_.find(target, &lo);  // first word whose cumulative block sum reaches the target
+      if (wstart_[w + 1] == wstart_[w]) {  // an empty word can only be hit through rounding: resolve exactly
+        ++n_fallbacks;
+        return {exact_discrete_index(probs_.data(), npool_, u), 0.0, -1.0, u};
+      }
+      r = wstart_[w];
+      const int rend = wstart_[w + 1];
+      for (; r < rend - 1; ++r) {
+        if (lo + (double)probs_[r] >= target) break;
+        lo += (double)probs_[r];
+      }
+      hi = lo + (double)probs_[r];
     }
-    int r = wstart_[w];
-    const int rend = wstart_[w + 1];
-    for (; r < rend - 1; ++r) {
-      if (lo + (double)probs_[r] >= target) break;
-      lo += (double)probs_[r];
-    }
-    const double hi = lo + (double)probs_[r];
     const double tol = guard_tol * T;
     // accept only when the target is clearly inside (lo, hi]; anything near a boundary (or a block-level miss) is
     // resolved by the exact routine
-    if (T > 0.0 && target - lo > tol && hi - target > tol) return r;
-    if (T > 0.0 && r == 0 && target <= hi - tol) return r;
-    if (T > 0.0 && r == npool_ - 1 && target - lo > tol) return r;
+    if (T > 0.0 && target - lo > tol && hi - target > tol) return {r, lo, hi, u};
+    if (T > 0.0 && r == 0 && target <= hi - tol) return {r, lo, hi, u};
+    if (T > 0.0 && r == npool_ - 1 && target - lo > tol) return {r, lo, hi, u};
     ++n_fallbacks;
-    return exact_discrete_index(probs_.data(), npool_, u);
+    return {exact_discrete_index(probs_.data(), npool_, u), 0.0, -1.0, u};
+  }
+  // A draw resolved before the weights of ranks a and b dropped by da, db (<= 0): still the same rank afterwards?
+  // (the cumulative bounds move by the deltas of the lower ranks, the total by both; same guard zone as above)
+  bool redraw_unchanged(PoolDraw& d, int a, double da, int b, double db) const {
+    if (d.hi < d.lo) return false;  // came from the exact routine: no bounds kept
+    const double lo = d.lo + (a < d.r ? da : 0.0) + (b < d.r ? db : 0.0);
+    const double hi = lo + (double)probs_[d.r];
+    const double T = pool_total_, target = d.u * T, tol = guard_tol * T;
+    if (!(T > 0.0)) return false;
+    const bool ok = (target - lo > tol && hi - target > tol) || (d.r == 0 && target <= hi - tol) || (d.r == npool_ - 1 && target - lo > tol);
+    if (ok) d.lo = lo, d.hi = hi;
+    return ok;
+  }
+  // std::generate_canonical<double, 53>(std::mt19937&): two 32-bit draws a, b -> round_to_double(a + b 2^32) / 2^64
+  // (random.tcc: the sum is accumulated in double, one rounding, then divided by the exact range 2^64; results
+  // >= 1 are replaced by the largest double below 1).  The u64 -> double conversion rounds identically.
+  double canonical53() {
+    const uint64_t a = point_index_engine_(), b = point_index_engine_();
+    const double r = (double)(a | (b << 32)) * 5.421010862427522e-20;  // 2^-64
+    return r >= 1.0 ? 0.99999999999999988898 : r;
   }
 
   // SelectRandomTriangle with the same draws, decisions and side effects as the literal version below, but
@@ -600,6 +705,9 @@ struct GenHost {
 #if defined(__x86_64__)
       have_bmi2_ = __builtin_cpu_supports("bmi2");
       have_avx512_ = __builtin_cpu_supports("avx512f");
+      simd_draw_ = have_avx512_;
+      if (const char* e = getenv("HOP_SELECT_SIMD_DRAW")) simd_draw_ = have_avx512_ && atoi(e) != 0;
+      if (const char* e = getenv("HOP_SELECT_LOOKAHEAD")) lookahead_ = std::max(1, std::min(8, atoi(e)));
 #endif
       bsum_.assign(W, 0.0);
       wstart_.assign(W + 1, 0);
@@ -645,8 +753,23 @@ struct GenHost {
       }
       wstart_[W] = k;
     }
-    fw_blk_.build_d(bsum_.data(), W);
-    pool_total_ = fw_blk_.total();
+    if (simd_draw_) {
+      // two levels of inclusive running sums over the words: c1_ inside super-blocks of 16 words, c0_ over super-blocks
+      nsb_ = (W + 15) / 16;
+      c1_.assign((size_t)nsb_ * 16, HUGE_VAL);
+      c0_.assign((size_t)((nsb_ + 7) & ~7), HUGE_VAL);
+      double tot = 0.0;
+      for (int sb = 0; sb < nsb_; ++sb) {
+        double acc = 0.0;
+        for (int w = 16 * sb; w < std::min(W, 16 * sb + 16); ++w) acc += bsum_[w], c1_[w] = acc;
+        tot += acc;
+        c0_[sb] = tot;
+      }
+      pool_total_ = tot;
+    } else {
+      fw_blk_.build_d(bsum_.data(), W);
+      pool_total_ = fw_blk_.total();
+    }
     t_pool += now() - tp, tp = now();
     sum_pool += npool;
     if (npool < 3) return false;
@@ -659,44 +782,52 @@ struct GenHost {
     // ahead are only reused if the current iteration did not change the weights; the engine ends exactly where the
     // reference's would (an unused look-ahead pair is rolled back).
     const std::mt19937 engine_before = point_index_engine_;
-    auto canon = [&]() { return std::generate_canonical<double, std::numeric_limits<double>::digits>(point_index_engine_); };
-    size_t drawn_pairs = 0;
-    double nu0 = 0, nu1 = 0;
-    int ns = -1, nt = -1;
-    bool have_next = false, next_valid = false;
-    size_t used_pairs = 0;
+    // Every iteration consumes exactly two canonical variates (four engine calls), whatever its outcome, so the pairs
+    // of the next LOOKAHEAD iterations are drawn early and their matrix words prefetched: the key test bit(p2,p3) is a
+    // random access into the N^2/8-byte matrix (a DRAM + TLB miss at C2 sizes, longer than one iteration).  When an
+    // iteration changes the weights, each queued draw is re-validated in O(1) (redraw_unchanged) or redone; the engine
+    // ends exactly where the reference's would (unused look-ahead pairs are rolled back).
+    constexpr int MAXLA = 8;
+    const int LOOKAHEAD = lookahead_;
+    PoolDraw q0[MAXLA + 1], q1[MAXLA + 1];
+    int qhead = 0, qlen = 0;
+    size_t drawn_pairs = 0, used_pairs = 0;
+    auto push_pair = [&]() {
+      const double u0 = canonical53(), u1 = canonical53();
+      ++drawn_pairs;
+      const int at = (qhead + qlen) % (LOOKAHEAD + 1);
+      q0[at] = draw_pool_index(u0), q1[at] = draw_pool_index(u1);
+      if (q0[at].r != q1[at].r) __builtin_prefetch(&M[(size_t)pool_ids_[q0[at].r] * W + (pool_ids_[q1[at].r] >> 6)], 0, 1);
+      ++qlen;
+    };
     for (size_t it = 0; it < max_it && it < (size_t)INT_MAX; ++it) {  // the reference's counter is an int
       ++n_pair_iters;
-      int second, third;
-      if (have_next) {
-        if (next_valid) second = ns, third = nt;
-        else second = draw_pool_index(nu0), third = draw_pool_index(nu1);
-      } else {
-        const double u0 = canon(), u1 = canon();
-        ++drawn_pairs;
-        second = draw_pool_index(u0), third = draw_pool_index(u1);
-      }
+      while (qlen < LOOKAHEAD + 1 && it + (size_t)qlen < max_it) push_pair();
+      const int second = q0[qhead].r, third = q1[qhead].r;
+      qhead = (qhead + 1) % (LOOKAHEAD + 1), --qlen;
       used_pairs = it + 1;
-      // look ahead (only if another iteration can follow)
-      have_next = false;
-      if (it + 1 < max_it) {
-        nu0 = canon(), nu1 = canon();
-        ++drawn_pairs;
-        ns = draw_pool_index(nu0), nt = draw_pool_index(nu1);
-        have_next = true, next_valid = true;
-        if (ns != nt) __builtin_prefetch(&M[(size_t)pool_ids_[ns] * W + (pool_ids_[nt] >> 6)], 0, 1);
-      }
-      if (second == third) continue;
-      if (!bit(pool_ids_[second], pool_ids_[third])) continue;
-      next_valid = false;  // the weights change below
+      if (second == third) { ++n_same; continue; }
+      if (!bit(pool_ids_[second], pool_ids_[third])) { ++n_nobit; continue; }
+      ++n_geom;
+      // the weights of both points drop (matchBase.hpp:163-164); the block sums follow by the exact differences
+      double dlt[2];
+      int q = 0;
       for (int r : {second, third}) {
-        probs_[r] *= opt.dispersion;
+        const float old = probs_[r];
+        probs_[r] = old * opt.dispersion;
+        const double d = (double)probs_[r] - (double)old;
         const int w = pool_ids_[r] >> 6;
-        double s = 0.0;
-        for (int q = wstart_[w]; q < wstart_[w + 1]; ++q) s += (double)probs_[q];
-        fw_blk_.add(w, s - bsum_[w]);
-        bsum_[w] = s;
-        pool_total_ = fw_blk_.total();
+        bsum_[w] += d;
+#if defined(__x86_64__)
+        if (simd_draw_) {
+          suffix_add_avx512(c1_.data() + 16 * (w >> 4), w & 15, 16, d);
+          suffix_add_avx512(c0_.data(), w >> 4, (int)c0_.size(), d);
+        }
+        else
+#endif
+          fw_blk_.add(w, d);
+        pool_total_ += d;
+        dlt[q++] = d;
       }
       const V3 u = ppos(pool_ids_[second]) - p0;
       const V3 w = ppos(pool_ids_[third]) - p0;
@@ -706,6 +837,14 @@ struct GenHost {
         base2 = pool_ids_[second];
         base3 = pool_ids_[third];
         break;
+      }
+      // keep the queued draws that the change did not move, redo the others
+      for (int k = 0; k < qlen; ++k) {
+        const int at = (qhead + k) % (LOOKAHEAD + 1);
+        bool moved = false;
+        if (!redraw_unchanged(q0[at], second, dlt[0], third, dlt[1])) q0[at] = draw_pool_index(q0[at].u), moved = true;
+        if (!redraw_unchanged(q1[at], second, dlt[0], third, dlt[1])) q1[at] = draw_pool_index(q1[at].u), moved = true;
+        if (moved && q0[at].r != q1[at].r) __builtin_prefetch(&M[(size_t)pool_ids_[q0[at].r] * W + (pool_ids_[q1[at].r] >> 6)], 0, 1);
       }
     }
     if (drawn_pairs != used_pairs) {  // roll the engine back to "used_pairs pairs consumed"

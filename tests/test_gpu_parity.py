@@ -41,7 +41,7 @@ def _rot_err_deg(Ra, Rb):
 
 
 # ------------------------------------------------------------------------------------------------ Verify
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_verify_matches_reference_golden(ctx, golden_dir, mode):
     """K4 against Verify values produced by the reference build (exact integer inlier counts)."""
     g = np.load(os.path.join(golden_dir, "s4pcs_case1.npz"))
@@ -72,6 +72,12 @@ def test_verify_brute_grid_oracle_agree_large(ctx, orc, synth):
     a = ctx.verify_batch(T, 0.003, 0)
     b = ctx.verify_batch(T, 0.003, 1)
     assert np.array_equal(a, b)
+    assert np.array_equal(a, ctx.verify_batch(T, 0.003, 2))
+    # poses right at the inlier boundary (noise of the order of delta) and far-off poses (empty cells)
+    T2 = synth.replay_poses(Tg, 2048, seed=9, max_rot_deg=60, max_trans=0.05)
+    for delta in (0.003, 0.0011):
+        r0 = ctx.verify_batch(T2, delta, 0)
+        assert np.array_equal(r0, ctx.verify_batch(T2, delta, 1)) and np.array_equal(r0, ctx.verify_batch(T2, delta, 2))
     o = orc.verify_batch(P, Qs, T[:96], 0.003, use_tree=True)
     assert np.array_equal(a[:96], o)
     assert a.max() > 5
@@ -79,11 +85,12 @@ def test_verify_brute_grid_oracle_agree_large(ctx, orc, synth):
     perm = rng.permutation(len(P))
     ctx.verify_set_clouds(P[perm], Qs)
     assert np.array_equal(ctx.verify_batch(T, 0.003, 0), a)
+    assert np.array_equal(ctx.verify_batch(T, 0.003, 2), a)
 
 
 # ------------------------------------------------------------------------------------------------ generator
 @pytest.mark.parametrize("case", ["case1", "case2"])
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_generator_matches_reference_golden(ctx, api, orc, golden_dir, case, mode):
     g = np.load(os.path.join(golden_dir, f"s4pcs_{case}.npz"))
     sample_size, succ, n_calls = (int(v) for v in g["opts"])
@@ -162,7 +169,7 @@ def _scoring_case(synth, n_scene, n_model, H, seed=7):
     return sc, mx, mn, poses
 
 
-@pytest.mark.parametrize("nn_mode", [0, 1])
+@pytest.mark.parametrize("nn_mode", [0, 1, 2])
 def test_lcp_scores_bit_equal_to_oracle(ctx, api, orc, synth, nn_mode):
     sc, mx, mn, poses = _scoring_case(synth, 3000, 2500, 48)
     ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.0)
@@ -179,7 +186,7 @@ def test_lcp_scores_bit_equal_to_oracle(ctx, api, orc, synth, nn_mode):
     assert np.array_equal(best_pose, poses[exp])
 
 
-@pytest.mark.parametrize("nn_mode", [0, 1])
+@pytest.mark.parametrize("nn_mode", [0, 1, 2])
 def test_lcp_ragged_and_empty_edge_cases(ctx, api, orc, synth, nn_mode):
     """Sizes that are not multiples of any tile (1 scene point .. 2049 model points), and a pose far away."""
     sc, mx, mn, poses = _scoring_case(synth, 777, 2049, 5)
@@ -260,6 +267,14 @@ def test_icp_and_lcp_grid_equal_brute_bitwise_large(ctx, api, synth):
     same = np.all(res[0][2] == res[2][2], axis=(1, 2))
     assert same.mean() > 0.5 and np.array_equal(res[0][3][same], res[2][3][same])
     assert res[0][0].max() >= 4, "some hypotheses must need several iterations"
+    # computeLCP alone on identical poses (the refined set of mode 0): all three NN modes return the same bits
+    lcp = []
+    for mode in (0, 1, 2):
+        ctx.hypos_upload(res[0][2])
+        ctx.lcp_select_best(0.001, 10.0, mode)
+        lcp.append(ctx.hypos_download()[1].copy())
+    assert np.array_equal(lcp[0], lcp[1]) and np.array_equal(lcp[0], lcp[2])
+    assert (lcp[0] > 0).sum() > 10
 
 
 # ------------------------------------------------------------------------------------------------ resident set
