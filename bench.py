@@ -104,6 +104,11 @@ class Workload:
 
     def step(self):
         c = self.ctx
+        tf = time.perf_counter()
+        # a new frame arrives: both clouds are handed over again, so every per-frame structure derived from them
+        # (Morton order, voxel grids, NN cell lists of the scene, Verify lists, hand-scene grid) is rebuilt inside the step
+        c.set_scene(self.sc.xyz, self.sc.nrm, self.sc.conf, 0.8)
+        self.handt42.setCurScene(self.hxyz, self.hnrm, self.swivel)
         t0 = time.perf_counter()
         self.hand_search()
         t1 = time.perf_counter()
@@ -117,7 +122,7 @@ class Workload:
         best, score, idx = c.lcp_select_best(0.001, 10.0, self.args.nn_mode)
         t4 = time.perf_counter()
         return dict(h=h, h_gen=st.n_hypotheses, n_cand=st.n_candidates, n_bases=st.n_bases, best=best, score=score,
-                    t_pso=t1 - t0, t_gen=t2 - t1, t_icp=t3 - t2, t_lcp=t4 - t3, ms_select=st.ms_select)
+                    t_frame=t0 - tf, t_pso=t1 - t0, t_gen=t2 - t1, t_icp=t3 - t2, t_lcp=t4 - t3, ms_select=st.ms_select)
 
 
 def cpu_baseline(w, budget_s):
@@ -280,7 +285,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "valu_fp32": {"achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / VALU_PEAK_TFLOPS,
                                        "note": "brute-force NN is FP32-VALU bound (~1300 flop/B); both fractions reported, SURVEY.md 8(d)"}},
-            "stage_ms_per_step": {"pso": 1e3 * np.mean([i["t_pso"] for i in infos]), "generate": 1e3 * np.mean([i["t_gen"] for i in infos]),
+            "stage_ms_per_step": {"frame_handover": 1e3 * np.mean([i["t_frame"] for i in infos]), "pso": 1e3 * np.mean([i["t_pso"] for i in infos]), "generate": 1e3 * np.mean([i["t_gen"] for i in infos]),
                                   "generate_host_select": float(np.mean([i["ms_select"] for i in infos])),
                                   "icp": 1e3 * np.mean([i["t_icp"] for i in infos]), "lcp": 1e3 * np.mean([i["t_lcp"] for i in infos])},
             "device_ms_total": {k: v for k, v in tm.items() if k.startswith("ms_")},

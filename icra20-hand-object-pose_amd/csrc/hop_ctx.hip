@@ -76,12 +76,12 @@ struct GridStore {
 };
 
 struct CellListStore {
-  DevBuf start_d, pts_d, nrm_d, u2_d, count_d;
+  DevBuf start_d, pts_d, nrm_d, u2_d, count_d, work_d, keep_d;
   hop::CellListDev c{};
   bool valid = false;
   float cell = 0, max_dist = 0;
   void release() {
-    start_d.release(), pts_d.release(), nrm_d.release(), u2_d.release(), count_d.release();
+    start_d.release(), pts_d.release(), nrm_d.release(), u2_d.release(), count_d.release(), work_d.release(), keep_d.release();
     valid = false;
   }
 };
@@ -165,7 +165,7 @@ struct hop_ctx {
   // voxel grids: centred P for verify_mode 1; model rest frames and scene for nn_mode 1
   GridStore verify_grid, model_grid[2], scene_grid, hand_grid;
   std::vector<float> hand_scene_h[3];
-  CellListStore model_cells[2], scene_cells, verify_cells;
+  CellListStore model_cells[2], scene_cells, verify_cells, hand_cells;
   float grid_delta = 0;
 
   // batch workspaces of the generator
@@ -387,12 +387,26 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   if (ncell > (size_t)1 << 28) return HOP_E_CAPACITY;
   HIPCHK(c, cs.count_d.ensure(sizeof(int) * (ncell + 1)));
   HIPCHK(c, cs.start_d.ensure(sizeof(int) * (ncell + 1)));
+  HIPCHK(c, cs.u2_d.ensure(sizeof(int) * (ncell + 1)));  // flags of the cells that have candidates at all
   a.count = cs.count_d.as<int>();
-  HIPCHK(c, hipMemsetAsync(a.count + ncell, 0, sizeof(int), c->stream));
-  launch_cell_list_local(a, g, false, exist_mode, c->stream);
+  int* flag = cs.u2_d.as<int>();
+  int* scan = cs.start_d.as<int>();
+  // stage 1: flag cells with candidates, compact them (in cell order) into a work list
+  launch_cell_list_local_flag(a, g, flag, c->stream);
   size_t tmp_bytes = 0;
-  HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, a.count, cs.start_d.as<int>(), (int)(ncell + 1), c->stream));
+  HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, flag, scan, (int)(ncell + 1), c->stream));
   HIPCHK(c, c->sort_tmp.ensure(tmp_bytes + 16));
+  HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->sort_tmp.p, tmp_bytes, flag, scan, (int)(ncell + 1), c->stream));
+  int nwork = 0;
+  HIPCHK(c, hipMemcpyAsync(&nwork, scan + ncell, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, cs.work_d.ensure(sizeof(int) * (size_t)std::max(nwork, 1)));
+  HIPCHK(c, cs.keep_d.ensure(sizeof(int) * (size_t)std::max(nwork, 1) * cell_list_local_keep()));
+  int* work = cs.work_d.as<int>();
+  int* keep = cs.keep_d.as<int>();
+  launch_cell_list_local_work(flag, scan, (int)ncell, work, c->stream);
+  // stage 2: one wave per listed cell, count then write around a scan of the counts
+  launch_cell_list_local(a, g, false, exist_mode, work, nwork, keep, c->stream);
   HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->sort_tmp.p, tmp_bytes, a.count, cs.start_d.as<int>(), (int)(ncell + 1), c->stream));
   int total = 0;
   HIPCHK(c, hipMemcpyAsync(&total, cs.start_d.as<int>() + ncell, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -400,12 +414,12 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   HIPCHK(c, cs.pts_d.ensure(sizeof(float4) * (size_t)std::max(total, 1)));
   if (normals) HIPCHK(c, cs.nrm_d.ensure(sizeof(float4) * (size_t)std::max(total, 1)));
   a.start = cs.start_d.as<int>(), a.pts = cs.pts_d.as<float4>(), a.nrm = normals ? cs.nrm_d.as<float4>() : nullptr;
-  launch_cell_list_local(a, g, true, exist_mode, c->stream);
+  launch_cell_list_local(a, g, true, exist_mode, work, nwork, keep, c->stream);
   cs.c.ox = a.ox, cs.c.oy = a.oy, cs.c.oz = a.oz, cs.c.cell = a.cell, cs.c.inv_cell = 1.0f / a.cell;
   cs.c.dx = a.dx, cs.c.dy = a.dy, cs.c.dz = a.dz;
   cs.c.start = cs.start_d.as<int>(), cs.c.pts = cs.pts_d.as<float4>(), cs.c.nrm = normals ? cs.nrm_d.as<float4>() : nullptr;
   cs.valid = true, cs.cell = a.cell, cs.max_dist = max_dist;
-  if (getenv("HOP_PROFILE_SELECT")) std::printf("local cell lists: %zu cells, %d entries, cell %.5f\n", ncell, total, a.cell);
+  if (getenv("HOP_PROFILE_SELECT")) std::printf("local cell lists: %zu cells (%d with candidates), %d entries, cell %.5f\n", ncell, nwork, total, a.cell);
   return HOP_OK;
 }
 
@@ -588,7 +602,7 @@ void hop_ctx_destroy(hop_ctx* c) {
                     &c->pso_terms_d, &c->pso_sum_d, &c->pso_cnt_d};
   for (DevBuf* b : bufs) b->release();
   c->verify_grid.release(), c->model_grid[0].release(), c->model_grid[1].release(), c->scene_grid.release(), c->hand_grid.release();
-  c->model_cells[0].release(), c->model_cells[1].release(), c->scene_cells.release(), c->verify_cells.release();
+  c->model_cells[0].release(), c->model_cells[1].release(), c->scene_cells.release(), c->verify_cells.release(), c->hand_cells.release();
   c->ppf_matrix_h.release(), c->bases_h.release(), c->cnt_h.release(), c->pso_particles_h.release(), c->pso_out_h.release();
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1425,6 +1439,7 @@ int hop_hand_set_scene(hop_ctx* c, const float* scene_xyz, int n_scene, const fl
   c->hand_n_scene = n_scene, c->hand_n_lookup = n_lookup, c->hand_n_swivel = n_swivel;
   for (int k = 0; k < 3; ++k) c->hand_scene_h[k].assign(scene_xyz + (size_t)k * n_scene, scene_xyz + (size_t)(k + 1) * n_scene);
   c->hand_grid.valid = false;
+  c->hand_cells.valid = false;
   c->have_hand_scene = true;
   return HOP_OK;
 }
@@ -1460,10 +1475,8 @@ int hop_hand_pso_eval_batch(hop_ctx* c, const double* angles, int n, double* cos
   const hop_finger_args& a = c->finger;
   HIPCHK(c, c->pso_particles_h.ensure(sizeof(PsoParticle) * (size_t)n));
   HIPCHK(c, c->pso_particles_d.ensure(sizeof(PsoParticle) * (size_t)n));
-  HIPCHK(c, c->pso_match_d.ensure(sizeof(int) * (size_t)n));
-  HIPCHK(c, c->pso_sum_d.ensure(sizeof(float) * (size_t)n));
-  HIPCHK(c, c->pso_cnt_d.ensure(sizeof(int) * (size_t)n));
-  HIPCHK(c, c->pso_terms_d.ensure(sizeof(float) * (size_t)n * std::max(c->hand_n_swivel, 1)));
+  HIPCHK(c, c->pso_match_d.ensure(sizeof(int) * 3 * (size_t)n));  // match count | outer count | outer sum, one read-back
+  HIPCHK(c, c->pso_terms_d.ensure(sizeof(float) * (size_t)n * (std::max(c->hand_n_swivel, 1) + 4)));
   HIPCHK(c, c->pso_out_h.ensure((sizeof(int) * 2 + sizeof(float)) * (size_t)n));
   PsoParticle* P = static_cast<PsoParticle*>(c->pso_particles_h.p);
   M4 model2handbase, finger_out2parent;
@@ -1507,7 +1520,7 @@ int hop_hand_pso_eval_batch(hop_ctx* c, const double* angles, int n, double* cos
     for (int k = 0; k < 12; ++k) pp.T[k] = cur.m[k], pp.Tinv[k] = inv.m[k];
   }
   HIPCHK(c, hipMemcpyAsync(c->pso_particles_d.p, P, sizeof(PsoParticle) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->pso_match_d.p, 0, sizeof(int) * (size_t)n, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->pso_match_d.p, 0, sizeof(int) * 3 * (size_t)n, c->stream));
   PsoArgs pa{};
   pa.particles = c->pso_particles_d.as<PsoParticle>();
   const CloudDevice& Mo = c->hand_model_d;
@@ -1518,7 +1531,7 @@ int hop_hand_pso_eval_batch(hop_ctx* c, const double* angles, int n, double* cos
   pa.dist_thres = a.dist_thres, pa.cos_normal_thres = a.cos_normal_thres, pa.check_normal = a.check_normal;
   pa.fp_min_z = a.fp_min[2], pa.fp_stride_z = a.fp_stride_z, pa.fp_num_division = a.fp_num_division;
   pa.hist_min_y = c->finger_hist_d.as<float>();
-  {
+  if (getenv("HOP_PSO_RINGS")) {
     const float cell = a.dist_thres / 2.f + GRID_MARGIN;
     if (!c->hand_grid.valid || c->hand_grid.cell != cell) {
       const int rc = build_grid(c, c->hand_grid, c->hand_scene_h[0].data(), c->hand_scene_h[1].data(), c->hand_scene_h[2].data(), c->hand_n_scene, cell);
@@ -1527,10 +1540,24 @@ int hop_hand_pso_eval_batch(hop_ctx* c, const double* angles, int n, double* cos
     pa.scene_grid = c->hand_grid.g;
     pa.max_ring = (int)std::ceil((a.dist_thres + 2 * GRID_MARGIN) / cell);
     pa.use_grid = 1;
+  } else {
+    // NN cell lists of the hand scene for this gating distance (per frame; shared by the four finger searches)
+    const float cell = a.dist_thres + 8 * GRID_MARGIN;
+    if (!c->hand_grid.valid || c->hand_grid.cell != cell) {
+      const int rc = build_grid(c, c->hand_grid, c->hand_scene_h[0].data(), c->hand_scene_h[1].data(), c->hand_scene_h[2].data(), c->hand_n_scene, cell);
+      if (rc) return rc;
+      c->hand_cells.valid = false;
+    }
+    if (!c->hand_cells.valid || c->hand_cells.max_dist != a.dist_thres) {
+      const int rc = build_cell_lists_local(c, c->hand_cells, c->hand_grid, nullptr, a.dist_thres, 3, 0);
+      if (rc) return rc;
+    }
+    pa.scene_cells = c->hand_cells.c;
+    pa.use_grid = 2;
   }
   pa.n_particles = n;
   pa.match_count = c->pso_match_d.as<int>(), pa.outer_terms = c->pso_terms_d.as<float>();
-  pa.outer_sum = c->pso_sum_d.as<float>(), pa.outer_cnt = c->pso_cnt_d.as<int>();
+  pa.outer_cnt = c->pso_match_d.as<int>() + n, pa.outer_sum = reinterpret_cast<float*>(c->pso_match_d.as<int>() + 2 * (size_t)n);
   {
     SpanGuard sg(c, T_PSO);
     launch_pso(pa, n, c->stream);
@@ -1540,9 +1567,7 @@ int hop_hand_pso_eval_batch(hop_ctx* c, const double* angles, int n, double* cos
   int* h_match = static_cast<int*>(c->pso_out_h.p);
   int* h_cnt = h_match + n;
   float* h_sum = reinterpret_cast<float*>(h_cnt + n);
-  HIPCHK(c, hipMemcpyAsync(h_match, c->pso_match_d.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(h_cnt, c->pso_cnt_d.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(h_sum, c->pso_sum_d.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_match, c->pso_match_d.p, sizeof(int) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int p = 0; p < n; ++p) {
     if (early[p]) continue;

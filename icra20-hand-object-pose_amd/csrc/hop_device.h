@@ -228,7 +228,8 @@ struct PsoArgs {
   const float* hist_min_y;
   GridDev scene_grid;  // hand scene on a voxel grid (cell = dist_thres/2): exact NN within dist_thres by ring search
   int max_ring;
-  int use_grid;
+  int use_grid;             // 0 brute force, 1 ring search on scene_grid, 2 NN cell lists
+  CellListDev scene_cells;  // hand scene NN cell lists (max_dist = dist_thres)
   int n_particles;
   int* match_count;
   float* outer_terms;  // [n_swivel][n_particles]
@@ -252,7 +253,11 @@ void launch_lcp_forward(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_sum(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_grid(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s);
-void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool write, int exist_mode, hipStream_t s);
+void launch_cell_list_local_flag(const CellListBuildArgs& a, const GridDev& g, int* flag, hipStream_t s);
+void launch_cell_list_local_work(const int* flag, const int* flag_scan, int ncell, int* work, hipStream_t s);
+void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool write, int exist_mode, const int* work, int nwork, int* keep_buf,
+                            hipStream_t s);
+int cell_list_local_keep();
 void launch_verify_cells(const VerifyArgs& a, const CellListDev& cl, int blocks, hipStream_t s);
 void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s);
 int icp_blocks_per_hyp(int ns, bool cells);

@@ -886,107 +886,245 @@ template __global__ void k_cell_list_build<true>(CellListBuildArgs);
 // (the scene), where scanning the whole cloud per cell would be far too slow.
 // EXIST mode (Verify only asks "is any point within max_dist"): a cell all of whose queries are within max_dist of one
 // and the same point (U(C) <= max_dist - margin) keeps just that point -- the first candidate then always hits.
-#define LOCAL_LCAP 40
-template <bool WRITE>
-__global__ __launch_bounds__(64) void k_cell_list_local(CellListBuildArgs a, GridDev g, int exist_mode) {
-  __shared__ float4 cand[LOCAL_LCAP * 64];  // [slot][lane]: the list candidates of this lane's cell
-  const int lane = threadIdx.x;
-  const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cidx >= a.dx * a.dy * a.dz) return;
-  float lo[3], hi[3];
-  cell_box(a, cidx, lo, hi);
+// stage 1 (one thread per list cell): does any grid row the cell can draw candidates from hold a point?
+__device__ __forceinline__ void local_ranges(const CellListBuildArgs& a, const GridDev& g, const float lo[3], const float hi[3], int& x0, int& x1,
+                                             int& y0, int& y1, int& z0, int& z1) {
   const float R = a.max_dist + a.margin + 1.0e-6f;
-  const int x0 = max((int)floorf((lo[0] - R - g.ox) * g.inv_cell), 0), x1 = min((int)floorf((hi[0] + R - g.ox) * g.inv_cell), g.dx - 1);
-  const int y0 = max((int)floorf((lo[1] - R - g.oy) * g.inv_cell), 0), y1 = min((int)floorf((hi[1] + R - g.oy) * g.inv_cell), g.dy - 1);
-  const int z0 = max((int)floorf((lo[2] - R - g.oz) * g.inv_cell), 0), z1 = min((int)floorf((hi[2] + R - g.oz) * g.inv_cell), g.dz - 1);
-  // pass 1: U(C) and the point that realises it
-  float u2 = 3.0e38f;
-  float4 best = make_float4(0, 0, 0, 0);
-  if (x0 <= x1)
-    for (int z = z0; z <= z1; ++z)
-      for (int y = y0; y <= y1; ++y) {
-        const int row = (z * g.dy + y) * g.dx;
-        const int e = g.cell_start[row + x1 + 1];
-        for (int k = g.cell_start[row + x0]; k < e; ++k) {
-          const float4 t = g.pts[k];
-          const float m2 = box_maxdist2(lo, hi, t.x, t.y, t.z);
-          if (m2 < u2) u2 = m2, best = t;
-        }
-      }
-  if (u2 > 1.0e38f) {
-    if (!WRITE) a.count[cidx] = 0;
+  x0 = max((int)floorf((lo[0] - R - g.ox) * g.inv_cell), 0), x1 = min((int)floorf((hi[0] + R - g.ox) * g.inv_cell), g.dx - 1);
+  y0 = max((int)floorf((lo[1] - R - g.oy) * g.inv_cell), 0), y1 = min((int)floorf((hi[1] + R - g.oy) * g.inv_cell), g.dy - 1);
+  z0 = max((int)floorf((lo[2] - R - g.oz) * g.inv_cell), 0), z1 = min((int)floorf((hi[2] + R - g.oz) * g.inv_cell), g.dz - 1);
+}
+__global__ __launch_bounds__(256) void k_cell_list_local_flag(CellListBuildArgs a, GridDev g, int* __restrict__ flag) {
+  const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ncell = a.dx * a.dy * a.dz;
+  if (cidx > ncell) return;
+  if (cidx == ncell) {  // sentinel slot of the scans
+    flag[cidx] = 0;
+    a.count[cidx] = 0;
     return;
   }
+  float lo[3], hi[3];
+  cell_box(a, cidx, lo, hi);
+  int x0, x1, y0, y1, z0, z1;
+  local_ranges(a, g, lo, hi, x0, x1, y0, y1, z0, z1);
+  int any = 0;
+  if (x0 <= x1)
+    for (int z = z0; z <= z1 && !any; ++z)
+      for (int y = y0; y <= y1 && !any; ++y) {
+        const int row = (z * g.dy + y) * g.dx;
+        any = g.cell_start[row + x1 + 1] > g.cell_start[row + x0];
+      }
+  flag[cidx] = any;
+  a.count[cidx] = 0;
+}
+// work[k] = k-th flagged cell (flag_scan = exclusive scan of flag)
+__global__ __launch_bounds__(256) void k_cell_list_local_work(const int* __restrict__ flag, const int* __restrict__ flag_scan, int ncell,
+                                                              int* __restrict__ work) {
+  const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cidx < ncell && flag[cidx]) work[flag_scan[cidx]] = cidx;
+}
+
+// stage 2 (one wave per flagged cell): U(C) over the candidate rows, survivors of the threshold and of the point that
+// realises U(C) into an LDS list, pairwise domination among them, ballot-compacted output.  Lanes own candidate rows.
+#define LOCAL_WCAP 512
+#define LOCAL_KEEP 32  /* results of the counting pass up to this length are replayed by the writing pass */
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, GridDev g, int exist_mode, const int* __restrict__ work, int nwork,
+                                                         int* __restrict__ keep_buf) {
+  __shared__ int list_s[4][LOCAL_WCAP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wi = blockIdx.x * 4 + wave;
+  if (wi >= nwork) return;  // whole waves leave; no block-level barrier below
+  int* list = list_s[wave];
+  const int cidx = work[wi];
+  int* keepw = keep_buf + (size_t)wi * LOCAL_KEEP;
+  if (WRITE) {
+    const int pos = a.start[cidx], cnt = a.start[cidx + 1] - pos;
+    if (cnt == 0) return;
+    if (cnt <= LOCAL_KEEP) {  // replay
+      if (lane < cnt) {
+        const float4 m = g.pts[keepw[lane]];
+        a.pts[pos + lane] = m;
+        if (a.nrm) {
+          const int id = __float_as_int(m.w);
+          a.nrm[pos + lane] = make_float4(a.nx[id], a.ny[id], a.nz[id], 0.f);
+        }
+      }
+      return;
+    }
+  }
+  float lo[3], hi[3];
+  cell_box(a, cidx, lo, hi);
+  int x0, x1, y0, y1, z0, z1;
+  local_ranges(a, g, lo, hi, x0, x1, y0, y1, z0, z1);
+  const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+  // step 1: U(C) and the point that realises it (ties: lowest grid position)
+  float u2 = 3.0e38f;
+  int kb = 0x7fffffff;
+  int maxlen = 0;
+  for (int r = lane; r < nrows; r += 64) {
+    const int row = ((z0 + r / ny) * g.dy + (y0 + r % ny)) * g.dx;
+    const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
+    maxlen = max(maxlen, e - b);
+    for (int k = b; k < e; ++k) {
+      const float4 t = g.pts[k];
+      const float m2 = box_maxdist2(lo, hi, t.x, t.y, t.z);
+      if (m2 < u2 || (m2 == u2 && k < kb)) u2 = m2, kb = k;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ou = __shfl_xor(u2, off);
+    const int ok = __shfl_xor(kb, off);
+    if (ou < u2 || (ou == u2 && ok < kb)) u2 = ou, kb = ok;
+    maxlen = max(maxlen, __shfl_xor(maxlen, off));
+  }
   const int pos = WRITE ? a.start[cidx] : 0;
+  const float4 best = g.pts[kb];
   const float all_r = a.max_dist - a.margin;
   if (exist_mode && all_r > 0.f && sqrtf(u2) * 1.00001f <= all_r) {
-    if (WRITE) a.pts[pos] = best;
-    else a.count[cidx] = 1;
+    if (lane == 0) {
+      if (WRITE) a.pts[pos] = best;
+      else a.count[cidx] = 1, keepw[0] = kb;
+    }
     return;
   }
   const float u = sqrtf(u2) * 1.00001f + a.margin;
   const float th = fminf(u, a.max_dist + a.margin);
   const float thr2 = th * th * 1.00001f;
-  // pass 2: list candidates (mindist <= threshold) that the point realising U(C) does not dominate -- it removes most
-  // of them -- into this lane's LDS column, in grid order
   const double blo[3] = {(double)lo[0] - a.margin, (double)lo[1] - a.margin, (double)lo[2] - a.margin};
   const double bhi[3] = {(double)hi[0] + a.margin, (double)hi[1] + a.margin, (double)hi[2] + a.margin};
-  const int best_id = __float_as_int(best.w);
+  // step 2: survivors of the threshold and of `best`, in (position-in-row, row) order
   int L = 0;
-  for (int z = z0; z <= z1; ++z)
-    for (int y = y0; y <= y1; ++y) {
-      const int row = (z * g.dy + y) * g.dx;
-      const int e = g.cell_start[row + x1 + 1];
-      for (int k = g.cell_start[row + x0]; k < e; ++k) {
+  for (int r0 = 0; r0 < nrows; r0 += 64) {
+    const int r = r0 + lane;
+    int b = 0, e = 0;
+    if (r < nrows) {
+      const int row = ((z0 + r / ny) * g.dy + (y0 + r % ny)) * g.dx;
+      b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
+    }
+    for (int j = 0; j < maxlen; ++j) {
+      const int k = b + j;
+      bool in = false;
+      if (k < e) {
         const float4 t = g.pts[k];
-        if (!(box_mindist2(lo, hi, t.x, t.y, t.z) <= thr2)) continue;
-        if (__float_as_int(t.w) != best_id && dominates(best, t, blo, bhi, a.dom_eps)) continue;
-        if (L < LOCAL_LCAP) cand[L * 64 + lane] = t;
-        ++L;
+        in = box_mindist2(lo, hi, t.x, t.y, t.z) <= thr2 && (k == kb || !dominates(best, t, blo, bhi, a.dom_eps));
       }
+      const unsigned long long m = __ballot(in);
+      if (in) {
+        const int at = L + __popcll(m & ((1ull << lane) - 1ull));
+        if (at < LOCAL_WCAP) list[at] = k;
+      }
+      L += __popcll(m);
     }
-  int kept = 0;
-  if (L <= LOCAL_LCAP) {
-    // pass 3: domination among the survivors
-    for (int i = 0; i < L; ++i) {
-      const float4 m = cand[i * 64 + lane];
-      bool dominated = false;
-      for (int j = 0; j < L && !dominated; ++j)
-        if (j != i) dominated = dominates(cand[j * 64 + lane], m, blo, bhi, a.dom_eps);
-      if (dominated) continue;
-      if (WRITE) {
-        a.pts[pos + kept] = m;
-        if (a.nrm) {
-          const int id = __float_as_int(m.w);
-          a.nrm[pos + kept] = make_float4(a.nx[id], a.ny[id], a.nz[id], 0.f);
-        }
-      }
-      ++kept;
-    }
-  } else {  // more survivors than the LDS column holds (not seen at the sizes built here): keep them all
-    for (int z = z0; z <= z1; ++z)
-      for (int y = y0; y <= y1; ++y) {
-        const int row = (z * g.dy + y) * g.dx;
-        const int e = g.cell_start[row + x1 + 1];
-        for (int k = g.cell_start[row + x0]; k < e; ++k) {
-          const float4 t = g.pts[k];
-          if (!(box_mindist2(lo, hi, t.x, t.y, t.z) <= thr2)) continue;
-          if (__float_as_int(t.w) != best_id && dominates(best, t, blo, bhi, a.dom_eps)) continue;
-          if (WRITE) {
-            a.pts[pos + kept] = t;
-            if (a.nrm) {
-              const int id = __float_as_int(t.w);
-              a.nrm[pos + kept] = make_float4(a.nx[id], a.ny[id], a.nz[id], 0.f);
-            }
-          }
-          ++kept;
-        }
-      }
   }
-  if (!WRITE) a.count[cidx] = kept;
+  __builtin_amdgcn_wave_barrier();
+  int kept = 0;
+  if (L <= LOCAL_WCAP) {
+    // step 3a: a few rounds of pruning against the next-closest survivor (by farthest-corner distance): these remove
+    // almost everything that pairwise testing would, at O(L) per round.  Removed entries are marked ~k.
+    float pm2 = u2;
+    int pk = kb;
+    for (int round = 0; round < 12 && L > 8; ++round) {
+      float c2 = 3.0e38f;
+      int ck = 0x7fffffff;
+      for (int i = lane; i < L; i += 64) {
+        const int k = list[i];
+        if (k < 0) continue;
+        const float4 t = g.pts[k];
+        const float m2 = box_maxdist2(lo, hi, t.x, t.y, t.z);
+        const bool after = m2 > pm2 || (m2 == pm2 && k > pk);  // pivots advance in (m2, k) order
+        if (after && (m2 < c2 || (m2 == c2 && k < ck))) c2 = m2, ck = k;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float oc = __shfl_xor(c2, off);
+        const int ok = __shfl_xor(ck, off);
+        if (oc < c2 || (oc == c2 && ok < ck)) c2 = oc, ck = ok;
+      }
+      if (ck == 0x7fffffff) break;
+      pm2 = c2, pk = ck;
+      const float4 pv = g.pts[ck];
+      for (int i = lane; i < L; i += 64) {
+        const int k = list[i];
+        if (k < 0 || k == ck) continue;
+        if (dominates(pv, g.pts[k], blo, bhi, a.dom_eps)) list[i] = ~k;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // compact the survivors (order preserved)
+    int L2 = 0;
+    for (int i0 = 0; i0 < L; i0 += 64) {
+      const int i = i0 + lane;
+      const int k = i < L ? list[i] : -1;
+      const unsigned long long m = __ballot(k >= 0);
+      __builtin_amdgcn_wave_barrier();
+      if (k >= 0) list[L2 + __popcll(m & ((1ull << lane) - 1ull))] = k;
+      L2 += __popcll(m);
+      __builtin_amdgcn_wave_barrier();
+    }
+    L = L2;
+    // step 3b: pairwise domination among what is left
+    for (int i0 = 0; i0 < L; i0 += 64) {
+      const int i = i0 + lane;
+      bool keep = false;
+      float4 m = make_float4(0, 0, 0, 0);
+      int km = -1;
+      if (i < L) {
+        km = list[i];
+        m = g.pts[km];
+        keep = true;
+        for (int j = 0; j < L && keep; ++j)
+          if (j != i) keep = !dominates(g.pts[list[j]], m, blo, bhi, a.dom_eps);
+      }
+      const unsigned long long kmask = __ballot(keep);
+      if (keep) {
+        const int n = kept + __popcll(kmask & ((1ull << lane) - 1ull));
+        if (WRITE) {
+          a.pts[pos + n] = m;
+          if (a.nrm) {
+            const int id = __float_as_int(m.w);
+            a.nrm[pos + n] = make_float4(a.nx[id], a.ny[id], a.nz[id], 0.f);
+          }
+        } else if (n < LOCAL_KEEP) keepw[n] = km;
+      }
+      kept += __popcll(kmask);
+    }
+  } else {
+    // more survivors than the list holds (not seen at the sizes built here): keep them all, same order as step 2
+    for (int r0 = 0; r0 < nrows; r0 += 64) {
+      const int r = r0 + lane;
+      int b = 0, e = 0;
+      if (r < nrows) {
+        const int row = ((z0 + r / ny) * g.dy + (y0 + r % ny)) * g.dx;
+        b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
+      }
+      for (int j = 0; j < maxlen; ++j) {
+        const int k = b + j;
+        bool in = false;
+        float4 t = make_float4(0, 0, 0, 0);
+        if (k < e) {
+          t = g.pts[k];
+          in = box_mindist2(lo, hi, t.x, t.y, t.z) <= thr2 && (k == kb || !dominates(best, t, blo, bhi, a.dom_eps));
+        }
+        const unsigned long long m = __ballot(in);
+        if (WRITE && in) {
+          const int at = pos + kept + __popcll(m & ((1ull << lane) - 1ull));
+          a.pts[at] = t;
+          if (a.nrm) {
+            const int id = __float_as_int(t.w);
+            a.nrm[at] = make_float4(a.nx[id], a.ny[id], a.nz[id], 0.f);
+          }
+        }
+        kept += __popcll(m);
+      }
+    }
+    if (!WRITE && kept <= LOCAL_KEEP) kept = LOCAL_KEEP + 1;  // unreachable in practice (L > LOCAL_WCAP); never replay this path
+  }
+  if (!WRITE && lane == 0) a.count[cidx] = kept;
 }
-template __global__ void k_cell_list_local<false>(CellListBuildArgs, GridDev, int);
-template __global__ void k_cell_list_local<true>(CellListBuildArgs, GridDev, int);
+template __global__ void k_cell_list_local<false>(CellListBuildArgs, GridDev, int, const int*, int, int*);
+template __global__ void k_cell_list_local<true>(CellListBuildArgs, GridDev, int, const int*, int, int*);
 
 // Scan of one cell list.  The candidates are ranked by their squared distance to the query IN THE CLOUD'S REST FRAME
 // (qg, 8 flops each); the reference's distance expression -- query against the candidate moved by T, in the query's
@@ -1500,7 +1638,16 @@ __global__ __launch_bounds__(256) void k_pso_match(PsoArgs a) {
       qn[r] = v3(0, 0, 0);
     }
   }
-  if (a.use_grid) {
+  if (a.use_grid == 2) {
+    // NN cell lists of the hand scene (max_dist = dist_thres): the list position is turned back into the scene index
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int j = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+      int pos = -1;
+      if (j < a.nm) cells_nn_plain(a.scene_cells, q[r], best[r], pos);
+      if (pos >= 0) bidx[r] = __float_as_int(a.scene_cells.pts[pos].w);
+    }
+  } else if (a.use_grid) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int j = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
@@ -1537,20 +1684,31 @@ template __global__ void k_pso_match<2>(PsoArgs);
 
 __global__ __launch_bounds__(256) void k_pso_outer(PsoArgs a) {
   // lanes = particles (each keeps its inverse transform in registers), the block walks a tile of scene points;
-  // terms are stored point-major so that both this kernel and the sequential sum access them coalesced.
+  // terms are stored as float4 groups of four consecutive points per particle, [point/4][particle][point%4], so that
+  // this kernel writes and the sequential sum reads 16 bytes per lane, coalesced.
   const int p = blockIdx.y * blockDim.x + threadIdx.x;
   const bool live = p < a.n_particles && !a.particles[min(p, a.n_particles - 1)].skip;
   float Ti[12];
   for (int k = 0; k < 12; ++k) Ti[k] = live ? a.particles[p].Tinv[k] : 0.f;
-  const int per = (a.n_swivel + gridDim.x - 1) / gridDim.x;
-  const int i0 = blockIdx.x * per, i1 = min(a.n_swivel, i0 + per);
-  for (int i = i0; i < i1; ++i) {
-    const V3 pt = m4_point(Ti, v3(a.wx[i], a.wy[i], a.wz[i]));
-    int bin = (int)(fmaxf(pt.z - a.fp_min_z, 0.0f) / a.fp_stride_z);  // FingerProperty::getBinAlongZ, Hand.cpp:244-250
-    bin = max(bin, 0);
-    bin = min(bin, a.fp_num_division - 1);
-    const float lim = a.hist_min_y[bin];
-    if (live) a.outer_terms[(size_t)i * a.n_particles + p] = (pt.y >= lim) ? -1.f : fabsf(pt.y - lim);
+  const int groups = (a.n_swivel + 3) / 4;
+  const int per = (groups + gridDim.x - 1) / gridDim.x;
+  const int g0 = blockIdx.x * per, g1 = min(groups, g0 + per);
+  for (int gi = g0; gi < g1; ++gi) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = 4 * gi + u;
+      v[u] = -1.f;  // padding behind the last point: "no contribution"
+      if (i < a.n_swivel) {
+        const V3 pt = m4_point(Ti, v3(a.wx[i], a.wy[i], a.wz[i]));
+        int bin = (int)(fmaxf(pt.z - a.fp_min_z, 0.0f) / a.fp_stride_z);  // FingerProperty::getBinAlongZ, Hand.cpp:244-250
+        bin = max(bin, 0);
+        bin = min(bin, a.fp_num_division - 1);
+        const float lim = a.hist_min_y[bin];
+        v[u] = (pt.y >= lim) ? -1.f : fabsf(pt.y - lim);
+      }
+    }
+    if (live) reinterpret_cast<float4*>(a.outer_terms)[(size_t)gi * a.n_particles + p] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -1560,27 +1718,28 @@ __global__ __launch_bounds__(64) void k_pso_outer_sum(PsoArgs a, int n_particles
   if (a.particles[p].skip) return;
   float sum = 0.f;
   int cnt = 0;
-  // the additions stay in scene order (bit-equal to the CPU loop); the loads are issued 32 at a time so that
-  // their latency overlaps instead of serialising the loop
-  constexpr int U = 32;
-  int i = 0;
-  for (; i + U <= a.n_swivel; i += U) {
-    float v[U];
+  // The additions stay in scene order (bit-equal to the CPU loop).  Skipped terms (marker -1, or NaN) are added as
+  // +0, which leaves the non-negative running sum unchanged, so the dependent chain is one v_add per point.  Four
+  // waves are all this launch has, so memory latency is its whole cost: 48 x 16-byte loads are kept in flight per lane.
+  constexpr int U = 48;
+  const float4* t = reinterpret_cast<const float4*>(a.outer_terms) + p;
+  const int groups = (a.n_swivel + 3) / 4;
+  auto add = [&](float v) {
+    const bool in = v >= 0.f;
+    sum += in ? v : 0.f;
+    cnt += in ? 1 : 0;
+  };
+  int gi = 0;
+  for (; gi + U <= groups; gi += U) {
+    float4 v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = a.outer_terms[(size_t)(i + u) * n_particles + p];
+    for (int u = 0; u < U; ++u) v[u] = t[(size_t)(gi + u) * n_particles];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (v[u] >= 0.f) {
-        sum += v[u];
-        ++cnt;
-      }
+    for (int u = 0; u < U; ++u) add(v[u].x), add(v[u].y), add(v[u].z), add(v[u].w);
   }
-  for (; i < a.n_swivel; ++i) {
-    const float v = a.outer_terms[(size_t)i * n_particles + p];
-    if (v >= 0.f) {
-      sum += v;
-      ++cnt;
-    }
+  for (; gi < groups; ++gi) {
+    const float4 v = t[(size_t)gi * n_particles];
+    add(v.x), add(v.y), add(v.z), add(v.w);
   }
   a.outer_sum[p] = sum;
   a.outer_cnt[p] = cnt;
@@ -1677,11 +1836,20 @@ void launch_cell_list_count(const CellListBuildArgs& a, hipStream_t s) {
 void launch_cell_list_fill(const CellListBuildArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_cell_list_build<true>, dim3(a.dx * a.dy * a.dz), dim3(64), 0, s, a);
 }
-void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool write, int exist_mode, hipStream_t s) {
-  const int n = a.dx * a.dy * a.dz;
-  if (write) hipLaunchKernelGGL(k_cell_list_local<true>, dim3((n + 63) / 64), dim3(64), 0, s, a, g, exist_mode);
-  else hipLaunchKernelGGL(k_cell_list_local<false>, dim3((n + 63) / 64), dim3(64), 0, s, a, g, exist_mode);
+void launch_cell_list_local_flag(const CellListBuildArgs& a, const GridDev& g, int* flag, hipStream_t s) {
+  const int n = a.dx * a.dy * a.dz + 1;
+  hipLaunchKernelGGL(k_cell_list_local_flag, dim3((n + 255) / 256), dim3(256), 0, s, a, g, flag);
 }
+void launch_cell_list_local_work(const int* flag, const int* flag_scan, int ncell, int* work, hipStream_t s) {
+  hipLaunchKernelGGL(k_cell_list_local_work, dim3((ncell + 255) / 256), dim3(256), 0, s, flag, flag_scan, ncell, work);
+}
+void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool write, int exist_mode, const int* work, int nwork, int* keep_buf,
+                            hipStream_t s) {
+  if (nwork <= 0) return;
+  if (write) hipLaunchKernelGGL(k_cell_list_local<true>, dim3((nwork + 3) / 4), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
+  else hipLaunchKernelGGL(k_cell_list_local<false>, dim3((nwork + 3) / 4), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
+}
+int cell_list_local_keep() { return LOCAL_KEEP; }
 void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s) {
   const int nb = (a.ns + 255) / 256;
   hipLaunchKernelGGL(k_lcp_cells, dim3((unsigned)(nb * ((hb + 7) / 8) * 8)), dim3(256), 0, s, a, hb, nb);
