@@ -35,8 +35,8 @@ VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak, same guide
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", type=int, default=20000)
     ap.add_argument("--model", type=int, default=5000)
     ap.add_argument("--bases", type=int, default=2048)
@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--hand-scene", type=int, default=20000)
     ap.add_argument("--verify-mode", type=int, default=2, help="0 brute-force LDS scan, 1 voxel grid, 2 EXIST-mode cell lists (identical counts)")
     ap.add_argument("--nn-mode", type=int, default=2, help="ICP / computeLCP nearest neighbour: 0 brute force, 1 voxel grid, 2 NN cell lists for ICP (identical results)")
+    ap.add_argument("--inflight", type=int, default=2, help="frames in flight per GPU (one context each): the host base selection of one "
+                    "frame overlaps the device work of the others; 1 = strictly one frame at a time")
+    ap.add_argument("--no-serial-frame", action="store_true", help="skip the extra undisturbed frame used for per-kernel timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     return ap.parse_args()
@@ -59,6 +62,8 @@ TRUE_ANGLES = {"finger_1_1": math.radians(10), "finger_1_2": math.radians(6), "f
 
 
 class Workload:
+    """Host-side inputs of the frame (shared) and one device context per frame in flight."""
+
     def __init__(self, args, rank):
         import hop_loader
         self.hop = hop_loader.load()
@@ -73,24 +78,26 @@ class Workload:
         self.hand = synth.t42_hand()
         self.hxyz, self.hnrm = synth.make_hand_scene(self.hand, TRUE_ANGLES, args.hand_scene, seed=5)
         self.swivel = self.hxyz[self.hxyz[:, 0] < -0.1]
+        self.slots = []
 
-    def setup_device(self, device):
+    def setup_device(self, device, n_slots=1):
         api = self.api
-        self.ctx = api.Context(device)
-        c = self.ctx
-        c.set_scene(self.sc.xyz, self.sc.nrm, self.sc.conf, 0.8)
-        c.set_model(api.HOP_MODEL_5MM, *self.model)
-        c.set_model(api.HOP_MODEL_1MM, *self.model)
-        c.set_ppf_keys(self.keys)
         CFG["hand_match"]["pso"]["n_pop"] = self.args.particles
-        self.handt42 = api.HandT42(CFG, self.hand, ctx=c)
-        self.handt42.gripper_min_dist = 0.0144
-        self.handt42.setCurScene(self.hxyz, self.hnrm, self.swivel)
-        self.opts = c.default_s4pcs_opts(sample_size=100, success_quadrilaterals=self.args.bases, max_time_seconds=0,
-                                         n_trials=self.args.bases, random_seed=5489 + self.rank, verify_mode=self.args.verify_mode)
+        for _ in range(n_slots):
+            c = api.Context(device)
+            c.set_scene(self.sc.xyz, self.sc.nrm, self.sc.conf, 0.8)
+            c.set_model(api.HOP_MODEL_5MM, *self.model)
+            c.set_model(api.HOP_MODEL_1MM, *self.model)
+            c.set_ppf_keys(self.keys)
+            h = api.HandT42(CFG, self.hand, ctx=c)
+            h.gripper_min_dist = 0.0144
+            h.setCurScene(self.hxyz, self.hnrm, self.swivel)
+            opts = c.default_s4pcs_opts(sample_size=100, success_quadrilaterals=self.args.bases, max_time_seconds=0,
+                                        n_trials=self.args.bases, random_seed=5489 + self.rank, verify_mode=self.args.verify_mode)
+            self.slots.append(dict(ctx=c, hand=h, opts=opts))
+        self.ctx = self.slots[0]["ctx"]
 
-    def hand_search(self):
-        h = self.handt42
+    def hand_search(self, h):
         for name in h._tf_self:
             h._tf_self[name] = np.eye(4, dtype=np.float32)
         # order of main_realdata_auto.cpp:114-139 (camera on the finger-2 side)
@@ -102,26 +109,29 @@ class Workload:
             h.matchOneComponentPSO("finger_1_2", 0, 90, True, 0.005, 60, 5)
         return m1, m2
 
-    def step(self):
-        c = self.ctx
+    def step(self, slot=0, topk=0, id_offset=0):
+        """One frame on one context.  Returns the stage times and, if topk > 0, the packed top-k table."""
+        S = self.slots[slot]
+        c, h = S["ctx"], S["hand"]
         tf = time.perf_counter()
         # a new frame arrives: both clouds are handed over again, so every per-frame structure derived from them
-        # (Morton order, voxel grids, NN cell lists of the scene, Verify lists, hand-scene grid) is rebuilt inside the step
+        # (Morton order, voxel grids, NN cell lists of the scene, Verify lists, hand-scene lists) is rebuilt inside the step
         c.set_scene(self.sc.xyz, self.sc.nrm, self.sc.conf, 0.8)
-        self.handt42.setCurScene(self.hxyz, self.hnrm, self.swivel)
+        h.setCurScene(self.hxyz, self.hnrm, self.swivel)
         t0 = time.perf_counter()
-        self.hand_search()
+        self.hand_search(h)
         t1 = time.perf_counter()
-        _, _, st = c.s4pcs_generate(self.opts, download=False)
+        _, _, st = c.s4pcs_generate(S["opts"], download=False)
         t2 = time.perf_counter()
         c.hypos_keep_topk(self.args.hyps)
-        h = c.hypos_count()
-        c.icp_refine(10, 45.0, 0.01, nn_mode=self.args.nn_mode)
-        c.synchronize()
+        hh = c.hypos_count()
+        it, _ = c.icp_refine(10, 45.0, 0.01, nn_mode=self.args.nn_mode, want_stats=True)
         t3 = time.perf_counter()
         best, score, idx = c.lcp_select_best(0.001, 10.0, self.args.nn_mode)
         t4 = time.perf_counter()
-        return dict(h=h, h_gen=st.n_hypotheses, n_cand=st.n_candidates, n_bases=st.n_bases, best=best, score=score,
+        rows = c.topk_pack(topk, id_offset=id_offset)[0] if topk > 0 else None
+        return dict(h=hh, h_gen=st.n_hypotheses, n_cand=st.n_candidates, n_bases=st.n_bases, best=best, score=score,
+                    icp_hyp_iters=int(np.sum(it)), n_pairs=st.n_pairs, n_quads=st.n_quads, rows=rows,
                     t_frame=t0 - tf, t_pso=t1 - t0, t_gen=t2 - t1, t_icp=t3 - t2, t_lcp=t4 - t3, ms_select=st.ms_select)
 
 
@@ -162,6 +172,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import threading
     import torch
     dist = None
     if world > 1:
@@ -173,13 +184,13 @@ def main():
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    F = max(1, args.inflight)
     w = Workload(args, rank)
-    w.setup_device(local_rank)
+    w.setup_device(local_rank, F)
     api = w.api
     K = 128  # rows of the exchanged top-k table
 
-    def exchange():
-        rows, n = w.ctx.topk_pack(K, id_offset=rank * (1 << 24))
+    def exchange(rows):
         if world == 1:
             return rows
         t = torch.from_numpy(rows).to(dev)
@@ -189,27 +200,75 @@ def main():
         return merged
 
     def barrier():
-        w.ctx.synchronize()
+        for S in w.slots:
+            S["ctx"].synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        w.step()
-        exchange()
-    w.ctx.timing_enable(True)
-    w.ctx.timing_reset()
+    def run_frames(n):
+        """n frames, F in flight: worker s runs frames s, s+F, ... on its own context (host selection of one frame
+        overlaps device work of the others); the main thread performs the per-frame exchange in frame order."""
+        infos = [None] * n
+        ready = [threading.Event() for _ in range(n)]
+        errors = []
+
+        def worker(slot):
+            try:
+                for f in range(slot, n, F):
+                    infos[f] = w.step(slot, K, rank * (1 << 24))
+                    ready[f].set()
+            except BaseException as e:  # surface the failure in the main thread
+                errors.append(e)
+                for ev in ready:
+                    ev.set()
+
+        threads = [threading.Thread(target=worker, args=(s,)) for s in range(min(F, n))]
+        for t in threads:
+            t.start()
+        table = None
+        for f in range(n):
+            ready[f].wait()
+            if errors:
+                break
+            table = exchange(infos[f]["rows"])
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return infos, table
+
+    if args.warmup > 0:
+        run_frames(F * ((args.warmup + F - 1) // F))   # every context sees at least one warm-up frame
+    for S in w.slots:
+        S["ctx"].timing_enable(True)
+        S["ctx"].timing_reset()
     barrier()
     t0 = time.perf_counter()
-    infos = []
-    for _ in range(args.steps):
-        infos.append(w.step())
-        table = exchange()
+    infos, table = run_frames(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    tm = w.ctx.timing_get()
-    w.ctx.timing_enable(False)
+    tm = {}
+    for S in w.slots:
+        for k, v in S["ctx"].timing_get().items():
+            tm[k] = tm.get(k, 0) + v
+        S["ctx"].timing_enable(False)
+
+    # With several frames in flight the event spans of one frame's kernels include time spent sharing the device with
+    # the other frame's kernels.  One more frame is therefore run ALONE, after the timed region (it does not enter
+    # `value`), to measure every kernel undisturbed; both measurements are reported.
+    tm_serial, info_serial = None, None
+    if F > 1 and not args.no_serial_frame:
+        c0 = w.slots[0]["ctx"]
+        c0.timing_enable(True)
+        c0.timing_reset()
+        info_serial = w.step(0, K, rank * (1 << 24))
+        c0.synchronize()
+        tm_serial = c0.timing_get()
+        c0.timing_enable(False)
+        if world > 1:
+            exchange(info_serial["rows"])   # keep the collective sequence identical on every rank
 
     h_local = sum(i["h"] for i in infos)
     if world > 1:
@@ -225,37 +284,46 @@ def main():
     if rank == 0:
         N, M = w.ctx.L.hop_scene_size(w.ctx.h), args.model
         steps = max(args.steps, 1)
-        # dominant kernel: the one with the largest share of device time
-        kern = {
-            "k_lcp_forward": (tm["ms_lcp_fwd"], tm["n_lcp_launches"]),
-            "k_lcp_reverse": (tm["ms_lcp_rev"], tm["n_lcp_launches"]),
-            "k_icp_nn": (tm["ms_icp_nn"], tm["n_icp_nn_launches"]),
-            "k_verify": (tm["ms_verify"], tm["n_verify_launches"]),
-        }
-        dom = max(kern, key=lambda k: kern[k][0])
-        ms_dom, n_dom = kern[dom]
         H = infos[-1]["h"]
-        bytes_per_hyp = 24 * (N + M) + 72                     # SoA xyz+normal of both clouds once, pose in, score out
-        flops_per_hyp_pass = 8 * N * M + 18 * M + 30 * N      # one brute-force NN pass
-        if dom.startswith("k_lcp"):
-            hyps_per_launch = H * steps / max(n_dom, 1)
-            passes = 1.0
-        elif dom == "k_icp_nn":
-            hyps_per_launch = H * steps / max(n_dom, 1)        # upper bound: converged hypotheses exit early
-            passes = 1.0
-        else:
-            hyps_per_launch = sum(i["n_cand"] for i in infos) / max(n_dom, 1)
-            passes = 1.0
-        avg_ms = ms_dom / max(n_dom, 1)
-        if dom == "k_verify":
-            nq = 100
-            alg_bytes = hyps_per_launch * (12 * (N + nq) + 64 + 4)
-            alg_flops = hyps_per_launch * (8.0 * N * nq)
-        else:
-            alg_bytes = hyps_per_launch * bytes_per_hyp
-            alg_flops = hyps_per_launch * flops_per_hyp_pass * passes
-        ach_gbs = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        ach_tf = alg_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        nq = 100
+        bytes_per_hyp = 24 * (N + M) + 72                      # SoA xyz+normal of both clouds once, pose in, score out
+        flops_per_hyp = 8 * N * M + 18 * M + 30 * N             # one brute-force NN pass (the reference's work per hypothesis)
+        def kernel_table(tmx, frames):
+            """per kernel: (device ms, launches, algorithmic bytes, brute-force-equivalent flops) over `frames`"""
+            nf = len(frames)
+            hyp_iters = sum(i["icp_hyp_iters"] for i in frames)     # hypothesis-iterations ICP actually ran
+            n_cand = sum(i["n_cand"] for i in frames)
+            kern = {
+                "k_icp_corr_cells": (tmx["ms_icp_nn"], tmx["n_icp_nn_launches"], hyp_iters * bytes_per_hyp, hyp_iters * flops_per_hyp),
+                "k_icp_accum": (tmx["ms_icp_accum"], tmx["n_icp_nn_launches"], hyp_iters * bytes_per_hyp, 0.0),
+                "k_lcp_cells": (tmx["ms_lcp_fwd"] + tmx["ms_lcp_rev"], tmx["n_lcp_launches"], H * nf * bytes_per_hyp, 2.0 * H * nf * flops_per_hyp),
+                "k_lcp_sum": (tmx["ms_lcp_sum"], tmx["n_lcp_launches"], H * nf * (8 * N + 4), 0.0),
+                "k_verify_cells": (tmx["ms_verify"], tmx["n_verify_launches"], n_cand * (12 * (N + nq) + 68), n_cand * 8.0 * N * nq),
+                "k_quads": (tmx["ms_quads"], tmx["n_quads_launches"],
+                            sum(i["n_pairs"] for i in frames) * 8 + sum(i["n_quads"] for i in frames) * 36 + n_cand * 88, 0.0),
+                "k_ppf_matrix": (tmx["ms_ppf_matrix"], nf, nf * (24 * N + N * N / 8), 0.0),
+            }
+            if args.nn_mode < 2:
+                kern["k_icp_nn"] = kern.pop("k_icp_corr_cells")
+                kern.pop("k_icp_accum")
+            return kern
+
+        def roofline_of(kern, dom, frames):
+            ms_dom, n_dom, alg_bytes_total, alg_flops_total = kern[dom]
+            avg_ms = ms_dom / max(n_dom, 1)
+            alg_bytes = alg_bytes_total / max(n_dom, 1)
+            ach_gbs = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            ach_tf = alg_flops_total / max(n_dom, 1) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            nf = max(len(frames), 1)
+            return {"kernel": dom, "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
+                    "avg_launch_ms": avg_ms, "launches": n_dom, "algorithmic_bytes_per_launch": alg_bytes,
+                    "brute_force_equivalent_fp32_TFLOPs": ach_tf,
+                    "per_kernel": {k: {"ms_per_frame": v[0] / nf, "launches_per_frame": v[1] / nf,
+                                       "algorithmic_GBps": (v[2] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else 0.0)} for k, v in kern.items()}}
+
+        kern = kernel_table(tm, infos)
+        dom = max(kern, key=lambda k: kern[k][0])
+        roof = roofline_of(kern, dom, infos)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
@@ -263,6 +331,19 @@ def main():
                 traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        roof = {"bound": "hbm", **roof, "traffic": traffic,
+                "definition": "achieved = algorithmic bytes per launch (SURVEY.md 8(d): 24*(N+M)+72 B per hypothesis and NN pass, x the "
+                              "hypotheses -- for ICP the hypothesis-iterations -- one launch processes) / mean launch duration from HIP events "
+                              "on the context stream over the timed region",
+                "brute_force_note": "flops the reference's brute-force NN would spend on the same units; the cell-list kernels do ~1e-3 of "
+                                    "them, so brute_force_equivalent_fp32_TFLOPs (peak %.1f) is a speed-up measure, not a utilisation" % VALU_PEAK_TFLOPS}
+        if tm_serial is not None:
+            ks = kernel_table(tm_serial, [info_serial])
+            roof["serial_frame"] = {"note": "same kernels measured on one extra frame run alone after the timed region "
+                                            "(frames_in_flight > 1 stretches the spans above by cross-frame sharing of the device)",
+                                    **roofline_of(ks, dom, [info_serial])}
+        hyp_iters = sum(i["icp_hyp_iters"] for i in infos)
+        stage = lambda key: 1e3 * float(np.mean([i[key] for i in infos]))
         out = {
             "metric": "pose hypotheses/sec (gen+ICP+LCP) per frame",
             "value": h_total / elapsed,
@@ -277,18 +358,16 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "C2: ellipse, 2048 Super4PCS base trials + 200-particle hand search, 20k-pt scene / 5k-pt model",
-                       "scene_points": N, "model_points": M, "base_trials": args.bases, "sample_size": 100,
+                       "scene_points": N, "model_points": M, "base_trials": args.bases, "sample_size": nq,
                        "hypotheses_scored_per_rank": H, "pso_particles": args.particles, "hand_scene_points": args.hand_scene,
-                       "verify_mode": args.verify_mode, "nn_mode": args.nn_mode, "parallelism": f"hypothesis-parallel x{world}, all-gather top-{K}"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": n_dom,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "valu_fp32": {"achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / VALU_PEAK_TFLOPS,
-                                       "note": "brute-force NN is FP32-VALU bound (~1300 flop/B); both fractions reported, SURVEY.md 8(d)"}},
-            "stage_ms_per_step": {"frame_handover": 1e3 * np.mean([i["t_frame"] for i in infos]), "pso": 1e3 * np.mean([i["t_pso"] for i in infos]), "generate": 1e3 * np.mean([i["t_gen"] for i in infos]),
-                                  "generate_host_select": float(np.mean([i["ms_select"] for i in infos])),
-                                  "icp": 1e3 * np.mean([i["t_icp"] for i in infos]), "lcp": 1e3 * np.mean([i["t_lcp"] for i in infos])},
+                       "verify_mode": args.verify_mode, "nn_mode": args.nn_mode, "frames_in_flight": F,
+                       "parallelism": f"hypothesis-parallel x{world}, all-gather top-{K}"},
+            "roofline": roof,
+            "stage_ms_per_frame": {"frame_handover": stage("t_frame"), "pso": stage("t_pso"), "generate": stage("t_gen"),
+                                   "generate_host_select": float(np.mean([i["ms_select"] for i in infos])),
+                                   "icp": stage("t_icp"), "lcp": stage("t_lcp")},
             "device_ms_total": {k: v for k, v in tm.items() if k.startswith("ms_")},
+            "icp_hypothesis_iterations_per_step": hyp_iters / steps,
             "hypotheses_generated_per_step": infos[-1]["h_gen"], "candidates_verified_per_step": infos[-1]["n_cand"],
             "best_lcp_score": infos[-1]["score"],
         }

@@ -81,7 +81,8 @@ class Timing(C.Structure):
                 ("ms_pso", C.c_double), ("ms_ppf_matrix", C.c_double), ("n_verify_launches", C.c_longlong),
                 ("n_icp_nn_launches", C.c_longlong), ("n_lcp_launches", C.c_longlong), ("n_pso_launches", C.c_longlong),
                 ("pairs_verify", C.c_longlong), ("pairs_icp", C.c_longlong), ("pairs_lcp", C.c_longlong),
-                ("pairs_pso", C.c_longlong)]
+                ("pairs_pso", C.c_longlong), ("ms_icp_accum", C.c_double), ("ms_lcp_sum", C.c_double), ("ms_quads", C.c_double),
+                ("ms_build", C.c_double), ("n_quads_launches", C.c_longlong), ("n_build_launches", C.c_longlong)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

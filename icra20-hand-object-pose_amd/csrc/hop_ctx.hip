@@ -111,7 +111,7 @@ struct CloudDevice {
   const float* plane(int k) const { return buf.as<float>() + (size_t)k * n; }
 };
 
-enum TimeCat { T_VERIFY = 0, T_GEN_OTHER, T_ICP_NN, T_ICP_SOLVE, T_LCP_FWD, T_LCP_REV, T_PSO, T_PPF, T_NCAT };
+enum TimeCat { T_VERIFY = 0, T_GEN_OTHER, T_ICP_NN, T_ICP_SOLVE, T_LCP_FWD, T_LCP_REV, T_PSO, T_PPF, T_ICP_ACCUM, T_LCP_SUM, T_QUADS, T_BUILD, T_NCAT };
 
 struct TimedSpan {
   hipEvent_t a, b;
@@ -249,6 +249,10 @@ void resolve_spans(hop_ctx* c) {
       case T_LCP_REV: slot = &c->timing.ms_lcp_rev; break;
       case T_PSO: slot = &c->timing.ms_pso; break;
       case T_PPF: slot = &c->timing.ms_ppf_matrix; break;
+      case T_ICP_ACCUM: slot = &c->timing.ms_icp_accum; break;
+      case T_LCP_SUM: slot = &c->timing.ms_lcp_sum; break;
+      case T_QUADS: slot = &c->timing.ms_quads; break;
+      case T_BUILD: slot = &c->timing.ms_build; break;
     }
     if (slot) *slot += ms;
     c->event_pool.push_back(s.a);
@@ -391,6 +395,8 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   a.count = cs.count_d.as<int>();
   int* flag = cs.u2_d.as<int>();
   int* scan = cs.start_d.as<int>();
+  c->timing.n_build_launches += 1;
+  SpanGuard sg_build(c, T_BUILD);
   // stage 1: flag cells with candidates, compact them (in cell order) into a work list
   launch_cell_list_local_flag(a, g, flag, c->stream);
   size_t tmp_bytes = 0;
@@ -888,7 +894,11 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
       qa.cands = c->cands_d.as<Candidate>(), qa.cand_counts = c->cand_counts_d.as<int>(), qa.cand_count = counters, qa.cand_cap = cand_cap;
       qa.nquads = nquads_all + batch_first_trace;
       qa.overflow = counters + 2;
-      launch_quads(qa, nb, 64, c->stream);
+      {
+        SpanGuard sq(c, T_QUADS);
+        launch_quads(qa, nb, 64, c->stream);
+      }
+      c->timing.n_quads_launches += 1;
     }
     VerifyArgs va{};
     va.px = c->gp_d.plane(0), va.py = c->gp_d.plane(1), va.pz = c->gp_d.plane(2), va.np = N;
@@ -1195,9 +1205,12 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
         SpanGuard sg(c, T_ICP_NN);
         if (cells) {
           launch_icp_corr_cells(a, hb, c->stream);
-          launch_icp_accum(a, hb, c->stream);
         } else if (o->nn_mode == 1) launch_icp_nn_grid(a, hb, c->stream);
         else launch_icp_nn(a, hb, c->stream);
+      }
+      if (cells) {
+        SpanGuard sg(c, T_ICP_ACCUM);
+        launch_icp_accum(a, hb, c->stream);
       }
       {
         SpanGuard sg(c, T_ICP_SOLVE);
@@ -1289,7 +1302,10 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
         launch_lcp_forward(a, hb, c->stream);
       }
     }
-    launch_lcp_sum(a, hb, c->stream);
+    {
+      SpanGuard sg(c, T_LCP_SUM);
+      launch_lcp_sum(a, hb, c->stream);
+    }
     c->timing.n_lcp_launches += 1;
   }
   c->timing.pairs_lcp += 2ll * H * (long long)S.n * Mo.n;

@@ -276,35 +276,16 @@ __global__ __launch_bounds__(256) void k_quad_prep(QuadPrepArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_quads(QuadArgs a) {
-  const int b = blockIdx.y;
-  const BaseDev& B = a.bases[b];
-  const int n1 = min(a.cnt1[b], a.cap), n2 = min(a.cnt2[b], a.cap);
-  const long long total = (long long)n1 * n2;
-  const int eg = a.geom.eg_size;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-    // consecutive lanes walk consecutive first pairs for one second pair: the query is wave-uniform most of
-    // the time (scalar loads), the elements are read coalesced.
-    const int id2 = (int)(t / n1), id1 = (int)(t % n1);
-    const QuadElem e = a.elems[(size_t)b * a.cap + id1];
-    const QuadQuery& q = a.queries[(size_t)b * a.cap + id2];
-    const int dx = e.cx - q.cx, dy = e.cy - q.cy, dz = e.cz - q.cz;
-    bool ok = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
-    ok = ok && e.cx >= 0 && e.cx < eg && e.cy >= 0 && e.cy < eg && e.cz >= 0 && e.cz < eg;
-    ok = ok && q.cx >= 0 && q.cx < eg && q.cy >= 0 && q.cy < eg && q.cz >= 0 && q.cz < eg;
-    ok = ok && e.nid >= 0 && e.nid < 343 && ((q.mask[e.nid >> 5] >> (e.nid & 31)) & 1u);
-    if (ok) {
-      const V3 d = v3(q.px, q.py, q.pz) - v3(e.px, e.py, e.pz);
-      ok = vsqn(d) <= a.dist_thr2;  // squared norm vs the UNSQUARED threshold (FunctorSuper4pcs.h:277)
-    }
-    {
-      const unsigned long long m = __ballot(ok);
-      if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&a.nquads[b], __popcll(m));
-    }
-    if (!ok) continue;
+// TryCongruentSet (cse.hpp:229-291) for one accepted (first pair, second pair): 3-point rigid fit, RMS gate, candidate
+// record.  Called with all lanes of the wave converged (`have` marks the lanes that carry a pair): the slot in the
+// candidate array comes from one wave-aggregated atomic.
+__device__ __forceinline__ void quad_fit_emit(const QuadArgs& a, const BaseDev& B, int b, bool have, int id1, int id2) {
+  bool emit = false;
+  Candidate cd;
+  if (have) {
     const unsigned p1 = a.pairs1[(size_t)b * a.cap + id1], p2 = a.pairs2[(size_t)b * a.cap + id2];
     const int qa = p1 >> 16, qb = p1 & 0xffff, qc = p2 >> 16;
-    // TryCongruentSet (cse.hpp:229-291): only the first three points enter the fit
+    // only the first three points enter the fit
     V3 ref[3], cand[3];
     for (int k = 0; k < 3; ++k) ref[k] = v3(B.bpos[k][0], B.bpos[k][1], B.bpos[k][2]);
     cand[0] = v3(a.qx[qa], a.qy[qa], a.qz[qa]);
@@ -314,24 +295,86 @@ __global__ __launch_bounds__(256) void k_quads(QuadArgs a) {
     const V3 c2 = ((cand[0] + cand[1]) + cand[2]) / 3.f;
     float T[16], rms;
     const bool fit = rigid_3pt(ref, cand, c1, c2, T, &rms);
-    if (!(fit && rms >= 0.f && rms < a.delta)) continue;
-    const int slot = atomicAdd(a.cand_count, 1);
-    if (slot >= a.cand_cap) {
-      *a.overflow = 1;
-      continue;
+    if (fit && rms >= 0.f && rms < a.delta) {
+      emit = true;
+      for (int k = 0; k < 12; ++k) cd.T[k] = T[k];
+      cd.c1[0] = c1.x, cd.c1[1] = c1.y, cd.c1[2] = c1.z;
+      cd.c2[0] = c2.x, cd.c2[1] = c2.y, cd.c2[2] = c2.z;
+      // canonical order key: base trial, then first pair in (i,j,flip) order, then second pair
+      const unsigned long long k1 = ((unsigned long long)max(qa, qb) << 12 | (unsigned long long)min(qa, qb)) << 1 | (qa < qb ? 1u : 0u);
+      const int qd = p2 & 0xffff;
+      const unsigned long long k2 = ((unsigned long long)max(qc, qd) << 12 | (unsigned long long)min(qc, qd)) << 1 | (qc < qd ? 1u : 0u);
+      cd.key = ((unsigned long long)(a.base_index0 + b) << 50) | (k1 << 25) | k2;
     }
-    Candidate cd;
-    for (int k = 0; k < 12; ++k) cd.T[k] = T[k];
-    cd.c1[0] = c1.x, cd.c1[1] = c1.y, cd.c1[2] = c1.z;
-    cd.c2[0] = c2.x, cd.c2[1] = c2.y, cd.c2[2] = c2.z;
-    // canonical order key: base trial, then first pair in (i,j,flip) order, then second pair
-    const unsigned long long k1 = ((unsigned long long)max(qa, qb) << 12 | (unsigned long long)min(qa, qb)) << 1 | (qa < qb ? 1u : 0u);
-    const int qd = p2 & 0xffff;
-    const unsigned long long k2 = ((unsigned long long)max(qc, qd) << 12 | (unsigned long long)min(qc, qd)) << 1 | (qc < qd ? 1u : 0u);
-    cd.key = ((unsigned long long)(a.base_index0 + b) << 50) | (k1 << 25) | k2;
-    a.cands[slot] = cd;
-    a.cand_counts[slot] = 0;
   }
+  const unsigned long long m = __ballot(emit);
+  if (!m) return;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(a.cand_count, __popcll(m));
+  base = __shfl(base, leader);
+  if (!emit) return;
+  const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+  if (slot >= a.cand_cap) {
+    *a.overflow = 1;
+    return;
+  }
+  a.cands[slot] = cd;
+  a.cand_counts[slot] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_quads(QuadArgs a) {
+  __shared__ int queue_s[4][2][128];  // per wave: accepted (id1, id2) waiting for a full wave of fits
+  const int b = blockIdx.y;
+  const BaseDev& B = a.bases[b];
+  const int n1 = min(a.cnt1[b], a.cap), n2 = min(a.cnt2[b], a.cap);
+  const int eg = a.geom.eg_size;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int* queue1 = queue_s[wave][0];
+  int* queue2 = queue_s[wave][1];
+  int nq_wave = 0, qn = 0;
+  // one second pair (query) per wave at a time -- wave-uniform, read once -- against all first pairs (elements), 64 per
+  // step, read coalesced.  The pairs that pass the cheap tests (~0.2 %) are queued and fitted 64 at a time, so the long
+  // rigid-fit code always runs with full lanes.
+  for (int id2 = blockIdx.x * 4 + wave; id2 < n2; id2 += gridDim.x * 4) {
+    const QuadQuery& q = a.queries[(size_t)b * a.cap + id2];
+    const bool qok = q.cx >= 0 && q.cx < eg && q.cy >= 0 && q.cy < eg && q.cz >= 0 && q.cz < eg;
+    if (!qok) continue;
+    for (int id1 = lane; id1 < ((n1 + 63) & ~63); id1 += 64) {
+      bool ok = id1 < n1;
+      if (ok) {
+        const QuadElem e = a.elems[(size_t)b * a.cap + id1];
+        const int dx = e.cx - q.cx, dy = e.cy - q.cy, dz = e.cz - q.cz;
+        ok = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+        ok = ok && e.cx >= 0 && e.cx < eg && e.cy >= 0 && e.cy < eg && e.cz >= 0 && e.cz < eg;
+        ok = ok && e.nid >= 0 && e.nid < 343 && ((q.mask[e.nid >> 5] >> (e.nid & 31)) & 1u);
+        if (ok) {
+          const V3 d = v3(q.px, q.py, q.pz) - v3(e.px, e.py, e.pz);
+          ok = vsqn(d) <= a.dist_thr2;  // squared norm vs the UNSQUARED threshold (FunctorSuper4pcs.h:277)
+        }
+      }
+      const unsigned long long m = __ballot(ok);
+      if (!m) continue;
+      if (ok) {
+        const int at = qn + __popcll(m & ((1ull << lane) - 1ull));
+        queue1[at] = id1, queue2[at] = id2;
+      }
+      qn += __popcll(m);
+      nq_wave += __popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      if (qn >= 64) {
+        const int f1 = queue1[qn - 64 + lane], f2 = queue2[qn - 64 + lane];
+        qn -= 64;
+        __builtin_amdgcn_wave_barrier();
+        quad_fit_emit(a, B, b, true, f1, f2);
+      }
+    }
+  }
+  if (qn > 0) {
+    const int f1 = lane < qn ? queue1[lane] : 0, f2 = lane < qn ? queue2[lane] : 0;
+    quad_fit_emit(a, B, b, lane < qn, f1, f2);
+  }
+  if (lane == 0 && nq_wave) atomicAdd(&a.nquads[b], nq_wave);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -216,6 +216,12 @@ typedef struct {
   double ms_verify, ms_gen_other, ms_icp_nn, ms_icp_solve, ms_lcp_fwd, ms_lcp_rev, ms_pso, ms_ppf_matrix;
   long long n_verify_launches, n_icp_nn_launches, n_lcp_launches, n_pso_launches;
   long long pairs_verify, pairs_icp, pairs_lcp, pairs_pso; /* algorithmic point-pair evaluations */
+  /* per-kernel spans of the cell-list paths: ms_icp_nn is the correspondence kernel alone when nn_mode >= 2
+   * (ms_icp_accum the normal-equation kernel), ms_lcp_fwd the fused computeLCP kernel, ms_lcp_sum the ordered sum,
+   * ms_quads the congruent-quadrilateral kernel (also included in ms_gen_other), ms_build the per-frame
+   * acceleration structures (grids, NN cell lists). */
+  double ms_icp_accum, ms_lcp_sum, ms_quads, ms_build;
+  long long n_quads_launches, n_build_launches;
 } hop_timing;
 int hop_timing_reset(hop_ctx* ctx);
 int hop_timing_get(hop_ctx* ctx, hop_timing* out);
