@@ -685,8 +685,11 @@ int hop_set_scene(hop_ctx* c, const float* xyz, const float* nrm, const float* c
     }
     const int rc = upload_cloud(c, c->scene_sorted_d, sorted);
     if (rc) return rc;
-    HIPCHK(c, c->scene_perm_d.ensure(sizeof(int) * (size_t)std::max(m, 1)));
+    HIPCHK(c, c->scene_perm_d.ensure(sizeof(int) * 2 * (size_t)std::max(m, 1)));
+    std::vector<int> inv(std::max(m, 1));
+    for (int k = 0; k < m; ++k) inv[perm[k]] = k;
     HIPCHK(c, hipMemcpyAsync(c->scene_perm_d.p, perm.data(), sizeof(int) * (size_t)std::max(m, 1), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->scene_perm_d.as<int>() + std::max(m, 1), inv.data(), sizeof(int) * (size_t)std::max(m, 1), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return upload_cloud(c, c->scene_d, raw);
@@ -1243,7 +1246,7 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
     HIPCHK(c, c->lcp_rev_idx.ensure(sizeof(int) * (size_t)Mo.n * HB));
     HIPCHK(c, c->lcp_rev_d2.ensure(sizeof(float) * (size_t)Mo.n * HB));
   }
-  HIPCHK(c, c->lcp_terms.ensure(sizeof(float) * 2 * (size_t)S.n * HB + 64));
+  HIPCHK(c, c->lcp_terms.ensure(sizeof(float) * 2 * (size_t)S.n * (lcp_cells ? lcp_cells_row_stride(HB) : HB) + 64));
   LcpArgs a{};
   a.sx = S.plane(0), a.sy = S.plane(1), a.sz = S.plane(2), a.snx = S.plane(3), a.sny = S.plane(4), a.snz = S.plane(5), a.ns = S.n;
   a.mx = Mo.plane(0), a.my = Mo.plane(1), a.mz = Mo.plane(2), a.mnx = Mo.plane(3), a.mny = Mo.plane(4), a.mnz = Mo.plane(5), a.nm = Mo.n;
@@ -1284,6 +1287,7 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
     const CloudDevice& Q = c->scene_sorted_d;
     a.qx = Q.plane(0), a.qy = Q.plane(1), a.qz = Q.plane(2), a.qnx = Q.plane(3), a.qny = Q.plane(4), a.qnz = Q.plane(5);
     a.perm = c->scene_perm_d.as<int>();
+    a.inv_perm = a.perm + std::max(S.n, 1);
   }
   for (int h0 = 0; h0 < H; h0 += HB) {
     const int hb = std::min(HB, H - h0);
@@ -1304,7 +1308,8 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
     }
     {
       SpanGuard sg(c, T_LCP_SUM);
-      launch_lcp_sum(a, hb, c->stream);
+      if (lcp_cells) launch_lcp_sum_t(a, hb, c->stream);
+      else launch_lcp_sum(a, hb, c->stream);
     }
     c->timing.n_lcp_launches += 1;
   }

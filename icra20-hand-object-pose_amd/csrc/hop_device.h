@@ -177,6 +177,7 @@ struct LcpArgs {
   // `perm` maps the sorted position back to the caller's index, where the terms are stored.
   const float *qx, *qy, *qz, *qnx, *qny, *qnz;
   const int* perm;
+  const int* inv_perm;  // caller index -> sorted position (cell-list path: the term table is indexed by sorted position)
 };
 
 struct IcpState {
@@ -253,6 +254,8 @@ void launch_lcp_forward(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_sum(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_grid(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s);
+void launch_lcp_sum_t(const LcpArgs& a, int hb, hipStream_t s);
+int lcp_cells_row_stride(int hb);
 void launch_cell_list_local_flag(const CellListBuildArgs& a, const GridDev& g, int* flag, hipStream_t s);
 void launch_cell_list_local_work(const int* flag, const int* flag_scan, int ncell, int* work, hipStream_t s);
 void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool write, int exist_mode, const int* work, int nwork, int* keep_buf,
@@ -260,6 +263,8 @@ void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool w
 int cell_list_local_keep();
 void launch_verify_cells(const VerifyArgs& a, const CellListDev& cl, int blocks, hipStream_t s);
 void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s);
+void launch_lcp_sum_t(const LcpArgs& a, int hb, hipStream_t s);
+int lcp_cells_row_stride(int hb);
 int icp_blocks_per_hyp(int ns, bool cells);
 void launch_icp_init(IcpState* st, int hb, hipStream_t s);
 void launch_icp_nn(const IcpArgs& a, int hb, hipStream_t s);

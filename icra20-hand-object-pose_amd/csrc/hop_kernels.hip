@@ -1225,39 +1225,92 @@ __device__ __forceinline__ void cells_nn_plain(const CellListDev& c, V3 q, float
   }
 }
 
-// computeLCP on NN cell lists (nn_mode 2): forward NN through the model's lists (rest frame), reciprocal NN through
-// the scene grid.  Blocks are numbered so that all blocks of one hypothesis land on the same XCD (block b runs on XCD
-// b % 8): the scattered 8-byte term stores of one hypothesis then meet in one L2 and leave it as full lines, and the
-// hypothesis' pose / list reads are shared there too.
-__global__ __launch_bounds__(256) void k_lcp_cells(LcpArgs a, int hb, int nb) {
-  __shared__ float sT[12], sTi[12];
-  const int bid = blockIdx.x, r = bid & 7, t = bid >> 3;
-  const int hl = (t / nb) * 8 + r, bx = t % nb;
-  if (hl >= hb) return;
-  const int h = a.h0 + hl;
-  block_pose_and_inverse(a.pose + (size_t)h * 16, sT, sTi);
-  const int k = bx * blockDim.x + threadIdx.x;
-  if (k >= a.ns) return;
-  const int i = a.perm[k];  // caller's index of this scene point
-  const V3 s = v3(a.qx[k], a.qy[k], a.qz[k]);
-  float best = 3.0e38f;
-  int pos = -1;
-  cells_nn(a.model_cells, m4_point(sTi, s), sT, s, best, pos);
-  float f = -1.f, g = -1.f;
-  if (pos >= 0 && best < a.dist * a.dist) {
-    const float4 mp = a.model_cells.pts[pos], mnr = a.model_cells.nrm[pos];
-    const V3 nmod = m4_dir(sT, v3(mnr.x, mnr.y, mnr.z));
-    f = lcp_term(v3(a.qnx[k], a.qny[k], a.qnz[k]), nmod, best, a.dist, a.cos_thres);
-    const V3 pm = m4_point(sT, v3(mp.x, mp.y, mp.z));
-    float rbest = 3.0e38f;
-    int rk = -1;
-    cells_nn_plain(a.scene_cells, pm, rbest, rk);
-    if (rk >= 0) {
-      const float4 sn = a.scene_cells.nrm[rk];
-      g = lcp_term(nmod, v3(sn.x, sn.y, sn.z), rbest, a.dist, a.cos_thres);
+// computeLCP on NN cell lists (nn_mode 2): forward NN through the model's lists (rest frame), reciprocal NN through the
+// scene's lists.  A block covers 64 Morton-consecutive scene points x LCP_TH hypotheses (each wave one hypothesis at a
+// time: neighbouring lanes touch neighbouring cells); the terms go through LDS into a POINT-major table
+// terms[sorted position][hypothesis], LCP_TH x 8 B = one full 128-byte line per point and block.  The ordered sum then
+// reads that table row by row in the caller's point order with lanes = hypotheses, which is coalesced whatever the
+// order of the rows -- so neither kernel scatters (the hypothesis-major layout cost 4x write amplification plus the
+// read-for-ownership traffic of partial lines: 17 GB of HBM traffic per launch instead of 0.8).
+constexpr int LCP_TH = 16;
+__global__ __launch_bounds__(256) void k_lcp_cells(LcpArgs a, int hb, int hs, int npt) {
+  __shared__ float sT[LCP_TH][12], sTi[LCP_TH][12];
+  __shared__ float2 out[64][LCP_TH + 1];
+  const int pt = blockIdx.x % npt, ht = blockIdx.x / npt;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < LCP_TH) {
+    const int hl = ht * LCP_TH + threadIdx.x;
+    if (hl < hb) {
+      M4 P;
+      const float* pose = a.pose + (size_t)(a.h0 + hl) * 16;
+      for (int k = 0; k < 16; ++k) P.m[k] = pose[k];
+      const M4 inv = m4_inverse_affine(P);
+      for (int k = 0; k < 12; ++k) sT[threadIdx.x][k] = P.m[k], sTi[threadIdx.x][k] = inv.m[k];
     }
   }
-  reinterpret_cast<float2*>(a.terms)[(size_t)hl * a.ns + i] = make_float2(f, g);
+  __syncthreads();
+  const int k = pt * 64 + lane;
+  const bool kin = k < a.ns;
+  V3 s = v3(0, 0, 0), sn = v3(0, 0, 0);
+  if (kin) s = v3(a.qx[k], a.qy[k], a.qz[k]), sn = v3(a.qnx[k], a.qny[k], a.qnz[k]);
+  for (int j = 0; j < LCP_TH / 4; ++j) {
+    const int hh = wave * (LCP_TH / 4) + j, hl = ht * LCP_TH + hh;
+    float f = -1.f, g = -1.f;
+    if (kin && hl < hb) {
+      const float* T = sT[hh];
+      float best = 3.0e38f;
+      int pos = -1;
+      cells_nn(a.model_cells, m4_point(sTi[hh], s), T, s, best, pos);
+      if (pos >= 0 && best < a.dist * a.dist) {
+        const float4 mp = a.model_cells.pts[pos], mnr = a.model_cells.nrm[pos];
+        const V3 nmod = m4_dir(T, v3(mnr.x, mnr.y, mnr.z));
+        f = lcp_term(sn, nmod, best, a.dist, a.cos_thres);
+        const V3 pm = m4_point(T, v3(mp.x, mp.y, mp.z));
+        float rbest = 3.0e38f;
+        int rk = -1;
+        cells_nn_plain(a.scene_cells, pm, rbest, rk);
+        if (rk >= 0) {
+          const float4 rn = a.scene_cells.nrm[rk];
+          g = lcp_term(nmod, v3(rn.x, rn.y, rn.z), rbest, a.dist, a.cos_thres);
+        }
+      }
+    }
+    out[lane][hh] = make_float2(f, g);
+  }
+  __syncthreads();
+  float2* tt = reinterpret_cast<float2*>(a.terms);
+  for (int e = threadIdx.x; e < 64 * LCP_TH; e += 256) {
+    const int p = e / LCP_TH, hh = e % LCP_TH;
+    const int kk = pt * 64 + p;
+    if (kk < a.ns) tt[(size_t)kk * hs + ht * LCP_TH + hh] = out[p][hh];
+  }
+}
+
+// ordered sum over the point-major table: lanes = hypotheses, rows visited in the caller's point order (inv[i] = sorted
+// position of caller point i); additions in exactly that order, loads issued 32 rows ahead
+__global__ __launch_bounds__(64) void k_lcp_sum_t(LcpArgs a, int hb, int hs) {
+  const int hl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hl >= hb) return;
+  const float2* tt = reinterpret_cast<const float2*>(a.terms) + hl;
+  float cp = 0.f;
+  constexpr int U = 32;
+  int i = 0;
+  for (; i + U <= a.ns; i += U) {
+    float2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = tt[(size_t)a.inv_perm[i + u] * hs];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (v[u].x >= 0.f) cp += v[u].x;
+      if (v[u].y >= 0.f) cp += v[u].y;
+    }
+  }
+  for (; i < a.ns; ++i) {
+    const float2 v = tt[(size_t)a.inv_perm[i] * hs];
+    if (v.x >= 0.f) cp += v.x;
+    if (v.y >= 0.f) cp += v.y;
+  }
+  a.score[a.h0 + hl] = cp;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1893,9 +1946,13 @@ void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool w
   else hipLaunchKernelGGL(k_cell_list_local<false>, dim3((nwork + 3) / 4), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
 }
 int cell_list_local_keep() { return LOCAL_KEEP; }
+int lcp_cells_row_stride(int hb) { return ((hb + LCP_TH - 1) / LCP_TH) * LCP_TH; }
 void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s) {
-  const int nb = (a.ns + 255) / 256;
-  hipLaunchKernelGGL(k_lcp_cells, dim3((unsigned)(nb * ((hb + 7) / 8) * 8)), dim3(256), 0, s, a, hb, nb);
+  const int npt = (a.ns + 63) / 64, nht = (hb + LCP_TH - 1) / LCP_TH;
+  hipLaunchKernelGGL(k_lcp_cells, dim3((unsigned)(npt * nht)), dim3(256), 0, s, a, hb, lcp_cells_row_stride(hb), npt);
+}
+void launch_lcp_sum_t(const LcpArgs& a, int hb, hipStream_t s) {
+  hipLaunchKernelGGL(k_lcp_sum_t, dim3((hb + 63) / 64), dim3(64), 0, s, a, hb, lcp_cells_row_stride(hb));
 }
 void launch_lcp_grid(const LcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_lcp_grid, dim3((a.ns + 255) / 256, hb), dim3(256), 0, s, a);
