@@ -431,7 +431,7 @@ class PoseEstimator:
         thres = float(self.cfg.get("pose_estimator_high_confidence_thres", 0.8))
         return self.ctx.set_scene(object_segment_xyz, object_segment_nrm, confidence, thres)
 
-    def runSuper4pcs(self, ppfs, n_trials=0, verify_mode=0):
+    def runSuper4pcs(self, ppfs, n_trials=0, verify_mode=2):
         """PoseEstimator.cpp:62-100.  ``ppfs``: (n,4) int key table (the reference passes a std::map whose
         keys are these rows).  Returns False when no hypothesis is found, as the reference does."""
         self.ctx.set_ppf_keys(ppfs)
@@ -452,10 +452,10 @@ class PoseEstimator:
         self.ctx.cluster_poses(angle_diff, dist_diff, [s["x"], s["y"], s["z"]], assign_id)
 
     def refineByICP(self):
-        self.ctx.icp_refine(10, float(self.cfg["icp_angle_thres"]), float(self.cfg["icp_dist_thres"]), max_hypotheses=100)
+        self.ctx.icp_refine(10, float(self.cfg["icp_angle_thres"]), float(self.cfg["icp_dist_thres"]), max_hypotheses=100, nn_mode=2)
 
     def selectBest(self):
-        pose, score, idx = self.ctx.lcp_select_best(float(self.cfg["lcp"]["dist"]), float(self.cfg["lcp"]["normal_angle"]))
+        pose, score, idx = self.ctx.lcp_select_best(float(self.cfg["lcp"]["dist"]), float(self.cfg["lcp"]["normal_angle"]), 2)
         return PoseHypo(pose, idx, score)
 
     def hypos(self):

@@ -726,7 +726,7 @@ void hop_s4pcs_default_opts(hop_s4pcs_opts* o) {
   if (!o) return;
   o->sample_size = 100, o->overlap = 0.2f, o->delta = 0.003f, o->dispersion = 0.5f;
   o->success_quadrilaterals = 10, o->max_time_seconds = 1, o->n_trials = 0, o->random_seed = 5489u;
-  o->max_normal_difference = -1.f, o->max_color_distance = -1.f, o->verify_mode = 0;
+  o->max_normal_difference = -1.f, o->max_color_distance = -1.f, o->verify_mode = 2;
 }
 
 int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_out, float* lcp_out, int cap, int* n_out,

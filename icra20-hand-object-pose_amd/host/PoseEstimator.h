@@ -71,13 +71,13 @@ class PoseEstimator {
 
   // refineByICP (PoseEstimator.cpp:235-275)
   void refineByICP() {
-    hop_icp_opts o{10, cfg->getf("icp_angle_thres"), cfg->getf("icp_dist_thres"), 100, 0};
+    hop_icp_opts o{10, cfg->getf("icp_angle_thres"), cfg->getf("icp_dist_thres"), 100, 2};  // nn_mode 2: NN cell lists
     hop::check(hop_icp_refine(ctx_, &o, nullptr, nullptr), ctx_, "hop_icp_refine");
   }
 
   // selectBest (PoseEstimator.cpp:465-502)
   void selectBest(PoseHypo& best_hypo) {
-    hop_lcp_opts o{cfg->getf("lcp.dist"), cfg->getf("lcp.normal_angle"), 0};
+    hop_lcp_opts o{cfg->getf("lcp.dist"), cfg->getf("lcp.normal_angle"), 2};  // nn_mode 2: NN cell lists
     float score = 0;
     int idx = 0;
     hop::check(hop_lcp_select_best(ctx_, &o, best_hypo._pose, &score, &idx), ctx_, "hop_lcp_select_best");

@@ -83,7 +83,7 @@ typedef struct {
   unsigned int random_seed;   /* gr MatchBase Options::randomSeed, std::mt19937::default_seed = 5489 */
   float max_normal_difference; /* must be < 0 (as shipped); other filters are not implemented */
   float max_color_distance;    /* must be < 0 */
-  int verify_mode;            /* 0 = brute force LDS-tiled, 1 = voxel-grid accelerated (same counts) */
+  int verify_mode;            /* 0 = brute force LDS-tiled, 1 = voxel grid, 2 = EXIST-mode NN cell lists (all: same counts) */
 } hop_s4pcs_opts;
 
 typedef struct {
@@ -129,7 +129,7 @@ typedef struct {
   float angle_deg;     /* icp_angle_thres = 45     (config_autodataset.yaml:127) */
   float max_corr_dist; /* icp_dist_thres  = 0.01   (:126) */
   int max_hypotheses;
-  int nn_mode;         /* 0 brute force, 1 grid accelerated */
+  int nn_mode;         /* 0 brute force, 1 ring-expanding voxel grid, 2 NN cell lists (same correspondences) */
 } hop_icp_opts;
 int hop_icp_refine(hop_ctx* ctx, const hop_icp_opts* opts, int* iterations_out /*H or NULL*/,
                    int* converged_out /*H or NULL*/);
@@ -140,7 +140,7 @@ int hop_icp_refine(hop_ctx* ctx, const hop_icp_opts* opts, int* iterations_out /
 typedef struct {
   float dist;      /* lcp.dist = 0.001          (config_autodataset.yaml:116) */
   float angle_deg; /* lcp.normal_angle = 10     (:117) */
-  int nn_mode;     /* 0 brute force, 1 grid accelerated */
+  int nn_mode;     /* 0 brute force, 1 voxel grids, 2 NN cell lists (same scores, bit for bit) */
 } hop_lcp_opts;
 int hop_lcp_select_best(hop_ctx* ctx, const hop_lcp_opts* opts, float* best_pose16_out,
                         float* best_score_out, int* best_index_out);

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -442,3 +443,87 @@ def test_full_chain_pose_within_1mm_1deg_of_oracle(ctx, api, orc, synth):
 def test_library_fails_loudly_without_fallback(api):
     with pytest.raises(api.HopError):
         api.Context(99)  # no such device: an error code, not a CPU path
+
+
+# ------------------------------------------------------------------------------------------------ C++ host
+def _write_cloud(path, xyz, nrm=None, conf=None):
+    """frame-dir cloud format of host/app/main_realdata_auto.cpp: int32 n, int32 has_conf, xyz planes, normal planes, [conf]"""
+    xyz = np.asarray(xyz, np.float32)
+    nrm = np.zeros_like(xyz) if nrm is None else np.asarray(nrm, np.float32)
+    with open(path, "wb") as f:
+        np.array([len(xyz), 0 if conf is None else 1], np.int32).tofile(f)
+        np.ascontiguousarray(xyz.T).tofile(f)
+        np.ascontiguousarray(nrm.T).tofile(f)
+        if conf is not None:
+            np.asarray(conf, np.float32).tofile(f)
+
+
+def test_cpp_host_app_equals_python_mirror(api, hop, synth, tmp_path):
+    """The C++ host above the C-ABI (host/app/main_realdata_auto.cpp: the reference driver's call order,
+    main_realdata_auto.cpp:99-205) and the Python mirror run the same frame: same finger angles, same best pose."""
+    import subprocess
+    cfg_path = os.path.join(ROOT, "icra20-hand-object-pose_amd", "config", "config_autodataset.yaml")
+    from hop_amd import config as hop_config
+    cfg = hop_config.load_config(cfg_path)
+    exe = os.path.join(ROOT, "icra20-hand-object-pose_amd", "lib", "main_realdata_auto")
+    assert os.path.exists(exe), "build() must have produced the host application"
+    mx5, mn5 = synth.ellipsoid_model_spacing(0.005)
+    mx1, mn1 = synth.ellipsoid_model(4000)
+    keys = synth.ppf_key_table()
+    sc = synth.make_scene(1200, seed=7)
+    hand = synth.t42_hand()
+    true = {"finger_1_1": math.radians(10), "finger_1_2": math.radians(6), "finger_2_1": math.radians(12), "finger_2_2": math.radians(5)}
+    hxyz, hnrm = synth.make_hand_scene(hand, true, 4000, seed=5)
+    swivel = hxyz[hxyz[:, 0] < -0.1]
+    frame = tmp_path / "frame"
+    out = tmp_path / "out"
+    frame.mkdir()
+    out.mkdir()
+    _write_cloud(frame / "model.bin", mx5, mn5)
+    _write_cloud(frame / "model001.bin", mx1, mn1)
+    _write_cloud(frame / "object_segment.bin", sc.xyz, sc.nrm, sc.conf)
+    with open(frame / "ppf_keys.bin", "wb") as f:
+        np.array([len(keys)], np.int32).tofile(f)
+        np.ascontiguousarray(keys, np.int32).tofile(f)
+    with open(frame / "hand.txt", "w") as f:
+        for name in hand.clouds:
+            if name == "base_link":
+                continue
+            x, n = hand.clouds[name]
+            _write_cloud(frame / f"{name}.bin", x, n)
+            f.write(f"{name} {hand.parents[name]} {name}.bin " + " ".join(repr(float(v)) for v in hand.tf_in_parent[name].reshape(16)) + "\n")
+    _write_cloud(frame / "hand_scene.bin", hxyz)
+    _write_cloud(frame / "hand_region.bin", hxyz, hnrm)
+    _write_cloud(frame / "hand_swivel.bin", swivel)
+    (frame / "cam_side.txt").write_text("1\n")
+    r = subprocess.run([exe, cfg_path, str(frame), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cpp_pose = np.loadtxt(out / "model2scene.txt").astype(np.float32)
+    cpp_angles = {ln.split()[0]: float(ln.split()[1]) for ln in (out / "finger_angles.txt").read_text().splitlines()}
+
+    est = api.PoseEstimator(cfg, (mx5, mn5), (mx1, mn1))
+    h = api.HandT42(cfg, hand, ctx=est.ctx)
+    ext = np.abs(mx1.min(axis=0) - mx1.max(axis=0))
+    h.gripper_min_dist = 0.8 * float(ext.min())  # main_realdata_auto.cpp:41-45
+    h.setCurScene(hxyz, hnrm, swivel)
+    hm = cfg["hand_match"]
+    py_angles = {}
+    for first, second in (("finger_2_1", "finger_2_2"), ("finger_1_1", "finger_1_2")):
+        if h.matchOneComponentPSO(first, 0, 120, False, hm["finger1_dist_thres"], hm["finger1_normal_angle"], hm["finger1_min_match"]):
+            py_angles[first] = h.last_angle
+            if h.matchOneComponentPSO(second, 0, 90, True, hm["finger2_dist_thres"], hm["finger2_normal_angle"], hm["finger2_min_match"]):
+                py_angles[second] = h.last_angle
+    est.setCurScene(sc.xyz, sc.nrm, sc.conf)
+    assert est.runSuper4pcs(keys)
+    est.clusterPoses(30, 0.015, True)
+    est.refineByICP()
+    est.clusterPoses(5, 0.003, False)
+    best = est.selectBest()
+    assert set(cpp_angles) == set(py_angles) and len(py_angles) >= 2
+    for k, v in py_angles.items():
+        assert abs(cpp_angles[k] - v) < 1e-6, (k, cpp_angles[k], v)
+    assert np.abs(cpp_pose - best._pose).max() < 1e-6
+    a = mx1 @ cpp_pose[:3, :3].T + cpp_pose[:3, 3]
+    b = mx1 @ sc.gt_pose[:3, :3].T + sc.gt_pose[:3, 3]
+    from scipy.spatial import cKDTree
+    assert cKDTree(b).query(a)[0].mean() < 0.005
