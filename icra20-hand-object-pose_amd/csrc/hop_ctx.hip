@@ -155,6 +155,8 @@ struct hop_ctx {
   unsigned long long* ppf_matrix_cached = nullptr;
   size_t ppf_matrix_cached_bytes = 0;
   bool ppf_matrix_registered = false;
+  DevBuf angle_thr_d;
+  bool angle_thr_tried = false, angle_thr_ok = false;
   int ppf_words = 0;
   std::vector<BaseTraceHost> trace;
   bool have_gen_state = false;
@@ -598,6 +600,7 @@ void hop_ctx_destroy(hop_ctx* c) {
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
   if (c->ppf_matrix_registered) (void)hipHostUnregister(c->ppf_matrix_cached);
   std::free(c->ppf_matrix_cached);
+  c->angle_thr_d.release();
   DevBuf* bufs[] = {&c->scene_d.buf, &c->scene_sorted_d.buf, &c->scene_perm_d, &c->model_d[0].buf, &c->model_d[1].buf, &c->key_bitmap_d, &c->gp_d.buf, &c->gq_d.buf, &c->gq_unit_d,
                     &c->ppf_matrix_d, &c->vp_d.buf, &c->vq_d.buf, &c->bases_d, &c->pairs1_d,
                     &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
@@ -803,6 +806,17 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
     a.nx = c->gp_d.plane(3), a.ny = c->gp_d.plane(4), a.nz = c->gp_d.plane(5);
     a.n = N, a.words = W, a.bitmap = c->key_bitmap_d.as<unsigned>(), a.dist_bins = c->key_dist_bins;
     a.out = c->ppf_matrix_d.as<unsigned long long>();
+    if (!c->angle_thr_tried) {  // once per context: cosine thresholds of the angle bins, verified against acosf
+      c->angle_thr_tried = true;
+      float thr[32];
+      if (!getenv("HOP_PPF_LITERAL") && build_angle_thresholds(thr)) {
+        HIPCHK(c, c->angle_thr_d.ensure(sizeof(thr)));
+        HIPCHK(c, hipMemcpyAsync(c->angle_thr_d.p, thr, sizeof(thr), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->angle_thr_ok = true;
+      }
+    }
+    a.angle_thr = c->angle_thr_ok ? c->angle_thr_d.as<float>() : nullptr;
     {
       SpanGuard sg(c, T_PPF);
       launch_ppf_matrix(a, c->stream);

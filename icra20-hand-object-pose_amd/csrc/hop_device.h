@@ -32,6 +32,7 @@ struct PpfMatrixArgs {
   const unsigned* bitmap;                  // key set as a direct-address bitmap
   int dist_bins;
   unsigned long long* out;  // n x words
+  const float* angle_thr;   // 32 cosine thresholds of the angle bins (ppf_angle_bin_thr), or null: literal acosf path
 };
 
 struct PairArgs {

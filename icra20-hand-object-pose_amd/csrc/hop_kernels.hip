@@ -113,8 +113,11 @@ __device__ __forceinline__ void wave_count_by_key(bool flag, int key, int* __res
 // One wave owns 64 consecutive columns j (coalesced plane reads, kept in registers) and walks a tile of
 // rows i whose data sits in LDS (broadcast reads); __ballot packs the 64 answers of a row into one word.
 // ------------------------------------------------------------------------------------------------
+template <bool THR>
 __global__ __launch_bounds__(256) void k_ppf_matrix(PpfMatrixArgs a) {
   __shared__ float rows[PPF_ROWS][8];
+  __shared__ float sthr[32];
+  if (THR && threadIdx.x < 32) sthr[threadIdx.x] = a.angle_thr[threadIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int jb = blockIdx.x * 4 + wave;  // 64-column block
   const int j = jb * 64 + lane;
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void k_ppf_matrix(PpfMatrixArgs a) {
     const V3 ni = v3(rows[r][3], rows[r][4], rows[r][5]);
     bool member = false;
     int key[4];
-    if (jvalid && (i0 + r) != j && ppf_key(pi, ni, pj, nj, key)) {
+    if (jvalid && (i0 + r) != j && (THR ? ppf_key_thr(pi, ni, pj, nj, sthr, key) : ppf_key(pi, ni, pj, nj, key))) {
       // direct-address bitmap: dist bin k0/5 in [0,dmax], angle bins k/10 in [0,18]
       const int d = key[0] / 5, a1 = key[1] / 10, a2 = key[2] / 10, a3 = key[3] / 10;
       if (key[0] >= 0 && d < a.dist_bins && (unsigned)a1 < 19u && (unsigned)a2 < 19u && (unsigned)a3 < 19u) {
@@ -1861,7 +1864,8 @@ __global__ void k_grid_cell_ids(const float* __restrict__ x, const float* __rest
 // ------------------------------------------------------------------------------------------------
 void launch_ppf_matrix(const PpfMatrixArgs& a, hipStream_t s) {
   dim3 grid((a.words + 3) / 4, (a.n + PPF_ROWS - 1) / PPF_ROWS);
-  hipLaunchKernelGGL(k_ppf_matrix, grid, dim3(256), 0, s, a);
+  if (a.angle_thr) hipLaunchKernelGGL(k_ppf_matrix<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_ppf_matrix<false>, grid, dim3(256), 0, s, a);
 }
 void launch_pairs(const PairArgs& a, int nbases, hipStream_t s) {
   const long long total = (long long)a.nq * a.nq;

@@ -193,6 +193,32 @@ HOP_HD bool ppf_angle_bin(float c, int* bin) {
   *bin = ppf_closest_bin((int)deg, 10);
   return true;
 }
+// The angle component of the key is a step function of the cosine c: ppf_closest_bin((int)deg, 10) = 10 * #{k in 0..17 :
+// deg(c) >= 5 + 10 k}, and deg(c) is non-increasing in c.  With thr[k] = the largest float whose bin is >= 10 (k+1)
+// (found and verified on the host against ppf_angle_bin itself, hop_select.h: build_angle_thresholds), the bin is a
+// count of thresholds >= c: five comparisons of a binary search instead of three divisions, a square root and a
+// double division per angle.  thr has 32 entries, [18..31] = -2 (never reached).
+HOP_HD bool ppf_angle_bin_thr(float c, const float* thr, int* bin) {
+  if (!(fabsf(c) <= 1.0f)) return false;  // NaN or outside [-1,1]: acosf gives NaN, the key is invalid
+  int pos = 0;
+  if (c <= thr[pos + 15]) pos += 16;
+  if (c <= thr[pos + 7]) pos += 8;
+  if (c <= thr[pos + 3]) pos += 4;
+  if (c <= thr[pos + 1]) pos += 2;
+  if (c <= thr[pos]) pos += 1;
+  *bin = 10 * pos;
+  return true;
+}
+HOP_HD bool ppf_key_thr(V3 p1, V3 n1p, V3 p2, V3 n2p, const float* thr, int key[4]) {
+  const float nrm = vnorm(p1 - p2) * 1000.f;
+  if (!(nrm < 2147483648.0f)) return false;
+  key[0] = ppf_closest_bin((int)nrm, 5);
+  const V3 d = vnormalized(p2 - p1);
+  if (!ppf_angle_bin_thr(vdot(n1p, d), thr, &key[1])) return false;
+  if (!ppf_angle_bin_thr(vdot(n2p, d), thr, &key[2])) return false;
+  if (!ppf_angle_bin_thr(vdot(n1p, n2p), thr, &key[3])) return false;
+  return true;
+}
 // n1p/n2p: the point normals after the two extra normalisations computePPF applies (matchBase.hpp:53-56)
 HOP_HD bool ppf_key(V3 p1, V3 n1p, V3 p2, V3 n2p, int key[4]) {
   const float nrm = vnorm(p1 - p2) * 1000.f;

@@ -345,6 +345,56 @@ inline void build_key_bitmap(const int32_t* keys4, int nkeys, std::vector<unsign
 }
 
 // key membership of the ordered pair (p1 -> p2) on the host (same arithmetic as k_ppf_matrix)
+// Thresholds of ppf_angle_bin_thr (hop_math.h), derived from ppf_angle_bin itself and verified against it:
+//  * thr[k] by bisection over the ordered floats of [-1, 1] (bin >= 10 (k+1) holds on a prefix of them),
+//  * every float within 2048 ulps of each threshold, and 400 000 floats spread over [-1, 1] (plus the endpoints and
+//    the branch points of acosf), must classify identically through the thresholds and through acosf.
+// Returns false if any check fails (the caller then keeps the literal kernel).
+inline bool build_angle_thresholds(float thr[32]) {
+  auto ord = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i < 0 ? (int32_t)0x80000000 - i : i; };  // monotone float -> int
+  auto unord = [](int32_t o) { int32_t i = o < 0 ? (int32_t)0x80000000 - o : o; float f; std::memcpy(&f, &i, 4); return f; };
+  auto exact = [](float c) { int b = -1; return ppf_angle_bin(c, &b) ? b : -1; };
+  const int32_t lo0 = ord(-1.0f), hi0 = ord(1.0f);
+  for (int k = 0; k < 32; ++k) thr[k] = -2.0f;
+  for (int k = 0; k < 18; ++k) {
+    // largest c with exact(c) >= 10 (k+1); exact(-1) = 180 always qualifies
+    int32_t lo = lo0, hi = hi0;  // invariant: exact(unord(lo)) >= target; search the last such
+    const int target = 10 * (k + 1);
+    if (exact(unord(lo)) < target) return false;
+    if (exact(unord(hi)) >= target) return false;
+    while (hi - lo > 1) {
+      const int32_t mid = lo + (hi - lo) / 2;
+      if (exact(unord(mid)) >= target) lo = mid;
+      else hi = mid;
+    }
+    thr[k] = unord(lo);
+  }
+  auto check = [&](float c) {
+    int b = -1;
+    const bool ok = ppf_angle_bin_thr(c, thr, &b);
+    return ok && b == exact(c);
+  };
+  for (int k = 0; k < 18; ++k) {
+    const int32_t o = ord(thr[k]);
+    for (int32_t d = -2048; d <= 2048; ++d) {
+      const int32_t q = o + d;
+      if (q < lo0 || q > hi0) continue;
+      if (!check(unord(q))) return false;
+    }
+  }
+  const long long span = (long long)hi0 - (long long)lo0;
+  for (int s = 0; s <= 400000; ++s)
+    if (!check(unord((int32_t)(lo0 + span * s / 400000)))) return false;
+  for (float c : {-1.0f, 1.0f, 0.0f, -0.0f, 0.5f, -0.5f, 1e-9f, -1e-9f})
+    for (int32_t d = -64; d <= 64; ++d) {
+      const int32_t q = ord(c) + d;
+      if (q >= lo0 && q <= hi0 && !check(unord(q))) return false;
+    }
+  int b;
+  if (ppf_angle_bin_thr(1.0000001f, thr, &b) || ppf_angle_bin_thr(-1.0000001f, thr, &b) || ppf_angle_bin_thr(NAN, thr, &b)) return false;
+  return true;
+}
+
 inline bool ppf_member_host(V3 p1, V3 n1p, V3 p2, V3 n2p, const std::vector<unsigned>& bitmap, int dist_bins) {
   int key[4];
   if (!ppf_key(p1, n1p, p2, n2p, key)) return false;

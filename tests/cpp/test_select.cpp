@@ -117,9 +117,46 @@ static void test_fast_equals_literal() {
   }
 }
 
+// angle-bin thresholds (k_ppf_matrix fast path) against the literal acosf route, on random cosines, on every float
+// around the bin boundaries cos(5 + 10 k deg), and on invalid inputs
+static void test_angle_thresholds() {
+  float thr[32];
+  CHECK(build_angle_thresholds(thr));
+  for (int k = 0; k + 1 < 18; ++k) CHECK(thr[k] > thr[k + 1]);
+  std::mt19937 e(123);
+  std::uniform_real_distribution<float> U(-1.f, 1.f);
+  for (int i = 0; i < 4000000; ++i) {
+    const float c = U(e);
+    int a = -1, b = -2;
+    const bool oa = ppf_angle_bin(c, &a), ob = ppf_angle_bin_thr(c, thr, &b);
+    if (oa != ob || a != b) {
+      CHECK(false);
+      break;
+    }
+  }
+  for (int k = 0; k < 18; ++k) {
+    float c = (float)std::cos((5.0 + 10.0 * k) * M_PI / 180.0);
+    for (int d = 0; d < 3000; ++d) c = std::nextafter(c, -2.f);
+    for (int d = 0; d < 6000; ++d, c = std::nextafter(c, 2.f)) {
+      int a = -1, b = -2;
+      const bool oa = ppf_angle_bin(c, &a), ob = ppf_angle_bin_thr(c, thr, &b);
+      if (oa != ob || a != b) {
+        CHECK(false);
+        break;
+      }
+    }
+  }
+  int b;
+  CHECK(!ppf_angle_bin_thr(1.5f, thr, &b) && !ppf_angle_bin_thr(NAN, thr, &b));
+  int a;
+  CHECK(ppf_angle_bin_thr(1.f, thr, &b) && ppf_angle_bin(1.f, &a) && a == b && b == 0);
+  CHECK(ppf_angle_bin_thr(-1.f, thr, &b) && ppf_angle_bin(-1.f, &a) && a == b && b == 180);
+}
+
 int main() {
   test_exact_index();
   test_fast_equals_literal();
+  test_angle_thresholds();
   std::printf(fails ? "FAILED (%d)\n" : "OK\n", fails);
   return fails ? 1 : 0;
 }
