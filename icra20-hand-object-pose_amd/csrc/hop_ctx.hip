@@ -76,12 +76,12 @@ struct GridStore {
 };
 
 struct CellListStore {
-  DevBuf start_d, pts_d, nrm_d, u2_d, count_d, work_d, keep_d;
+  DevBuf start_d, pts_d, nrm_d, u2_d, count_d, work_d, keep_d, range_d;
   hop::CellListDev c{};
   bool valid = false;
   float cell = 0, max_dist = 0;
   void release() {
-    start_d.release(), pts_d.release(), nrm_d.release(), u2_d.release(), count_d.release(), work_d.release(), keep_d.release();
+    start_d.release(), pts_d.release(), nrm_d.release(), u2_d.release(), count_d.release(), work_d.release(), keep_d.release(), range_d.release();
     valid = false;
   }
 };
@@ -178,7 +178,7 @@ struct hop_ctx {
   int n_hyp = 0;
 
   // scoring workspaces
-  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv, icp_corr_idx, icp_hist;
+  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv, icp_corr_idx, icp_hist, pose_inv;
 
   // hand
   CloudDevice hand_scene_d, hand_lookup_d, hand_swivel_d, hand_model_d;
@@ -370,6 +370,10 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
   cs.c.ox = a.ox, cs.c.oy = a.oy, cs.c.oz = a.oz, cs.c.cell = cell, cs.c.inv_cell = 1.0f / cell;
   cs.c.dx = a.dx, cs.c.dy = a.dy, cs.c.dz = a.dz;
   cs.c.start = cs.start_d.as<int>(), cs.c.pts = cs.pts_d.as<float4>(), cs.c.nrm = cs.nrm_d.as<float4>();
+  HIPCHK(c, cs.range_d.ensure(sizeof(int2) * ncell));
+  launch_cell_ranges(cs.c.start, (int)ncell, cs.range_d.as<int2>(), c->stream);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  cs.c.range = cs.range_d.as<int2>();
   cs.valid = true, cs.cell = cell, cs.max_dist = max_dist;
   if (getenv("HOP_PROFILE_SELECT")) std::printf("cell lists: %zu cells, %zu entries (%.1f per cell), cell %.4f\n", ncell, total, (double)total / (double)ncell, cell);
   return HOP_OK;
@@ -426,6 +430,9 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   cs.c.ox = a.ox, cs.c.oy = a.oy, cs.c.oz = a.oz, cs.c.cell = a.cell, cs.c.inv_cell = 1.0f / a.cell;
   cs.c.dx = a.dx, cs.c.dy = a.dy, cs.c.dz = a.dz;
   cs.c.start = cs.start_d.as<int>(), cs.c.pts = cs.pts_d.as<float4>(), cs.c.nrm = normals ? cs.nrm_d.as<float4>() : nullptr;
+  HIPCHK(c, cs.range_d.ensure(sizeof(int2) * ncell));
+  launch_cell_ranges(cs.c.start, (int)ncell, cs.range_d.as<int2>(), c->stream);
+  cs.c.range = cs.range_d.as<int2>();
   cs.valid = true, cs.cell = a.cell, cs.max_dist = max_dist;
   if (getenv("HOP_PROFILE_SELECT")) std::printf("local cell lists: %zu cells (%d with candidates), %d entries, cell %.5f\n", ncell, nwork, total, a.cell);
   return HOP_OK;
@@ -606,7 +613,7 @@ void hop_ctx_destroy(hop_ctx* c) {
                     &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
                     &c->hyp_score, &c->hyp_id, &c->hyp_key, &c->hyp_inv, &c->tmp_pose, &c->tmp_score, &c->tmp_id, &c->sort_keys_alt,
                     &c->sort_vals, &c->sort_vals_alt, &c->sort_tmp, &c->lcp_rev_idx, &c->lcp_rev_d2, &c->lcp_terms, &c->icp_moved,
-                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->icp_corr_idx, &c->icp_hist, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
+                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->icp_corr_idx, &c->icp_hist, &c->pose_inv, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
                     &c->hand_swivel_d.buf, &c->hand_model_d.buf, &c->finger_hist_d, &c->pso_particles_d, &c->pso_match_d,
                     &c->pso_terms_d, &c->pso_sum_d, &c->pso_cnt_d};
   for (DevBuf* b : bufs) b->release();
@@ -1208,6 +1215,9 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     HIPCHK(c, c->icp_corr_idx.ensure(sizeof(int) * (size_t)S.n * HB));
     HIPCHK(c, c->icp_hist.ensure(sizeof(float) * 12 * (size_t)std::max(o->max_iter, 1) * HB));
     a.corr_idx = c->icp_corr_idx.as<int>(), a.hist = c->icp_hist.as<float>();
+    HIPCHK(c, c->pose_inv.ensure(sizeof(float) * 12 * (size_t)H));
+    launch_pose_inverse(a.pose, H, c->pose_inv.as<float>(), c->stream);
+    a.pose_inv = c->pose_inv.as<float>();
     // these paths walk the scene in Morton order (the per-hypothesis sums are order-insensitive up to f64 rounding)
     const CloudDevice& Q = c->scene_sorted_d;
     a.sx = Q.plane(0), a.sy = Q.plane(1), a.sz = Q.plane(2), a.snx = Q.plane(3), a.sny = Q.plane(4), a.snz = Q.plane(5);
@@ -1279,6 +1289,9 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
         if (rc) return rc;
       }
       a.model_cells = cs.c;
+      HIPCHK(c, c->pose_inv.ensure(sizeof(float) * 12 * (size_t)H));
+      launch_pose_inverse(a.pose, H, c->pose_inv.as<float>(), c->stream);
+      a.pose_inv = c->pose_inv.as<float>();
     } else if (!gm.valid || gm.cell != cell) {
       const CloudHost& mh = c->gen.model_h[HOP_MODEL_1MM];
       const int rc = build_grid(c, gm, mh.x.data(), mh.y.data(), mh.z.data(), mh.n, cell);

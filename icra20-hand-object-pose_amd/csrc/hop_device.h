@@ -122,6 +122,7 @@ struct CellListDev {
   float ox, oy, oz, inv_cell, cell;
   int dx, dy, dz;
   const int* start;   // dx*dy*dz + 1
+  const int2* range;  // dx*dy*dz: (start[c], start[c+1]) side by side -- what the lookups read
   const float4* pts;  // concatenated lists; .w = original index (int bits)
   const float4* nrm;  // normals of the same entries (or null)
 };
@@ -178,6 +179,7 @@ struct LcpArgs {
   // `perm` maps the sorted position back to the caller's index, where the terms are stored.
   const float *qx, *qy, *qz, *qnx, *qny, *qnz;
   const int* perm;
+  const float* pose_inv;  // [H][12] inverse poses (cell-list path)
   const int* inv_perm;  // caller index -> sorted position (cell-list path: the term table is indexed by sorted position)
 };
 
@@ -205,6 +207,7 @@ struct IcpArgs {
   CellListDev cells;   // nn_mode 2: NN cell lists of the model in its rest frame
   int* corr_idx;       // nn_mode 2: [hb][ns] list position of the accepted correspondence (or -1)
   float* hist;         // nn_mode 2: [hb][max_iter][12] increments solved so far
+  const float* pose_inv;  // nn_mode 2: [H][12] inverse of the input poses
 };
 
 struct PsoParticle {
@@ -262,6 +265,8 @@ void launch_cell_list_local_work(const int* flag, const int* flag_scan, int ncel
 void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool write, int exist_mode, const int* work, int nwork, int* keep_buf,
                             hipStream_t s);
 int cell_list_local_keep();
+void launch_pose_inverse(const float* pose, int n, float* inv12, hipStream_t s);
+void launch_cell_ranges(const int* start, int ncell, int2* range, hipStream_t s);
 void launch_verify_cells(const VerifyArgs& a, const CellListDev& cl, int blocks, hipStream_t s);
 void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_sum_t(const LcpArgs& a, int hb, hipStream_t s);

@@ -479,7 +479,8 @@ __global__ __launch_bounds__(256) void k_verify_cells(VerifyArgs a, CellListDev 
       const float fx = (q.x - cl.ox) * cl.inv_cell, fy = (q.y - cl.oy) * cl.inv_cell, fz = (q.z - cl.oz) * cl.inv_cell;
       if (fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)cl.dx && fy < (float)cl.dy && fz < (float)cl.dz) {
         const int cidx = ((int)fz * cl.dy + (int)fy) * cl.dx + (int)fx;
-        const int beg = cl.start[cidx], end = cl.start[cidx + 1];
+        const int2 rg = cl.range[cidx];
+        const int beg = rg.x, end = rg.y;
         for (int k = beg; k < end; ++k) {
           const float4 t = cl.pts[k];
           const float dx = q.x - t.x, dy = q.y - t.y, dz = q.z - t.z;
@@ -1178,28 +1179,40 @@ template __global__ void k_cell_list_local<true>(CellListBuildArgs, GridDev, int
 // `tol` below: 2*d*delta + relative 1e-4, delta = a few ulps of the coordinate magnitude), so whenever the runner-up
 // is within tol of the winner the lane falls back to the literal scan (exact expression, (d^2, index) order).
 // Result: list position of the nearest neighbour (or -1) and the exact squared distance.
+template <int B>
 __device__ __forceinline__ void cells_nn(const CellListDev& c, V3 qg, const float* T, V3 q, float& best, int& bpos) {
   const float fx = (qg.x - c.ox) * c.inv_cell, fy = (qg.y - c.oy) * c.inv_cell, fz = (qg.z - c.oz) * c.inv_cell;
   if (!(fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)c.dx && fy < (float)c.dy && fz < (float)c.dz)) return;
   const int cidx = ((int)fz * c.dy + (int)fy) * c.dx + (int)fx;
-  const int beg = c.start[cidx], end = c.start[cidx + 1];
+  const int2 rg = c.range[cidx];  // one 8-byte load
+  const int beg = rg.x, end = rg.y;
   if (beg >= end) return;
   float b1 = 3.0e38f, b2 = 3.0e38f;
   int k1 = beg;
-  for (int k = beg; k < end; ++k) {
-    const float4 t = c.pts[k];
-    const float dx = qg.x - t.x, dy = qg.y - t.y, dz = qg.z - t.z;
-    const float d = dx * dx + dy * dy + dz * dz;
-    b2 = fminf(b2, fmaxf(b1, d));
-    k1 = d < b1 ? k : k1;
-    b1 = fminf(b1, d);
+  float wx = 0.f, wy = 0.f, wz = 0.f;  // the winner stays in registers (no second gather)
+  // B entries per step: the loads are issued together (one exposed latency per B candidates); entries past the end
+  // re-read the last one and are skipped.  B = 4 for the ICP lists (3.7 entries per non-trivial cell), 1 for the
+  // 1 mm computeLCP lists (mostly one entry: wider steps only add cache accesses there).
+  for (int k = beg; k < end; k += B) {
+    float4 t[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) t[u] = c.pts[min(k + u, end - 1)];
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      const float dx = qg.x - t[u].x, dy = qg.y - t[u].y, dz = qg.z - t[u].z;
+      const float d = (u == 0 || k + u < end) ? dx * dx + dy * dy + dz * dz : 3.0e38f;
+      b2 = fminf(b2, fmaxf(b1, d));
+      const bool better = d < b1;
+      k1 = better ? k + u : k1;
+      wx = better ? t[u].x : wx, wy = better ? t[u].y : wy, wz = better ? t[u].z : wz;
+      b1 = fminf(b1, d);
+    }
   }
   const float mag = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), 0.25f));
   const float delta = mag * 2.0e-6f;
   const float tol = 2.f * sqrtf(b1) * delta + 1.0e-4f * b1 + delta * delta;
   if (b2 - b1 > tol) {
-    const float4 t = c.pts[k1];
-    best = sqdist_flann(q, m4_point(T, v3(t.x, t.y, t.z)));
+    best = sqdist_flann(q, m4_point(T, v3(wx, wy, wz)));
     bpos = k1;
     return;
   }
@@ -1218,7 +1231,8 @@ __device__ __forceinline__ void cells_nn_plain(const CellListDev& c, V3 q, float
   const float fx = (q.x - c.ox) * c.inv_cell, fy = (q.y - c.oy) * c.inv_cell, fz = (q.z - c.oz) * c.inv_cell;
   if (!(fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)c.dx && fy < (float)c.dy && fz < (float)c.dz)) return;
   const int cidx = ((int)fz * c.dy + (int)fy) * c.dx + (int)fx;
-  const int beg = c.start[cidx], end = c.start[cidx + 1];
+  const int2 rg = c.range[cidx];
+  const int beg = rg.x, end = rg.y;
   int bj = 0x7fffffff;
   for (int k = beg; k < end; ++k) {
     const float4 t = c.pts[k];
@@ -1237,21 +1251,10 @@ __device__ __forceinline__ void cells_nn_plain(const CellListDev& c, V3 q, float
 // read-for-ownership traffic of partial lines: 17 GB of HBM traffic per launch instead of 0.8).
 constexpr int LCP_TH = 16;
 __global__ __launch_bounds__(256) void k_lcp_cells(LcpArgs a, int hb, int hs, int npt) {
-  __shared__ float sT[LCP_TH][12], sTi[LCP_TH][12];
   __shared__ float2 out[64][LCP_TH + 1];
   const int pt = blockIdx.x % npt, ht = blockIdx.x / npt;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x < LCP_TH) {
-    const int hl = ht * LCP_TH + threadIdx.x;
-    if (hl < hb) {
-      M4 P;
-      const float* pose = a.pose + (size_t)(a.h0 + hl) * 16;
-      for (int k = 0; k < 16; ++k) P.m[k] = pose[k];
-      const M4 inv = m4_inverse_affine(P);
-      for (int k = 0; k < 12; ++k) sT[threadIdx.x][k] = P.m[k], sTi[threadIdx.x][k] = inv.m[k];
-    }
-  }
-  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: the pose pointers below stay in SGPRs
   const int k = pt * 64 + lane;
   const bool kin = k < a.ns;
   V3 s = v3(0, 0, 0), sn = v3(0, 0, 0);
@@ -1260,10 +1263,11 @@ __global__ __launch_bounds__(256) void k_lcp_cells(LcpArgs a, int hb, int hs, in
     const int hh = wave * (LCP_TH / 4) + j, hl = ht * LCP_TH + hh;
     float f = -1.f, g = -1.f;
     if (kin && hl < hb) {
-      const float* T = sT[hh];
+      const float* __restrict__ T = a.pose + (size_t)(a.h0 + hl) * 16;  // wave-uniform: scalar loads
+      const float* __restrict__ Ti = a.pose_inv + (size_t)(a.h0 + hl) * 12;
       float best = 3.0e38f;
       int pos = -1;
-      cells_nn(a.model_cells, m4_point(sTi[hh], s), T, s, best, pos);
+      cells_nn<1>(a.model_cells, m4_point(Ti, s), T, s, best, pos);
       if (pos >= 0 && best < a.dist * a.dist) {
         const float4 mp = a.model_cells.pts[pos], mnr = a.model_cells.nrm[pos];
         const V3 nmod = m4_dir(T, v3(mnr.x, mnr.y, mnr.z));
@@ -1509,18 +1513,18 @@ __device__ __forceinline__ void icp_chain_point_normal(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void k_icp_corr_cells(IcpArgs a) {
-  __shared__ float sT[12], sTi[12];
   const int hl = blockIdx.y, h = a.h0 + hl;
   const IcpState& st = a.state[hl];
   if (!st.active) return;
-  block_pose_and_inverse(a.pose + (size_t)h * 16, sT, sTi);
+  const float* __restrict__ sT = a.pose + (size_t)h * 16;         // wave-uniform: scalar loads
+  const float* __restrict__ sTi = a.pose_inv + (size_t)h * 12;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.ns) return;
   V3 p = v3(a.sx[i], a.sy[i], a.sz[i]);
   icp_chain_point(a.hist + (size_t)hl * a.max_iter * 12, a.iter, p);
   float best = 3.0e38f;
   int pos = -1;
-  cells_nn(a.cells, m4_point(sTi, p), sT, p, best, pos);
+  cells_nn<4>(a.cells, m4_point(sTi, p), sT, p, best, pos);
   a.corr_idx[(size_t)hl * a.ns + i] = (pos >= 0 && best <= a.max_d2) ? pos : -1;
 }
 
@@ -1693,6 +1697,20 @@ __global__ void k_icp_finish(IcpArgs a, int hb, int* iters_out, int* conv_out) {
   for (int i = 0; i < 16; ++i) pose[i] = out.m[i];
   if (iters_out) iters_out[a.h0 + hl] = st.iterations;
   if (conv_out) conv_out[a.h0 + hl] = st.converged;
+}
+
+// inverse of every hypothesis pose (affine), once per stage: the cell-list kernels map queries into the model's rest
+// frame with it and read it through scalar loads instead of inverting per block
+__global__ void k_pose_inverse(const float* __restrict__ pose, int n, float* __restrict__ inv12) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= n) return;
+  M4 P;
+  for (int k = 0; k < 16; ++k) P.m[k] = pose[(size_t)h * 16 + k];
+  const M4 inv = m4_inverse_affine(P);
+  for (int k = 0; k < 12; ++k) inv12[(size_t)h * 12 + k] = inv.m[k];
+}
+void launch_pose_inverse(const float* pose, int n, float* inv12, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_pose_inverse, dim3((n + 63) / 64), dim3(64), 0, s, pose, n, inv12);
 }
 
 __global__ void k_icp_init(IcpState* st, int hb) {
@@ -1950,6 +1968,13 @@ void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool w
   else hipLaunchKernelGGL(k_cell_list_local<false>, dim3((nwork + 3) / 4), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
 }
 int cell_list_local_keep() { return LOCAL_KEEP; }
+__global__ __launch_bounds__(256) void k_cell_ranges(const int* __restrict__ start, int ncell, int2* __restrict__ range) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < ncell) range[c] = make_int2(start[c], start[c + 1]);
+}
+void launch_cell_ranges(const int* start, int ncell, int2* range, hipStream_t s) {
+  hipLaunchKernelGGL(k_cell_ranges, dim3((ncell + 255) / 256), dim3(256), 0, s, start, ncell, range);
+}
 int lcp_cells_row_stride(int hb) { return ((hb + LCP_TH - 1) / LCP_TH) * LCP_TH; }
 void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s) {
   const int npt = (a.ns + 63) / 64, nht = (hb + LCP_TH - 1) / LCP_TH;
