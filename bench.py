@@ -379,9 +379,18 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget_s)
             except Exception as e:  # the baseline is reported, never required for the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "hypotheses/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which is flushed at exit when stdout is a pipe: flush it now
+        # so that the JSON line is the last line of the output
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
