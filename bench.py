@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--particles", type=int, default=200)
     ap.add_argument("--hand-scene", type=int, default=20000)
     ap.add_argument("--verify-mode", type=int, default=2, help="0 brute-force LDS scan, 1 voxel grid, 2 EXIST-mode cell lists (identical counts)")
-    ap.add_argument("--nn-mode", type=int, default=2, help="ICP / computeLCP nearest neighbour: 0 brute force, 1 voxel grid, 2 NN cell lists for ICP (identical results)")
+    ap.add_argument("--nn-mode", type=int, default=3, help="ICP / computeLCP nearest neighbour: 0 brute force, 1 voxel grids, 2 NN cell lists, "
+                    "3 NN cell lists with ICP search and accumulation in one kernel (identical correspondences in all modes)")
     ap.add_argument("--inflight", type=int, default=6, help="frames in flight per GPU (one context each): the host base selection of one "
                     "frame overlaps the device work of the others; 1 = strictly one frame at a time")
     ap.add_argument("--no-serial-frame", action="store_true", help="skip the extra undisturbed frame used for per-kernel timing")
@@ -308,6 +309,9 @@ def main():
             }
             if args.nn_mode < 2:
                 kern["k_icp_nn"] = kern.pop("k_icp_corr_cells")
+                kern.pop("k_icp_accum")
+            elif args.nn_mode == 3:
+                kern["k_icp_fused"] = kern.pop("k_icp_corr_cells")
                 kern.pop("k_icp_accum")
             return kern
 

@@ -452,7 +452,7 @@ class PoseEstimator:
         self.ctx.cluster_poses(angle_diff, dist_diff, [s["x"], s["y"], s["z"]], assign_id)
 
     def refineByICP(self):
-        self.ctx.icp_refine(10, float(self.cfg["icp_angle_thres"]), float(self.cfg["icp_dist_thres"]), max_hypotheses=100, nn_mode=2)
+        self.ctx.icp_refine(10, float(self.cfg["icp_angle_thres"]), float(self.cfg["icp_dist_thres"]), max_hypotheses=100, nn_mode=3)
 
     def selectBest(self):
         pose, score, idx = self.ctx.lcp_select_best(float(self.cfg["lcp"]["dist"]), float(self.cfg["lcp"]["normal_angle"]), 2)

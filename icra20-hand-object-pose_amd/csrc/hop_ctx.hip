@@ -1230,12 +1230,14 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
       a.iter = it;
       {
         SpanGuard sg(c, T_ICP_NN);
-        if (cells) {
+        if (o->nn_mode == 3) {
+          launch_icp_fused(a, hb, c->stream);
+        } else if (cells) {
           launch_icp_corr_cells(a, hb, c->stream);
         } else if (o->nn_mode == 1) launch_icp_nn_grid(a, hb, c->stream);
         else launch_icp_nn(a, hb, c->stream);
       }
-      if (cells) {
+      if (cells && o->nn_mode != 3) {
         SpanGuard sg(c, T_ICP_ACCUM);
         launch_icp_accum(a, hb, c->stream);
       }

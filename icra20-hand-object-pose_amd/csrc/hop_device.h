@@ -277,6 +277,7 @@ void launch_icp_nn(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_nn_grid(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_corr_cells(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_accum(const IcpArgs& a, int hb, hipStream_t s);
+void launch_icp_fused(const IcpArgs& a, int hb, hipStream_t s);
 void launch_cell_list_bounds(const CellListBuildArgs& a, hipStream_t s);
 void launch_cell_list_count(const CellListBuildArgs& a, hipStream_t s);
 void launch_cell_list_fill(const CellListBuildArgs& a, hipStream_t s);

@@ -1584,6 +1584,64 @@ __global__ __launch_bounds__(256) void k_icp_accum(IcpArgs a) {
 }
 template __global__ void k_icp_accum<ICP_ACCUM_R>(IcpArgs);
 
+// nn_mode 3: correspondence search and accumulation in one launch (no correspondence array in between).  Same
+// arithmetic as the split pair; R points per lane share one block-level reduction of the 32 accumulators.
+template <int R>
+__global__ __launch_bounds__(256) void k_icp_fused(IcpArgs a) {
+  __shared__ double red[4][ICP_NACC];
+  const int hl = blockIdx.y, h = a.h0 + hl;
+  const IcpState& st = a.state[hl];
+  if (!st.active) return;
+  const float* __restrict__ pose = a.pose + (size_t)h * 16;
+  const float* __restrict__ sTi = a.pose_inv + (size_t)h * 12;
+  const float* __restrict__ hist = a.hist + (size_t)hl * a.max_iter * 12;
+  double acc[ICP_NACC];
+#pragma unroll
+  for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
+  for (int r = 0; r < R; ++r) {
+    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    if (i >= a.ns) continue;
+    V3 q = v3(a.sx[i], a.sy[i], a.sz[i]), qn = v3(a.snx[i], a.sny[i], a.snz[i]);
+    icp_chain_point_normal(hist, a.iter, q, qn);
+    float d2 = 3.0e38f;
+    int pos = -1;
+    cells_nn<4>(a.cells, m4_point(sTi, q), pose, q, d2, pos);
+    if (pos < 0 || !(d2 <= a.max_d2)) continue;
+    const float4 tp = a.cells.pts[pos], tn = a.cells.nrm[pos];
+    const V3 nt = m4_dir(pose, v3(tn.x, tn.y, tn.z));
+    if (!(vdot(qn, nt) >= a.cos_thr)) continue;
+    const V3 tq = m4_point(pose, v3(tp.x, tp.y, tp.z));
+    const V3 c = vcross(q, nt);
+    const double J[6] = {c.x, c.y, c.z, nt.x, nt.y, nt.z};
+    const double res = (double)vdot(q - tq, nt);
+    int k = 0;
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+#pragma unroll
+      for (int v = 0; v <= u; ++v) {
+        acc[k] = fma(J[u], J[v], acc[k]);
+        ++k;
+      }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) acc[21 + u] = fma(-J[u], res, acc[21 + u]);
+    acc[27] += (double)d2;
+    acc[28] += 1.0;
+    acc[29] += (double)q.x, acc[30] += (double)q.y, acc[31] += (double)q.z;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < ICP_NACC; ++k) {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < ICP_NACC) {
+    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NACC + threadIdx.x] = s;
+  }
+}
+template __global__ void k_icp_fused<ICP_ACCUM_R>(IcpArgs);
+
 __device__ bool chol6(double A[6][6], const double b[6], double x[6]) {
   double L[6][6];
   for (int i = 0; i < 6; ++i)
@@ -1941,6 +1999,9 @@ void launch_icp_nn_grid(const IcpArgs& a, int hb, hipStream_t s) {
 }
 void launch_icp_corr_cells(const IcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_corr_cells, dim3((a.ns + 255) / 256, hb), dim3(256), 0, s, a);
+}
+void launch_icp_fused(const IcpArgs& a, int hb, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_fused<ICP_ACCUM_R>, dim3(icp_blocks_per_hyp(a.ns, true), hb), dim3(256), 0, s, a);
 }
 void launch_icp_accum(const IcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_accum<ICP_ACCUM_R>, dim3(icp_blocks_per_hyp(a.ns, true), hb), dim3(256), 0, s, a);

@@ -71,7 +71,7 @@ class PoseEstimator {
 
   // refineByICP (PoseEstimator.cpp:235-275)
   void refineByICP() {
-    hop_icp_opts o{10, cfg->getf("icp_angle_thres"), cfg->getf("icp_dist_thres"), 100, 2};  // nn_mode 2: NN cell lists
+    hop_icp_opts o{10, cfg->getf("icp_angle_thres"), cfg->getf("icp_dist_thres"), 100, 3};  // nn_mode 3: NN cell lists, fused search + accumulation
     hop::check(hop_icp_refine(ctx_, &o, nullptr, nullptr), ctx_, "hop_icp_refine");
   }
 

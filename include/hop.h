@@ -129,7 +129,8 @@ typedef struct {
   float angle_deg;     /* icp_angle_thres = 45     (config_autodataset.yaml:127) */
   float max_corr_dist; /* icp_dist_thres  = 0.01   (:126) */
   int max_hypotheses;
-  int nn_mode;         /* 0 brute force, 1 ring-expanding voxel grid, 2 NN cell lists (same correspondences) */
+  int nn_mode;         /* 0 brute force, 1 ring-expanding voxel grid, 2 NN cell lists, 3 NN cell lists with search and
+                      * accumulation in one kernel (same correspondences in all modes) */
 } hop_icp_opts;
 int hop_icp_refine(hop_ctx* ctx, const hop_icp_opts* opts, int* iterations_out /*H or NULL*/,
                    int* converged_out /*H or NULL*/);

@@ -206,7 +206,7 @@ def test_lcp_ragged_and_empty_edge_cases(ctx, api, orc, synth, nn_mode):
 
 
 # ------------------------------------------------------------------------------------------------ ICP
-@pytest.mark.parametrize("nn_mode", [0, 1, 2])
+@pytest.mark.parametrize("nn_mode", [0, 1, 2, 3])
 def test_icp_matches_oracle_and_recovers_pose(ctx, api, orc, synth, nn_mode):
     sc, mx, mn, poses = _scoring_case(synth, 2500, 1500, 24)
     # small perturbations so that ICP converges to the truth
@@ -229,7 +229,7 @@ def test_icp_matches_oracle_and_recovers_pose(ctx, api, orc, synth, nn_mode):
     assert ok >= 20
 
 
-@pytest.mark.parametrize("nn_mode", [0, 1, 2])
+@pytest.mark.parametrize("nn_mode", [0, 1, 2, 3])
 def test_icp_too_few_correspondences_returns_input(ctx, api, orc, synth, nn_mode):
     sc, mx, mn, poses = _scoring_case(synth, 500, 400, 3)
     poses[:, :3, 3] += 5.0  # nothing within 1 cm -> not converged -> identity (Utils.cpp:218-225)
@@ -251,7 +251,7 @@ def test_icp_and_lcp_grid_equal_brute_bitwise_large(ctx, api, synth):
     ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
     ctx.set_model(api.HOP_MODEL_1MM, mx, mn)
     res = []
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         ctx.hypos_upload(poses)
         it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=mode, want_stats=True)
         p, _, _ = ctx.hypos_download()
@@ -268,6 +268,8 @@ def test_icp_and_lcp_grid_equal_brute_bitwise_large(ctx, api, synth):
     same = np.all(res[0][2] == res[2][2], axis=(1, 2))
     assert same.mean() > 0.5 and np.array_equal(res[0][3][same], res[2][3][same])
     assert res[0][0].max() >= 4, "some hypotheses must need several iterations"
+    # mode 3 (search and accumulation fused) visits the points in the same order as mode 2: the very same bits
+    assert np.array_equal(res[2][0], res[3][0]) and np.array_equal(res[2][2], res[3][2]) and np.array_equal(res[2][3], res[3][3])
     # computeLCP alone on identical poses (the refined set of mode 0): all three NN modes return the same bits
     lcp = []
     for mode in (0, 1, 2):
