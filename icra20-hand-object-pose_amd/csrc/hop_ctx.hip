@@ -134,6 +134,7 @@ struct hop_ctx {
   // host-side clouds and generator state (scene = _scene_high_confidence)
   GenState gen;
   CloudDevice scene_d;
+  CloudDevice scene_unit_d, scene_sorted_unit_d;  // planes 3..5: unit normals (computeLCP on cell lists), caller / Morton order
   CloudDevice scene_sorted_d;  // scoring copy in Morton order (grid paths), + permutation back to caller order
   DevBuf scene_perm_d;
   CloudDevice model_d[2];
@@ -608,7 +609,7 @@ void hop_ctx_destroy(hop_ctx* c) {
   if (c->ppf_matrix_registered) (void)hipHostUnregister(c->ppf_matrix_cached);
   std::free(c->ppf_matrix_cached);
   c->angle_thr_d.release();
-  DevBuf* bufs[] = {&c->scene_d.buf, &c->scene_sorted_d.buf, &c->scene_perm_d, &c->model_d[0].buf, &c->model_d[1].buf, &c->key_bitmap_d, &c->gp_d.buf, &c->gq_d.buf, &c->gq_unit_d,
+  DevBuf* bufs[] = {&c->scene_d.buf, &c->scene_sorted_d.buf, &c->scene_unit_d.buf, &c->scene_sorted_unit_d.buf, &c->scene_perm_d, &c->model_d[0].buf, &c->model_d[1].buf, &c->key_bitmap_d, &c->gp_d.buf, &c->gq_d.buf, &c->gq_unit_d,
                     &c->ppf_matrix_d, &c->vp_d.buf, &c->vq_d.buf, &c->bases_d, &c->pairs1_d,
                     &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
                     &c->hyp_score, &c->hyp_id, &c->hyp_key, &c->hyp_inv, &c->tmp_pose, &c->tmp_score, &c->tmp_id, &c->sort_keys_alt,
@@ -1308,13 +1309,30 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
     a.scene_grid = c->scene_grid.g;
     if (lcp_cells) {
       if (!c->scene_cells.valid || c->scene_cells.max_dist != o->dist) {
-        const int rc = build_cell_lists_local(c, c->scene_cells, c->scene_grid, &c->scene_d, o->dist, 1, 0);
+        // unit normals of the scene, caller order (for the lists) and sorted order (for the walk): computeLCP normalises
+        // a normal at every use, which for a scene normal is the same value every time
+        const int ns = S.n;
+        for (CloudDevice* u : {&c->scene_unit_d, &c->scene_sorted_unit_d}) {
+          u->n = ns;
+          HIPCHK(c, u->buf.ensure(sizeof(float) * 6 * (size_t)std::max(ns, 1)));
+        }
+        auto unit = [&](const CloudDevice& src, CloudDevice& dst) {
+          float* b = dst.buf.as<float>();
+          launch_unit_normals(src.plane(3), src.plane(4), src.plane(5), ns, b + 3 * (size_t)ns, b + 4 * (size_t)ns, b + 5 * (size_t)ns, c->stream);
+        };
+        unit(c->scene_d, c->scene_unit_d);
+        unit(c->scene_sorted_d, c->scene_sorted_unit_d);
+        const int rc = build_cell_lists_local(c, c->scene_cells, c->scene_grid, &c->scene_unit_d, o->dist, 1, 0);
         if (rc) return rc;
       }
       a.scene_cells = c->scene_cells.c;
     }
     const CloudDevice& Q = c->scene_sorted_d;
     a.qx = Q.plane(0), a.qy = Q.plane(1), a.qz = Q.plane(2), a.qnx = Q.plane(3), a.qny = Q.plane(4), a.qnz = Q.plane(5);
+    if (lcp_cells) {
+      const CloudDevice& U = c->scene_sorted_unit_d;
+      a.qnx = U.plane(3), a.qny = U.plane(4), a.qnz = U.plane(5);
+    }
     a.perm = c->scene_perm_d.as<int>();
     a.inv_perm = a.perm + std::max(S.n, 1);
   }

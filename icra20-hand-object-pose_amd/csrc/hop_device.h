@@ -266,6 +266,7 @@ void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool w
                             hipStream_t s);
 int cell_list_local_keep();
 void launch_pose_inverse(const float* pose, int n, float* inv12, hipStream_t s);
+void launch_unit_normals(const float* nx, const float* ny, const float* nz, int n, float* ux, float* uy, float* uz, hipStream_t s);
 void launch_cell_ranges(const int* start, int ncell, int2* range, hipStream_t s);
 void launch_verify_cells(const VerifyArgs& a, const CellListDev& cl, int blocks, hipStream_t s);
 void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s);

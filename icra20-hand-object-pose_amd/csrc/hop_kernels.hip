@@ -600,6 +600,25 @@ __device__ __forceinline__ float lcp_term(V3 n1, V3 n2, float d2, float dist_thr
   return -1.f;  // "no contribution" marker (real terms are >= 0: d>cos>0 and d2<dist^2)
 }
 
+// the same term for normals that are already normalised (the reference normalises both at every use; a scene normal's
+// normalised value does not depend on the hypothesis, so the cell-list path keeps it precomputed, and the posed model
+// normal is normalised once for the forward and the reciprocal term)
+__device__ __forceinline__ float lcp_term_unit(V3 u1, V3 u2, float d2, float dist_thres, float cos_thres) {
+  const float d = vdot(u1, u2);
+  if (d > cos_thres) return d * (1 - sqrtf(d2) / dist_thres) * 1.0f;
+  return -1.f;
+}
+__global__ __launch_bounds__(256) void k_unit_normals(const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz, int n,
+                                                     float* __restrict__ ux, float* __restrict__ uy, float* __restrict__ uz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 u = vnormalized(v3(nx[i], ny[i], nz[i]));
+  ux[i] = u.x, uy[i] = u.y, uz[i] = u.z;
+}
+void launch_unit_normals(const float* nx, const float* ny, const float* nz, int n, float* ux, float* uy, float* uz, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_unit_normals, dim3((n + 255) / 256), dim3(256), 0, s, nx, ny, nz, n, ux, uy, uz);
+}
+
 template <int R>
 __global__ __launch_bounds__(256) void k_lcp_forward(LcpArgs a) {
   __shared__ float4 tile[NN_TILE];
@@ -1270,15 +1289,15 @@ __global__ __launch_bounds__(256) void k_lcp_cells(LcpArgs a, int hb, int hs, in
       cells_nn<1>(a.model_cells, m4_point(Ti, s), T, s, best, pos);
       if (pos >= 0 && best < a.dist * a.dist) {
         const float4 mp = a.model_cells.pts[pos], mnr = a.model_cells.nrm[pos];
-        const V3 nmod = m4_dir(T, v3(mnr.x, mnr.y, mnr.z));
-        f = lcp_term(sn, nmod, best, a.dist, a.cos_thres);
+        const V3 nmod = vnormalized(m4_dir(T, v3(mnr.x, mnr.y, mnr.z)));  // normalised once, used by both terms
+        f = lcp_term_unit(sn, nmod, best, a.dist, a.cos_thres);             // sn, rn: unit normals (k_unit_normals)
         const V3 pm = m4_point(T, v3(mp.x, mp.y, mp.z));
         float rbest = 3.0e38f;
         int rk = -1;
         cells_nn_plain(a.scene_cells, pm, rbest, rk);
         if (rk >= 0) {
           const float4 rn = a.scene_cells.nrm[rk];
-          g = lcp_term(nmod, v3(rn.x, rn.y, rn.z), rbest, a.dist, a.cos_thres);
+          g = lcp_term_unit(nmod, v3(rn.x, rn.y, rn.z), rbest, a.dist, a.cos_thres);
         }
       }
     }
