@@ -1308,7 +1308,13 @@ __global__ __launch_bounds__(256) void k_lcp_cells(LcpArgs a, int hb, int hs, in
   for (int e = threadIdx.x; e < 64 * LCP_TH; e += 256) {
     const int p = e / LCP_TH, hh = e % LCP_TH;
     const int kk = pt * 64 + p;
-    if (kk < a.ns) tt[(size_t)kk * hs + ht * LCP_TH + hh] = out[p][hh];
+    if (kk < a.ns) {
+      // streaming store: the 1.6 GB table is written once and read once by the sum; it should not evict the lists
+      const float2 v = out[p][hh];
+      unsigned long long bits;
+      memcpy(&bits, &v, 8);
+      __builtin_nontemporal_store(bits, reinterpret_cast<unsigned long long*>(tt + (size_t)kk * hs + ht * LCP_TH + hh));
+    }
   }
 }
 
