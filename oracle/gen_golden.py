@@ -33,6 +33,9 @@ CASES = [
     ("case1", 300, 7, 1, 100, 10),   # as-shipped option values (config_autodataset.yaml:133-140)
     ("case2", 500, 3, 1, 100, 10),
     ("case3", 250, 21, 2, 60, 4),    # repeated calls on one matcher (hypotheses accumulate)
+    # BASELINE configs[0] ("C1-synthetic-model"): the hand-region cloud of the reference's example/depth7.png
+    # (tests/golden/depth7_hand_region.npz, made by tools/make_depth7_fixture.py) against the synthetic ellipse
+    ("depth7", -1, 0, 1, 100, 10),
 ]
 
 
@@ -54,7 +57,16 @@ def canonical_hypos(pose, lcp):
 def gen_case(name, n_scene, seed, n_calls, sample_size, succ):
     mx, mn = synth.ellipsoid_model_spacing(0.005)
     keys = synth.ppf_key_table()
-    sc = synth.make_scene(n_scene, seed=seed)
+    if n_scene < 0:
+        g = np.load(os.path.join(OUT, "depth7_hand_region.npz"))
+
+        class Real:
+            xyz, nrm = g["xyz"], g["nrm"]
+            conf = np.ones(len(g["xyz"]), np.float32)
+            gt_pose = np.eye(4, dtype=np.float32)
+        sc = Real
+    else:
+        sc = synth.make_scene(n_scene, seed=seed)
     r = orc.RefS4PCS(sample_size=sample_size, success_quadrilaterals=succ)
     r.set_keys(keys)
     n = r.run(sc.xyz, sc.nrm, sc.conf, mx, mn, n_calls)
@@ -148,6 +160,9 @@ if __name__ == "__main__":
     if not orc.ref_available():
         orc.build()
     os.makedirs(OUT, exist_ok=True)
-    gen_kats()
+    only = sys.argv[1:]
+    if not only:
+        gen_kats()
     for c in CASES:
-        gen_case(*c)
+        if not only or c[0] in only:
+            gen_case(*c)

@@ -90,7 +90,7 @@ def test_verify_brute_grid_oracle_agree_large(ctx, orc, synth):
 
 
 # ------------------------------------------------------------------------------------------------ generator
-@pytest.mark.parametrize("case", ["case1", "case2"])
+@pytest.mark.parametrize("case", ["case1", "case2", "depth7"])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_generator_matches_reference_golden(ctx, api, orc, golden_dir, case, mode):
     g = np.load(os.path.join(golden_dir, f"s4pcs_{case}.npz"))
@@ -529,3 +529,43 @@ def test_cpp_host_app_equals_python_mirror(api, hop, synth, tmp_path):
     b = mx1 @ sc.gt_pose[:3, :3].T + sc.gt_pose[:3, 3]
     from scipy.spatial import cKDTree
     assert cKDTree(b).query(a)[0].mean() < 0.005
+
+
+def test_c1_depth7_full_chain_within_1mm_1deg_of_oracle(ctx, api, orc, synth, golden_dir):
+    """BASELINE.json configs[0] ("C1-synthetic-model"): the hand-region cloud of the reference's
+    example/depth7.png (fixture made by tools/make_depth7_fixture.py: back-projection, hand-base crop, 3 mm voxels)
+    with the as-shipped option values and the synthetic ellipse.  The north star's criterion: the pose returned by the
+    GPU chain within 1 mm / 1 degree of the CPU restatement's on the same frame."""
+    g = np.load(os.path.join(golden_dir, "depth7_hand_region.npz"))
+    xyz, nrm = g["xyz"], g["nrm"]
+    conf = np.ones(len(xyz), np.float32)
+    assert 1500 < len(xyz) < 2100 and int(g["counts"][0]) == 68600  # valid depth pixels of the example frame
+    mx5, mn5 = synth.ellipsoid_model_spacing(0.005)
+    mx1, mn1 = synth.ellipsoid_model(4000)
+    keys = synth.ppf_key_table()
+    sym = [180, 180, 180]
+    ctx.set_scene(xyz, nrm, conf, 0.8)
+    ctx.set_model(api.HOP_MODEL_5MM, mx5, mn5)
+    ctx.set_model(api.HOP_MODEL_1MM, mx1, mn1)
+    ctx.set_ppf_keys(keys)
+    o = ctx.default_s4pcs_opts(max_time_seconds=0)   # sample 100, overlap 0.2, delta 3 mm, 10 successful bases
+    pose, lcp, st = ctx.s4pcs_generate(o)
+    ctx.cluster_poses(30.0, 0.015, sym, True)
+    ctx.icp_refine(10, 45.0, 0.01, max_hypotheses=100, nn_mode=3)
+    ctx.cluster_poses(5.0, 0.003, sym, False)
+    best, score, idx = ctx.lcp_select_best(0.001, 10.0, 2)
+    oo = orc.OracleS4PCS()
+    oo.set_keys(keys)
+    oo.run(xyz, nrm, conf, mx5, mn5, 1)
+    op, ol = oo.hypos()
+    assert len(ol) > 1000 and np.array_equal(ol, lcp)
+    keep = orc.cluster_poses(op, ol, np.arange(len(ol)), 30.0, 0.015, sym)
+    p1, l1 = op[keep][:100], ol[keep][:100]
+    p2, _, _ = orc.icp_refine_batch(xyz, nrm, mx5, mn5, p1, 10, 45.0, 0.01)
+    keep2 = orc.cluster_poses(p2, l1, np.arange(len(l1)), 5.0, 0.003, sym)
+    p3 = p2[keep2]
+    s3 = orc.compute_lcp_batch(xyz, nrm, mx1, mn1, p3, 0.001, 10.0)
+    ob = p3[int(np.flatnonzero(s3 == s3.max())[0])]
+    assert np.linalg.norm(best[:3, 3] - ob[:3, 3]) < 1e-3
+    assert _rot_err_deg(best[:3, :3].astype(np.float64), ob[:3, :3].astype(np.float64)) < 1.0
+    assert abs(score - s3.max()) <= 1e-4 * s3.max()

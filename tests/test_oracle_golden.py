@@ -66,7 +66,7 @@ def test_kat_rigid(orc, golden_dir):
             assert np.array_equal(T, g["rigid_T"][k])   # bit-equal transform
 
 
-@pytest.mark.parametrize("case", ["case1", "case2", "case3"])
+@pytest.mark.parametrize("case", ["case1", "case2", "case3", "depth7"])
 def test_generator_matches_reference(orc, golden_dir, case):
     g = np.load(os.path.join(golden_dir, f"s4pcs_{case}.npz"))
     sample_size, succ, n_calls = (int(v) for v in g["opts"])
