@@ -75,6 +75,10 @@ class PsoSettings(C.Structure):
                 ("err_tol", C.c_double), ("lower_rad", C.c_double), ("upper_rad", C.c_double), ("seed", C.c_uint64)]
 
 
+class HandLink(C.Structure):
+    _fields_ = [("xyz", C.POINTER(C.c_float)), ("n", C.c_int), ("sq_dist_thres", C.c_float)]
+
+
 class Timing(C.Structure):
     _fields_ = [("ms_verify", C.c_double), ("ms_gen_other", C.c_double), ("ms_icp_nn", C.c_double),
                 ("ms_icp_solve", C.c_double), ("ms_lcp_fwd", C.c_double), ("ms_lcp_rev", C.c_double),
@@ -120,6 +124,7 @@ SIGNATURES = {
     "hop_topk_merge": (C.c_int, [fp, C.c_int, C.c_int, fp, ip]),
     "hop_hand_set_scene": (C.c_int, [_vp, fp, C.c_int, fp, C.c_int, fp, C.c_int]),
     "hop_hand_set_finger": (C.c_int, [_vp, C.POINTER(FingerArgs)]),
+    "hop_hand_remove_surrounding": (C.c_int, [_vp, fp, fp, C.c_int, fp, C.POINTER(HandLink), C.c_int, fp, fp, C.c_float, fp, fp, fp, ip, ip]),
     "hop_hand_pso_eval_batch": (C.c_int, [_vp, dp, C.c_int, dp]),
     "hop_pso_default_settings": (None, [C.POINTER(PsoSettings)]),
     "hop_hand_pso_search": (C.c_int, [_vp, C.POINTER(PsoSettings), dp, dp]),
@@ -340,6 +345,26 @@ class Context:
         S, Ln, W = soa(scene_xyz), soa(lookup_nrm), soa(swivel_xyz)
         self._chk(self.L.hop_hand_set_scene(self.h, F(S), S.shape[1], F(Ln), Ln.shape[1], F(W), W.shape[1]), "hop_hand_set_scene")
 
+    def hand_remove_surrounding(self, scene_xyz, scene_nrm, handbase_in_cam, links, finger12_in_handbase, finger22_in_handbase, min_z):
+        """links: list of (xyz (n,3) in the hand-base frame, squared distance threshold), in name order.
+        Returns (xyz, nrm, conf, keep_index) of the survivors, in input order, camera frame."""
+        X, Nn = soa(scene_xyz), soa(scene_nrm)
+        n = X.shape[1]
+        clouds = [soa(l[0]) for l in links]
+        arr = (HandLink * max(len(links), 1))()
+        for k, (cl, l) in enumerate(zip(clouds, links)):
+            arr[k].xyz, arr[k].n, arr[k].sq_dist_thres = F(cl), cl.shape[1], float(np.float32(l[1]))
+        ox, on = np.zeros((3, max(n, 1)), np.float32), np.zeros((3, max(n, 1)), np.float32)
+        oc, ki = np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.int32)
+        T = np.ascontiguousarray(handbase_in_cam, np.float32).reshape(16)
+        f1 = np.ascontiguousarray(finger12_in_handbase, np.float32).reshape(16)
+        f2 = np.ascontiguousarray(finger22_in_handbase, np.float32).reshape(16)
+        k = C.c_int(0)
+        self._chk(self.L.hop_hand_remove_surrounding(self.h, F(X), F(Nn), n, F(T), arr, len(links), F(f1), F(f2), float(min_z), F(ox), F(on),
+                                                     F(oc), I(ki), C.byref(k)), "hop_hand_remove_surrounding")
+        k = k.value
+        return ox[:, :k].T.copy(), on[:, :k].T.copy(), oc[:k].copy(), ki[:k].copy()
+
     def hand_set_finger(self, args: "FingerArgs"):
         self._chk(self.L.hop_hand_set_finger(self.h, C.byref(args)), "hop_hand_set_finger")
 
@@ -528,6 +553,37 @@ class HandT42:
     def setCurScene(self, scene_removed_noise_xyz, scene_hand_region_nrm, scene_remove_swivel_xyz):
         """Products of Hand::setCurScene (Hand.cpp:327-332), all in the hand-base frame."""
         self.ctx.hand_set_scene(scene_removed_noise_xyz, scene_hand_region_nrm, scene_remove_swivel_xyz)
+
+    def makeHandCloud(self):
+        """Hand::makeHandCloud (Hand.cpp:537-556): every component cloud in the hand-base frame at the current finger
+        state, keyed by name (the reference keeps a kd-tree per component; std::map order = sorted names)."""
+        out = {}
+        for name in sorted(self.hand.clouds):
+            T = self.getTFHandBase(name) if name != "base_link" else np.eye(4, dtype=np.float32)
+            x = np.asarray(self.hand.clouds[name][0], np.float32)
+            p = np.empty_like(x)
+            for k in range(3):   # pcl::transformPointCloud: ((m0 x + m1 y) + m2 z) + m3 in float
+                p[:, k] = ((T[k, 0] * x[:, 0] + T[k, 1] * x[:, 1]) + T[k, 2] * x[:, 2]) + T[k, 3]
+            out[name] = p
+        self._hand_clouds = out
+        return out
+
+    @staticmethod
+    def local_dist_thres(name, dist_thres):
+        """Hand.cpp:812-821 (squared metres, stored as float)."""
+        if name in ("finger_2_1", "finger_1_1"):
+            return np.float32(0.005 * 0.005)
+        if name in ("base", "swivel_1", "swivel_2"):
+            return np.float32(0.02 * 0.02)
+        return np.float32(dist_thres)
+
+    def removeSurroundingPointsAndAssignProbability(self, scene_xyz, scene_nrm, handbase_in_cam, dist_thres):
+        """HandT42::removeSurroundingPointsAndAssignProbability (Hand.cpp:779-888); ``dist_thres`` is the SQUARED
+        near_hand_dist as at the call site (main_realdata_auto.cpp:147-148).  Returns (xyz, nrm, confidence, index)."""
+        clouds = getattr(self, "_hand_clouds", None) or self.makeHandCloud()
+        links = [(clouds[name], self.local_dist_thres(name, dist_thres)) for name in sorted(clouds)]
+        return self.ctx.hand_remove_surrounding(scene_xyz, scene_nrm, handbase_in_cam, links, self.getTFHandBase("finger_1_2"),
+                                                self.getTFHandBase("finger_2_2"), float(self._finger_properties["finger_1_2"]["min"][2]))
 
     def getTFHandBase(self, name):
         """Hand.cpp:505-523 (float matrix products, link -> hand base)."""

@@ -156,7 +156,7 @@ struct hop_ctx {
   unsigned long long* ppf_matrix_cached = nullptr;
   size_t ppf_matrix_cached_bytes = 0;
   bool ppf_matrix_registered = false;
-  DevBuf angle_thr_d;
+  DevBuf angle_thr_d, sur_in, sur_ws, sur_links, sur_out;
   bool angle_thr_tried = false, angle_thr_ok = false;
   int ppf_words = 0;
   std::vector<BaseTraceHost> trace;
@@ -608,7 +608,7 @@ void hop_ctx_destroy(hop_ctx* c) {
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
   if (c->ppf_matrix_registered) (void)hipHostUnregister(c->ppf_matrix_cached);
   std::free(c->ppf_matrix_cached);
-  c->angle_thr_d.release();
+  c->angle_thr_d.release(), c->sur_in.release(), c->sur_ws.release(), c->sur_links.release(), c->sur_out.release();
   DevBuf* bufs[] = {&c->scene_d.buf, &c->scene_sorted_d.buf, &c->scene_unit_d.buf, &c->scene_sorted_unit_d.buf, &c->scene_perm_d, &c->model_d[0].buf, &c->model_d[1].buf, &c->key_bitmap_d, &c->gp_d.buf, &c->gq_d.buf, &c->gq_unit_d,
                     &c->ppf_matrix_d, &c->vp_d.buf, &c->vq_d.buf, &c->bases_d, &c->pairs1_d,
                     &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
@@ -1733,6 +1733,80 @@ int hop_hand_pso_search(hop_ctx* c, const hop_pso_settings* s, double* best_angl
   }
   if (best_angle_out) *best_angle_out = inv_tf(gbest);
   if (objval_out) *objval_out = (double)(float)best_check;
+  return HOP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- N3a
+int hop_hand_remove_surrounding(hop_ctx* c, const float* scene_xyz, const float* scene_nrm, int n, const float handbase_in_cam[16],
+                                const hop_hand_link* links, int n_links, const float finger12_in_handbase[16],
+                                const float finger22_in_handbase[16], float finger12_min_z, float* out_xyz, float* out_nrm, float* out_conf,
+                                int* keep_index, int* n_out) {
+  if (!c || !scene_xyz || !scene_nrm || n < 0 || !handbase_in_cam || (!links && n_links > 0) || n_links < 0 || !finger12_in_handbase ||
+      !finger22_in_handbase || !out_xyz || !out_nrm || !out_conf || !n_out)
+    return HOP_E_INVALID;
+  *n_out = 0;
+  if (n == 0) return HOP_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t N = (size_t)n;
+  // inputs: scene planes, concatenated link clouds
+  std::vector<float4> lp;
+  std::vector<int> ls(n_links + 1, 0);
+  std::vector<float> lt(std::max(n_links, 1), 0.f);
+  for (int l = 0; l < n_links; ++l) {
+    if (links[l].n < 0 || (links[l].n > 0 && !links[l].xyz)) return HOP_E_INVALID;
+    for (int j = 0; j < links[l].n; ++j)
+      lp.push_back(make_float4(links[l].xyz[j], links[l].xyz[(size_t)links[l].n + j], links[l].xyz[2 * (size_t)links[l].n + j], 0.f));
+    ls[l + 1] = (int)lp.size();
+    lt[l] = links[l].sq_dist_thres;
+  }
+  HIPCHK(c, c->sur_in.ensure(sizeof(float) * 6 * N));
+  HIPCHK(c, c->sur_ws.ensure(sizeof(float) * 6 * N + sizeof(float) * N + sizeof(int) * 2 * (N + 1)));
+  HIPCHK(c, c->sur_links.ensure(sizeof(float4) * std::max<size_t>(lp.size(), 1) + sizeof(int) * (n_links + 1) + sizeof(float) * std::max(n_links, 1)));
+  HIPCHK(c, c->sur_out.ensure(sizeof(float) * 7 * N + sizeof(int) * N));
+  float* in = c->sur_in.as<float>();
+  HIPCHK(c, hipMemcpyAsync(in, scene_xyz, sizeof(float) * 3 * N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(in + 3 * N, scene_nrm, sizeof(float) * 3 * N, hipMemcpyHostToDevice, c->stream));
+  float4* lpd = c->sur_links.as<float4>();
+  int* lsd = reinterpret_cast<int*>(lpd + std::max<size_t>(lp.size(), 1));
+  float* ltd = reinterpret_cast<float*>(lsd + n_links + 1);
+  if (!lp.empty()) HIPCHK(c, hipMemcpyAsync(lpd, lp.data(), sizeof(float4) * lp.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(lsd, ls.data(), sizeof(int) * (n_links + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(ltd, lt.data(), sizeof(float) * std::max(n_links, 1), hipMemcpyHostToDevice, c->stream));
+  M4 hb, f1, f2;
+  std::memcpy(hb.m, handbase_in_cam, sizeof(float) * 16);
+  std::memcpy(f1.m, finger12_in_handbase, sizeof(float) * 16);
+  std::memcpy(f2.m, finger22_in_handbase, sizeof(float) * 16);
+  const M4 cam2hb = m4_inverse_affine(hb), f1i = m4_inverse_affine(f1), f2i = m4_inverse_affine(f2);
+  SurroundArgs a{};
+  a.sx = in, a.sy = in + N, a.sz = in + 2 * N, a.snx = in + 3 * N, a.sny = in + 4 * N, a.snz = in + 5 * N, a.n = n;
+  for (int k = 0; k < 12; ++k) a.cam2hb[k] = cam2hb.m[k], a.hb2cam[k] = hb.m[k], a.f1inv[k] = f1i.m[k], a.f2inv[k] = f2i.m[k];
+  a.link_pts = lpd, a.link_start = lsd, a.link_thres = ltd, a.n_links = n_links, a.min_z = finger12_min_z;
+  float* ws = c->sur_ws.as<float>();
+  a.hbp = ws, a.conf = ws + 6 * N;
+  int* keep = reinterpret_cast<int*>(ws + 7 * N);
+  int* pos = keep + (N + 1);
+  a.keep = keep;
+  HIPCHK(c, hipMemsetAsync(keep + N, 0, sizeof(int), c->stream));
+  launch_hand_surround(a, c->stream);
+  size_t tmp_bytes = 0;
+  HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, keep, pos, n + 1, c->stream));
+  HIPCHK(c, c->sort_tmp.ensure(tmp_bytes + 16));
+  HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->sort_tmp.p, tmp_bytes, keep, pos, n + 1, c->stream));
+  SurroundOutArgs o{};
+  o.hbp = a.hbp, o.conf = a.conf, o.keep = keep, o.pos = pos, o.n = n;
+  for (int k = 0; k < 12; ++k) o.hb2cam[k] = hb.m[k];
+  float* od = c->sur_out.as<float>();
+  o.ox = od, o.oy = od + N, o.oz = od + 2 * N, o.onx = od + 3 * N, o.ony = od + 4 * N, o.onz = od + 5 * N, o.oconf = od + 6 * N;
+  o.oindex = reinterpret_cast<int*>(od + 7 * N);
+  launch_hand_surround_out(o, c->stream);
+  int kept = 0;
+  HIPCHK(c, hipMemcpyAsync(&kept, pos + N, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(out_xyz, od, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(out_nrm, od + 3 * N, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(out_conf, od + 6 * N, sizeof(float) * N, hipMemcpyDeviceToHost, c->stream));
+  if (keep_index) HIPCHK(c, hipMemcpyAsync(keep_index, o.oindex, sizeof(int) * N, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_out = kept;
   return HOP_OK;
 }
 

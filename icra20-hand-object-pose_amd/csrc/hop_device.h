@@ -242,6 +242,31 @@ struct PsoArgs {
   int* outer_cnt;
 };
 
+struct SurroundArgs {
+  const float *sx, *sy, *sz, *snx, *sny, *snz;  // scene, camera frame
+  int n;
+  float cam2hb[12], hb2cam[12], f1inv[12], f2inv[12];
+  const float4* link_pts;   // all links concatenated, hand-base frame; .w unused
+  const int* link_start;    // n_links + 1
+  const float* link_thres;  // squared distance threshold per link
+  int n_links;
+  float min_z;
+  float* hbp;               // [6][n] scratch: point and normal in the hand-base frame
+  float* conf;              // [n]
+  int* keep;                // [n] 0/1
+};
+struct SurroundOutArgs {
+  const float* hbp;
+  const float* conf;
+  const int *keep, *pos;    // flag and its exclusive scan
+  int n;
+  float hb2cam[12];
+  float *ox, *oy, *oz, *onx, *ony, *onz, *oconf;
+  int* oindex;
+};
+void launch_hand_surround(const SurroundArgs& a, hipStream_t s);
+void launch_hand_surround_out(const SurroundOutArgs& a, hipStream_t s);
+
 // launchers (hop_kernels.hip)
 void launch_ppf_matrix(const PpfMatrixArgs& a, hipStream_t s);
 void launch_pairs(const PairArgs& a, int nbases, hipStream_t s);

@@ -1946,6 +1946,70 @@ __global__ __launch_bounds__(64) void k_pso_outer_sum(PsoArgs a, int n_particles
 }
 
 // ------------------------------------------------------------------------------------------------
+// N3a: HandT42::removeSurroundingPointsAndAssignProbability (Hand.cpp:779-888).  One thread per scene point; the link
+// clouds (a few hundred points each) are scanned by brute force -- every lane of a wave reads the same link point, so
+// a load serves 64 queries.  Links are visited in the reference's map order with its early exit.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hand_surround(SurroundArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const V3 p = m4_point(a.cam2hb, v3(a.sx[i], a.sy[i], a.sz[i]));
+  const V3 nn = m4_dir(a.cam2hb, v3(a.snx[i], a.sny[i], a.snz[i]));
+  bool is_near = false;
+  float min_dist = 1.0f;
+  for (int l = 0; l < a.n_links && !is_near; ++l) {
+    const int b = a.link_start[l], e = a.link_start[l + 1];
+    if (b >= e) continue;
+    float best = 3.402823466e+38f;
+    int bj = b;
+    for (int j = b; j < e; ++j) {
+      const float4 q = a.link_pts[j];
+      const float d2 = sqdist_flann(p, v3(q.x, q.y, q.z));
+      if (d2 < best) best = d2, bj = j;
+    }
+    min_dist = fminf(min_dist, sqrtf(best));
+    const float thr = a.link_thres[l];
+    if (best <= thr) {
+      is_near = true;
+      break;
+    }
+    const float4 nei = a.link_pts[bj];
+    const float sq_planar = (p.x - nei.x) * (p.x - nei.x) + (p.y - nei.y) * (p.y - nei.y);
+    if (sq_planar <= thr && (double)fabsf(p.z - nei.z) <= 0.005) is_near = true;
+  }
+  bool keep = !is_near;
+  if (keep) {
+    const V3 p1 = m4_point(a.f1inv, p), p2 = m4_point(a.f2inv, p);
+    if ((p1.y < 0 && p1.z >= a.min_z) || (p2.y < 0 && p2.z >= a.min_z)) keep = false;
+  }
+  const size_t n = (size_t)a.n;
+  a.hbp[i] = p.x, a.hbp[n + i] = p.y, a.hbp[2 * n + i] = p.z;
+  a.hbp[3 * n + i] = nn.x, a.hbp[4 * n + i] = nn.y, a.hbp[5 * n + i] = nn.z;
+  // expf of the CPU library is correctly rounded for all practical purposes: the double exponential rounded to
+  // float reproduces it
+  a.conf[i] = 1 - (float)exp((double)(-231.04906018664843f * min_dist));
+  a.keep[i] = keep ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_hand_surround_out(SurroundOutArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n || !a.keep[i]) return;
+  const size_t n = (size_t)a.n;
+  const int k = a.pos[i];
+  const V3 pc = m4_point(a.hb2cam, v3(a.hbp[i], a.hbp[n + i], a.hbp[2 * n + i]));
+  const V3 nc = m4_dir(a.hb2cam, v3(a.hbp[3 * n + i], a.hbp[4 * n + i], a.hbp[5 * n + i]));
+  a.ox[k] = pc.x, a.oy[k] = pc.y, a.oz[k] = pc.z;
+  a.onx[k] = nc.x, a.ony[k] = nc.y, a.onz[k] = nc.z;
+  a.oconf[k] = a.conf[i];
+  a.oindex[k] = i;
+}
+void launch_hand_surround(const SurroundArgs& a, hipStream_t s) {
+  if (a.n > 0) hipLaunchKernelGGL(k_hand_surround, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_hand_surround_out(const SurroundOutArgs& a, hipStream_t s) {
+  if (a.n > 0) hipLaunchKernelGGL(k_hand_surround_out, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
 // voxel-grid construction over a fixed cloud (counting sort by cell): count, scan on host, fill.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_grid_cell_ids(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,

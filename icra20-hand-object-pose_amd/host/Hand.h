@@ -121,6 +121,58 @@ class Hand {
     }
   }
 
+  // Hand::makeHandCloud (Hand.cpp:537-556): every component cloud in the hand-base frame at the current finger state
+  // (the reference keeps one kd-tree per component in a std::map, i.e. in name order)
+  void makeHandCloud() {
+    _hand_clouds.clear();
+    for (auto& h : _clouds) {
+      Mat4 T = Mat4::Identity();
+      if (h.first != "base_link") getTFHandBase(h.first, T);
+      const hop::Cloud& src = h.second;
+      hop::Cloud dst;
+      dst.n = src.n;
+      dst.xyz.resize(3 * (size_t)src.n);
+      const float *x = src.xyz.data(), *y = x + src.n, *z = y + src.n;
+      for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < src.n; ++i)
+          dst.xyz[(size_t)k * src.n + i] = ((T.m[4 * k] * x[i] + T.m[4 * k + 1] * y[i]) + T.m[4 * k + 2] * z[i]) + T.m[4 * k + 3];
+      _hand_clouds[h.first] = dst;
+    }
+  }
+
+  // HandT42::removeSurroundingPointsAndAssignProbability (Hand.cpp:779-888); dist_thres is the SQUARED near_hand_dist,
+  // as at the call site (main_realdata_auto.cpp:147-148).  Survivors in input order, camera frame, with confidence.
+  hop::Cloud removeSurroundingPointsAndAssignProbability(const hop::Cloud& scene, const Mat4& handbase_in_cam, float dist_thres) {
+    if (_hand_clouds.empty()) makeHandCloud();
+    std::vector<hop_hand_link> links;
+    for (auto& h : _hand_clouds) {
+      float local = dist_thres;  // Hand.cpp:812-821
+      if (h.first == "finger_2_1" || h.first == "finger_1_1") local = (float)(0.005 * 0.005);
+      else if (h.first == "base" || h.first == "swivel_1" || h.first == "swivel_2") local = (float)(0.02 * 0.02);
+      links.push_back(hop_hand_link{h.second.xyz.data(), h.second.n, local});
+    }
+    Mat4 f12, f22;
+    getTFHandBase("finger_1_2", f12);
+    getTFHandBase("finger_2_2", f22);
+    hop::Cloud out;
+    out.xyz.resize(3 * (size_t)scene.n), out.nrm.resize(3 * (size_t)scene.n), out.conf.resize(scene.n);
+    int kept = 0;
+    hop::check(hop_hand_remove_surrounding(ctx_, scene.xyz.data(), scene.nrm.data(), scene.n, handbase_in_cam.m, links.data(), (int)links.size(),
+                                           f12.m, f22.m, _finger_properties["finger_1_2"]._min_z, out.xyz.data(), out.nrm.data(),
+                                           out.conf.data(), nullptr, &kept),
+               ctx_, "hop_hand_remove_surrounding");
+    // compact the planes from stride scene.n to stride kept
+    hop::Cloud r;
+    r.n = kept;
+    r.xyz.resize(3 * (size_t)kept), r.nrm.resize(3 * (size_t)kept), r.conf.assign(out.conf.begin(), out.conf.begin() + kept);
+    for (int k = 0; k < 3; ++k)
+      for (int i = 0; i < kept; ++i) {
+        r.xyz[(size_t)k * kept + i] = out.xyz[(size_t)k * scene.n + i];
+        r.nrm[(size_t)k * kept + i] = out.nrm[(size_t)k * scene.n + i];
+      }
+    return r;
+  }
+
   void initPSO() {  // Hand.cpp:587-600
     hop_pso_default_settings(&_pso_settings);
     _pso_settings.n_pop = cfg->geti("hand_match.pso.n_pop");
@@ -218,6 +270,7 @@ class Hand {
   std::map<std::string, FingerProperty> _finger_properties;
   std::map<std::string, bool> _component_status;
   std::map<std::string, float> _finger_angles;
+  std::map<std::string, hop::Cloud> _hand_clouds;  // Hand::makeHandCloud products (hand-base frame)
   ConfigParser* cfg;
   hop_pso_settings _pso_settings;
 

@@ -210,6 +210,26 @@ int hop_hand_pso_search(hop_ctx* ctx, const hop_pso_settings* s, double* best_an
                         double* objval_out);
 
 /* ------------------------------------------------------------------------------------------------
+ * "Next" row N3a: HandT42::removeSurroundingPointsAndAssignProbability (Hand.cpp:779-888), the step
+ * between the hand search and the generator (main_realdata_auto.cpp:142-148): scene points near any hand link are
+ * removed, the others get the confidence 1 - exp(-lambda d) of their distance to the hand, points on the outer side of
+ * the distal fingers are removed, and the survivors return in the camera frame.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* xyz;     /* link cloud in the hand-base frame (Hand::makeHandCloud, Hand.cpp:537-556), SoA planes x[n] y[n] z[n] */
+  int n;
+  float sq_dist_thres;  /* local_dist_thres of this link (Hand.cpp:812-821), squared metres */
+} hop_hand_link;
+/* scene_xyz/scene_nrm: camera frame, SoA planes of n points.  links: in the reference's std::map (name) order.
+ * Outputs: SoA planes of capacity n (plane stride n), the first *n_out entries valid, in input order (the reference's
+ * order depends on OpenMP scheduling); keep_index[k] = input index of survivor k (may be NULL). */
+int hop_hand_remove_surrounding(hop_ctx* ctx, const float* scene_xyz, const float* scene_nrm, int n,
+                                const float handbase_in_cam[16], const hop_hand_link* links, int n_links,
+                                const float finger12_in_handbase[16], const float finger22_in_handbase[16],
+                                float finger12_min_z, float* out_xyz, float* out_nrm, float* out_conf,
+                                int* keep_index, int* n_out);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): device time in ms of the kernels launched by the last call of the
  * named stage, measured with HIP events on the ctx stream; and launch counts.
  * ---------------------------------------------------------------------------------------------- */

@@ -1698,4 +1698,61 @@ void orc_finger_property(const float* xyz, int n, int num_division, float* min3,
       }
 }
 
+
+// "next" row N3a -- HandT42::removeSurroundingPointsAndAssignProbability (Hand.cpp:779-888), restated.
+// scene: camera frame, SoA xyz / normal planes.  links: the clouds of Hand::makeHandCloud (Hand.cpp:537-556, hand-base
+// frame) in std::map (name) order, each with its local_dist_thres (Hand.cpp:812-821, squared metres).  A point survives
+// when no link is "near" (NN within the threshold, or planar distance within it and |dz| <= 5 mm, Hand.cpp:826-840) and
+// it is not on the outer side of either distal finger (Hand.cpp:869-884).  Survivors come back in input order (the
+// reference's order depends on OpenMP scheduling), in the camera frame after the reference's round trip through the
+// hand-base frame, with confidence 1 - exp(-lambda * min_dist) (Hand.cpp:844).  keep_index: input index of each.
+int orc_hand_remove_surrounding(const float* scene_xyz, const float* scene_nrm, int n, const float* handbase_in_cam16, const float* const* link_xyz,
+                                const int* link_n, const float* link_sq_thres, int n_links, const float* finger12_in_handbase16,
+                                const float* finger22_in_handbase16, float min_z, float* out_xyz, float* out_nrm, float* out_conf,
+                                int* keep_index) {
+  const M4 hb = load4(handbase_in_cam16), cam2hb = inverse_affine(hb);
+  const M4 f1i = inverse_affine(load4(finger12_in_handbase16)), f2i = inverse_affine(load4(finger22_in_handbase16));
+  const std::vector<V3> sp = soa_to_v3(scene_xyz, n), sn = soa_to_v3(scene_nrm, n);
+  std::vector<std::vector<V3>> links(n_links);
+  for (int l = 0; l < n_links; ++l) links[l] = soa_to_v3(link_xyz[l], link_n[l]);
+  const float lambda = 231.04906018664843f;
+  int kept = 0;
+  for (int i = 0; i < n; ++i) {
+    const V3 p = pcl_transform_point(cam2hb, sp[i]);
+    const V3 nn = pcl_rotate_normal(cam2hb, sn[i]);
+    bool is_near = false;
+    float min_dist = 1.0f;
+    for (int l = 0; l < n_links && !is_near; ++l) {
+      if (links[l].empty()) continue;  // nearestKSearch returns 0
+      float best = FLT_MAX;
+      int bj = -1;
+      for (int j = 0; j < (int)links[l].size(); ++j) {
+        const V3& q = links[l][j];
+        const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;  // FLANN L2_Simple order
+        if (d2 < best) best = d2, bj = j;
+      }
+      min_dist = std::min(min_dist, std::sqrt(best));
+      if (best <= link_sq_thres[l]) {
+        is_near = true;
+        break;
+      }
+      const V3& nei = links[l][bj];
+      const float sq_planar = (p.x - nei.x) * (p.x - nei.x) + (p.y - nei.y) * (p.y - nei.y);
+      if (sq_planar <= link_sq_thres[l] && std::abs(p.z - nei.z) <= 0.005) is_near = true;
+    }
+    if (is_near) continue;
+    const V3 p1 = pcl_transform_point(f1i, p), p2 = pcl_transform_point(f2i, p);
+    if (p1.y < 0 && p1.z >= min_z) continue;
+    if (p2.y < 0 && p2.z >= min_z) continue;
+    const V3 pc = pcl_transform_point(hb, p), nc = pcl_rotate_normal(hb, nn);
+    out_xyz[kept] = pc.x, out_xyz[n + kept] = pc.y, out_xyz[2 * (size_t)n + kept] = pc.z;
+    out_nrm[kept] = nc.x, out_nrm[n + kept] = nc.y, out_nrm[2 * (size_t)n + kept] = nc.z;
+    out_conf[kept] = 1 - std::exp(-lambda * min_dist);
+    keep_index[kept] = i;
+    ++kept;
+  }
+  return kept;
+}
+
 }  // extern "C"

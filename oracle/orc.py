@@ -134,6 +134,8 @@ def lib():
         L.orc_pso_objective_batch.argtypes = [C.POINTER(FingerArgs), dp, C.c_int, dp]
         L.orc_pso_search.argtypes = [C.POINTER(FingerArgs), C.POINTER(PsoSettings), dp, dp]
         L.orc_finger_property.argtypes = [fp, C.c_int, C.c_int, fp, fp, fp, fp]
+        L.orc_hand_remove_surrounding.restype = C.c_int
+        L.orc_hand_remove_surrounding.argtypes = [fp, fp, C.c_int, fp, C.POINTER(fp), ip, fp, C.c_int, fp, fp, C.c_float, fp, fp, fp, ip]
         L.orc_compute_ppf.argtypes = [fp, fp, fp, fp, ip]
         L.orc_pair_ppf_is_good.argtypes = [fp, fp, fp, fp]
         L.orc_rigid.argtypes = [fp, fp, fp, fp]
@@ -332,3 +334,21 @@ def cluster_poses(poses, lcp, ids, angle_deg, dist, sym_deg):
     keep = np.zeros(len(T), np.int32)
     n = lib().orc_cluster_poses(F(T), F(lcp), I(ids), len(T), angle_deg, dist, F(sym), I(keep))
     return keep[:n].copy()
+
+
+def hand_remove_surrounding(scene_xyz, scene_nrm, handbase_in_cam, links, finger12_in_handbase, finger22_in_handbase, min_z):
+    """links: list of (xyz (n,3) in the hand-base frame, squared distance threshold), in name order.
+    Returns (xyz, nrm, conf, keep_index) of the survivors."""
+    n = len(scene_xyz)
+    X, Nn = soa(scene_xyz), soa(scene_nrm)
+    clouds = [soa(l[0]) for l in links]
+    arr = (C.POINTER(C.c_float) * len(links))(*[F(c) for c in clouds])
+    ln = np.array([len(l[0]) for l in links], np.int32)
+    th = np.array([l[1] for l in links], np.float32)
+    ox, on = np.zeros((3, max(n, 1)), np.float32), np.zeros((3, max(n, 1)), np.float32)
+    oc, ki = np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.int32)
+    T = np.ascontiguousarray(handbase_in_cam, np.float32).reshape(16)
+    f1 = np.ascontiguousarray(finger12_in_handbase, np.float32).reshape(16)
+    f2 = np.ascontiguousarray(finger22_in_handbase, np.float32).reshape(16)
+    k = lib().orc_hand_remove_surrounding(F(X), F(Nn), n, F(T), arr, I(ln), F(th), len(links), F(f1), F(f2), float(min_z), F(ox), F(on), F(oc), I(ki))
+    return ox[:, :k].T.copy(), on[:, :k].T.copy(), oc[:k].copy(), ki[:k].copy()

@@ -569,3 +569,46 @@ def test_c1_depth7_full_chain_within_1mm_1deg_of_oracle(ctx, api, orc, synth, go
     assert np.linalg.norm(best[:3, 3] - ob[:3, 3]) < 1e-3
     assert _rot_err_deg(best[:3, :3].astype(np.float64), ob[:3, :3].astype(np.float64)) < 1.0
     assert abs(score - s3.max()) <= 1e-4 * s3.max()
+
+
+# ------------------------------------------------------------------------------------------------ next row N3a
+def test_remove_surrounding_points_equals_oracle(api, orc, synth, hop):
+    """HandT42::removeSurroundingPointsAndAssignProbability (Hand.cpp:779-888; SURVEY.md 8(f) N3): same survivors as
+    the CPU restatement, same coordinates bit for bit, confidences within one float ulp (expf vs exp-in-double)."""
+    from hop_amd import config as hop_config
+    cfg = hop_config.load_config()
+    hand = synth.t42_hand()
+    true = {"finger_1_1": math.radians(10), "finger_1_2": math.radians(6), "finger_2_1": math.radians(12), "finger_2_2": math.radians(5)}
+    hxyz, hnrm = synth.make_hand_scene(hand, true, 6000, seed=5)          # hand-base frame: hand surface + object blob
+    rng = np.random.default_rng(3)
+    extra = rng.uniform([-0.2, -0.1, -0.1], [0.0, 0.1, 0.05], size=(3000, 3)).astype(np.float32)   # free space around the hand
+    hb_xyz = np.concatenate([hxyz, extra])
+    hb_nrm = np.concatenate([hnrm, np.tile(np.float32([0, 0, 1]), (len(extra), 1))])
+    handbase_in_cam = synth.se3(synth.rot_from_axis_angle(np.array([0.3, -0.5, 0.8]), 1.1), [0.05, -0.02, 0.45]).astype(np.float32)
+    cam_xyz = (hb_xyz.astype(np.float64) @ handbase_in_cam[:3, :3].T.astype(np.float64) + handbase_in_cam[:3, 3]).astype(np.float32)
+    cam_nrm = (hb_nrm.astype(np.float64) @ handbase_in_cam[:3, :3].T.astype(np.float64)).astype(np.float32)
+    h = api.HandT42(cfg, hand)
+    for name, ang in true.items():                                        # the finger state found by the hand search
+        a = np.float32(ang)
+        T = np.eye(4, dtype=np.float32)
+        T[1, 1], T[1, 2], T[2, 1], T[2, 2] = np.cos(a), -np.sin(a), np.sin(a), np.cos(a)
+        h._tf_self[name] = T
+    near2 = float(np.float32(0.01) * np.float32(0.01))
+    x, n, c, idx = h.removeSurroundingPointsAndAssignProbability(cam_xyz, cam_nrm, handbase_in_cam, near2)
+    clouds = h.makeHandCloud()
+    links = [(clouds[k], h.local_dist_thres(k, near2)) for k in sorted(clouds)]
+    ox, on, oc, oidx = orc.hand_remove_surrounding(cam_xyz, cam_nrm, handbase_in_cam, links, h.getTFHandBase("finger_1_2"),
+                                                   h.getTFHandBase("finger_2_2"), float(h._finger_properties["finger_1_2"]["min"][2]))
+    assert np.array_equal(idx, oidx)
+    assert 0.05 * len(cam_xyz) < len(idx) < 0.95 * len(cam_xyz)           # both outcomes are exercised
+    assert np.array_equal(x, ox) and np.array_equal(n, on)
+    ulp = np.spacing(np.maximum(np.abs(oc), np.float32(1e-30)))
+    assert np.all(np.abs(c - oc) <= ulp)
+    assert (np.abs(c - oc) == 0).mean() > 0.99
+    assert c.min() > 0.5 and c.max() <= 1 and (c < 0.99).sum() > 10
+    # the hand's own surface is gone, far free-space points stay with high confidence
+    kept_hand = np.isin(np.arange(len(hxyz)), idx).mean()
+    assert kept_hand < 0.7
+    # empty input
+    x0, n0, c0, i0 = h.removeSurroundingPointsAndAssignProbability(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), handbase_in_cam, near2)
+    assert len(c0) == 0
