@@ -156,7 +156,7 @@ struct hop_ctx {
   unsigned long long* ppf_matrix_cached = nullptr;
   size_t ppf_matrix_cached_bytes = 0;
   bool ppf_matrix_registered = false;
-  DevBuf angle_thr_d, sur_in, sur_ws, sur_links, sur_out;
+  DevBuf fit_queue_d, fit_count_d, angle_thr_d, sur_in, sur_ws, sur_links, sur_out;
   bool angle_thr_tried = false, angle_thr_ok = false;
   int ppf_words = 0;
   std::vector<BaseTraceHost> trace;
@@ -608,7 +608,7 @@ void hop_ctx_destroy(hop_ctx* c) {
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
   if (c->ppf_matrix_registered) (void)hipHostUnregister(c->ppf_matrix_cached);
   std::free(c->ppf_matrix_cached);
-  c->angle_thr_d.release(), c->sur_in.release(), c->sur_ws.release(), c->sur_links.release(), c->sur_out.release();
+  c->fit_queue_d.release(), c->fit_count_d.release(), c->angle_thr_d.release(), c->sur_in.release(), c->sur_ws.release(), c->sur_links.release(), c->sur_out.release();
   DevBuf* bufs[] = {&c->scene_d.buf, &c->scene_sorted_d.buf, &c->scene_unit_d.buf, &c->scene_sorted_unit_d.buf, &c->scene_perm_d, &c->model_d[0].buf, &c->model_d[1].buf, &c->key_bitmap_d, &c->gp_d.buf, &c->gq_d.buf, &c->gq_unit_d,
                     &c->ppf_matrix_d, &c->vp_d.buf, &c->vq_d.buf, &c->bases_d, &c->pairs1_d,
                     &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
@@ -862,6 +862,8 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
   HIPCHK(c, c->cands_d.ensure(sizeof(Candidate) * (size_t)cand_cap));
   HIPCHK(c, c->cand_counts_d.ensure(sizeof(int) * (size_t)cand_cap));
   HIPCHK(c, c->counters_d.ensure(sizeof(int) * 16));
+  HIPCHK(c, c->fit_queue_d.ensure(sizeof(int4) * (size_t)cand_cap * 4));  // FIT_QUEUES sub-queues of cand_cap/FIT_QUEUES*4 entries
+  HIPCHK(c, c->fit_count_d.ensure(sizeof(int) * FIT_QUEUES));
   int rc = ensure_hyp_capacity(c, hyp_cap);
   if (rc) return rc;
   int* counters = c->counters_d.as<int>();  // [0] cand_count, [1] hyp_count, [2] overflow
@@ -894,7 +896,8 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
     HIPCHK(c, hipEventRecord(stage_ev[flip], c->stream));
     stage_used[flip] = true;
     flip ^= 1;
-    HIPCHK(c, hipMemsetAsync(counters, 0, sizeof(int), c->stream));  // cand_count
+    HIPCHK(c, hipMemsetAsync(counters, 0, sizeof(int), c->stream));      // cand_count
+    HIPCHK(c, hipMemsetAsync(c->fit_count_d.p, 0, sizeof(int) * FIT_QUEUES, c->stream));
     int* cnt1 = cnt1_all + batch_first_trace;
     int* cnt2 = cnt2_all + batch_first_trace;
     {
@@ -919,6 +922,7 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
       qa.cands = c->cands_d.as<Candidate>(), qa.cand_counts = c->cand_counts_d.as<int>(), qa.cand_count = counters, qa.cand_cap = cand_cap;
       qa.nquads = nquads_all + batch_first_trace;
       qa.overflow = counters + 2;
+      qa.fit_queue = c->fit_queue_d.as<int4>(), qa.fit_count = c->fit_count_d.as<int>(), qa.fit_cap = cand_cap / FIT_QUEUES * 4;
       {
         SpanGuard sq(c, T_QUADS);
         launch_quads(qa, nb, 64, c->stream);

@@ -217,8 +217,8 @@ __global__ __launch_bounds__(256) void k_quad_prep(QuadPrepArgs a) {
   const BaseDev& B = a.bases[b];
   const int n1 = min(a.cnt1[b], a.cap), n2 = min(a.cnt2[b], a.cap);
   const NsetGeom g = a.geom;
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n1 + n2; t += gridDim.x * blockDim.x) {
-    if (t < n1) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n1; t += gridDim.x * blockDim.x) {
+    {
       const unsigned pr = a.pairs1[(size_t)b * a.cap + t];
       const int i0 = pr >> 16, i1 = pr & 0xffff;
       const V3 u1 = v3(a.ux[i0], a.uy[i0], a.uz[i0]), u2 = v3(a.ux[i1], a.uy[i1], a.uz[i1]);
@@ -231,51 +231,60 @@ __global__ __launch_bounds__(256) void k_quad_prep(QuadPrepArgs a) {
       const V3 ip = w1 + (w2 - w1) * B.inv1;
       e.px = ip.x, e.py = ip.y, e.pz = ip.z;
       a.elems[(size_t)b * a.cap + t] = e;
+    }
+  }
+  // second pairs: one wave per query, one lane per ring sample (nb_sample <= 64): the 64 quaternion rotations and
+  // normal-bin look-ups of a query run side by side instead of as a 64-step loop in one lane
+  __shared__ unsigned smask[4][12];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int s = blockIdx.x * 4 + wave; s < n2; s += gridDim.x * 4) {
+    const unsigned pr = a.pairs2[(size_t)b * a.cap + s];
+    const int i0 = pr >> 16, i1 = pr & 0xffff;
+    const V3 u1 = v3(a.ux[i0], a.uy[i0], a.uz[i0]), u2 = v3(a.ux[i1], a.uy[i1], a.uz[i1]);
+    const V3 query = u1 + B.inv2 * (u2 - u1);
+    const V3 queryn = vnormalized(u2 - u1);
+    // Quaternion::setFromTwoVectors((0,0,1), queryn) then q * ringvec (Geometry/Quaternion.h:578-612,471-481)
+    const V3 v1 = vnormalized(queryn);
+    float c = v1.x * 0.f + (v1.y * 0.f + v1.z * 1.f);  // v1.dot((0,0,1))
+    V3 qv;
+    float qw;
+    if (c < -1.f + 1e-5f) {
+      // Eigen falls back to a JacobiSVD null vector here; analytic stand-in (DESIGN.md "known deviations")
+      c = fmaxf(c, -1.f);
+      V3 axis = vnormalized(v3(-v1.y, v1.x, 0.f));
+      if (vsqn(axis) == 0.f) axis = v3(1.f, 0.f, 0.f);
+      const float w2q = (1.f + c) * 0.5f;
+      qw = sqrtf(w2q);
+      qv = axis * sqrtf(1.f - w2q);
     } else {
-      const int s = t - n1;
-      const unsigned pr = a.pairs2[(size_t)b * a.cap + s];
-      const int i0 = pr >> 16, i1 = pr & 0xffff;
-      const V3 u1 = v3(a.ux[i0], a.uy[i0], a.uz[i0]), u2 = v3(a.ux[i1], a.uy[i1], a.uz[i1]);
-      const V3 query = u1 + B.inv2 * (u2 - u1);
-      const V3 queryn = vnormalized(u2 - u1);
+      const V3 axis = vcross(v3(0.f, 0.f, 1.f), v1);
+      const float s2 = sqrtf((1.f + c) * 2.f);
+      const float invs = 1.f / s2;
+      qv = axis * invs;
+      qw = s2 * 0.5f;
+    }
+    if (lane < 11) smask[wave][lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < B.nb_sample) {
+      const V3 rv = v3(B.ring[lane][0], B.ring[lane][1], B.ring[lane][2]);
+      V3 uv = vcross(qv, rv);
+      uv = uv + uv;
+      const V3 rot = (rv + qw * uv) + vcross(qv, uv);
+      const int id = nset_index_normal(g, vnormalized(rot));
+      if (id >= 0 && id < 343) atomicOr(&smask[wave][id >> 5], 1u << (id & 31));
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
       QuadQuery q;
       q.cx = (short)(int)(query.x / g.epsilon), q.cy = (short)(int)(query.y / g.epsilon), q.cz = (short)(int)(query.z / g.epsilon);
       q.pad = 0;
       const V3 w1 = v3(a.qx[i0], a.qy[i0], a.qz[i0]), w2 = v3(a.qx[i1], a.qy[i1], a.qz[i1]);
       const V3 qq = w1 + B.inv2 * (w2 - w1);
       q.px = qq.x, q.py = qq.y, q.pz = qq.z;
-      // Quaternion::setFromTwoVectors((0,0,1), queryn) then q * ringvec (Geometry/Quaternion.h:578-612,471-481)
-      const V3 v1 = vnormalized(queryn);
-      float c = v1.z;  // v1.dot((0,0,1)) = x*0 + (y*0 + z*1)
-      c = v1.x * 0.f + (v1.y * 0.f + v1.z * 1.f);
-      V3 qv;
-      float qw;
-      if (c < -1.f + 1e-5f) {
-        // Eigen falls back to a JacobiSVD null vector here; analytic stand-in (DESIGN.md "known deviations")
-        c = fmaxf(c, -1.f);
-        V3 axis = vnormalized(v3(-v1.y, v1.x, 0.f));
-        if (vsqn(axis) == 0.f) axis = v3(1.f, 0.f, 0.f);
-        const float w2q = (1.f + c) * 0.5f;
-        qw = sqrtf(w2q);
-        qv = axis * sqrtf(1.f - w2q);
-      } else {
-        const V3 axis = vcross(v3(0.f, 0.f, 1.f), v1);
-        const float s2 = sqrtf((1.f + c) * 2.f);
-        const float invs = 1.f / s2;
-        qv = axis * invs;
-        qw = s2 * 0.5f;
-      }
-      for (int w = 0; w < 11; ++w) q.mask[w] = 0u;
-      for (int k = 0; k < B.nb_sample; ++k) {
-        const V3 rv = v3(B.ring[k][0], B.ring[k][1], B.ring[k][2]);
-        V3 uv = vcross(qv, rv);
-        uv = uv + uv;
-        const V3 rot = (rv + qw * uv) + vcross(qv, uv);
-        const int id = nset_index_normal(g, vnormalized(rot));
-        if (id >= 0 && id < 343) q.mask[id >> 5] |= 1u << (id & 31);
-      }
+      for (int w = 0; w < 11; ++w) q.mask[w] = smask[wave][w];
       a.queries[(size_t)b * a.cap + s] = q;
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -326,19 +335,33 @@ __device__ __forceinline__ void quad_fit_emit(const QuadArgs& a, const BaseDev& 
   a.cand_counts[slot] = 0;
 }
 
+// Stage 1 of K3b: the cheap tests of FindCongruentQuadrilaterals on (first pair) x (second pair).  One second pair
+// (query) per wave at a time -- wave-uniform, read once -- against all first pairs (elements), 64 per step, read
+// coalesced.  The ~0.2 % that pass go into a device-wide queue (one wave-aggregated atomic per step that has any), so that
+// the long rigid-fit code of stage 2 always runs with full lanes whatever the per-wave yield.
 __global__ __launch_bounds__(256) void k_quads(QuadArgs a) {
-  __shared__ int queue_s[4][2][128];  // per wave: accepted (id1, id2) waiting for a full wave of fits
+  __shared__ int queue_s[4][2][128];  // per wave: accepted (id1, id2) on their way to the device-wide queue
   const int b = blockIdx.y;
-  const BaseDev& B = a.bases[b];
   const int n1 = min(a.cnt1[b], a.cap), n2 = min(a.cnt2[b], a.cap);
   const int eg = a.geom.eg_size;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int* queue1 = queue_s[wave][0];
   int* queue2 = queue_s[wave][1];
   int nq_wave = 0, qn = 0;
-  // one second pair (query) per wave at a time -- wave-uniform, read once -- against all first pairs (elements), 64 per
-  // step, read coalesced.  The pairs that pass the cheap tests (~0.2 %) are queued and fitted 64 at a time, so the long
-  // rigid-fit code always runs with full lanes.
+  // FIT_QUEUES sub-queues (by block column) keep the counters from becoming one hot address; a wave pays for one
+  // returning atomic per 64 accepted pairs (plus one at its end), not per step
+  const int qi = blockIdx.x & (FIT_QUEUES - 1);
+  auto flush = [&](int from, int count) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(a.fit_count + qi, count);
+    base = __shfl(base, 0);
+    if (lane < count) {
+      const int at = base + lane;
+      if (at < a.fit_cap) a.fit_queue[(size_t)qi * a.fit_cap + at] = make_int4(b, queue1[from + lane], queue2[from + lane], 0);
+      else *a.overflow = 1;
+    }
+  };
   for (int id2 = blockIdx.x * 4 + wave; id2 < n2; id2 += gridDim.x * 4) {
     const QuadQuery& q = a.queries[(size_t)b * a.cap + id2];
     const bool qok = q.cx >= 0 && q.cx < eg && q.cy >= 0 && q.cy < eg && q.cz >= 0 && q.cz < eg;
@@ -366,18 +389,27 @@ __global__ __launch_bounds__(256) void k_quads(QuadArgs a) {
       nq_wave += __popcll(m);
       __builtin_amdgcn_wave_barrier();
       if (qn >= 64) {
-        const int f1 = queue1[qn - 64 + lane], f2 = queue2[qn - 64 + lane];
+        flush(qn - 64, 64);
         qn -= 64;
         __builtin_amdgcn_wave_barrier();
-        quad_fit_emit(a, B, b, true, f1, f2);
       }
     }
   }
-  if (qn > 0) {
-    const int f1 = lane < qn ? queue1[lane] : 0, f2 = lane < qn ? queue2[lane] : 0;
-    quad_fit_emit(a, B, b, lane < qn, f1, f2);
-  }
+  if (qn > 0) flush(0, qn);
   if (lane == 0 && nq_wave) atomicAdd(&a.nquads[b], nq_wave);
+}
+
+// Stage 2: one queued quadrilateral per lane
+__global__ __launch_bounds__(256) void k_quad_fit(QuadArgs a) {
+  const int qi = blockIdx.y;
+  const int n = min(a.fit_count[qi], a.fit_cap);
+  const int stride = gridDim.x * blockDim.x;
+  for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
+    const int i = i0 + threadIdx.x;
+    const bool have = i < n;
+    const int4 e = have ? a.fit_queue[(size_t)qi * a.fit_cap + i] : make_int4(0, 0, 0, 0);
+    quad_fit_emit(a, a.bases[e.x], e.x, have, e.y, e.z);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2038,12 +2070,14 @@ void launch_pairs(const PairArgs& a, int nbases, hipStream_t s) {
   hipLaunchKernelGGL(k_pairs, grid, dim3(256), 0, s, a);
 }
 void launch_quad_prep(const QuadPrepArgs& a, int nbases, int max_items, hipStream_t s) {
-  dim3 grid(max(1, min(64, (max_items + 255) / 256)), nbases);
+  (void)max_items;
+  dim3 grid(16, nbases);  // 64 waves per base: ~12 second pairs per wave at C2 sizes
   hipLaunchKernelGGL(k_quad_prep, grid, dim3(256), 0, s, a);
 }
 void launch_quads(const QuadArgs& a, int nbases, int blocks_per_base, hipStream_t s) {
   dim3 grid(blocks_per_base, nbases);
   hipLaunchKernelGGL(k_quads, grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_quad_fit, dim3(8, FIT_QUEUES), dim3(256), 0, s, a);
 }
 void launch_verify_cells(const VerifyArgs& a, const CellListDev& cl, int blocks, hipStream_t s) {
   hipLaunchKernelGGL(k_verify_cells, dim3(blocks), dim3(256), 0, s, a, cl);
