@@ -387,10 +387,12 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   const GridDev& g = gs.g;
   CellListBuildArgs a{};
   a.margin = 4 * GRID_MARGIN;
-  if (!(g.cell >= max_dist + a.margin) || sub < 1) return HOP_E_STATE;
+  if (!(g.cell > 0) || sub < 1) return HOP_E_STATE;
+  // the list grid is the ring grid padded by enough ring cells to reach max_dist beyond the cloud's box, subdivided
+  const int pad = (int)std::ceil((max_dist + a.margin + 1.0e-6f) / g.cell);
   a.cell = g.cell / (float)sub;
-  a.ox = g.ox - g.cell, a.oy = g.oy - g.cell, a.oz = g.oz - g.cell;
-  a.dx = (g.dx + 2) * sub, a.dy = (g.dy + 2) * sub, a.dz = (g.dz + 2) * sub;
+  a.ox = g.ox - pad * g.cell, a.oy = g.oy - pad * g.cell, a.oz = g.oz - pad * g.cell;
+  a.dx = (g.dx + 2 * pad) * sub, a.dy = (g.dy + 2 * pad) * sub, a.dz = (g.dz + 2 * pad) * sub;
   a.max_dist = max_dist;
   if (normals) a.n = normals->n, a.nx = normals->plane(3), a.ny = normals->plane(4), a.nz = normals->plane(5);
   a.dom_eps = 64.f * max_dist * (4.f * 6.0e-8f) + 1.0e-12f;
@@ -1614,14 +1616,14 @@ int hop_hand_pso_eval_batch(hop_ctx* c, const double* angles, int n, double* cos
     pa.use_grid = 1;
   } else {
     // NN cell lists of the hand scene for this gating distance (per frame; shared by the four finger searches)
-    const float cell = a.dist_thres + 8 * GRID_MARGIN;
+    const float cell = (a.dist_thres + 8 * GRID_MARGIN) / 2.f;  // finer than the gate: short candidate rows, many of them
     if (!c->hand_grid.valid || c->hand_grid.cell != cell) {
       const int rc = build_grid(c, c->hand_grid, c->hand_scene_h[0].data(), c->hand_scene_h[1].data(), c->hand_scene_h[2].data(), c->hand_n_scene, cell);
       if (rc) return rc;
       c->hand_cells.valid = false;
     }
     if (!c->hand_cells.valid || c->hand_cells.max_dist != a.dist_thres) {
-      const int rc = build_cell_lists_local(c, c->hand_cells, c->hand_grid, nullptr, a.dist_thres, 3, 0);
+      const int rc = build_cell_lists_local(c, c->hand_cells, c->hand_grid, nullptr, a.dist_thres, 2, 0);
       if (rc) return rc;
     }
     pa.scene_cells = c->hand_cells.c;

@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local_work(const int* __restr
 // stage 2 (one wave per flagged cell): U(C) over the candidate rows, survivors of the threshold and of the point that
 // realises U(C) into an LDS list, pairwise domination among them, ballot-compacted output.  Lanes own candidate rows.
 #define LOCAL_WCAP 512
-#define LOCAL_KEEP 32  /* results of the counting pass up to this length are replayed by the writing pass */
+#define LOCAL_KEEP 64  /* results of the counting pass up to this length are replayed by the writing pass */
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, GridDev g, int exist_mode, const int* __restrict__ work, int nwork,
                                                          int* __restrict__ keep_buf) {
