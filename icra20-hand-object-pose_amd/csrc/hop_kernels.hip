@@ -1230,8 +1230,10 @@ template __global__ void k_cell_list_local<true>(CellListBuildArgs, GridDev, int
 // `tol` below: 2*d*delta + relative 1e-4, delta = a few ulps of the coordinate magnitude), so whenever the runner-up
 // is within tol of the winner the lane falls back to the literal scan (exact expression, (d^2, index) order).
 // Result: list position of the nearest neighbour (or -1) and the exact squared distance.
+// `moved` receives the winner moved by T (the point the exact distance was measured to): callers that need it again
+// (ICP residual, computeLCP reciprocal query) do not recompute it.
 template <int B>
-__device__ __forceinline__ void cells_nn(const CellListDev& c, V3 qg, const float* T, V3 q, float& best, int& bpos) {
+__device__ __forceinline__ void cells_nn(const CellListDev& c, V3 qg, const float* T, V3 q, float& best, int& bpos, V3& moved) {
   const float fx = (qg.x - c.ox) * c.inv_cell, fy = (qg.y - c.oy) * c.inv_cell, fz = (qg.z - c.oz) * c.inv_cell;
   if (!(fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)c.dx && fy < (float)c.dy && fz < (float)c.dz)) return;
   const int cidx = ((int)fz * c.dy + (int)fy) * c.dx + (int)fx;
@@ -1261,18 +1263,21 @@ __device__ __forceinline__ void cells_nn(const CellListDev& c, V3 qg, const floa
   }
   const float mag = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), 0.25f));
   const float delta = mag * 2.0e-6f;
-  const float tol = 2.f * sqrtf(b1) * delta + 1.0e-4f * b1 + delta * delta;
+  // the hardware square root (1 ulp) is inflated by 1e-3: tol only has to be an upper bound
+  const float tol = 2.002f * __builtin_amdgcn_sqrtf(b1) * delta + 1.0e-4f * b1 + delta * delta;
   if (b2 - b1 > tol) {
-    best = sqdist_flann(q, m4_point(T, v3(wx, wy, wz)));
+    moved = m4_point(T, v3(wx, wy, wz));
+    best = sqdist_flann(q, moved);
     bpos = k1;
     return;
   }
   int bj = 0x7fffffff;
   for (int k = beg; k < end; ++k) {
     const float4 t = c.pts[k];
-    const float d2 = sqdist_flann(q, m4_point(T, v3(t.x, t.y, t.z)));
+    const V3 tm = m4_point(T, v3(t.x, t.y, t.z));
+    const float d2 = sqdist_flann(q, tm);
     const int j = __float_as_int(t.w);
-    if (d2 < best || (d2 == best && j < bj)) best = d2, bj = j, bpos = k;
+    if (d2 < best || (d2 == best && j < bj)) best = d2, bj = j, bpos = k, moved = tm;
   }
 }
 
@@ -1318,12 +1323,12 @@ __global__ __launch_bounds__(256) void k_lcp_cells(LcpArgs a, int hb, int hs, in
       const float* __restrict__ Ti = a.pose_inv + (size_t)(a.h0 + hl) * 12;
       float best = 3.0e38f;
       int pos = -1;
-      cells_nn<1>(a.model_cells, m4_point(Ti, s), T, s, best, pos);
+      V3 pm;  // the matched model point under the hypothesis
+      cells_nn<1>(a.model_cells, m4_point(Ti, s), T, s, best, pos, pm);
       if (pos >= 0 && best < a.dist * a.dist) {
-        const float4 mp = a.model_cells.pts[pos], mnr = a.model_cells.nrm[pos];
+        const float4 mnr = a.model_cells.nrm[pos];
         const V3 nmod = vnormalized(m4_dir(T, v3(mnr.x, mnr.y, mnr.z)));  // normalised once, used by both terms
         f = lcp_term_unit(sn, nmod, best, a.dist, a.cos_thres);             // sn, rn: unit normals (k_unit_normals)
-        const V3 pm = m4_point(T, v3(mp.x, mp.y, mp.z));
         float rbest = 3.0e38f;
         int rk = -1;
         cells_nn_plain(a.scene_cells, pm, rbest, rk);
@@ -1581,7 +1586,8 @@ __global__ __launch_bounds__(256) void k_icp_corr_cells(IcpArgs a) {
   icp_chain_point(a.hist + (size_t)hl * a.max_iter * 12, a.iter, p);
   float best = 3.0e38f;
   int pos = -1;
-  cells_nn<4>(a.cells, m4_point(sTi, p), sT, p, best, pos);
+  V3 moved;
+  cells_nn<4>(a.cells, m4_point(sTi, p), sT, p, best, pos, moved);
   a.corr_idx[(size_t)hl * a.ns + i] = (pos >= 0 && best <= a.max_d2) ? pos : -1;
 }
 
@@ -1662,12 +1668,12 @@ __global__ __launch_bounds__(256) void k_icp_fused(IcpArgs a) {
     icp_chain_point_normal(hist, a.iter, q, qn);
     float d2 = 3.0e38f;
     int pos = -1;
-    cells_nn<4>(a.cells, m4_point(sTi, q), pose, q, d2, pos);
+    V3 tq;  // the correspondence moved by the pose, as the distance was measured
+    cells_nn<4>(a.cells, m4_point(sTi, q), pose, q, d2, pos, tq);
     if (pos < 0 || !(d2 <= a.max_d2)) continue;
-    const float4 tp = a.cells.pts[pos], tn = a.cells.nrm[pos];
+    const float4 tn = a.cells.nrm[pos];
     const V3 nt = m4_dir(pose, v3(tn.x, tn.y, tn.z));
     if (!(vdot(qn, nt) >= a.cos_thr)) continue;
-    const V3 tq = m4_point(pose, v3(tp.x, tp.y, tp.z));
     const V3 c = vcross(q, nt);
     const double J[6] = {c.x, c.y, c.z, nt.x, nt.y, nt.z};
     const double res = (double)vdot(q - tq, nt);
