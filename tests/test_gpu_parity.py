@@ -612,3 +612,37 @@ def test_remove_surrounding_points_equals_oracle(api, orc, synth, hop):
     # empty input
     x0, n0, c0, i0 = h.removeSurroundingPointsAndAssignProbability(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), handbase_in_cam, near2)
     assert len(c0) == 0
+
+
+def test_c5_scene_size_cell_lists_equal_brute_force(ctx, api, synth):
+    """BASELINE.json configs[4] sizes per point cloud (50 000-point scene, 5000-point model), a handful of hypotheses:
+    the cell-list paths (ICP nn_mode 3, computeLCP nn_mode 2, Verify mode 2) against the brute-force kernels."""
+    sc = synth.make_scene(50000, seed=13)
+    mx, mn = synth.ellipsoid_model(5000)
+    poses = synth.replay_poses(sc.gt_pose, 48, seed=13, max_rot_deg=30.0, max_trans=0.015)
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.0)
+    ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
+    ctx.set_model(api.HOP_MODEL_1MM, mx, mn)
+    out = {}
+    for mode in (0, 3):
+        ctx.hypos_upload(poses)
+        it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=mode, want_stats=True)
+        p, _, _ = ctx.hypos_download()
+        out[mode] = (it.copy(), cv.copy(), p.copy())
+    assert np.array_equal(out[0][0], out[3][0]) and np.array_equal(out[0][1], out[3][1])
+    assert np.abs(out[0][2] - out[3][2]).max() < 2e-6
+    scores = {}
+    for mode in (0, 2):
+        ctx.hypos_upload(out[0][2])
+        ctx.lcp_select_best(0.001, 10.0, mode)
+        scores[mode] = ctx.hypos_download()[1].copy()
+    assert np.array_equal(scores[0], scores[2]) and scores[0].max() > 100
+    rng = np.random.default_rng(5)
+    P = (sc.xyz - sc.xyz.mean(axis=0)).astype(np.float32)
+    Qs = mx[rng.choice(len(mx), 100, replace=False)]
+    cq = Qs.mean(axis=0)
+    Tg = sc.gt_pose.copy()
+    Tg[:3, 3] = Tg[:3, :3] @ cq + Tg[:3, 3] - sc.xyz.mean(axis=0)
+    T = synth.replay_poses(Tg, 256, seed=7, max_rot_deg=25, max_trans=0.01)
+    ctx.verify_set_clouds(P, (Qs - cq).astype(np.float32))
+    assert np.array_equal(ctx.verify_batch(T, 0.003, 0), ctx.verify_batch(T, 0.003, 2))
