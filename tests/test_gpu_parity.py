@@ -646,3 +646,18 @@ def test_c5_scene_size_cell_lists_equal_brute_force(ctx, api, synth):
     T = synth.replay_poses(Tg, 256, seed=7, max_rot_deg=25, max_trans=0.01)
     ctx.verify_set_clouds(P, (Qs - cq).astype(np.float32))
     assert np.array_equal(ctx.verify_batch(T, 0.003, 0), ctx.verify_batch(T, 0.003, 2))
+
+
+def test_recall_tool_gpu_matches_oracle_on_synthetic_frames():
+    """tools/recall_eval.py (BASELINE metric, second half: ADD(-S) recall vs the CPU reference path) on a few frames of
+    the synthetic substitute: every GPU pose within 1 mm / 1 degree of the oracle's, same recall."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "recall_eval.py"), "--frames", "6", "--scene", "1500"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["frames_gpu_pose_within_1mm_1deg_of_cpu"] == 6
+    assert out["recall_adi_10mm_gpu"] == out["recall_adi_10mm_cpu"] and out["recall_adi_5mm_gpu"] == out["recall_adi_5mm_cpu"]
+    assert out["recall_adi_10mm_gpu"] >= 0.8

@@ -1,0 +1,116 @@
+#!/usr/bin/env python
+"""tools/recall_eval.py -- second half of BASELINE.json's metric: "ADD<1cm recall vs CPU ref".
+
+The reference's datasets (986 real frames, 12000 simulated frames, meshes) are not part of its repository, so, as
+SURVEY.md 8(d) prescribes for C3/C4, a seeded synthetic substitute is used: frame f = hop_amd.synth.make_scene(n, seed=1000+f)
+(random pose of the ellipse, camera-facing half, noise, clutter) against the ellipse model.  Every frame goes through the
+as-shipped chain of main_realdata_auto.cpp:187-204 (generate with 10 successful bases -> cluster(30 deg, 15 mm) ->
+ICP on <= 100 -> cluster(5 deg, 3 mm) -> selectBest), once on the GPU through libhop and once through the CPU oracle
+(test infrastructure; this script is a measurement tool like bench.py's cpu_baseline leg, never part of the product).
+Reported: ADI (the symmetric ADD-S of scripts/eval_utils.py:181-200: mean distance from each model point under the
+estimate to the nearest model point under the ground truth) recall at 5 mm and 10 mm for both, and how many frames agree
+within 1 mm / 1 degree.
+
+    python tools/recall_eval.py --frames 50 --scene 2000
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+from scipy.spatial import cKDTree
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def adi(model, est, gt):
+    a = model @ est[:3, :3].T + est[:3, 3]
+    b = model @ gt[:3, :3].T + gt[:3, 3]
+    return float(cKDTree(b).query(a)[0].mean())
+
+
+def rot_err_deg(A, B):
+    c = (np.trace(A.T @ B) - 1) / 2
+    return float(np.degrees(np.arccos(np.clip(c, -1, 1))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=50)
+    ap.add_argument("--scene", type=int, default=2000)
+    ap.add_argument("--no-oracle", action="store_true")
+    args = ap.parse_args()
+    import hop_loader
+    hop = hop_loader.load()
+    from hop_amd import api
+    synth = hop.synth
+    mx5, mn5 = synth.ellipsoid_model_spacing(0.005)
+    mx1, mn1 = synth.ellipsoid_model(4000)
+    keys = synth.ppf_key_table()
+    sym = [180, 180, 180]
+    ctx = api.Context(0)
+    ctx.set_model(api.HOP_MODEL_5MM, mx5, mn5)
+    ctx.set_model(api.HOP_MODEL_1MM, mx1, mn1)
+    ctx.set_ppf_keys(keys)
+    orc = None
+    if not args.no_oracle:
+        import orc as _orc
+        _orc.build()
+        orc = _orc
+    rows = []
+    t_gpu = t_cpu = 0.0
+    for f in range(args.frames):
+        sc = synth.make_scene(args.scene, seed=1000 + f)
+        t0 = time.perf_counter()
+        ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8)
+        o = ctx.default_s4pcs_opts(max_time_seconds=0)
+        _, _, st = ctx.s4pcs_generate(o, download=False)
+        if st.n_hypotheses > 0:
+            ctx.cluster_poses(30.0, 0.015, sym, True)
+            ctx.icp_refine(10, 45.0, 0.01, max_hypotheses=100, nn_mode=3)
+            ctx.cluster_poses(5.0, 0.003, sym, False)
+            best, score, _ = ctx.lcp_select_best(0.001, 10.0, 2)
+        else:
+            best = np.eye(4, dtype=np.float32)
+        t_gpu += time.perf_counter() - t0
+        row = {"frame": f, "adi_gpu": adi(mx1, best.astype(np.float64), sc.gt_pose.astype(np.float64))}
+        if orc is not None:
+            t0 = time.perf_counter()
+            oo = orc.OracleS4PCS()
+            oo.set_keys(keys)
+            oo.run(sc.xyz, sc.nrm, sc.conf, mx5, mn5, 1)
+            op, ol = oo.hypos()
+            if len(ol):
+                keep = orc.cluster_poses(op, ol, np.arange(len(ol)), 30.0, 0.015, sym)
+                p1, l1 = op[keep][:100], ol[keep][:100]
+                p2, _, _ = orc.icp_refine_batch(sc.xyz, sc.nrm, mx5, mn5, p1, 10, 45.0, 0.01)
+                keep2 = orc.cluster_poses(p2, l1, np.arange(len(l1)), 5.0, 0.003, sym)
+                p3 = p2[keep2]
+                s3 = orc.compute_lcp_batch(sc.xyz, sc.nrm, mx1, mn1, p3, 0.001, 10.0)
+                ob = p3[int(np.flatnonzero(s3 == s3.max())[0])]
+            else:
+                ob = np.eye(4, dtype=np.float32)
+            t_cpu += time.perf_counter() - t0
+            row["adi_cpu"] = adi(mx1, ob.astype(np.float64), sc.gt_pose.astype(np.float64))
+            row["dt_mm"] = 1e3 * float(np.linalg.norm(best[:3, 3] - ob[:3, 3]))
+            row["drot_deg"] = rot_err_deg(best[:3, :3].astype(np.float64), ob[:3, :3].astype(np.float64))
+        rows.append(row)
+    a = np.array([r["adi_gpu"] for r in rows])
+    out = {"frames": args.frames, "scene_points": args.scene, "data": "synthetic substitute (seeds 1000+f)",
+           "recall_adi_5mm_gpu": float((a < 0.005).mean()), "recall_adi_10mm_gpu": float((a < 0.010).mean()),
+           "gpu_s_per_frame": t_gpu / args.frames}
+    if orc is not None:
+        b = np.array([r["adi_cpu"] for r in rows])
+        agree = np.array([(r["dt_mm"] < 1.0 and r["drot_deg"] < 1.0) for r in rows])
+        out.update({"recall_adi_5mm_cpu": float((b < 0.005).mean()), "recall_adi_10mm_cpu": float((b < 0.010).mean()),
+                    "frames_gpu_pose_within_1mm_1deg_of_cpu": int(agree.sum()), "cpu_s_per_frame": t_cpu / args.frames,
+                    "max_dt_mm": float(max(r["dt_mm"] for r in rows)), "max_drot_deg": float(max(r["drot_deg"] for r in rows))})
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
