@@ -437,7 +437,14 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   launch_cell_ranges(cs.c.start, (int)ncell, cs.range_d.as<int2>(), c->stream);
   cs.c.range = cs.range_d.as<int2>();
   cs.valid = true, cs.cell = a.cell, cs.max_dist = max_dist;
-  if (getenv("HOP_PROFILE_SELECT")) std::printf("local cell lists: %zu cells (%d with candidates), %d entries, cell %.5f\n", ncell, nwork, total, a.cell);
+  if (getenv("HOP_PROFILE_SELECT")) {
+    std::vector<int> cnt(ncell);
+    (void)hipMemcpy(cnt.data(), a.count, sizeof(int) * ncell, hipMemcpyDeviceToHost);
+    int mx = 0, over64 = 0, over192 = 0;
+    for (int v : cnt) mx = std::max(mx, v), over64 += v > 64, over192 += v > 192;
+    std::printf("local cell lists: %zu cells (%d with candidates), %d entries, cell %.5f, longest %d, >64: %d, >192: %d\n", ncell, nwork, total,
+                a.cell, mx, over64, over192);
+  }
   return HOP_OK;
 }
 

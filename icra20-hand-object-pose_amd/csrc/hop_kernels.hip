@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local_work(const int* __restr
 // stage 2 (one wave per flagged cell): U(C) over the candidate rows, survivors of the threshold and of the point that
 // realises U(C) into an LDS list, pairwise domination among them, ballot-compacted output.  Lanes own candidate rows.
 #define LOCAL_WCAP 512
-#define LOCAL_KEEP 64  /* results of the counting pass up to this length are replayed by the writing pass */
+#define LOCAL_KEEP 192  /* results of the counting pass up to this length are replayed by the writing pass */
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, GridDev g, int exist_mode, const int* __restrict__ work, int nwork,
                                                          int* __restrict__ keep_buf) {
@@ -1040,12 +1040,12 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
     const int pos = a.start[cidx], cnt = a.start[cidx + 1] - pos;
     if (cnt == 0) return;
     if (cnt <= LOCAL_KEEP) {  // replay
-      if (lane < cnt) {
-        const float4 m = g.pts[keepw[lane]];
-        a.pts[pos + lane] = m;
+      for (int i = lane; i < cnt; i += 64) {
+        const float4 m = g.pts[keepw[i]];
+        a.pts[pos + i] = m;
         if (a.nrm) {
           const int id = __float_as_int(m.w);
-          a.nrm[pos + lane] = make_float4(a.nx[id], a.ny[id], a.nz[id], 0.f);
+          a.nrm[pos + i] = make_float4(a.nx[id], a.ny[id], a.nz[id], 0.f);
         }
       }
       return;
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
     // almost everything that pairwise testing would, at O(L) per round.  Removed entries are marked ~k.
     float pm2 = u2;
     int pk = kb;
-    for (int round = 0; round < 12 && L > 8; ++round) {
+    for (int round = 0; round < 48 && L > 8; ++round) {
       float c2 = 3.0e38f;
       int ck = 0x7fffffff;
       for (int i = lane; i < L; i += 64) {
@@ -1172,7 +1172,9 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
         km = list[i];
         m = g.pts[km];
         keep = true;
-        for (int j = 0; j < L && keep; ++j)
+        // (a few cells far from a dense cloud keep hundreds of survivors: the O(L^2) pass is skipped there -- longer
+        // lists, same answers -- rather than letting a handful of waves set the kernel's duration)
+        for (int j = 0; j < L && keep && L <= 160; ++j)
           if (j != i) keep = !dominates(g.pts[list[j]], m, blo, bhi, a.dom_eps);
       }
       const unsigned long long kmask = __ballot(keep);
