@@ -35,8 +35,8 @@ VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak, same guide
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--scene", type=int, default=20000)
     ap.add_argument("--model", type=int, default=5000)
     ap.add_argument("--bases", type=int, default=2048)
@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--verify-mode", type=int, default=2, help="0 brute-force LDS scan, 1 voxel grid, 2 EXIST-mode cell lists (identical counts)")
     ap.add_argument("--nn-mode", type=int, default=3, help="ICP / computeLCP nearest neighbour: 0 brute force, 1 voxel grids, 2 NN cell lists, "
                     "3 NN cell lists with ICP search and accumulation in one kernel (identical correspondences in all modes)")
-    ap.add_argument("--inflight", type=int, default=6, help="frames in flight per GPU (one context each): the host base selection of one "
+    ap.add_argument("--inflight", type=int, default=8, help="frames in flight per GPU (one context each): the host base selection of one "
                     "frame overlaps the device work of the others; 1 = strictly one frame at a time")
     ap.add_argument("--no-serial-frame", action="store_true", help="skip the extra undisturbed frame used for per-kernel timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
