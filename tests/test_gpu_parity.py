@@ -661,3 +661,46 @@ def test_recall_tool_gpu_matches_oracle_on_synthetic_frames():
     assert out["frames_gpu_pose_within_1mm_1deg_of_cpu"] == 6
     assert out["recall_adi_10mm_gpu"] == out["recall_adi_10mm_cpu"] and out["recall_adi_5mm_gpu"] == out["recall_adi_5mm_cpu"]
     assert out["recall_adi_10mm_gpu"] >= 0.8
+
+
+def test_contexts_in_flight_are_independent(api, synth):
+    """bench.py keeps several frames in flight, one hop_ctx and one host thread each: contexts share nothing, so frames
+    run concurrently must return exactly what they return one at a time."""
+    import threading
+    mx5, mn5 = synth.ellipsoid_model_spacing(0.005)
+    mx1, mn1 = synth.ellipsoid_model(4000)
+    keys = synth.ppf_key_table()
+    scenes = [synth.make_scene(3000, seed=40 + k) for k in range(3)]
+
+    def frame(ctx, sc, out, slot):
+        ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8)
+        o = ctx.default_s4pcs_opts(success_quadrilaterals=64, n_trials=64, max_time_seconds=0)
+        ctx.s4pcs_generate(o, download=False)
+        ctx.hypos_keep_topk(512)
+        it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=3, want_stats=True)
+        best, score, idx = ctx.lcp_select_best(0.001, 10.0, 2)
+        pose, sc_, ids = ctx.hypos_download()
+        out[slot] = (it.copy(), pose.copy(), sc_.copy(), best.copy(), score, idx)
+
+    ctxs = []
+    for _ in range(3):
+        c = api.Context(0)
+        c.set_model(api.HOP_MODEL_5MM, mx5, mn5)
+        c.set_model(api.HOP_MODEL_1MM, mx1, mn1)
+        c.set_ppf_keys(keys)
+        ctxs.append(c)
+    serial, conc = {}, {}
+    for k in range(3):
+        frame(ctxs[k], scenes[k], serial, k)
+    for rep in range(2):
+        ts = [threading.Thread(target=frame, args=(ctxs[(k + rep) % 3], scenes[k], conc, k)) for k in range(3)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for k in range(3):
+            a, b = serial[k], conc[k]
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+            assert np.array_equal(a[3], b[3]) and a[4] == b[4] and a[5] == b[5]
+    for c in ctxs:
+        c.close()
