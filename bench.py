@@ -178,15 +178,24 @@ def main():
     dist = None
     # HOP_BENCH_FORCE_DIST=1 runs the collective path with a single rank (self-test of the multi-GPU code on one GPU)
     use_dist = world > 1 or bool(os.environ.get("HOP_BENCH_FORCE_DIST"))
+    # HOP_BENCH_BACKEND=gloo (self-test only): ranks may then share one GPU; the table travels through host memory
+    backend = os.environ.get("HOP_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend != "nccl":
+        local_rank = local_rank % max(ndev, 1)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = dev if backend == "nccl" else torch.device("cpu")   # where the collectives run
 
     F = max(1, args.inflight)
     w = Workload(args, rank)
@@ -197,8 +206,8 @@ def main():
     def exchange(rows):
         if not use_dist:
             return rows
-        t = torch.from_numpy(rows).to(dev)
-        out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=dev)
+        t = torch.from_numpy(rows).to(xdev)
+        out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=xdev)
         dist.all_gather_into_tensor(out, t)
         merged, _ = api.topk_merge(out.cpu().numpy(), K)
         return merged
@@ -276,7 +285,7 @@ def main():
 
     h_local = sum(i["h"] for i in infos)
     if use_dist:
-        t = torch.tensor([elapsed, float(h_local)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, float(h_local)], dtype=torch.float64, device=xdev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
