@@ -79,7 +79,7 @@ struct CellListStore {
   DevBuf start_d, pts_d, nrm_d, u2_d, count_d, work_d, keep_d, range_d;
   hop::CellListDev c{};
   bool valid = false;
-  float cell = 0, max_dist = 0;
+  float cell = 0, max_dist = 0, coord_mag = 0;
   void release() {
     start_d.release(), pts_d.release(), nrm_d.release(), u2_d.release(), count_d.release(), work_d.release(), keep_d.release(), range_d.release();
     valid = false;
@@ -156,6 +156,7 @@ struct hop_ctx {
   unsigned long long* ppf_matrix_cached = nullptr;
   size_t ppf_matrix_cached_bytes = 0;
   bool ppf_matrix_registered = false;
+  float coord_mag = 4.f;  // power of two >= 4 m bounding every coordinate handed over so far (float error scale of the lists)
   DevBuf fit_queue_d, fit_count_d, angle_thr_d, sur_in, sur_ws, sur_links, sur_out;
   bool angle_thr_tried = false, angle_thr_ok = false;
   int ppf_words = 0;
@@ -347,7 +348,9 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
   a.max_dist = max_dist, a.margin = 4 * GRID_MARGIN;
   a.nx = d.plane(3), a.ny = d.plane(4), a.nz = d.plane(5);
   // domination margin: far above the float error of a squared distance <= max_dist^2 between points of magnitude <= 4 m
-  a.dom_eps = 64.f * max_dist * (4.f * 6.0e-8f) + 1.0e-12f;
+  // domination margin: far above the float error of a squared distance <= max_dist^2 between points whose coordinates
+  // (in the frame where the reference measures it: the scene's) stay below c->coord_mag metres
+  a.dom_eps = 64.f * max_dist * (c->coord_mag * 6.0e-8f) + 1.0e-12f;
   const size_t ncell = (size_t)a.dx * a.dy * a.dz;
   if (ncell > (size_t)1 << 24) return HOP_E_CAPACITY;
   HIPCHK(c, cs.u2_d.ensure(sizeof(float) * ncell));
@@ -375,7 +378,7 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
   launch_cell_ranges(cs.c.start, (int)ncell, cs.range_d.as<int2>(), c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   cs.c.range = cs.range_d.as<int2>();
-  cs.valid = true, cs.cell = cell, cs.max_dist = max_dist;
+  cs.valid = true, cs.cell = cell, cs.max_dist = max_dist, cs.coord_mag = c->coord_mag;
   if (getenv("HOP_PROFILE_SELECT")) std::printf("cell lists: %zu cells, %zu entries (%.1f per cell), cell %.4f\n", ncell, total, (double)total / (double)ncell, cell);
   return HOP_OK;
 }
@@ -395,7 +398,7 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   a.dx = (g.dx + 2 * pad) * sub, a.dy = (g.dy + 2 * pad) * sub, a.dz = (g.dz + 2 * pad) * sub;
   a.max_dist = max_dist;
   if (normals) a.n = normals->n, a.nx = normals->plane(3), a.ny = normals->plane(4), a.nz = normals->plane(5);
-  a.dom_eps = 64.f * max_dist * (4.f * 6.0e-8f) + 1.0e-12f;
+  a.dom_eps = 64.f * max_dist * (c->coord_mag * 6.0e-8f) + 1.0e-12f;
   const size_t ncell = (size_t)a.dx * a.dy * a.dz;
   if (ncell > (size_t)1 << 28) return HOP_E_CAPACITY;
   HIPCHK(c, cs.count_d.ensure(sizeof(int) * (ncell + 1)));
@@ -436,7 +439,7 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   HIPCHK(c, cs.range_d.ensure(sizeof(int2) * ncell));
   launch_cell_ranges(cs.c.start, (int)ncell, cs.range_d.as<int2>(), c->stream);
   cs.c.range = cs.range_d.as<int2>();
-  cs.valid = true, cs.cell = a.cell, cs.max_dist = max_dist;
+  cs.valid = true, cs.cell = a.cell, cs.max_dist = max_dist, cs.coord_mag = c->coord_mag;
   if (getenv("HOP_PROFILE_SELECT")) {
     std::vector<int> cnt(ncell);
     (void)hipMemcpy(cnt.data(), a.count, sizeof(int) * ncell, hipMemcpyDeviceToHost);
@@ -668,6 +671,11 @@ int hop_set_scene(hop_ctx* c, const float* xyz, const float* nrm, const float* c
   for (size_t k = 0; k < keep.size(); ++k) {
     const int i = keep[k];
     raw.nx[k] = nrm[i], raw.ny[k] = nrm[n + i], raw.nz[k] = nrm[2 * (size_t)n + i];
+  }
+  {
+    float m = 0.f;
+    for (size_t k = 0; k < keep.size(); ++k) m = std::max(m, std::max(std::fabs(raw.x[k]), std::max(std::fabs(raw.y[k]), std::fabs(raw.z[k]))));
+    while (c->coord_mag < m) c->coord_mag *= 2.f;  // model-side lists built for a smaller scale are rebuilt on next use
   }
   c->have_gen_state = false;
   c->verify_grid.valid = false;
@@ -1221,7 +1229,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     float cell = o->max_corr_dist / 6.f;
     if (const char* e = getenv("HOP_ICP_CELL_DIV")) cell = o->max_corr_dist / (float)atof(e);
     CellListStore& cs = c->model_cells[HOP_MODEL_5MM];
-    if (!cs.valid || cs.cell != cell || cs.max_dist != o->max_corr_dist) {
+    if (!cs.valid || cs.cell != cell || cs.max_dist != o->max_corr_dist || cs.coord_mag < c->coord_mag) {
       const int rc = build_cell_lists(c, cs, c->gen.model_h[HOP_MODEL_5MM], c->model_d[HOP_MODEL_5MM], o->max_corr_dist, cell);
       if (rc) return rc;
     }
@@ -1300,7 +1308,7 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
     GridStore& gm = c->model_grid[HOP_MODEL_1MM];
     if (lcp_cells) {
       CellListStore& cs = c->model_cells[HOP_MODEL_1MM];
-      if (!cs.valid || cs.cell != o->dist || cs.max_dist != o->dist) {
+      if (!cs.valid || cs.cell != o->dist || cs.max_dist != o->dist || cs.coord_mag < c->coord_mag) {
         const int rc = build_cell_lists(c, cs, c->gen.model_h[HOP_MODEL_1MM], c->model_d[HOP_MODEL_1MM], o->dist, o->dist);
         if (rc) return rc;
       }

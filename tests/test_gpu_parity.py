@@ -704,3 +704,31 @@ def test_contexts_in_flight_are_independent(api, synth):
             assert np.array_equal(a[3], b[3]) and a[4] == b[4] and a[5] == b[5]
     for c in ctxs:
         c.close()
+
+
+def test_cell_lists_far_from_the_origin_equal_brute_force(ctx, api, synth):
+    """The float error of the reference's distance expression grows with the coordinate magnitude; the list margins
+    scale with it (hop_ctx::coord_mag).  A frame 6 m from the camera: cell-list paths against brute force."""
+    sc = synth.make_scene(6000, seed=17)
+    mx, mn = synth.ellipsoid_model(3000)
+    shift = np.float32([1.5, -2.0, 5.5])
+    xyz = (sc.xyz + shift).astype(np.float32)
+    gt = sc.gt_pose.copy()
+    gt[:3, 3] += shift
+    poses = synth.replay_poses(gt, 64, seed=3, max_rot_deg=25.0, max_trans=0.01)
+    ctx.set_scene(xyz, sc.nrm, sc.conf, 0.0)
+    ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
+    ctx.set_model(api.HOP_MODEL_1MM, mx, mn)
+    out = {}
+    for mode in (0, 3):
+        ctx.hypos_upload(poses)
+        it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=mode, want_stats=True)
+        out[mode] = (it.copy(), cv.copy(), ctx.hypos_download()[0].copy())
+    assert np.array_equal(out[0][0], out[3][0]) and np.array_equal(out[0][1], out[3][1])
+    assert np.abs(out[0][2] - out[3][2]).max() < 2e-5   # float ulp at 6 m is 5e-7
+    sc_ = {}
+    for mode in (0, 2):
+        ctx.hypos_upload(out[0][2])
+        ctx.lcp_select_best(0.001, 10.0, mode)
+        sc_[mode] = ctx.hypos_download()[1].copy()
+    assert np.array_equal(sc_[0], sc_[2])
