@@ -123,6 +123,7 @@ SIGNATURES = {
     "hop_topk_pack": (C.c_int, [_vp, C.c_int, C.c_int, fp, ip]),
     "hop_topk_merge": (C.c_int, [fp, C.c_int, C.c_int, fp, ip]),
     "hop_hand_set_scene": (C.c_int, [_vp, fp, C.c_int, fp, C.c_int, fp, C.c_int]),
+    "hop_model_ppf_keys": (C.c_int, [_vp, fp, fp, C.c_int, ip, C.c_int, ip]),
     "hop_hand_set_finger": (C.c_int, [_vp, C.POINTER(FingerArgs)]),
     "hop_hand_remove_surrounding": (C.c_int, [_vp, fp, fp, C.c_int, fp, C.POINTER(HandLink), C.c_int, fp, fp, C.c_float, fp, fp, fp, ip, ip]),
     "hop_hand_pso_eval_batch": (C.c_int, [_vp, dp, C.c_int, dp]),
@@ -344,6 +345,14 @@ class Context:
     def hand_set_scene(self, scene_xyz, lookup_nrm, swivel_xyz):
         S, Ln, W = soa(scene_xyz), soa(lookup_nrm), soa(swivel_xyz)
         self._chk(self.L.hop_hand_set_scene(self.h, F(S), S.shape[1], F(Ln), Ln.shape[1], F(W), W.shape[1]), "hop_hand_set_scene")
+
+    def model_ppf_keys(self, xyz, nrm, cap=1 << 20):
+        """Key table of a model cloud (computePPF.cpp:88-100): (n_keys, 4) int32, sorted."""
+        X, Nn = soa(xyz), soa(nrm)
+        out = np.zeros((cap, 4), np.int32)
+        k = C.c_int(0)
+        self._chk(self.L.hop_model_ppf_keys(self.h, F(X), F(Nn), X.shape[1], I(out), cap, C.byref(k)), "hop_model_ppf_keys")
+        return out[:k.value].copy()
 
     def hand_remove_surrounding(self, scene_xyz, scene_nrm, handbase_in_cam, links, finger12_in_handbase, finger22_in_handbase, min_z):
         """links: list of (xyz (n,3) in the hand-base frame, squared distance threshold), in name order.

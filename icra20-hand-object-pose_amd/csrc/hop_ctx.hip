@@ -1757,6 +1757,71 @@ int hop_hand_pso_search(hop_ctx* c, const hop_pso_settings* s, double* best_angl
   return HOP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- N4 (computePPF pair loop)
+int hop_model_ppf_keys(hop_ctx* c, const float* xyz, const float* nrm, int n, int32_t* keys4_out, int cap, int* n_keys) {
+  if (!c || !xyz || !nrm || n < 0 || !n_keys || cap < 0 || (cap > 0 && !keys4_out)) return HOP_E_INVALID;
+  *n_keys = 0;
+  if (n < 2) return HOP_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  CloudHost h;
+  load_cloud_host(h, xyz, nrm, n, false);  // normals as given: the kernel normalises once, as the tool does
+  CloudDevice d;
+  int rc = upload_cloud(c, d, h);
+  if (rc) return rc;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = 0; i < n; ++i) {
+    mn[0] = std::min(mn[0], h.x[i]), mn[1] = std::min(mn[1], h.y[i]), mn[2] = std::min(mn[2], h.z[i]);
+    mx[0] = std::max(mx[0], h.x[i]), mx[1] = std::max(mx[1], h.y[i]), mx[2] = std::max(mx[2], h.z[i]);
+  }
+  const double diag = std::sqrt((double)(mx[0] - mn[0]) * (mx[0] - mn[0]) + (double)(mx[1] - mn[1]) * (mx[1] - mn[1]) +
+                                (double)(mx[2] - mn[2]) * (mx[2] - mn[2]));
+  if (!(diag * 1000.0 < 1.0e6)) {
+    d.buf.release();
+    return HOP_E_CAPACITY;
+  }
+  const int dist_bins = (int)(diag * 1000.0 / 5.0) + 3;
+  const size_t words = ((size_t)dist_bins * 19 * 19 * 19 + 31) / 32 + 1;
+  DevBuf bm;
+  rc = HOP_OK;
+  std::vector<unsigned> host(words);
+  int overflow = 0;
+  do {
+    if (bm.ensure(sizeof(unsigned) * words + sizeof(int)) != hipSuccess) {
+      rc = HOP_E_ALLOC;
+      break;
+    }
+    if (hipMemsetAsync(bm.p, 0, sizeof(unsigned) * words + sizeof(int), c->stream) != hipSuccess) {
+      rc = HOP_E_HIP;
+      break;
+    }
+    int* ovf = reinterpret_cast<int*>(bm.as<unsigned>() + words);
+    launch_model_ppf_keys(d.plane(0), d.plane(1), d.plane(2), d.plane(3), d.plane(4), d.plane(5), n, dist_bins, bm.as<unsigned>(), ovf, c->stream);
+    if (hipMemcpyAsync(host.data(), bm.p, sizeof(unsigned) * words, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(&overflow, ovf, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+      rc = HOP_E_HIP;
+  } while (false);
+  bm.release();
+  d.buf.release();
+  if (rc) return rc;
+  if (overflow) return HOP_E_CAPACITY;
+  int count = 0;
+  for (int dd = 0; dd < dist_bins; ++dd)
+    for (int a1 = 0; a1 < 19; ++a1)
+      for (int a2 = 0; a2 < 19; ++a2)
+        for (int a3 = 0; a3 < 19; ++a3) {
+          const size_t bit = (((size_t)dd * 19 + a1) * 19 + a2) * 19 + a3;
+          if (!((host[bit >> 5] >> (bit & 31)) & 1u)) continue;
+          if (count < cap) {
+            int32_t* k = keys4_out + 4 * (size_t)count;
+            k[0] = dd * 5, k[1] = a1 * 10, k[2] = a2 * 10, k[3] = a3 * 10;
+          }
+          ++count;
+        }
+  *n_keys = count;
+  return count > cap ? HOP_E_CAPACITY : HOP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- N3a
 int hop_hand_remove_surrounding(hop_ctx* c, const float* scene_xyz, const float* scene_nrm, int n, const float handbase_in_cam[16],
                                 const hop_hand_link* links, int n_links, const float finger12_in_handbase[16],

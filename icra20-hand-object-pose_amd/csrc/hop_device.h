@@ -268,6 +268,8 @@ struct SurroundOutArgs {
   float *ox, *oy, *oz, *onx, *ony, *onz, *oconf;
   int* oindex;
 };
+void launch_model_ppf_keys(const float* x, const float* y, const float* z, const float* nx, const float* ny, const float* nz, int n,
+                           int dist_bins, unsigned* bitmap, int* overflow, hipStream_t s);
 void launch_hand_surround(const SurroundArgs& a, hipStream_t s);
 void launch_hand_surround_out(const SurroundOutArgs& a, hipStream_t s);
 

@@ -1986,6 +1986,33 @@ __global__ __launch_bounds__(64) void k_pso_outer_sum(PsoArgs a, int n_particles
 }
 
 // ------------------------------------------------------------------------------------------------
+// N4: the pair loop of the offline computePPF tool (computePPF.cpp:17-38,88-100): key of every pair i < j of the model
+// cloud, collected in the same direct-address bitmap the generator looks keys up in.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_model_ppf_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                       const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz,
+                                                       int n, int dist_bins, unsigned* __restrict__ bitmap, int* __restrict__ overflow) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= n || j <= i) return;
+  const V3 p1 = v3(x[i], y[i], z[i]), p2 = v3(x[j], y[j], z[j]);
+  const V3 n1 = vnormalized(v3(nx[i], ny[i], nz[i])), n2 = vnormalized(v3(nx[j], ny[j], nz[j]));  // n.normalize(), once
+  int key[4];
+  if (!ppf_key(p1, n1, p2, n2, key)) return;  // NaN angle: the tool stores an INT_MIN key that can never be looked up
+  const int d = key[0] / 5, a1 = key[1] / 10, a2 = key[2] / 10, a3 = key[3] / 10;
+  if (key[0] < 0 || (unsigned)a1 >= 19u || (unsigned)a2 >= 19u || (unsigned)a3 >= 19u) return;
+  if (d >= dist_bins) {
+    *overflow = 1;
+    return;
+  }
+  const unsigned bit = ((unsigned)(d * 19 + a1) * 19u + (unsigned)a2) * 19u + (unsigned)a3;
+  atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+}
+void launch_model_ppf_keys(const float* x, const float* y, const float* z, const float* nx, const float* ny, const float* nz, int n,
+                           int dist_bins, unsigned* bitmap, int* overflow, hipStream_t s) {
+  if (n > 1) hipLaunchKernelGGL(k_model_ppf_keys, dim3((n + 255) / 256, n), dim3(256), 0, s, x, y, z, nx, ny, nz, n, dist_bins, bitmap, overflow);
+}
+
+// ------------------------------------------------------------------------------------------------
 // N3a: HandT42::removeSurroundingPointsAndAssignProbability (Hand.cpp:779-888).  One thread per scene point; the link
 // clouds (a few hundred points each) are scanned by brute force -- every lane of a wave reads the same link point, so
 // a load serves 64 queries.  Links are visited in the reference's map order with its early exit.

@@ -230,6 +230,16 @@ int hop_hand_remove_surrounding(hop_ctx* ctx, const float* scene_xyz, const floa
                                 int* keep_index, int* n_out);
 
 /* ------------------------------------------------------------------------------------------------
+ * "Next" row N4, the PPF key table of a model: the pair loop of the offline tool
+ * src/perception/src/app/computePPF.cpp:17-38,88-100 -- computePPF(points[i], points[j]) for every i < j on the 5 mm
+ * model cloud with its normals (normalised once, as there) -- so that the table runSuper4pcs consumes
+ * (hop_set_ppf_keys) can be regenerated for any object.  The tool's voxel / MLS-normal preprocessing is not part of it.
+ * keys4_out: up to `cap` rows of 4 int32 (dist mm, three angles in degrees), sorted lexicographically, unique;
+ * *n_keys is the number of distinct valid keys (HOP_E_CAPACITY if it exceeds cap).
+ * ---------------------------------------------------------------------------------------------- */
+int hop_model_ppf_keys(hop_ctx* ctx, const float* xyz, const float* nrm, int n, int32_t* keys4_out, int cap, int* n_keys);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): device time in ms of the kernels launched by the last call of the
  * named stage, measured with HIP events on the ctx stream; and launch counts.
  * ---------------------------------------------------------------------------------------------- */

@@ -1755,4 +1755,37 @@ int orc_hand_remove_surrounding(const float* scene_xyz, const float* scene_nrm, 
   return kept;
 }
 
+
+// "next" row N4 -- the pair loop of the offline computePPF tool (computePPF.cpp:17-38,88-100), restated: key of
+// (points[i], points[j]) for every i < j; normals normalised once (n.normalize()); float arithmetic in Eigen's order;
+// std::acos on a float argument is acosf.  Returns the number of distinct keys, the first `cap` of them sorted.
+int orc_model_ppf_keys(const float* xyz, const float* nrm, int n, int* keys4, int cap) {
+  const std::vector<V3> p = soa_to_v3(xyz, n), nn = soa_to_v3(nrm, n);
+  std::vector<V3> un(n);
+  for (int i = 0; i < n; ++i) un[i] = normalized(nn[i]);
+  std::set<std::array<int, 4>> keys;
+  auto closest = [](int value, int disc) {
+    const int lower = value - (value % disc), upper = lower + disc;
+    return (value - lower) < (upper - value) ? lower : upper;
+  };
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j) {
+      const float dist_f = norm(p[i] - p[j]) * 1000;
+      if (!(dist_f < 2147483648.0f)) continue;
+      const V3 d = normalized(p[j] - p[i]);
+      const float c1 = dot(un[i], d), c2 = dot(un[j], d), c3 = dot(un[i], un[j]);
+      const float a1 = acosf_fdlibm(c1), a2 = acosf_fdlibm(c2), a3 = acosf_fdlibm(c3);
+      if (!(a1 == a1) || !(a2 == a2) || !(a3 == a3)) continue;  // the tool stores an INT_MIN key nobody can look up
+      std::array<int, 4> k{closest((int)dist_f, 5), closest((int)((double)a1 / M_PI * 180), 10), closest((int)((double)a2 / M_PI * 180), 10),
+                           closest((int)((double)a3 / M_PI * 180), 10)};
+      keys.insert(k);
+    }
+  int c = 0;
+  for (const auto& k : keys) {
+    if (c < cap) std::memcpy(keys4 + 4 * (size_t)c, k.data(), sizeof(int) * 4);
+    ++c;
+  }
+  return c;
+}
+
 }  // extern "C"

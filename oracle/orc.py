@@ -134,6 +134,8 @@ def lib():
         L.orc_pso_objective_batch.argtypes = [C.POINTER(FingerArgs), dp, C.c_int, dp]
         L.orc_pso_search.argtypes = [C.POINTER(FingerArgs), C.POINTER(PsoSettings), dp, dp]
         L.orc_finger_property.argtypes = [fp, C.c_int, C.c_int, fp, fp, fp, fp]
+        L.orc_model_ppf_keys.restype = C.c_int
+        L.orc_model_ppf_keys.argtypes = [fp, fp, C.c_int, ip, C.c_int]
         L.orc_hand_remove_surrounding.restype = C.c_int
         L.orc_hand_remove_surrounding.argtypes = [fp, fp, C.c_int, fp, C.POINTER(fp), ip, fp, C.c_int, fp, fp, C.c_float, fp, fp, fp, ip]
         L.orc_compute_ppf.argtypes = [fp, fp, fp, fp, ip]
@@ -352,3 +354,10 @@ def hand_remove_surrounding(scene_xyz, scene_nrm, handbase_in_cam, links, finger
     f2 = np.ascontiguousarray(finger22_in_handbase, np.float32).reshape(16)
     k = lib().orc_hand_remove_surrounding(F(X), F(Nn), n, F(T), arr, I(ln), F(th), len(links), F(f1), F(f2), float(min_z), F(ox), F(on), F(oc), I(ki))
     return ox[:, :k].T.copy(), on[:, :k].T.copy(), oc[:k].copy(), ki[:k].copy()
+
+
+def model_ppf_keys(xyz, nrm, cap=1 << 20):
+    X, Nn = soa(xyz), soa(nrm)
+    out = np.zeros((cap, 4), np.int32)
+    k = lib().orc_model_ppf_keys(F(X), F(Nn), X.shape[1], I(out), cap)
+    return out[:k].copy()

@@ -732,3 +732,15 @@ def test_cell_lists_far_from_the_origin_equal_brute_force(ctx, api, synth):
         ctx.lcp_select_best(0.001, 10.0, mode)
         sc_[mode] = ctx.hypos_download()[1].copy()
     assert np.array_equal(sc_[0], sc_[2])
+
+
+def test_model_ppf_keys_equal_oracle(ctx, orc, synth):
+    """hop_model_ppf_keys (pair loop of the offline computePPF tool) against its CPU restatement:
+    the same sorted key set; and the table it returns is usable by the generator as is."""
+    mx, mn = synth.ellipsoid_model_spacing(0.005)
+    k = ctx.model_ppf_keys(mx, mn * np.float32(2.5))          # unnormalised normals: normalised once, as the tool does
+    o = orc.model_ppf_keys(mx, mn * np.float32(2.5))
+    assert len(k) > 500 and np.array_equal(k, o)
+    assert ctx.model_ppf_keys(mx[:1], mn[:1]).shape == (0, 4)
+    with pytest.raises(Exception):
+        ctx.model_ppf_keys(mx, mn, cap=10)                    # HOP_E_CAPACITY, not a silent truncation

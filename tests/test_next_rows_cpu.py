@@ -39,3 +39,18 @@ def test_remove_surrounding_hand_computed(orc):
     cam = (scene @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
     x3, _, c3, idx3 = orc.hand_remove_surrounding(cam, nrm, T, links, far, far, 0.0)
     assert idx3.tolist() == [2, 4] and np.abs(x3 - cam[[2, 4]]).max() < 1e-6 and np.allclose(c3, c, rtol=1e-4)
+
+
+def test_model_ppf_keys_restatement(orc, hop):
+    """Pair loop of the offline computePPF tool (computePPF.cpp:17-38,88-100): a hand-computable pair, and agreement
+    with the numpy construction the synthetic key table uses."""
+    # two points 10 mm apart along x with normals +z and +x: dist 10 -> bin 10; angles 90, 0, 90 -> bins 90, 0, 90
+    k = orc.model_ppf_keys(np.float32([[0, 0, 0], [0.01, 0, 0]]), np.float32([[0, 0, 2], [3, 0, 0]]))
+    assert k.tolist() == [[10, 90, 0, 90]]
+    synth = hop.synth
+    mx, mn = synth.ellipsoid_model_spacing(0.01)
+    a = orc.model_ppf_keys(mx, mn)
+    b = synth.ppf_keys_numpy(mx, mn)
+    sa, sb = set(map(tuple, a.tolist())), set(map(tuple, b.tolist()))
+    assert len(sa) > 100 and len(sa & sb) > 0.98 * len(sa | sb)   # numpy's arccos/float paths differ on a few boundary pairs
+    assert a.tolist() == sorted(a.tolist())
