@@ -863,7 +863,7 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
   const int n_trials = opts->n_trials > 0 ? opts->n_trials : 30;
   if (n_trials > 16384) return HOP_E_CAPACITY;  // 14 bits of the order key
   const bool never_stops_early = opts->success_quadrilaterals >= n_trials && opts->max_time_seconds <= 0;
-  int BATCH = never_stops_early ? 64 : std::min(32, n_trials);
+  int BATCH = never_stops_early ? 128 : std::min(32, n_trials);
   if (const char* e = getenv("HOP_GEN_BATCH")) BATCH = std::max(1, std::min(atoi(e), n_trials));
   const int pair_cap = NQ * (NQ - 1) + 2;
   const int cand_cap = 1 << 22;
