@@ -1,17 +1,17 @@
 #!/usr/bin/env python
-"""tools/recall_eval.py -- second half of BASELINE.json's metric: "ADD<1cm recall vs CPU ref".
+"""tests/recall_eval.py -- second half of BASELINE.json's metric: "ADD<1cm recall vs CPU ref".
 
 The reference's datasets (986 real frames, 12000 simulated frames, meshes) are not part of its repository, so, as
 SURVEY.md 8(d) prescribes for C3/C4, a seeded synthetic substitute is used: frame f = hop_amd.synth.make_scene(n, seed=1000+f)
 (random pose of the ellipse, camera-facing half, noise, clutter) against the ellipse model.  Every frame goes through the
 as-shipped chain of main_realdata_auto.cpp:187-204 (generate with 10 successful bases -> cluster(30 deg, 15 mm) ->
 ICP on <= 100 -> cluster(5 deg, 3 mm) -> selectBest), once on the GPU through libhop and once through the CPU oracle
-(test infrastructure; this script is a measurement tool like bench.py's cpu_baseline leg, never part of the product).
+(the oracle is test infrastructure: this script lives under tests/ and is never part of the product).
 Reported: ADI (the symmetric ADD-S of scripts/eval_utils.py:181-200: mean distance from each model point under the
 estimate to the nearest model point under the ground truth) recall at 5 mm and 10 mm for both, and how many frames agree
 within 1 mm / 1 degree.
 
-    python tools/recall_eval.py --frames 50 --scene 2000
+    python tests/recall_eval.py --frames 50 --scene 2000
 """
 import argparse
 import json

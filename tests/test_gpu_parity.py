@@ -649,12 +649,12 @@ def test_c5_scene_size_cell_lists_equal_brute_force(ctx, api, synth):
 
 
 def test_recall_tool_gpu_matches_oracle_on_synthetic_frames():
-    """tools/recall_eval.py (BASELINE metric, second half: ADD(-S) recall vs the CPU reference path) on a few frames of
+    """tests/recall_eval.py (BASELINE metric, second half: ADD(-S) recall vs the CPU reference path) on a few frames of
     the synthetic substitute: every GPU pose within 1 mm / 1 degree of the oracle's, same recall."""
     import json
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "recall_eval.py"), "--frames", "6", "--scene", "1500"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "recall_eval.py"), "--frames", "6", "--scene", "1500"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
