@@ -13,7 +13,7 @@ constexpr int NN_CH = 16;      // targets per min-chunk of the scan
 constexpr int PPF_ROWS = 64;   // rows of the PPF matrix handled per block
 constexpr int ICP_NACC = 32;   // 21 (lower triangle of J^T J) + 6 (J^T r) + mse + count + 3 (sum of matched source points)
 constexpr int FIT_QUEUES = 64;    // sub-queues between the quadrilateral test and fit stages (power of two)
-constexpr int ICP_ACCUM_R = 16;  // points per thread of the accumulation kernel of the cell-list path
+constexpr int ICP_ACCUM_R = 32;  // points per thread of the accumulation kernel of the cell-list path
 constexpr float GRID_MARGIN = 1.0e-5f;  // metres; bounds | ||T^-1 s - m|| - ||s - T m|| | for rigid float poses
 constexpr int MAX_RING = 64;   // samples on the normal cone (normalset.hpp:208-210; <= 2*ceil(2*pi*atan(pi)*3.5) = 56)
 
