@@ -489,7 +489,7 @@ class PoseEstimator:
         self.ctx.icp_refine(10, float(self.cfg["icp_angle_thres"]), float(self.cfg["icp_dist_thres"]), max_hypotheses=100, nn_mode=3)
 
     def selectBest(self):
-        pose, score, idx = self.ctx.lcp_select_best(float(self.cfg["lcp"]["dist"]), float(self.cfg["lcp"]["normal_angle"]), 2)
+        pose, score, idx = self.ctx.lcp_select_best(float(self.cfg["lcp"]["dist"]), float(self.cfg["lcp"]["normal_angle"]), -1)
         return PoseHypo(pose, idx, score)
 
     def hypos(self):

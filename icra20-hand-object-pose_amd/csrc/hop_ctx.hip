@@ -1287,7 +1287,11 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
   const CloudDevice& S = c->scene_d;
   const CloudDevice& Mo = c->model_d[HOP_MODEL_1MM];
   const size_t per_h = sizeof(float) * 2 * (size_t)S.n + sizeof(float) * 2 * (size_t)Mo.n;
-  const bool lcp_grid = o->nn_mode >= 1, lcp_cells = o->nn_mode >= 2;
+  // nn_mode < 0: pick by size.  All modes return the same bits; the cell lists need per-frame scene structures (~1-3 ms
+  // to build), which a small hypothesis set (the as-shipped <= 100) does not amortise: brute force is ~0.1 ms there.
+  int nn_mode = o->nn_mode;
+  if (nn_mode < 0) nn_mode = ((double)H * (double)S.n * (double)Mo.n < 2.0e10 && !c->scene_cells.valid) ? 0 : 2;
+  const bool lcp_grid = nn_mode >= 1, lcp_cells = nn_mode >= 2;
   const size_t ws_cap = lcp_grid ? ((size_t)4 << 30) : ((size_t)1 << 30);
   const int HB = (int)std::max<size_t>(1, std::min<size_t>((size_t)H, ws_cap / per_h));
   if (!lcp_grid) {

@@ -77,7 +77,7 @@ class PoseEstimator {
 
   // selectBest (PoseEstimator.cpp:465-502)
   void selectBest(PoseHypo& best_hypo) {
-    hop_lcp_opts o{cfg->getf("lcp.dist"), cfg->getf("lcp.normal_angle"), 2};  // nn_mode 2: NN cell lists
+    hop_lcp_opts o{cfg->getf("lcp.dist"), cfg->getf("lcp.normal_angle"), -1};  // nn_mode < 0: by size (cell lists or brute force: same bits)
     float score = 0;
     int idx = 0;
     hop::check(hop_lcp_select_best(ctx_, &o, best_hypo._pose, &score, &idx), ctx_, "hop_lcp_select_best");

@@ -141,7 +141,7 @@ int hop_icp_refine(hop_ctx* ctx, const hop_icp_opts* opts, int* iterations_out /
 typedef struct {
   float dist;      /* lcp.dist = 0.001          (config_autodataset.yaml:116) */
   float angle_deg; /* lcp.normal_angle = 10     (:117) */
-  int nn_mode;     /* 0 brute force, 1 voxel grids, 2 NN cell lists (same scores, bit for bit) */
+  int nn_mode;     /* 0 brute force, 1 voxel grids, 2 NN cell lists (same scores, bit for bit); < 0: chosen by problem size */
 } hop_lcp_opts;
 int hop_lcp_select_best(hop_ctx* ctx, const hop_lcp_opts* opts, float* best_pose16_out,
                         float* best_score_out, int* best_index_out);
