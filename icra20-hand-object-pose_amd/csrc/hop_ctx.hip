@@ -1234,7 +1234,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
       if (rc) return rc;
     }
     a.cells = cs.c;
-    HIPCHK(c, c->icp_corr_idx.ensure(sizeof(int) * (size_t)S.n * HB));
+    if (o->nn_mode != 3) HIPCHK(c, c->icp_corr_idx.ensure(sizeof(int) * (size_t)S.n * HB));  // the fused kernel keeps no correspondence array
     HIPCHK(c, c->icp_hist.ensure(sizeof(float) * 12 * (size_t)std::max(o->max_iter, 1) * HB));
     a.corr_idx = c->icp_corr_idx.as<int>(), a.hist = c->icp_hist.as<float>();
     HIPCHK(c, c->pose_inv.ensure(sizeof(float) * 12 * (size_t)H));
