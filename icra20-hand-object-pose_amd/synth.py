@@ -12,6 +12,8 @@ needs them is run on the stand-ins built here:
   ``src/perception/src/app/computePPF.cpp:56-107`` (keys of ordered pairs i<j of the 5 mm model).
 * ``t42_hand``         -- a parametric stand-in for the Yale T42 hand: 4 finger links (boxes sampled
   at 5 mm), each rotating about its local x axis, with the reference's link names.
+* ``ellipsoid_mesh`` / ``box_mesh`` / ``torus_mesh`` / ``lshape_mesh`` -- closed, outward-oriented triangle
+  meshes (row N1: the object mesh and the finger links' convex meshes the reference loads from OBJ files).
 * ``replay_poses``     -- ground truth composed with bounded perturbations (rot <= 30 deg,
   trans <= 15 mm) so that scoring kernels can be timed independently of the generator.
 
@@ -251,6 +253,118 @@ def _box_cloud(lo, hi, spacing):
     return np.concatenate(pts).astype(np.float32), np.concatenate(nrm).astype(np.float32)
 
 
+# --------------------------------------------------------------------------- triangle meshes (row N1)
+def _orient_outward(V, F, centre=None):
+    """Flip triangles whose normal points towards ``centre`` (star-shaped meshes only)."""
+    V64 = V.astype(np.float64)
+    c = V64.mean(axis=0) if centre is None else np.asarray(centre, dtype=np.float64)
+    a, b, d = V64[F[:, 0]], V64[F[:, 1]], V64[F[:, 2]]
+    n = np.cross(b - a, d - a)
+    flip = np.einsum("ij,ij->i", n, (a + b + d) / 3 - c) < 0
+    F = F.copy()
+    F[flip] = F[flip][:, [0, 2, 1]]
+    return F
+
+
+def icosphere(subdiv: int = 2):
+    t = (1.0 + math.sqrt(5.0)) / 2.0
+    V = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    F = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10),
+         (8, 6, 7), (9, 8, 1)]
+    V = [np.asarray(v, dtype=np.float64) / math.sqrt(1 + t * t) for v in V]
+    for _ in range(subdiv):
+        cache, F2 = {}, []
+
+        def mid(i, j):
+            key = (min(i, j), max(i, j))
+            if key not in cache:
+                m = V[i] + V[j]
+                V.append(m / np.linalg.norm(m))
+                cache[key] = len(V) - 1
+            return cache[key]
+
+        for a, b, c in F:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            F2 += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        F = F2
+    return np.asarray(V), np.asarray(F, dtype=np.int32)
+
+
+def ellipsoid_mesh(semi=SEMI_AXES, subdiv: int = 3):
+    """Closed convex mesh of the "ellipse" object (20 * 4**subdiv faces), outward orientation."""
+    V, F = icosphere(subdiv)
+    V = (V * np.asarray(semi, dtype=np.float64)).astype(np.float32)
+    return np.ascontiguousarray(V), np.ascontiguousarray(_orient_outward(V, F, (0, 0, 0)))
+
+
+def box_mesh(lo, hi, div=(2, 2, 4)):
+    """Closed box with ``div`` cells per axis on every side (2 triangles per cell), outward orientation."""
+    lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+    index, V, F = {}, [], []
+
+    def vid(p):
+        key = tuple(np.round(p, 9))
+        if key not in index:
+            index[key] = len(V)
+            V.append(p)
+        return index[key]
+
+    for ax in range(3):
+        o = [a for a in range(3) if a != ax]
+        for val in (lo[ax], hi[ax]):
+            g0 = np.linspace(lo[o[0]], hi[o[0]], div[o[0]] + 1)
+            g1 = np.linspace(lo[o[1]], hi[o[1]], div[o[1]] + 1)
+            for i in range(div[o[0]]):
+                for j in range(div[o[1]]):
+                    q = []
+                    for u, v in ((g0[i], g1[j]), (g0[i + 1], g1[j]), (g0[i + 1], g1[j + 1]), (g0[i], g1[j + 1])):
+                        p = np.zeros(3)
+                        p[o[0]], p[o[1]], p[ax] = u, v, val
+                        q.append(vid(p))
+                    F += [(q[0], q[1], q[2]), (q[0], q[2], q[3])]
+    V = np.asarray(V, dtype=np.float32)
+    F = np.asarray(F, dtype=np.int32)
+    return np.ascontiguousarray(V), np.ascontiguousarray(_orient_outward(V, F, 0.5 * (lo + hi)))
+
+
+def torus_mesh(R=0.035, r=0.012, nu=24, nv=12):
+    """Closed non-convex mesh (genus 1), outward orientation by construction."""
+    V, F = [], []
+    for i in range(nu):
+        u = 2 * math.pi * i / nu
+        for j in range(nv):
+            v = 2 * math.pi * j / nv
+            V.append(((R + r * math.cos(v)) * math.cos(u), (R + r * math.cos(v)) * math.sin(u), r * math.sin(v)))
+    for i in range(nu):
+        for j in range(nv):
+            a, b = i * nv + j, ((i + 1) % nu) * nv + j
+            c, d = ((i + 1) % nu) * nv + (j + 1) % nv, i * nv + (j + 1) % nv
+            F += [(a, b, c), (a, c, d)]
+    return np.asarray(V, dtype=np.float32), np.asarray(F, dtype=np.int32)
+
+
+def lshape_mesh(size=0.05, thick=0.02, div=3):
+    """Closed non-convex L-shaped prism with a reflex edge, built from an extruded polygon."""
+    s, t = size, thick
+    poly = [(0, 0), (s, 0), (s, t), (t, t), (t, s), (0, s)]  # counter-clockwise
+    n = len(poly)
+    zs = np.linspace(-0.5 * t, 0.5 * t, div + 1)
+    V = [(x, y, z) for z in zs for (x, y) in poly]
+    F = []
+    for k in range(div):
+        for i in range(n):
+            a, b = k * n + i, k * n + (i + 1) % n
+            c, d = (k + 1) * n + (i + 1) % n, (k + 1) * n + i
+            F += [(a, b, c), (a, c, d)]
+    caps = [(0, 1, 2), (0, 2, 3), (0, 3, 4), (0, 4, 5)]
+    top = div * n
+    for a, b, c in caps:
+        F += [(a, c, b), (top + a, top + b, top + c)]
+    return np.asarray(V, dtype=np.float32), np.asarray(F, dtype=np.int32)
+
+
 @dataclass
 class HandModel:
     """Kinematic stand-in: names, parents, link->parent transforms and per-link clouds (link frame).
@@ -263,6 +377,7 @@ class HandModel:
     parents: dict = field(default_factory=dict)
     tf_in_parent: dict = field(default_factory=dict)
     clouds: dict = field(default_factory=dict)  # name -> (xyz, nrm)
+    meshes: dict = field(default_factory=dict)  # name -> (V, F): Hand::_convex_meshes (Hand.cpp:526-530), link frame
 
 
 def t42_hand(spacing=0.005) -> HandModel:
@@ -289,6 +404,11 @@ def t42_hand(spacing=0.005) -> HandModel:
         h.parents[name] = parent
         h.tf_in_parent[name] = tf.astype(np.float32)
         h.clouds[name] = cloud
+    h.meshes["base_link"] = box_mesh((-0.06, -0.05, -0.02), (0.0, 0.05, 0.02), (3, 5, 2))
+    for name in ("finger_1_1", "finger_2_1"):
+        h.meshes[name] = box_mesh((-0.010, -0.006, -0.060), (0.010, 0.006, 0.0), (2, 2, 6))
+    for name in ("finger_1_2", "finger_2_2"):
+        h.meshes[name] = box_mesh((-0.009, -0.005, -0.045), (0.009, 0.005, 0.0), (2, 2, 5))
     return h
 
 

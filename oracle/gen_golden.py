@@ -156,6 +156,35 @@ def gen_kats():
     print("kat_pure ->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def sdf_query_points(rng, V, Fi, n_box=1200, n_far=300, n_vert=250, n_edge=250):
+    """Query points around a mesh: in and around the bounding box, far away, next to vertices and to edge midpoints."""
+    lo, hi = V.min(0), V.max(0)
+    c, e = (lo + hi) / 2, hi - lo
+    return np.concatenate([
+        c + (rng.random((n_box, 3)) - 0.5) * e * 1.6,
+        c + (rng.random((n_far, 3)) - 0.5) * e * 6,
+        V[rng.integers(0, len(V), n_vert)] + rng.normal(scale=1e-4, size=(n_vert, 3)),
+        (V[Fi[:, 0]] + V[Fi[:, 1]])[rng.integers(0, len(Fi), n_edge)] / 2 + rng.normal(scale=1e-3, size=(n_edge, 3)),
+    ]).astype(np.float32)
+
+
+def gen_sdf():
+    """Row N1: signed distances of the reference's own libigl (oracle/_ref/libref_sdf.so) on the synthetic meshes."""
+    rng = np.random.default_rng(2024)
+    meshes = {"ellipsoid": synth.ellipsoid_mesh(subdiv=2), "box": synth.box_mesh((0, 0, 0), (0.02, 0.012, 0.06)),
+              "torus": synth.torus_mesh(), "lshape": synth.lshape_mesh()}
+    data = {}
+    for name, (V, Fi) in meshes.items():
+        P = sdf_query_points(rng, V, Fi)
+        S, Ii, Cc = orc.ref_signed_distance(P, V, Fi)
+        data[f"{name}_V"], data[f"{name}_F"], data[f"{name}_P"] = V, Fi, P
+        data[f"{name}_S"], data[f"{name}_I"], data[f"{name}_C"] = S, Ii, Cc
+        print("sdf", name, "faces", len(Fi), "points", len(P), "inside", int((S < 0).sum()))
+    path = os.path.join(OUT, "sdf_igl.npz")
+    np.savez_compressed(path, **data)
+    print("sdf ->", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     if not orc.ref_available():
         orc.build()
@@ -163,6 +192,8 @@ if __name__ == "__main__":
     only = sys.argv[1:]
     if not only:
         gen_kats()
+    if not only or "sdf" in only:
+        gen_sdf()
     for c in CASES:
         if not only or c[0] in only:
             gen_case(*c)

@@ -141,6 +141,31 @@ int orc_pso_search(const orc_finger_args* a, const orc_pso_settings* s, double* 
 void orc_finger_property(const float* xyz, int n, int num_division, float* min3, float* max3,
                          float* stride_z, float* hist6xN);
 
+/* ---- SURVEY.md 8(f) row N1 (sdf_oracle.cpp) ---- */
+/* igl::signed_distance(P, V, F, SIGNED_DISTANCE_TYPE_PSEUDONORMAL, lower, upper, S, I, C, N) on float matrices
+ * (SDFchecker.cpp:115-134).  P: np x 3 row-major, V: nv x 3 row-major, F: nf x 3; pose16 (row-major, may be NULL) is
+ * applied to V first as SDFchecker::registerMesh / transformMesh do. */
+int orc_sdf_signed_distance(const float* P, int np, const float* V, int nv, const int* F, int nf, const float* pose16,
+                            float lower, float upper, float* S_out, int* I_out);
+/* pcl::VoxelGrid (Utils::downsamplePointCloud, Utils.cpp:334-340), xyz only; SoA planes in (stride n) and out (stride cap) */
+int orc_voxel_downsample(const float* xyz_planes, int n, float leaf, float* out_planes, int cap, int* n_out);
+typedef struct {
+  /* meshes as registered with SDFchecker: "object" at identity, the four finger links at getTFHandBase(link)
+   * (PoseEstimator.cpp:503-520); order finger_1_1, finger_1_2, finger_2_1, finger_2_2 */
+  const float* object_V; int object_nv; const int* object_F; int object_nf;
+  const float* finger_V[4]; int finger_nv[4]; const int* finger_F[4]; int finger_nf[4];
+  const float* finger_mesh_pose[4];  /* row-major 4x4 or NULL */
+  /* hand->_clouds[finger] (link frame, SoA planes) and getTFHandBase(finger); finger_status = _component_status */
+  const float* finger_xyz[4]; int finger_n[4]; const float* finger2handbase[4]; int finger_status[4];
+  const float* hand_cloud_xyz; int n_hand_cloud;                 /* hand->_hand_cloud, hand-base frame */
+  const float* cloud_without_hand_xyz; int n_cloud_without_hand; /* _cloud_withouthand_raw, camera frame */
+  float cam2handbase[16];
+  const float* model_xyz; int n_model;                           /* _model */
+  float model_center_init[3], smallest_dim, ob_diameter;
+  float collision_thres, non_touch_dist, collision_finger_dist, collision_finger_volume_ratio, voxel_size;
+} orc_physics_args;
+int orc_reject_by_collision(const orc_physics_args* a, const float* poses16, int H, unsigned char* keep, float* diag8);
+
 /* glibc-compatible float acos used by the PPF tests (restated from fdlibm e_acosf.c) */
 float orc_acosf(float x);
 

@@ -15,6 +15,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "_build", "liboracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libref_s4pcs.so")
+REF_SDF_SO = os.path.join(HERE, "_ref", "libref_sdf.so")
 
 fp = C.POINTER(C.c_float)
 dp = C.POINTER(C.c_double)
@@ -44,7 +45,7 @@ def soa(a):
 def build(force=False):
     """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
     if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(
-            os.path.getmtime(os.path.join(HERE, f)) for f in ("hop_oracle.cpp", "hop_oracle.h")):
+            os.path.getmtime(os.path.join(HERE, f)) for f in ("hop_oracle.cpp", "sdf_oracle.cpp", "hop_oracle.h")):
         subprocess.check_call(["make", "-C", HERE, "_build/liboracle.so"], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
 
@@ -97,6 +98,20 @@ class PsoSettings(C.Structure):
                 ("err_tol", C.c_double), ("lower_rad", C.c_double), ("upper_rad", C.c_double), ("seed", C.c_uint64)]
 
 
+class PhysicsArgs(C.Structure):
+    _fields_ = [("object_V", fp), ("object_nv", C.c_int), ("object_F", ip), ("object_nf", C.c_int),
+                ("finger_V", fp * 4), ("finger_nv", C.c_int * 4), ("finger_F", ip * 4), ("finger_nf", C.c_int * 4),
+                ("finger_mesh_pose", fp * 4),
+                ("finger_xyz", fp * 4), ("finger_n", C.c_int * 4), ("finger2handbase", fp * 4), ("finger_status", C.c_int * 4),
+                ("hand_cloud_xyz", fp), ("n_hand_cloud", C.c_int),
+                ("cloud_without_hand_xyz", fp), ("n_cloud_without_hand", C.c_int),
+                ("cam2handbase", C.c_float * 16),
+                ("model_xyz", fp), ("n_model", C.c_int),
+                ("model_center_init", C.c_float * 3), ("smallest_dim", C.c_float), ("ob_diameter", C.c_float),
+                ("collision_thres", C.c_float), ("non_touch_dist", C.c_float), ("collision_finger_dist", C.c_float),
+                ("collision_finger_volume_ratio", C.c_float), ("voxel_size", C.c_float)]
+
+
 _lib = None
 
 
@@ -138,6 +153,9 @@ def lib():
         L.orc_model_ppf_keys.argtypes = [fp, fp, C.c_int, ip, C.c_int]
         L.orc_hand_remove_surrounding.restype = C.c_int
         L.orc_hand_remove_surrounding.argtypes = [fp, fp, C.c_int, fp, C.POINTER(fp), ip, fp, C.c_int, fp, fp, C.c_float, fp, fp, fp, ip]
+        L.orc_sdf_signed_distance.argtypes = [fp, C.c_int, fp, C.c_int, ip, C.c_int, fp, C.c_float, C.c_float, fp, ip]
+        L.orc_voxel_downsample.argtypes = [fp, C.c_int, C.c_float, fp, C.c_int, ip]
+        L.orc_reject_by_collision.argtypes = [C.POINTER(PhysicsArgs), fp, C.c_int, C.POINTER(C.c_ubyte), fp]
         L.orc_compute_ppf.argtypes = [fp, fp, fp, fp, ip]
         L.orc_pair_ppf_is_good.argtypes = [fp, fp, fp, fp]
         L.orc_rigid.argtypes = [fp, fp, fp, fp]
@@ -361,3 +379,92 @@ def model_ppf_keys(xyz, nrm, cap=1 << 20):
     out = np.zeros((cap, 4), np.int32)
     k = lib().orc_model_ppf_keys(F(X), F(Nn), X.shape[1], I(out), cap)
     return out[:k].copy()
+
+
+# ---------------------------------------------------------------------------------------------- row N1
+FLT_MAX = float(np.finfo(np.float32).max)
+_ref_sdf = None
+
+
+def ref_sdf_available():
+    return os.path.exists(REF_SDF_SO)
+
+
+def ref_signed_distance(P, V, Fi, lower=-FLT_MAX, upper=FLT_MAX):
+    """The reference's own libigl (oracle/_ref/libref_sdf.so): (S, I, C)."""
+    global _ref_sdf
+    if _ref_sdf is None:
+        _ref_sdf = C.CDLL(REF_SDF_SO)
+        _ref_sdf.ref_igl_signed_distance.argtypes = [fp, C.c_int, fp, C.c_int, ip, C.c_int, C.c_float, C.c_float, fp, ip, fp]
+    P = np.ascontiguousarray(P, np.float32)
+    V = np.ascontiguousarray(V, np.float32)
+    Fi = np.ascontiguousarray(Fi, np.int32)
+    S, Ii, Cc = np.zeros(len(P), np.float32), np.zeros(len(P), np.int32), np.zeros((len(P), 3), np.float32)
+    _ref_sdf.ref_igl_signed_distance(F(P), len(P), F(V), len(V), I(Fi), len(Fi), lower, upper, F(S), I(Ii), F(Cc))
+    return S, Ii, Cc
+
+
+def sdf_signed_distance(P, V, Fi, pose=None, lower=-FLT_MAX, upper=FLT_MAX):
+    P = np.ascontiguousarray(P, np.float32)
+    V = np.ascontiguousarray(V, np.float32)
+    Fi = np.ascontiguousarray(Fi, np.int32)
+    S, Ii = np.zeros(len(P), np.float32), np.zeros(len(P), np.int32)
+    T = None if pose is None else np.ascontiguousarray(pose, np.float32).reshape(16)
+    lib().orc_sdf_signed_distance(F(P), len(P), F(V), len(V), I(Fi), len(Fi), None if T is None else F(T), lower, upper, F(S), I(Ii))
+    return S, Ii
+
+
+def voxel_downsample(xyz, leaf):
+    X = soa(xyz)
+    n = X.shape[1]
+    out = np.zeros((3, max(n, 1)), np.float32)
+    k = C.c_int(0)
+    lib().orc_voxel_downsample(F(X), n, leaf, F(out), max(n, 1), C.byref(k))
+    return out[:, :k.value].T.copy()
+
+
+def physics_args(p):
+    """p: dict with the fields of hop_amd.api.PhysicsInputs (numpy arrays); returns (PhysicsArgs, keepalive)."""
+    a, keep = PhysicsArgs(), []
+
+    def f32(x):
+        x = np.ascontiguousarray(x, np.float32)
+        keep.append(x)
+        return x
+
+    def i32(x):
+        x = np.ascontiguousarray(x, np.int32)
+        keep.append(x)
+        return x
+
+    V, Fi = f32(p["object_V"]), i32(p["object_F"])
+    a.object_V, a.object_nv, a.object_F, a.object_nf = F(V), len(V), I(Fi), len(Fi)
+    for k in range(4):
+        V, Fi = f32(p["finger_V"][k]), i32(p["finger_F"][k])
+        a.finger_V[k], a.finger_nv[k], a.finger_F[k], a.finger_nf[k] = F(V), len(V), I(Fi), len(Fi)
+        a.finger_mesh_pose[k] = F(f32(np.asarray(p["finger_mesh_pose"][k]).reshape(16)))
+        X = f32(soa(p["finger_xyz"][k]))
+        a.finger_xyz[k], a.finger_n[k] = F(X), X.shape[1]
+        a.finger2handbase[k] = F(f32(np.asarray(p["finger2handbase"][k]).reshape(16)))
+        a.finger_status[k] = int(p["finger_status"][k])
+    X = f32(soa(p["hand_cloud"]))
+    a.hand_cloud_xyz, a.n_hand_cloud = F(X), X.shape[1]
+    X = f32(soa(p["cloud_without_hand"]))
+    a.cloud_without_hand_xyz, a.n_cloud_without_hand = F(X), X.shape[1]
+    a.cam2handbase = (C.c_float * 16)(*np.asarray(p["cam2handbase"], np.float32).reshape(16))
+    X = f32(soa(p["model"]))
+    a.model_xyz, a.n_model = F(X), X.shape[1]
+    a.model_center_init = (C.c_float * 3)(*np.asarray(p["model_center_init"], np.float32))
+    for k in ("smallest_dim", "ob_diameter", "collision_thres", "non_touch_dist", "collision_finger_dist",
+              "collision_finger_volume_ratio", "voxel_size"):
+        setattr(a, k, float(p[k]))
+    return a, keep
+
+
+def reject_by_collision(p, poses):
+    a, keep = physics_args(p)
+    T = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    out = np.zeros(len(T), np.uint8)
+    diag = np.zeros((len(T), 8), np.float32)
+    lib().orc_reject_by_collision(C.byref(a), F(T), len(T), out.ctypes.data_as(C.POINTER(C.c_ubyte)), F(diag))
+    return out.astype(bool), diag

@@ -1,0 +1,497 @@
+// sdf_oracle.cpp -- TEST INFRASTRUCTURE ONLY (see hop_oracle.h).  CPU restatement of SURVEY.md 8(f) row N1:
+//   * igl::signed_distance with SIGNED_DISTANCE_TYPE_PSEUDONORMAL on float matrices, as SDFchecker calls it
+//     (src/perception/src/SDFchecker.cpp:115-134; vendored libigl: include/igl/signed_distance.cpp:18-208,
+//     pseudonormal_test.cpp:24-128, point_simplex_squared_distance.cpp:25-132, per_face_normals.cpp:13-38,
+//     per_vertex_normals.cpp:40-110 (angle weights: internal_angles.cpp:66-88), per_edge_normals.cpp:23-79,
+//     doublearea.cpp:75-200, barycentric_coordinates.cpp:51-100, project_to_line(_segment).cpp);
+//   * pcl::VoxelGrid::applyFilter as Utils::downsamplePointCloud uses it (Utils.cpp:334-340) -- PCL is not vendored
+//     by the reference and not installed here: restated from the published algorithm (PCL 1.8/1.9
+//     filters/include/pcl/filters/impl/voxel_grid.hpp:214-440), PARITY UNPINNED for this function;
+//   * PoseEstimator::rejectByCollisionOrNonTouching (src/perception/src/PoseEstimator.cpp:524-735).
+//
+// Pinning: orc_sdf_signed_distance is checked against oracle/_ref/libref_sdf.so -- the reference's own libigl compiled
+// in place (oracle/ref_sdf_driver.cpp) -- by tests/test_sdf_oracle.py and the vectors of tests/golden/sdf_*.npz.
+// The closest face is found by an exhaustive scan (lowest face index on exactly equal squared distances) where libigl
+// walks an AABB tree (AABB.cpp:360-452, first-visited face on ties); distances are the same float expression.
+//
+// Plain IEEE float arithmetic, -ffp-contract=off; 3-element Eigen reductions are c0+(c1+c2) (Redux.h:91-105).
+#include "hop_oracle.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <utility>
+#include <vector>
+
+namespace {
+
+struct F3 {
+  float x, y, z;
+};
+inline F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+inline F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline F3 operator*(float s, F3 a) { return f3(s * a.x, s * a.y, s * a.z); }
+inline F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+inline float dot3(F3 a, F3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+inline float sqn3(F3 a) { return a.x * a.x + (a.y * a.y + a.z * a.z); }
+inline float norm3(F3 a) { return std::sqrt(sqn3(a)); }
+inline F3 cross3(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline bool same3(F3 a, F3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+
+// point_simplex_squared_distance.cpp:43-113 (Ericson, Real-Time Collision Detection ch. 5), Scalar = float
+F3 closest_point_triangle(F3 p, F3 a, F3 b, F3 c) {
+  const F3 ab = b - a, ac = c - a, ap = p - a;
+  const float d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+  if (d1 <= 0.0f && d2 <= 0.0f) return a;
+  const F3 bp = p - b;
+  const float d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+  if (d3 >= 0.0f && d4 <= d3) return b;
+  const float vc = d1 * d4 - d3 * d2;
+  if (!same3(a, b)) {
+    if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+      const float v = d1 / (d1 - d3);
+      return a + v * ab;
+    }
+  }
+  const F3 cp = p - c;
+  const float d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+  if (d6 >= 0.0f && d5 <= d6) return c;
+  const float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+    const float w = d2 / (d2 - d6);
+    return a + w * ac;
+  }
+  const float va = d3 * d6 - d5 * d4;
+  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
+    const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    return b + w * (c - b);
+  }
+  // `Scalar denom = 1.0 / (va + vb + vc)`: the float sum is promoted, the quotient rounded back to float
+  const float denom = (float)(1.0 / (double)((va + vb) + vc));
+  const float v = vb * denom;
+  const float w = vc * denom;
+  return (a + ab * v) + ac * w;
+}
+
+struct Mesh {
+  int nv = 0, nf = 0;
+  std::vector<F3> V, FN, VN, EN;
+  std::vector<int> F;     // nf x 3
+  std::vector<int> EMAP;  // 3*nf: EMAP[c*nf + f] = unique edge of the directed edge opposite corner c of face f
+};
+
+void mesh_normals(Mesh& m) {
+  const int nf = m.nf, nv = m.nv;
+  // per_face_normals.cpp:22-37 (Z = 0)
+  m.FN.resize(nf);
+  for (int i = 0; i < nf; ++i) {
+    const F3 v1 = m.V[m.F[3 * i + 1]] - m.V[m.F[3 * i + 0]];
+    const F3 v2 = m.V[m.F[3 * i + 2]] - m.V[m.F[3 * i + 0]];
+    F3 n = cross3(v1, v2);
+    const float r = norm3(n);
+    if (r == 0)
+      n = f3(0, 0, 0);
+    else
+      n = f3(n.x / r, n.y / r, n.z / r);
+    m.FN[i] = n;
+  }
+  // per_vertex_normals.cpp:69-107 with PER_VERTEX_NORMALS_WEIGHTING_TYPE_ANGLE: W = internal_angles (float),
+  // squared_edge_lengths.cpp:36-40, internal_angles.cpp:75-86
+  m.VN.assign(nv, f3(0, 0, 0));
+  for (int i = 0; i < nf; ++i) {
+    const F3 a = m.V[m.F[3 * i + 0]], b = m.V[m.F[3 * i + 1]], c = m.V[m.F[3 * i + 2]];
+    const float L[3] = {sqn3(b - c), sqn3(c - a), sqn3(a - b)};
+    for (int j = 0; j < 3; ++j) {
+      const float s1 = L[j], s2 = L[(j + 1) % 3], s3 = L[(j + 2) % 3];
+      const float w = (float)std::acos((double)((s3 + s2) - s1) / (2. * std::sqrt(s3 * s2)));
+      F3& n = m.VN[m.F[3 * i + j]];
+      n = n + w * m.FN[i];
+    }
+  }
+  for (int v = 0; v < nv; ++v) {  // N.rowwise().normalize(): Dot.h:121-131, divides only when the squared norm is > 0
+    const float z = sqn3(m.VN[v]);
+    if (z > 0.f) {
+      const float r = std::sqrt(z);
+      m.VN[v] = f3(m.VN[v].x / r, m.VN[v].y / r, m.VN[v].z / r);
+    }
+  }
+  // per_edge_normals.cpp:36-78, uniform weights: the (unnormalised) sum of the face normals around each undirected edge
+  std::map<std::pair<int, int>, int> ids;
+  m.EMAP.assign(3 * (size_t)nf, 0);
+  for (int c = 0; c < 3; ++c)
+    for (int f = 0; f < nf; ++f) {  // oriented_facets: block c holds the edge opposite corner c
+      int u = m.F[3 * f + (c + 1) % 3], v = m.F[3 * f + (c + 2) % 3];
+      if (u > v) std::swap(u, v);
+      auto it = ids.find({u, v});
+      int id;
+      if (it == ids.end()) {
+        id = (int)ids.size();
+        ids[{u, v}] = id;
+      } else
+        id = it->second;
+      m.EMAP[(size_t)c * nf + f] = id;
+    }
+  m.EN.assign(ids.size(), f3(0, 0, 0));
+  for (int f = 0; f < nf; ++f)
+    for (int c = 0; c < 3; ++c) {
+      F3& n = m.EN[m.EMAP[(size_t)c * nf + f]];
+      n = n + m.FN[f];
+    }
+}
+
+// doublearea.cpp:75-109 (three row vectors, double output) -> :144-199 (Kahan's Heron formula on sorted lengths)
+double doublearea3(F3 A, F3 B, F3 C) {
+  double l[3] = {(double)norm3(B - C), (double)norm3(C - A), (double)norm3(A - B)};
+  std::sort(l, l + 3, [](double x, double y) { return x > y; });
+  const double arg = (l[0] + (l[1] + l[2])) * (l[2] - (l[0] - l[1])) * (l[2] + (l[0] - l[1])) * (l[0] + (l[1] - l[2]));
+  return 2.0 * 0.25 * std::sqrt(arg);  // NaN stays NaN (nan_replacement = NaN)
+}
+
+// pseudonormal_test.cpp:24-128; returns the sign s
+float pseudonormal_sign(const Mesh& m, F3 q, int f, F3 c) {
+  const F3 A = m.V[m.F[3 * f + 0]], B = m.V[m.F[3 * f + 1]], C = m.V[m.F[3 * f + 2]];
+  const double area = doublearea3(A, B, C);
+  const double MIN_DOUBLE_AREA = 1e-4, epsilon = 1e-12;
+  F3 n = m.FN[f];
+  if (area > MIN_DOUBLE_AREA) {
+    // barycentric_coordinates.cpp:88-100
+    const F3 v0 = B - A, v1 = C - A, v2 = c - A;
+    const float d00 = dot3(v0, v0), d01 = dot3(v0, v1), d11 = dot3(v1, v1), d20 = dot3(v2, v0), d21 = dot3(v2, v1);
+    const float denom = d00 * d11 - d01 * d01;
+    float b[3];
+    b[1] = (d11 * d20 - d01 * d21) / denom;
+    b[2] = (d00 * d21 - d01 * d20) / denom;
+    b[0] = 1.0f - (b[1] + b[2]);
+    int type = 0;
+    for (int x = 0; x < 3; ++x) type += (b[x] <= (float)epsilon) ? 1 : 0;
+    switch (type) {
+      case 2:
+        for (int x = 0; x < 3; ++x)
+          if (b[x] > (float)epsilon) {
+            n = m.VN[m.F[3 * f + x]];
+            break;
+          }
+        break;
+      case 1:
+        for (int x = 0; x < 3; ++x)
+          if (b[x] <= (float)epsilon) {
+            n = m.EN[m.EMAP[(size_t)m.nf * x + f]];
+            break;
+          }
+        break;
+      default:  // 3 (assert in debug builds) falls through to the face normal; NaN barycentrics give type 0
+      case 0: n = m.FN[f]; break;
+    }
+  } else {
+    bool found = false;
+    for (int v = 0; v < 3 && !found; ++v)
+      if ((double)norm3(c - m.V[m.F[3 * f + v]]) < epsilon) {
+        found = true;
+        n = m.VN[m.F[3 * f + v]];
+      }
+    for (int e = 0; e < 3 && !found; ++e) {
+      const F3 s = m.V[m.F[3 * f + (e + 1) % 3]], d = m.V[m.F[3 * f + (e + 2) % 3]];
+      // project_to_line.cpp:36-55 then project_to_line_segment.cpp:27-42; t and sqrD are double, the vectors float
+      const F3 DmS = d - s;
+      const double v_sqrlen = (double)sqn3(DmS);
+      const F3 SmP = s - c;
+      const F3 prod = f3(DmS.x * SmP.x, DmS.y * SmP.y, DmS.z * SmP.z);
+      double t = (double)(-(prod.x + (prod.y + prod.z))) / v_sqrlen;
+      const F3 projP = ((float)(1 - t)) * s + ((float)t) * d;
+      double sqrD = (double)sqn3(c - projP);
+      if (t < 0)
+        sqrD = (double)sqn3(c - s);
+      else if (t > 1)
+        sqrD = (double)sqn3(c - d);
+      if (std::sqrt(sqrD) < epsilon) {
+        n = m.EN[m.EMAP[(size_t)m.nf * e + f]];
+        found = true;
+      }
+    }
+    if (!found) n = m.FN[f];
+  }
+  return dot3(q - c, n) >= 0 ? 1.f : -1.f;
+}
+
+// signed_distance.cpp:125-206 for one query point
+float signed_distance_point(const Mesh& m, F3 q, float low_sqr_d, float up_sqr_d, int* face_out, F3* c_out) {
+  float best = up_sqr_d;  // AABB.cpp:379: sqr_d starts at up_sqr_d, strictly smaller candidates replace it
+  int bi = -1;
+  F3 bc = f3(0, 0, 0);
+  for (int f = 0; f < m.nf; ++f) {
+    const F3 c = closest_point_triangle(q, m.V[m.F[3 * f]], m.V[m.F[3 * f + 1]], m.V[m.F[3 * f + 2]]);
+    const float d = sqn3(q - c);
+    if (d < best) best = d, bi = f, bc = c;
+  }
+  if (face_out) *face_out = bi;
+  if (c_out) *c_out = bc;
+  if (best >= up_sqr_d || best <= low_sqr_d || bi < 0) {
+    if (face_out) *face_out = m.nf + 1;
+    return std::numeric_limits<float>::quiet_NaN();
+  }
+  return pseudonormal_sign(m, q, bi, bc) * std::sqrt(best);
+}
+
+void bounds_to_sqr(float lower, float upper, float* low_sqr_d, float* up_sqr_d) {
+  // signed_distance.cpp:117-121, Scalar = float
+  const float max_abs = std::max(std::abs(lower), std::abs(upper));
+  *up_sqr_d = (float)std::pow((double)max_abs, 2.0);
+  *low_sqr_d = (float)std::pow((double)std::max(max_abs - (upper - lower), 0.0f), 2.0);
+}
+
+Mesh make_mesh(const float* V, int nv, const int* F, int nf, const float* pose) {
+  Mesh m;
+  m.nv = nv, m.nf = nf;
+  m.V.resize(nv);
+  for (int i = 0; i < nv; ++i) {
+    const float x = V[3 * i], y = V[3 * i + 1], z = V[3 * i + 2];
+    if (pose)  // SDFchecker::transformVertices (SDFchecker.cpp:21-33): pose * [V;1], a 4x4 by 4xN float product
+      m.V[i] = f3(((pose[0] * x + pose[1] * y) + pose[2] * z) + pose[3], ((pose[4] * x + pose[5] * y) + pose[6] * z) + pose[7],
+                  ((pose[8] * x + pose[9] * y) + pose[10] * z) + pose[11]);
+    else
+      m.V[i] = f3(x, y, z);
+  }
+  m.F.assign(F, F + 3 * (size_t)nf);
+  mesh_normals(m);
+  return m;
+}
+
+void sdf_minmax(const Mesh& m, const std::vector<F3>& pts, float* min_d, float* max_d, std::vector<float>* dists) {
+  // SDFchecker.cpp:115-134 with lower = -FLT_MAX, upper = FLT_MAX as every call site passes them.  S.minCoeff() /
+  // maxCoeff() skip NaN here (a point exactly on the surface; Eigen's result for NaN input is unspecified).
+  float lo, up;
+  bounds_to_sqr(-FLT_MAX, FLT_MAX, &lo, &up);
+  float mn = std::numeric_limits<float>::infinity(), mx = -std::numeric_limits<float>::infinity();
+  if (dists) dists->resize(pts.size());
+  for (size_t i = 0; i < pts.size(); ++i) {
+    const float s = signed_distance_point(m, pts[i], lo, up, nullptr, nullptr);
+    if (dists) (*dists)[i] = s;
+    if (s < mn) mn = s;
+    if (s > mx) mx = s;
+  }
+  *min_d = mn, *max_d = mx;
+}
+
+inline void mat4_mul(const float* a, const float* b, float* o) {  // row-major, ((a0 b0 + a1 b1) + a2 b2) + a3 b3
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      o[4 * i + j] = ((a[4 * i] * b[j] + a[4 * i + 1] * b[4 + j]) + a[4 * i + 2] * b[8 + j]) + a[4 * i + 3] * b[12 + j];
+}
+inline F3 xform(const float* T, F3 p) {  // pcl::transformPointCloud: m00 x + m01 y + m02 z + m03, left to right
+  return f3(((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3], ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7],
+            ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11]);
+}
+inline float sqdist_flann(F3 a, F3 b) {
+  const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+int nearest(const std::vector<F3>& cloud, F3 q, float* sq) {
+  int bi = -1;
+  float bd = std::numeric_limits<float>::infinity();
+  for (size_t i = 0; i < cloud.size(); ++i) {
+    const float d = sqdist_flann(q, cloud[i]);
+    if (d < bd) bd = d, bi = (int)i;
+  }
+  *sq = bd;
+  return bi;
+}
+
+// pcl::VoxelGrid<PointT>::applyFilter, xyz only (leaf = (l,l,l), min_points_per_voxel 0, no field filter)
+void voxel_grid(const std::vector<F3>& in, float leaf, std::vector<F3>& out) {
+  out.clear();
+  if (in.empty()) return;
+  const float inv = 1.0f / leaf;
+  F3 mn = f3(FLT_MAX, FLT_MAX, FLT_MAX), mx = f3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+  bool any = false;
+  for (const F3& p : in) {
+    if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+    any = true;
+    mn = f3(std::min(mn.x, p.x), std::min(mn.y, p.y), std::min(mn.z, p.z));
+    mx = f3(std::max(mx.x, p.x), std::max(mx.y, p.y), std::max(mx.z, p.z));
+  }
+  if (!any) return;
+  const int minb[3] = {(int)std::floor(mn.x * inv), (int)std::floor(mn.y * inv), (int)std::floor(mn.z * inv)};
+  const int maxb[3] = {(int)std::floor(mx.x * inv), (int)std::floor(mx.y * inv), (int)std::floor(mx.z * inv)};
+  const int div[3] = {maxb[0] - minb[0] + 1, maxb[1] - minb[1] + 1, maxb[2] - minb[2] + 1};
+  const int mul[3] = {1, div[0], div[0] * div[1]};
+  struct Idx {
+    unsigned idx;
+    unsigned pt;
+    bool operator<(const Idx& o) const { return idx < o.idx; }
+  };
+  std::vector<Idx> v;
+  v.reserve(in.size());
+  for (size_t i = 0; i < in.size(); ++i) {
+    const F3& p = in[i];
+    if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+    const int i0 = (int)std::floor(p.x * inv) - minb[0], i1 = (int)std::floor(p.y * inv) - minb[1], i2 = (int)std::floor(p.z * inv) - minb[2];
+    v.push_back({(unsigned)(i0 * mul[0] + i1 * mul[1] + i2 * mul[2]), (unsigned)i});
+  }
+  std::sort(v.begin(), v.end());
+  size_t k = 0;
+  while (k < v.size()) {
+    size_t e = k + 1;
+    while (e < v.size() && v[e].idx == v[k].idx) ++e;
+    F3 s = f3(0, 0, 0);  // CentroidPoint: AccumulatorXYZ sums in an Eigen::Vector3f, divides by the count
+    for (size_t j = k; j < e; ++j) s = s + in[v[j].pt];
+    const float n = (float)(e - k);
+    out.push_back(f3(s.x / n, s.y / n, s.z / n));
+    k = e;
+  }
+}
+
+std::vector<F3> planes_to_pts(const float* xyz, int n) {
+  std::vector<F3> p(n);
+  for (int i = 0; i < n; ++i) p[i] = f3(xyz[i], xyz[(size_t)n + i], xyz[2 * (size_t)n + i]);
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orc_sdf_signed_distance(const float* P, int np, const float* V, int nv, const int* F, int nf, const float* pose16,
+                            float lower, float upper, float* S_out, int* I_out) {
+  const Mesh m = make_mesh(V, nv, F, nf, pose16);
+  float lo, up;
+  bounds_to_sqr(lower, upper, &lo, &up);
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int i = 0; i < np; ++i) {
+    int f = -1;
+    S_out[i] = signed_distance_point(m, f3(P[3 * i], P[3 * i + 1], P[3 * i + 2]), lo, up, &f, nullptr);
+    if (I_out) I_out[i] = f;
+  }
+  return 0;
+}
+
+int orc_voxel_downsample(const float* xyz_planes, int n, float leaf, float* out_planes, int cap, int* n_out) {
+  std::vector<F3> out;
+  voxel_grid(planes_to_pts(xyz_planes, n), leaf, out);
+  *n_out = (int)out.size();
+  const int m = std::min((int)out.size(), cap);
+  for (int i = 0; i < m; ++i) out_planes[i] = out[i].x, out_planes[(size_t)cap + i] = out[i].y, out_planes[2 * (size_t)cap + i] = out[i].z;
+  return (int)out.size() > cap ? -1 : 0;
+}
+
+// PoseEstimator::rejectByCollisionOrNonTouching (PoseEstimator.cpp:524-735).  keep[i] = 1 for the hypotheses the
+// reference pushes back into _pose_hypos.  diag (optional, H x 8): stage that decided (0 kept, 1 scene point inside,
+// 2 hand point colliding, 3 finger cloud colliding, 4 one side not touching, 5 model inside finger), the two single-
+// point distances, the min distances of the four finger clouds (NaN when skipped), the smallest model-to-finger min.
+int orc_reject_by_collision(const orc_physics_args* a, const float* poses16, int H, unsigned char* keep, float* diag) {
+  static const int ORDER[4] = {0, 1, 2, 3};  // std::map order: finger_1_1, finger_1_2, finger_2_1, finger_2_2
+  // finger clouds in the hand-base frame (PoseEstimator.cpp:538-551)
+  std::vector<F3> finger_pts[4];
+  for (int k = 0; k < 4; ++k) {
+    if (!a->finger_status[k]) continue;
+    std::vector<F3> p = planes_to_pts(a->finger_xyz[k], a->finger_n[k]);
+    for (F3& q : p) q = xform(a->finger2handbase[k], q);
+    finger_pts[k] = std::move(p);
+  }
+  // scene without the hand, hand-base frame, 5 mm voxel grid (:553-557)
+  std::vector<F3> cwh = planes_to_pts(a->cloud_without_hand_xyz, a->n_cloud_without_hand), cwh_ds;
+  for (F3& q : cwh) q = xform(a->cam2handbase, q);
+  voxel_grid(cwh, a->voxel_size, cwh_ds);
+  const std::vector<F3> hand_cloud = planes_to_pts(a->hand_cloud_xyz, a->n_hand_cloud);
+  const std::vector<F3> model = planes_to_pts(a->model_xyz, a->n_model);
+  Mesh finger_mesh[4];
+  for (int k = 0; k < 4; ++k) finger_mesh[k] = make_mesh(a->finger_V[k], a->finger_nv[k], a->finger_F[k], a->finger_nf[k], a->finger_mesh_pose[k]);
+
+  const float collision_dist = std::min(-a->smallest_dim * a->collision_thres, -0.007f);
+  const float inside_ob_dist = std::min(-a->smallest_dim / 5, -0.01f);
+  const float non_touch_dist = a->non_touch_dist;
+  const float collision_finger_dist = -a->collision_finger_dist;
+  const float NaN = std::numeric_limits<float>::quiet_NaN();
+
+#pragma omp parallel for schedule(dynamic)
+  for (int i = 0; i < H; ++i) {
+    float dg[8] = {0, NaN, NaN, NaN, NaN, NaN, NaN, NaN};
+    auto finish = [&](int stage) {
+      keep[i] = stage == 0;
+      dg[0] = (float)stage;
+      if (diag) std::memcpy(diag + 8 * (size_t)i, dg, sizeof(dg));
+    };
+    float m2h[16];
+    mat4_mul(a->cam2handbase, poses16 + 16 * (size_t)i, m2h);
+    // sdf.transformMesh("object", model2handbase): the reference transforms the registered vertices there and back
+    // for every hypothesis (accumulating rounding); here every hypothesis starts from the registered vertices.
+    const Mesh obj = make_mesh(a->object_V, a->object_nv, a->object_F, a->object_nf, m2h);
+    const F3 center = f3(((m2h[0] * a->model_center_init[0] + m2h[1] * a->model_center_init[1]) + m2h[2] * a->model_center_init[2]) + m2h[3] * 1.0f,
+                         ((m2h[4] * a->model_center_init[0] + m2h[5] * a->model_center_init[1]) + m2h[6] * a->model_center_init[2]) + m2h[7] * 1.0f,
+                         ((m2h[8] * a->model_center_init[0] + m2h[9] * a->model_center_init[1]) + m2h[10] * a->model_center_init[2]) + m2h[11] * 1.0f);
+    float mn, mx, sq;
+    // :598-617 nearest scene point to the object centre inside the object
+    int nn = nearest(cwh_ds, center, &sq);
+    if (nn >= 0) {
+      sdf_minmax(obj, {cwh_ds[nn]}, &mn, &mx, nullptr);
+      dg[1] = mn;
+      if (mn <= inside_ob_dist) {
+        finish(1);
+        continue;
+      }
+    }
+    // :620-642 nearest hand point to the object centre
+    nn = nearest(hand_cloud, center, &sq);
+    if (nn >= 0 && std::sqrt(sq) < a->ob_diameter / 2) {
+      sdf_minmax(obj, {hand_cloud[nn]}, &mn, &mx, nullptr);
+      dg[2] = mn;
+      if (mn < collision_dist) {
+        finish(2);
+        continue;
+      }
+    }
+    // :646-668 finger clouds against the object
+    bool rejected = false, non_touch[4] = {false, false, false, false};
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = ORDER[kk];
+      if (!a->finger_status[k]) continue;  // not in finger_cloud_eigens
+      if (!a->finger_status[0] && (k == 0 || k == 1)) continue;
+      if (!a->finger_status[2] && (k == 2 || k == 3)) continue;
+      sdf_minmax(obj, finger_pts[k], &mn, &mx, nullptr);
+      dg[3 + k] = mn;
+      if (mn <= collision_dist) {
+        rejected = true;
+        break;
+      }
+      if (mn > non_touch_dist && a->finger_status[k]) non_touch[k] = true;
+    }
+    if (rejected) {
+      finish(3);
+      continue;
+    }
+    if ((non_touch[0] && non_touch[1]) || (non_touch[2] && non_touch[3])) {
+      finish(4);
+      continue;
+    }
+    // :684-722 the object's points inside the finger meshes
+    std::vector<F3> P(model.size());
+    for (size_t j = 0; j < model.size(); ++j) P[j] = xform(m2h, model[j]);
+    float smallest = std::numeric_limits<float>::infinity();
+    for (int k = 0; k < 4 && !rejected; ++k) {
+      std::vector<float> d;
+      sdf_minmax(finger_mesh[k], P, &mn, &mx, &d);
+      smallest = std::min(smallest, mn);
+      if (mn < collision_finger_dist) {
+        rejected = true;
+        break;
+      }
+      int num_inside = 0;
+      for (float v : d)
+        if (v < 0) num_inside++;
+      // `num_inside/P.rows() > ratio`: integer division (int / Eigen::Index), :715
+      if ((float)((long)num_inside / (long)std::max<size_t>(P.size(), 1)) > a->collision_finger_volume_ratio) {
+        rejected = true;
+        break;
+      }
+    }
+    dg[7] = smallest;
+    finish(rejected ? 5 : 0);
+  }
+  return 0;
+}
+
+}  // extern "C"

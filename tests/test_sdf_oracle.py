@@ -1,0 +1,76 @@
+"""Row N1: the oracle's restatement of igl::signed_distance (pseudonormal) against the vectors the
+reference's own libigl produced (tests/golden/sdf_igl.npz, made by oracle/gen_golden.py from oracle/_ref/libref_sdf.so),
+and hand-checkable cases of the voxel grid and of the collision decision chain."""
+import os
+
+import numpy as np
+import pytest
+
+MESHES = ("ellipsoid", "box", "torus", "lshape")
+
+
+@pytest.mark.parametrize("name", MESHES)
+def test_oracle_sdf_matches_libigl_golden(orc, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "sdf_igl.npz"))
+    S, I = orc.sdf_signed_distance(g[f"{name}_P"], g[f"{name}_V"], g[f"{name}_F"])
+    # bit-exact signed distances (the face index may differ on exact ties: libigl reports the first face its AABB tree
+    # visits, the oracle the lowest index)
+    assert np.array_equal(S.view(np.int32), g[f"{name}_S"].view(np.int32))
+    assert (S < 0).sum() > 100 and (S > 0).sum() > 100
+    V, F = g[f"{name}_V"], g[f"{name}_F"]
+    differs = np.where(I != g[f"{name}_I"])[0]
+    # where the faces differ both are at the same distance: they share the closest point
+    for k in differs[:200]:
+        assert len(set(F[I[k]]) & set(F[g[f"{name}_I"][k]])) >= 1
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
+def test_oracle_sdf_matches_libigl_live(orc):
+    import importlib
+    synth = importlib.import_module("icra20-hand-object-pose_amd.synth")
+    if not orc.ref_sdf_available():
+        pytest.skip("oracle/_ref/libref_sdf.so not built")
+    rng = np.random.default_rng(5)
+    V, F = synth.ellipsoid_mesh(subdiv=3)
+    T = synth.se3(synth.random_rotation(rng), [0.1, -0.2, 0.6]).astype(np.float32)
+    Vt = synth.apply(T, V)
+    P = (Vt[rng.integers(0, len(Vt), 3000)] + rng.normal(scale=0.01, size=(3000, 3))).astype(np.float32)
+    S_ref, _, _ = orc.ref_signed_distance(P, Vt, F)
+    S, _ = orc.sdf_signed_distance(P, Vt, F)
+    assert np.array_equal(S.view(np.int32), S_ref.view(np.int32))
+
+
+def test_oracle_sdf_analytic_sphere(orc):
+    import importlib
+    synth = importlib.import_module("icra20-hand-object-pose_amd.synth")
+    V, F = synth.ellipsoid_mesh((0.05, 0.05, 0.05), subdiv=4)
+    rng = np.random.default_rng(1)
+    P = (rng.normal(size=(500, 3)) * 0.05).astype(np.float32)
+    S, _ = orc.sdf_signed_distance(P, V, F)
+    exact = np.linalg.norm(P, axis=1) - 0.05
+    assert np.abs(S - exact).max() < 2.5e-4  # faceting error of a 5120-face sphere of radius 5 cm
+    assert np.array_equal(np.sign(S)[np.abs(exact) > 3e-4], np.sign(exact)[np.abs(exact) > 3e-4])
+
+
+def test_oracle_sdf_point_on_surface_is_nan(orc):
+    """signed_distance.cpp:150-156 with the bounds SDFchecker passes (+-FLT_MAX): low_sqr_d is 0 and a query at zero
+    distance is 'out of bounds'."""
+    V = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    F = np.array([[0, 2, 1], [0, 1, 3], [0, 3, 2], [1, 2, 3]], np.int32)
+    S, I = orc.sdf_signed_distance(np.array([[0, 0, 0], [0.1, 0.1, 0.1], [2, 2, 2]], np.float32), V, F)
+    assert np.isnan(S[0]) and I[0] == len(F) + 1
+    assert S[1] < 0 < S[2]
+    assert abs(S[1] + 0.1) < 1e-6
+
+
+def test_oracle_voxel_grid_small(orc):
+    pts = np.array([[0.001, 0.001, 0.001], [0.002, 0.002, 0.003], [0.011, 0.001, 0.001], [0.001, 0.012, 0.001],
+                    [-0.001, 0.001, 0.001]], np.float32)
+    out = orc.voxel_downsample(pts, 0.01)
+    # cells in ascending (x + nx*(y + ny*z)) order: x-cell -1, 0 (two points), 1 on the first row, then the y=1 row
+    assert out.shape == (4, 3)
+    np.testing.assert_allclose(out[0], pts[4], atol=1e-7)
+    np.testing.assert_allclose(out[1], (pts[0] + pts[1]) / 2, atol=1e-7)
+    np.testing.assert_allclose(out[2], pts[2], atol=1e-7)
+    np.testing.assert_allclose(out[3], pts[3], atol=1e-7)
+    assert orc.voxel_downsample(np.zeros((0, 3), np.float32), 0.01).shape == (0, 3)
