@@ -79,6 +79,18 @@ class HandLink(C.Structure):
     _fields_ = [("xyz", C.POINTER(C.c_float)), ("n", C.c_int), ("sq_dist_thres", C.c_float)]
 
 
+class PhysicsArgs(C.Structure):
+    _fields_ = [("object_mesh", C.c_int), ("finger_mesh", C.c_int * 4),
+                ("finger_xyz", fp * 4), ("finger_n", C.c_int * 4), ("finger2handbase", fp * 4), ("finger_status", C.c_int * 4),
+                ("hand_cloud_xyz", fp), ("n_hand_cloud", C.c_int),
+                ("cloud_without_hand_xyz", fp), ("n_cloud_without_hand", C.c_int),
+                ("cam2handbase", C.c_float * 16),
+                ("model_xyz", fp), ("n_model", C.c_int),
+                ("model_center_init", C.c_float * 3), ("smallest_dim", C.c_float), ("ob_diameter", C.c_float),
+                ("collision_thres", C.c_float), ("non_touch_dist", C.c_float), ("collision_finger_dist", C.c_float),
+                ("collision_finger_volume_ratio", C.c_float), ("voxel_size", C.c_float)]
+
+
 class Timing(C.Structure):
     _fields_ = [("ms_verify", C.c_double), ("ms_gen_other", C.c_double), ("ms_icp_nn", C.c_double),
                 ("ms_icp_solve", C.c_double), ("ms_lcp_fwd", C.c_double), ("ms_lcp_rev", C.c_double),
@@ -129,6 +141,12 @@ SIGNATURES = {
     "hop_hand_pso_eval_batch": (C.c_int, [_vp, dp, C.c_int, dp]),
     "hop_pso_default_settings": (None, [C.POINTER(PsoSettings)]),
     "hop_hand_pso_search": (C.c_int, [_vp, C.POINTER(PsoSettings), dp, dp]),
+    "hop_sdf_register_mesh": (C.c_int, [_vp, C.c_int, fp, C.c_int, ip, C.c_int, fp]),
+    "hop_sdf_signed_distance": (C.c_int, [_vp, C.c_int, fp, C.c_int, fp, ip, fp, fp]),
+    "hop_voxel_downsample": (C.c_int, [_vp, fp, C.c_int, C.c_float, fp, C.c_int, ip]),
+    "hop_physics_set_frame": (C.c_int, [_vp, C.POINTER(PhysicsArgs)]),
+    "hop_reject_by_collision": (C.c_int, [_vp, C.POINTER(C.c_ubyte), fp, ip]),
+    "hop_physics_timing": (C.c_int, [_vp, dp, dp]),
     "hop_timing_reset": (C.c_int, [_vp]),
     "hop_timing_get": (C.c_int, [_vp, C.POINTER(Timing)]),
     "hop_timing_enable": (C.c_int, [_vp, C.c_int]),
@@ -291,6 +309,78 @@ class Context:
         out = np.zeros(len(T), np.int32)
         self._chk(self.L.hop_verify_batch(self.h, F(T), len(T), delta, mode, I(out)), "hop_verify_batch")
         return out
+
+    # ---- physics row (N1)
+    def sdf_register_mesh(self, mesh_id, V, Fi, pose=None):
+        V = np.ascontiguousarray(V, np.float32).reshape(-1, 3)
+        Fi = np.ascontiguousarray(Fi, np.int32).reshape(-1, 3)
+        T = None if pose is None else np.ascontiguousarray(pose, np.float32).reshape(16)
+        self._chk(self.L.hop_sdf_register_mesh(self.h, mesh_id, F(V), len(V), I(Fi), len(Fi), F(T) if T is not None else None),
+                  "hop_sdf_register_mesh")
+
+    def sdf_signed_distance(self, mesh_id, pts):
+        """SDFchecker::getSignedDistanceMinMaxWithRegistered: (dists, faces, min_dist, max_dist)."""
+        X = soa(pts)
+        n = X.shape[1]
+        d, f = np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.int32)
+        mn, mx = C.c_float(0), C.c_float(0)
+        self._chk(self.L.hop_sdf_signed_distance(self.h, mesh_id, F(X), n, F(d), I(f), C.byref(mn), C.byref(mx)), "hop_sdf_signed_distance")
+        return d[:n], f[:n], mn.value, mx.value
+
+    def voxel_downsample(self, xyz, leaf):
+        X = soa(xyz)
+        n = X.shape[1]
+        out = np.zeros((3, max(n, 1)), np.float32)
+        k = C.c_int(0)
+        self._chk(self.L.hop_voxel_downsample(self.h, F(X), n, leaf, F(out), max(n, 1), C.byref(k)), "hop_voxel_downsample")
+        return out[:, :k.value].T.copy()
+
+    def physics_set_frame(self, p):
+        """p: dict -- object_mesh, finger_mesh[4] (registered ids), finger_xyz[4] ((n,3), link frame), finger2handbase[4],
+        finger_status[4], hand_cloud, cloud_without_hand, cam2handbase, model, model_center_init and the scalars of
+        hop_physics_args."""
+        a, keep = PhysicsArgs(), []
+
+        def planes(x):
+            x = soa(x)
+            keep.append(x)
+            return x
+
+        a.object_mesh = int(p["object_mesh"])
+        for k in range(4):
+            a.finger_mesh[k] = int(p["finger_mesh"][k])
+            X = planes(p["finger_xyz"][k])
+            a.finger_xyz[k], a.finger_n[k] = F(X), X.shape[1]
+            T = np.ascontiguousarray(p["finger2handbase"][k], np.float32).reshape(16)
+            keep.append(T)
+            a.finger2handbase[k] = F(T)
+            a.finger_status[k] = int(p["finger_status"][k])
+        X = planes(p["hand_cloud"])
+        a.hand_cloud_xyz, a.n_hand_cloud = F(X), X.shape[1]
+        X = planes(p["cloud_without_hand"])
+        a.cloud_without_hand_xyz, a.n_cloud_without_hand = F(X), X.shape[1]
+        a.cam2handbase = (C.c_float * 16)(*np.asarray(p["cam2handbase"], np.float32).reshape(16))
+        X = planes(p["model"])
+        a.model_xyz, a.n_model = F(X), X.shape[1]
+        a.model_center_init = (C.c_float * 3)(*np.asarray(p["model_center_init"], np.float32))
+        for k in ("smallest_dim", "ob_diameter", "collision_thres", "non_touch_dist", "collision_finger_dist",
+                  "collision_finger_volume_ratio", "voxel_size"):
+            setattr(a, k, float(p[k]))
+        self._chk(self.L.hop_physics_set_frame(self.h, C.byref(a)), "hop_physics_set_frame")
+
+    def reject_by_collision(self):
+        """Filters the resident set; returns (keep mask, diag (H,8)) of the incoming set."""
+        H = self.hypos_count()
+        keep = np.zeros(max(H, 1), np.uint8)
+        diag = np.zeros((max(H, 1), 8), np.float32)
+        n = C.c_int(0)
+        self._chk(self.L.hop_reject_by_collision(self.h, keep.ctypes.data_as(C.POINTER(C.c_ubyte)), F(diag), C.byref(n)), "hop_reject_by_collision")
+        return keep[:H].astype(bool), diag[:H]
+
+    def physics_timing(self):
+        a, b = C.c_double(0), C.c_double(0)
+        self.L.hop_physics_timing(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     # ---- resident set
     def hypos_upload(self, poses, scores=None):

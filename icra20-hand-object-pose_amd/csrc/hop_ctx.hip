@@ -13,6 +13,7 @@
 #include "../../include/hop.h"
 #include "hop_device.h"
 #include "hop_select.h"
+#include "hop_ctx_ext.h"
 
 #include <hipcub/hipcub.hpp>
 #include <sys/mman.h>
@@ -37,32 +38,6 @@ using namespace hop;
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-struct DevBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  template <class T>
-  T* as() const { return static_cast<T*>(p); }
-  hipError_t ensure(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = bytes + bytes / 4 + 256;
-    hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) {
-      e = hipMalloc(&p, bytes);
-      want = bytes;
-    }
-    if (e == hipSuccess) cap = want;
-    return e;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-};
-
 struct GridStore {
   DevBuf cell_start_d, pts_d;
   hop::GridDev g{};
@@ -83,25 +58,6 @@ struct CellListStore {
   void release() {
     start_d.release(), pts_d.release(), nrm_d.release(), u2_d.release(), count_d.release(), work_d.release(), keep_d.release(), range_d.release();
     valid = false;
-  }
-};
-
-struct PinnedBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  hipError_t ensure(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    cap = 0;
-    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
-    if (e == hipSuccess) cap = bytes;
-    return e;
-  }
-  void release() {
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    cap = 0;
   }
 };
 
@@ -190,6 +146,9 @@ struct hop_ctx {
   DevBuf finger_hist_d, pso_particles_d, pso_match_d, pso_terms_d, pso_sum_d, pso_cnt_d;
   PinnedBuf pso_particles_h, pso_out_h;
   bool have_finger = false, have_hand_scene = false;
+
+  // row modules (hop_physics.hip)
+  HopExt* ext[HOP_EXT_SLOTS] = {};
 
   // timing
   bool timing_on = false;
@@ -571,6 +530,15 @@ int cluster_core(const float* pose16, const float* lcp, const int* ids, int H, f
 }  // namespace
 
 // ==================================================================================================
+// ---------------------------------------------------------------------------------------------- hop_ctx_ext.h
+hipStream_t hop_ctx_stream(hop_ctx* c) { return c->stream; }
+int hop_ctx_device(const hop_ctx* c) { return c->device; }
+void hop_ctx_set_error(hop_ctx* c, const std::string& msg) { c->last_error = msg; }
+HopExt*& hop_ctx_ext(hop_ctx* c, int slot) { return c->ext[slot]; }
+HopHypView hop_ctx_hyp(hop_ctx* c) { return HopHypView{c->hyp_pose.as<float>(), c->hyp_score.as<float>(), c->hyp_id.as<int>(), c->n_hyp}; }
+void hop_ctx_hyp_set_count(hop_ctx* c, int n) { c->n_hyp = n; }
+
+
 extern "C" {
 
 int hop_abi_version(void) { return HOP_ABI_VERSION; }
@@ -633,6 +601,10 @@ void hop_ctx_destroy(hop_ctx* c) {
   c->verify_grid.release(), c->model_grid[0].release(), c->model_grid[1].release(), c->scene_grid.release(), c->hand_grid.release();
   c->model_cells[0].release(), c->model_cells[1].release(), c->scene_cells.release(), c->verify_cells.release(), c->hand_cells.release();
   c->ppf_matrix_h.release(), c->bases_h.release(), c->cnt_h.release(), c->pso_particles_h.release(), c->pso_out_h.release();
+  for (HopExt*& e : c->ext) {
+    delete e;
+    e = nullptr;
+  }
   (void)hipStreamDestroy(c->stream);
   delete c;
 }

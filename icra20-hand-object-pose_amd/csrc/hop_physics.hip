@@ -1,0 +1,934 @@
+// hop_physics.hip -- SURVEY.md 8(f) row N1: PoseEstimator::rejectByCollisionOrNonTouching on the GPU
+// (src/perception/src/PoseEstimator.cpp:524-735) with its SDFchecker (SDFchecker.cpp:36-134, libigl's
+// signed_distance with pseudonormal signs) and the voxel grid it applies to the scene (Utils.cpp:334-340).
+//
+// What runs where
+//   * mesh registration (once per object, once per frame for the four finger links): the host transforms the vertices,
+//     computes the face / edge / vertex pseudonormals in libigl's operation order and builds the 4-wide box tree
+//     (hop_sdf.h); a few thousand faces, the counterpart of reading the OBJ file in the reference.
+//   * everything per point and per hypothesis runs in the kernels below: the voxel grid, the two nearest-point
+//     searches of the object centre, finger-cloud-to-object and object-to-finger-mesh signed distances, the decisions.
+// The reference moves the object mesh into the hand-base frame for every hypothesis (and libigl rebuilds its tree and
+// normals on every call); here the query points are moved into the mesh's frame instead, so every mesh is static.
+// Signed distances therefore agree with the oracle to float rounding of the rigid motion (about 1e-7 m), not bit for
+// bit; with a mesh and points given in the same frame (hop_sdf_signed_distance) they are bit-equal.
+#include "../../include/hop.h"
+#include "hop_ctx_ext.h"
+#include "hop_sdf.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <utility>
+#include <vector>
+
+using namespace hop;
+
+namespace {
+
+#define PHCHK(ctx, call)                                                              \
+  do {                                                                                \
+    hipError_t _e = (call);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      hop_ctx_set_error((ctx), std::string(#call) + ": " + hipGetErrorString(_e));    \
+      return HOP_E_HIP;                                                               \
+    }                                                                                 \
+  } while (0)
+
+constexpr int SDF_BLOCK = 128;
+constexpr int MAX_MESHES = HOP_SDF_MAX_MESHES;
+
+// ------------------------------------------------------------------------------------------------ host: mesh preparation
+struct HostMesh {
+  int nv = 0, nf = 0;
+  std::vector<V3> V, FN, VN, EN;
+  std::vector<int> F, EMAP;
+  float max_abs = 0;
+};
+
+// SDFchecker::transformVertices (SDFchecker.cpp:21-33) then the normals of igl/signed_distance.cpp:88-98
+void prepare_mesh(HostMesh& m, const float* V, int nv, const int32_t* F, int nf, const float* pose) {
+  m.nv = nv, m.nf = nf;
+  m.V.resize(nv);
+  m.max_abs = 0;
+  for (int i = 0; i < nv; ++i) {
+    const V3 p = v3(V[3 * i], V[3 * i + 1], V[3 * i + 2]);
+    m.V[i] = pose ? m4_point(pose, p) : p;
+    m.max_abs = std::max(m.max_abs, std::max(std::fabs(m.V[i].x), std::max(std::fabs(m.V[i].y), std::fabs(m.V[i].z))));
+  }
+  m.F.assign(F, F + 3 * (size_t)nf);
+  // per_face_normals.cpp:22-37
+  m.FN.resize(nf);
+  for (int i = 0; i < nf; ++i) {
+    const V3 a = m.V[F[3 * i]], b = m.V[F[3 * i + 1]], c = m.V[F[3 * i + 2]];
+    const V3 n = vcross(b - a, c - a);
+    const float r = vnorm(n);
+    m.FN[i] = r == 0 ? v3(0, 0, 0) : n / r;
+  }
+  // per_vertex_normals.cpp:69-107, angle weights (internal_angles.cpp:75-86 on squared_edge_lengths.cpp:36-40)
+  m.VN.assign(nv, v3(0, 0, 0));
+  for (int i = 0; i < nf; ++i) {
+    const V3 a = m.V[F[3 * i]], b = m.V[F[3 * i + 1]], c = m.V[F[3 * i + 2]];
+    const float L[3] = {vsqn(b - c), vsqn(c - a), vsqn(a - b)};
+    for (int j = 0; j < 3; ++j) {
+      const float s1 = L[j], s2 = L[(j + 1) % 3], s3 = L[(j + 2) % 3];
+      const float w = (float)std::acos((double)((s3 + s2) - s1) / (2. * std::sqrt(s3 * s2)));
+      V3& n = m.VN[F[3 * i + j]];
+      n = n + w * m.FN[i];
+    }
+  }
+  for (int v = 0; v < nv; ++v) m.VN[v] = vnormalized(m.VN[v]);
+  // per_edge_normals.cpp:36-78, uniform weights, not normalised
+  std::map<std::pair<int, int>, int> ids;
+  m.EMAP.assign(3 * (size_t)nf, 0);
+  for (int c = 0; c < 3; ++c)
+    for (int f = 0; f < nf; ++f) {
+      int u = F[3 * f + (c + 1) % 3], v = F[3 * f + (c + 2) % 3];
+      if (u > v) std::swap(u, v);
+      auto it = ids.emplace(std::make_pair(u, v), (int)ids.size()).first;
+      m.EMAP[(size_t)c * nf + f] = it->second;
+    }
+  m.EN.assign(ids.size(), v3(0, 0, 0));
+  for (int f = 0; f < nf; ++f)
+    for (int c = 0; c < 3; ++c) {
+      V3& n = m.EN[m.EMAP[(size_t)c * nf + f]];
+      n = n + m.FN[f];
+    }
+}
+
+struct TreeBuilder {
+  const HostMesh& m;
+  std::vector<int> order;      // faces, permuted in place
+  std::vector<V3> cen, lo, hi; // per face
+  std::vector<SdfNode> nodes;
+  std::vector<int> slot_face;  // leaf order
+  int max_depth = 0;
+
+  explicit TreeBuilder(const HostMesh& mesh) : m(mesh) {
+    const int nf = m.nf;
+    order.resize(nf), cen.resize(nf), lo.resize(nf), hi.resize(nf);
+    for (int f = 0; f < nf; ++f) {
+      order[f] = f;
+      const V3 a = m.V[m.F[3 * f]], b = m.V[m.F[3 * f + 1]], c = m.V[m.F[3 * f + 2]];
+      lo[f] = v3(std::min(a.x, std::min(b.x, c.x)), std::min(a.y, std::min(b.y, c.y)), std::min(a.z, std::min(b.z, c.z)));
+      hi[f] = v3(std::max(a.x, std::max(b.x, c.x)), std::max(a.y, std::max(b.y, c.y)), std::max(a.z, std::max(b.z, c.z)));
+      cen[f] = v3(0.5f * (lo[f].x + hi[f].x), 0.5f * (lo[f].y + hi[f].y), 0.5f * (lo[f].z + hi[f].z));
+    }
+  }
+  static float comp(V3 v, int ax) { return ax == 0 ? v.x : (ax == 1 ? v.y : v.z); }
+  // median split of order[b,e) along the longest axis of the centroid bounds; returns the split position
+  int split(int b, int e) {
+    V3 mn = cen[order[b]], mx = mn;
+    for (int i = b + 1; i < e; ++i) {
+      const V3 c = cen[order[i]];
+      mn = v3(std::min(mn.x, c.x), std::min(mn.y, c.y), std::min(mn.z, c.z));
+      mx = v3(std::max(mx.x, c.x), std::max(mx.y, c.y), std::max(mx.z, c.z));
+    }
+    const V3 ext = mx - mn;
+    const int ax = ext.x >= ext.y && ext.x >= ext.z ? 0 : (ext.y >= ext.z ? 1 : 2);
+    const int mid = b + (e - b) / 2;
+    std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [&](int f, int g) {
+      const float cf = comp(cen[f], ax), cg = comp(cen[g], ax);
+      return cf < cg || (cf == cg && f < g);
+    });
+    return mid;
+  }
+  void range_box(int b, int e, V3* blo, V3* bhi) const {
+    V3 mn = lo[order[b]], mx = hi[order[b]];
+    for (int i = b + 1; i < e; ++i) {
+      const V3 l = lo[order[i]], h = hi[order[i]];
+      mn = v3(std::min(mn.x, l.x), std::min(mn.y, l.y), std::min(mn.z, l.z));
+      mx = v3(std::max(mx.x, h.x), std::max(mx.y, h.y), std::max(mx.z, h.z));
+    }
+    *blo = mn, *bhi = mx;
+  }
+  // builds the node for order[b,e) (e - b > SDF_LEAF or the root) and returns its index
+  int build(int b, int e, int depth) {
+    max_depth = std::max(max_depth, depth);
+    const int idx = (int)nodes.size();
+    nodes.emplace_back();
+    int cuts[5], nc = 0;
+    cuts[0] = b;
+    if (e - b <= SDF_LEAF) {
+      cuts[1] = e, nc = 1;
+    } else {
+      const int mid = split(b, e);
+      int parts[3] = {b, mid, e};
+      nc = 0;
+      for (int h = 0; h < 2; ++h) {
+        const int pb = parts[h], pe = parts[h + 1];
+        if (pe - pb > SDF_LEAF) {
+          const int q = split(pb, pe);
+          cuts[nc++] = pb, cuts[nc++] = q;
+        } else
+          cuts[nc++] = pb;
+      }
+      cuts[nc] = e;
+    }
+    SdfNode nd;
+    std::memset(&nd, 0, sizeof(nd));
+    for (int k = 0; k < 4; ++k) {
+      for (int a = 0; a < 3; ++a) nd.lo[a][k] = INFINITY, nd.hi[a][k] = -INFINITY;
+      nd.child[k] = -1, nd.count[k] = 0;
+    }
+    for (int k = 0; k < nc; ++k) {
+      const int cb = cuts[k], ce = cuts[k + 1];
+      if (ce <= cb) continue;
+      V3 blo, bhi;
+      range_box(cb, ce, &blo, &bhi);
+      nd.lo[0][k] = blo.x, nd.lo[1][k] = blo.y, nd.lo[2][k] = blo.z;
+      nd.hi[0][k] = bhi.x, nd.hi[1][k] = bhi.y, nd.hi[2][k] = bhi.z;
+      if (ce - cb <= SDF_LEAF) {
+        nd.child[k] = -((int)slot_face.size() + 1);
+        nd.count[k] = (unsigned char)(ce - cb);
+        std::sort(order.begin() + cb, order.begin() + ce);
+        for (int i = cb; i < ce; ++i) slot_face.push_back(order[i]);
+      } else {
+        nd.child[k] = build(cb, ce, depth + 1);
+      }
+    }
+    nodes[idx] = nd;
+    return idx;
+  }
+};
+
+// libigl's AABB tree over the faces (AABB.cpp:73-200): per-axis ranks of the face barycentres (igl::sort is a std::sort of
+// an index map, sort.cpp:287-316), nodes split at the median rank along the longest box axis, one face per leaf.  Only
+// what sdf_precedes needs is kept.
+struct OrderTree {
+  const HostMesh& m;
+  std::vector<SdfOrderNode> nodes;
+  std::vector<int> face_leaf, rank;  // rank[3 f + d]
+  explicit OrderTree(const HostMesh& mesh) : m(mesh) {
+    const int nf = m.nf;
+    face_leaf.assign(nf, -1);
+    rank.resize(3 * (size_t)nf);
+    std::vector<float> bc(nf);
+    std::vector<size_t> idx(nf);
+    for (int d = 0; d < 3; ++d) {
+      for (int f = 0; f < nf; ++f) {
+        const V3 a = m.V[m.F[3 * f]], b = m.V[m.F[3 * f + 1]], c = m.V[m.F[3 * f + 2]];
+        bc[f] = d == 0 ? ((a.x + b.x) + c.x) / 3.0f : (d == 1 ? ((a.y + b.y) + c.y) / 3.0f : ((a.z + b.z) + c.z) / 3.0f);
+        idx[f] = f;
+      }
+      std::sort(idx.begin(), idx.end(), [&](size_t i, size_t j) { return bc[i] < bc[j]; });
+      for (int i = 0; i < nf; ++i) rank[3 * idx[i] + d] = i;
+    }
+    if (nf > 0) {
+      std::vector<int> all(nf);
+      for (int f = 0; f < nf; ++f) all[f] = f;
+      grow(all, -1, 0, false);
+    }
+  }
+  int grow(const std::vector<int>& I, int parent, int depth, bool is_left) {
+    const int idx = (int)nodes.size();
+    nodes.emplace_back();
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int f : I)
+      for (int c = 0; c < 3; ++c) {
+        const V3 v = m.V[m.F[3 * f + c]];
+        const float pv[3] = {v.x, v.y, v.z};
+        for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], pv[k]), hi[k] = std::max(hi[k], pv[k]);
+      }
+    SdfOrderNode nd;
+    for (int k = 0; k < 3; ++k) nd.lo[k] = lo[k], nd.hi[k] = hi[k];
+    nd.parent = parent, nd.info = (depth << 1) | (is_left ? 1 : 0);
+    nodes[idx] = nd;
+    if (I.size() == 1) {
+      face_leaf[I[0]] = idx;
+      return idx;
+    }
+    int ax = 0;
+    for (int k = 1; k < 3; ++k)
+      if (hi[k] - lo[k] > hi[ax] - lo[ax]) ax = k;
+    std::vector<int> r(I.size());
+    for (size_t i = 0; i < I.size(); ++i) r[i] = rank[3 * (size_t)I[i] + ax];
+    std::vector<int> t = r;
+    const size_t n = (t.size() - 1) / 2;
+    std::nth_element(t.begin(), t.begin() + n, t.end());
+    const int med = t[n];
+    std::vector<int> LI, RI;
+    for (size_t i = 0; i < I.size(); ++i) (r[i] <= med ? LI : RI).push_back(I[i]);
+    grow(LI, idx, depth + 1, true);
+    grow(RI, idx, depth + 1, false);
+    return idx;
+  }
+};
+
+struct MeshStore {
+  DevBuf tri_d, nrm_d, nodes_d, order_d, leaf_d;
+  SdfMeshDev dev{};
+  bool valid = false;
+  void release() { tri_d.release(), nrm_d.release(), nodes_d.release(), order_d.release(), leaf_d.release(), valid = false; }
+};
+
+struct Cloud3 {
+  DevBuf buf;  // 3 planes of n
+  int n = 0;
+  const float* x() const { return buf.as<float>(); }
+  const float* y() const { return buf.as<float>() + n; }
+  const float* z() const { return buf.as<float>() + 2 * (size_t)n; }
+};
+
+struct PhysParams {
+  float cam2handbase[16];
+  float center_init[3];
+  float ob_diameter, collision_dist, inside_ob_dist, non_touch_dist, collision_finger_dist, volume_ratio;
+  int finger_status[4];
+  int finger_active[4];  // finger cloud tested in the third check
+  int finger_off[5];     // ranges of the concatenated finger points
+  int object_mesh, finger_mesh[4];
+  int n_model;
+};
+
+struct Physics : HopExt {
+  MeshStore mesh[MAX_MESHES];
+  Cloud3 fingers, cwh_ds, hand, model, tmp_cloud, tmp_cloud2;
+  DevBuf keys, keys_alt, vals, vals_alt, flags, pos, starts, sort_tmp, scalars, xf, stage, fmin, diag, gather, tmp_pose, tmp_score, tmp_id, mats;
+  PhysParams P{};
+  bool have_frame = false;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  double ms_frame = 0, ms_reject = 0;
+  ~Physics() override {
+    for (auto& m : mesh) m.release();
+    DevBuf* bufs[] = {&fingers.buf, &cwh_ds.buf, &hand.buf, &model.buf, &tmp_cloud.buf, &tmp_cloud2.buf, &keys, &keys_alt, &vals, &vals_alt, &flags, &pos,
+                      &starts, &sort_tmp, &scalars, &xf, &stage, &fmin, &diag, &gather, &tmp_pose, &tmp_score, &tmp_id, &mats};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
+};
+
+Physics* physics(hop_ctx* c) {
+  HopExt*& e = hop_ctx_ext(c, HOP_EXT_PHYSICS);
+  if (!e) e = new Physics;
+  return static_cast<Physics*>(e);
+}
+
+// ------------------------------------------------------------------------------------------------ kernels
+__device__ __forceinline__ unsigned ordered_bits(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+constexpr unsigned ORDERED_NONE = 0xffffffffu;  // above every finite value and +inf: "no sample"
+
+// S[i] = igl::signed_distance of point i (optionally moved by T first) to the mesh
+__global__ void __launch_bounds__(SDF_BLOCK) k_sdf_query(SdfMeshDev m, const float* __restrict__ px, const float* __restrict__ py,
+                                                         const float* __restrict__ pz, int n, const float* __restrict__ T,
+                                                         float* __restrict__ S, int* __restrict__ face) {
+  __shared__ unsigned stk[SDF_STACK * SDF_BLOCK];
+  const int i = blockIdx.x * SDF_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  V3 q = v3(px[i], py[i], pz[i]);
+  if (T) q = m4_point(T, q);
+  int f;
+  S[i] = sdf_signed_distance(m, q, stk + threadIdx.x, SDF_BLOCK, &f);
+  if (face) face[i] = f;
+}
+
+// out = T * in (pcl::transformPointCloud order), SoA planes
+__global__ void k_transform_cloud(const float* __restrict__ ix, const float* __restrict__ iy, const float* __restrict__ iz, int n,
+                                  const float* __restrict__ T, float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 p = m4_point(T, v3(ix[i], iy[i], iz[i]));
+  ox[i] = p.x, oy[i] = p.y, oz[i] = p.z;
+}
+
+// ---- pcl::VoxelGrid (voxel_grid.hpp:214-440, xyz only)
+// scal[0..2] = min as ordered bits, [3..5] = max, [6] = finite points
+__global__ void k_vox_minmax(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n, unsigned* scal) {
+  __shared__ unsigned s[7];
+  if (threadIdx.x < 7) s[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+  __syncthreads();
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float a = x[i], b = y[i], c = z[i];
+    if (!isfinite(a) || !isfinite(b) || !isfinite(c)) continue;
+    atomicMin(&s[0], ordered_bits(a)), atomicMin(&s[1], ordered_bits(b)), atomicMin(&s[2], ordered_bits(c));
+    atomicMax(&s[3], ordered_bits(a)), atomicMax(&s[4], ordered_bits(b)), atomicMax(&s[5], ordered_bits(c));
+    atomicAdd(&s[6], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicMin(&scal[threadIdx.x], s[threadIdx.x]);
+  else if (threadIdx.x < 6) atomicMax(&scal[threadIdx.x], s[threadIdx.x]);
+  else if (threadIdx.x == 6) atomicAdd(&scal[6], s[6]);
+}
+struct VoxGeom {
+  float inv;
+  int minb[3];
+  int mul[3];
+};
+__global__ void k_vox_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n, VoxGeom g,
+                           unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = x[i], b = y[i], c = z[i];
+  unsigned k = 0xffffffffu;
+  if (isfinite(a) && isfinite(b) && isfinite(c)) {
+    const int i0 = (int)floorf(a * g.inv) - g.minb[0], i1 = (int)floorf(b * g.inv) - g.minb[1], i2 = (int)floorf(c * g.inv) - g.minb[2];
+    k = (unsigned)(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
+  }
+  keys[i] = k, vals[i] = (unsigned)i;
+}
+__global__ void k_vox_heads(const unsigned* __restrict__ keys, int n, unsigned* __restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+__global__ void k_vox_starts(const unsigned* __restrict__ flags, const unsigned* __restrict__ pos, int n, unsigned* __restrict__ starts,
+                             unsigned* __restrict__ n_seg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (flags[i]) starts[pos[i]] = (unsigned)i;
+  if (i == n - 1) *n_seg = pos[i] + flags[i];
+}
+// one thread per voxel: CentroidPoint sums xyz in float in the (stable) sorted order and divides by the count
+__global__ void k_vox_centroids(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const unsigned* __restrict__ vals,
+                                const unsigned* __restrict__ starts, int n_seg, int n_finite, float* __restrict__ ox, float* __restrict__ oy,
+                                float* __restrict__ oz) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_seg) return;
+  const int b = (int)starts[s], e = s + 1 < n_seg ? (int)starts[s + 1] : n_finite;
+  float sx = 0, sy = 0, sz = 0;
+  for (int j = b; j < e; ++j) {
+    const unsigned p = vals[j];
+    sx += x[p], sy += y[p], sz += z[p];
+  }
+  const float cnt = (float)(e - b);
+  ox[s] = sx / cnt, oy[s] = sy / cnt, oz[s] = sz / cnt;
+}
+
+// ---- rejectByCollisionOrNonTouching
+// per hypothesis: xf[h] = {model2handbase (12), its inverse (12), object centre in the hand-base frame (3), pad}
+constexpr int XF = 28;
+__global__ void k_phys_prepare(const float* __restrict__ pose, int H, PhysParams P, float* __restrict__ xf, int* __restrict__ stage,
+                               unsigned* __restrict__ fmin, float* __restrict__ diag) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  M4 c2h, m2s;
+  for (int k = 0; k < 16; ++k) c2h.m[k] = P.cam2handbase[k], m2s.m[k] = pose[16 * (size_t)h + k];
+  const M4 m2h = m4_mul(c2h, m2s);  // PoseEstimator.cpp:587
+  const M4 inv = m4_inverse_affine(m2h);
+  float* o = xf + (size_t)XF * h;
+  for (int k = 0; k < 12; ++k) o[k] = m2h.m[k], o[12 + k] = inv.m[k];
+  // cur_center = model2handbase * (centre, 1) (:589-590), a 4x4 by 4-vector product
+  const float* m = m2h.m;
+  o[24] = ((m[0] * P.center_init[0] + m[1] * P.center_init[1]) + m[2] * P.center_init[2]) + m[3] * 1.0f;
+  o[25] = ((m[4] * P.center_init[0] + m[5] * P.center_init[1]) + m[6] * P.center_init[2]) + m[7] * 1.0f;
+  o[26] = ((m[8] * P.center_init[0] + m[9] * P.center_init[1]) + m[10] * P.center_init[2]) + m[11] * 1.0f;
+  stage[h] = 0;
+  for (int k = 0; k < 12; ++k) fmin[12 * (size_t)h + k] = k < 8 ? ORDERED_NONE : 0u;  // 4 finger-cloud mins, 4 model mins, 4 inside counts
+  diag[8 * (size_t)h] = 0.f;
+  for (int k = 1; k < 8; ++k) diag[8 * (size_t)h + k] = __builtin_nanf("");
+}
+
+__device__ __forceinline__ unsigned long long nn_pack(float d, int i) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i; }
+
+// checks 1 and 2 (:598-642): nearest scene / hand point to the object centre, one block per hypothesis
+__global__ void __launch_bounds__(256) k_phys_center(SdfMeshDev obj, const float* __restrict__ xf, int H, PhysParams P, const float* __restrict__ sx,
+                                                     const float* __restrict__ sy, const float* __restrict__ sz, int ns, const float* __restrict__ hx,
+                                                     const float* __restrict__ hy, const float* __restrict__ hz, int nh, int* __restrict__ stage,
+                                                     float* __restrict__ diag) {
+  __shared__ unsigned long long best[2];
+  __shared__ unsigned stk[SDF_STACK];
+  const int h = blockIdx.x;
+  const float* X = xf + (size_t)XF * h;
+  const V3 c = v3(X[24], X[25], X[26]);
+  if (threadIdx.x < 2) best[threadIdx.x] = ~0ull;
+  __syncthreads();
+  unsigned long long b0 = ~0ull, b1 = ~0ull;
+  for (int i = threadIdx.x; i < ns; i += blockDim.x) {
+    const unsigned long long v = nn_pack(sqdist_flann(c, v3(sx[i], sy[i], sz[i])), i);
+    b0 = v < b0 ? v : b0;
+  }
+  for (int i = threadIdx.x; i < nh; i += blockDim.x) {
+    const unsigned long long v = nn_pack(sqdist_flann(c, v3(hx[i], hy[i], hz[i])), i);
+    b1 = v < b1 ? v : b1;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t0 = __shfl_down(b0, o), t1 = __shfl_down(b1, o);
+    b0 = t0 < b0 ? t0 : b0, b1 = t1 < b1 ? t1 : b1;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMin(&best[0], b0), atomicMin(&best[1], b1);
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const float* inv = X + 12;
+  int st = 0;
+  if (ns > 0) {
+    const int i = (int)(best[0] & 0xffffffffu);
+    const float s = sdf_signed_distance(obj, m4_point(inv, v3(sx[i], sy[i], sz[i])), stk, 1, nullptr);
+    diag[8 * (size_t)h + 1] = s;
+    if (s <= P.inside_ob_dist) st = 1;
+  }
+  if (st == 0 && nh > 0) {
+    const int i = (int)(best[1] & 0xffffffffu);
+    const float sq = __uint_as_float((unsigned)(best[1] >> 32));
+    if (sqrtf(sq) < P.ob_diameter / 2) {
+      const float s = sdf_signed_distance(obj, m4_point(inv, v3(hx[i], hy[i], hz[i])), stk, 1, nullptr);
+      diag[8 * (size_t)h + 2] = s;
+      if (s < P.collision_dist) st = 2;
+    }
+  }
+  stage[h] = st;
+  diag[8 * (size_t)h] = (float)st;
+}
+
+// check 3 (:646-668): the active finger clouds (hand-base frame, concatenated) against the object; grid (chunks, H)
+__global__ void __launch_bounds__(SDF_BLOCK) k_phys_fingers(SdfMeshDev obj, const float* __restrict__ xf, PhysParams P, const float* __restrict__ fx,
+                                                            const float* __restrict__ fy, const float* __restrict__ fz, const int* __restrict__ stage,
+                                                            unsigned* __restrict__ fmin) {
+  __shared__ unsigned stk[SDF_STACK * SDF_BLOCK];
+  __shared__ unsigned mn[4];
+  const int h = blockIdx.y;
+  if (stage[h] != 0) return;
+  if (threadIdx.x < 4) mn[threadIdx.x] = ORDERED_NONE;
+  __syncthreads();
+  const int n = P.finger_off[4];
+  const int i = blockIdx.x * SDF_BLOCK + threadIdx.x;
+  if (i < n) {
+    const int k = (i >= P.finger_off[1]) + (i >= P.finger_off[2]) + (i >= P.finger_off[3]);
+    const float* inv = xf + (size_t)XF * h + 12;
+    const float s = sdf_signed_distance(obj, m4_point(inv, v3(fx[i], fy[i], fz[i])), stk + threadIdx.x, SDF_BLOCK, nullptr);
+    if (s == s) atomicMin(&mn[k], ordered_bits(s));
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && mn[threadIdx.x] != ORDERED_NONE) atomicMin(&fmin[12 * (size_t)h + threadIdx.x], mn[threadIdx.x]);
+}
+
+__global__ void k_phys_decide_fingers(int H, PhysParams P, const unsigned* __restrict__ fmin, int* __restrict__ stage, float* __restrict__ diag) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H || stage[h] != 0) return;
+  bool rejected = false, non_touch[4] = {false, false, false, false};
+  for (int k = 0; k < 4; ++k) {
+    if (!P.finger_active[k]) continue;
+    const unsigned u = fmin[12 * (size_t)h + k];
+    const float m = u == ORDERED_NONE ? __builtin_inff() : from_ordered_bits(u);
+    diag[8 * (size_t)h + 3 + k] = m;
+    if (m <= P.collision_dist) rejected = true;
+    if (m > P.non_touch_dist && P.finger_status[k]) non_touch[k] = true;
+  }
+  int st = 0;
+  if (rejected) st = 3;
+  else if ((non_touch[0] && non_touch[1]) || (non_touch[2] && non_touch[3])) st = 4;
+  stage[h] = st;
+  diag[8 * (size_t)h] = (float)st;
+}
+
+// check 4 (:684-722): the object's points, moved into the hand-base frame, against the four finger meshes
+struct FingerMeshes {
+  SdfMeshDev m[4];
+};
+__global__ void __launch_bounds__(SDF_BLOCK) k_phys_model(FingerMeshes fm, const float* __restrict__ xf, int n_model, const float* __restrict__ mx,
+                                                          const float* __restrict__ my, const float* __restrict__ mz, const int* __restrict__ stage,
+                                                          unsigned* __restrict__ fmin) {
+  __shared__ unsigned stk[SDF_STACK * SDF_BLOCK];
+  __shared__ unsigned mn[4], inside[4];
+  const int h = blockIdx.y;
+  if (stage[h] != 0) return;
+  if (threadIdx.x < 4) mn[threadIdx.x] = ORDERED_NONE, inside[threadIdx.x] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * SDF_BLOCK + threadIdx.x;
+  if (i < n_model) {
+    const V3 p = m4_point(xf + (size_t)XF * h, v3(mx[i], my[i], mz[i]));
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      const float s = sdf_signed_distance(fm.m[k], p, stk + threadIdx.x, SDF_BLOCK, nullptr);
+      if (s == s) atomicMin(&mn[k], ordered_bits(s));
+      if (s < 0) atomicAdd(&inside[k], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    if (mn[threadIdx.x] != ORDERED_NONE) atomicMin(&fmin[12 * (size_t)h + 4 + threadIdx.x], mn[threadIdx.x]);
+    if (inside[threadIdx.x]) atomicAdd(&fmin[12 * (size_t)h + 8 + threadIdx.x], inside[threadIdx.x]);
+  }
+}
+
+__global__ void k_phys_decide_model(int H, PhysParams P, const unsigned* __restrict__ fmin, int* __restrict__ stage, float* __restrict__ diag) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H || stage[h] != 0) return;
+  bool rejected = false;
+  float smallest = __builtin_inff();
+  for (int k = 0; k < 4 && !rejected; ++k) {
+    const unsigned u = fmin[12 * (size_t)h + 4 + k];
+    const float m = u == ORDERED_NONE ? __builtin_inff() : from_ordered_bits(u);
+    smallest = fminf(smallest, m);
+    if (m < P.collision_finger_dist) rejected = true;
+    // `num_inside/P.rows() > ratio` is an integer division (:715)
+    const long q = (long)fmin[12 * (size_t)h + 8 + k] / (long)max(P.n_model, 1);
+    if ((float)q > P.volume_ratio) rejected = true;
+  }
+  diag[8 * (size_t)h + 7] = smallest;
+  stage[h] = rejected ? 5 : 0;
+  diag[8 * (size_t)h] = rejected ? 5.f : 0.f;
+}
+
+__global__ void k_phys_gather(const int* __restrict__ src, int n, const float* __restrict__ pose, const float* __restrict__ score, const int* __restrict__ id,
+                              float* __restrict__ opose, float* __restrict__ oscore, int* __restrict__ oid) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 16) return;
+  const int k = t >> 4, e = t & 15;
+  const int s = src[k];
+  opose[t] = pose[16 * (size_t)s + e];
+  if (e == 0) oscore[k] = score[s], oid[k] = id[s];
+}
+
+// ------------------------------------------------------------------------------------------------ host helpers
+int upload_planes(hop_ctx* c, Cloud3& dst, const float* planes, int n) {
+  hipStream_t st = hop_ctx_stream(c);
+  PHCHK(c, dst.buf.ensure(sizeof(float) * 3 * (size_t)std::max(n, 1)));
+  dst.n = n;
+  if (n > 0) PHCHK(c, hipMemcpyAsync(dst.buf.p, planes, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+  return HOP_OK;
+}
+
+// pcl::VoxelGrid on a device cloud (planes x,y,z of n); result into `out`
+int voxel_downsample_device(hop_ctx* c, Physics* ph, const float* x, const float* y, const float* z, int n, float leaf, Cloud3& out) {
+  hipStream_t st = hop_ctx_stream(c);
+  out.n = 0;
+  PHCHK(c, out.buf.ensure(sizeof(float) * 3));
+  if (n <= 0) return HOP_OK;
+  if (!(leaf > 0)) return HOP_E_INVALID;
+  PHCHK(c, ph->scalars.ensure(sizeof(unsigned) * 16));
+  const unsigned init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+  PHCHK(c, hipMemcpyAsync(ph->scalars.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+  k_vox_minmax<<<std::min((n + 255) / 256, 1024), 256, 0, st>>>(x, y, z, n, ph->scalars.as<unsigned>());
+  unsigned sc[8];
+  PHCHK(c, hipMemcpyAsync(sc, ph->scalars.p, sizeof(sc), hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipStreamSynchronize(st));
+  const int n_finite = (int)sc[6];
+  if (n_finite == 0) return HOP_OK;
+  auto dec = [](unsigned u) {
+    const unsigned b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+  };
+  VoxGeom g;
+  g.inv = 1.0f / leaf;
+  int64_t div[3];
+  for (int a = 0; a < 3; ++a) {
+    const float mn = dec(sc[a]), mx = dec(sc[3 + a]);
+    // voxel_grid.hpp:243-251: the index of a cell must fit an int
+    const double cells = ((double)mx - (double)mn) * (double)g.inv + 1;
+    if (cells > (double)INT_MAX) {
+      hop_ctx_set_error(c, "voxel grid: leaf size too small for the input (integer indices would overflow)");
+      return HOP_E_CAPACITY;
+    }
+    g.minb[a] = (int)std::floor(mn * g.inv);
+    div[a] = (int64_t)(int)std::floor(mx * g.inv) - g.minb[a] + 1;
+  }
+  if (div[0] * div[1] * div[2] > (int64_t)INT_MAX) {
+    hop_ctx_set_error(c, "voxel grid: leaf size too small for the input (integer indices would overflow)");
+    return HOP_E_CAPACITY;
+  }
+  g.mul[0] = 1, g.mul[1] = (int)div[0], g.mul[2] = (int)(div[0] * div[1]);
+  const size_t nb = sizeof(unsigned) * (size_t)n;
+  PHCHK(c, ph->keys.ensure(nb));
+  PHCHK(c, ph->keys_alt.ensure(nb));
+  PHCHK(c, ph->vals.ensure(nb));
+  PHCHK(c, ph->vals_alt.ensure(nb));
+  PHCHK(c, ph->flags.ensure(nb));
+  PHCHK(c, ph->pos.ensure(nb));
+  PHCHK(c, ph->starts.ensure(nb));
+  const int blocks = (n + 255) / 256;
+  k_vox_keys<<<blocks, 256, 0, st>>>(x, y, z, n, g, ph->keys.as<unsigned>(), ph->vals.as<unsigned>());
+  size_t tmp1 = 0, tmp2 = 0;
+  PHCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, ph->keys.as<unsigned>(), ph->keys_alt.as<unsigned>(), ph->vals.as<unsigned>(),
+                                              ph->vals_alt.as<unsigned>(), n, 0, 32, st));
+  PHCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), n_finite, st));
+  size_t tmp = std::max(tmp1, tmp2);
+  PHCHK(c, ph->sort_tmp.ensure(tmp + 16));
+  PHCHK(c, hipcub::DeviceRadixSort::SortPairs(ph->sort_tmp.p, tmp1, ph->keys.as<unsigned>(), ph->keys_alt.as<unsigned>(), ph->vals.as<unsigned>(),
+                                              ph->vals_alt.as<unsigned>(), n, 0, 32, st));
+  // non-finite points carry the largest key and sit behind the n_finite sorted ones
+  const int fb = (n_finite + 255) / 256;
+  k_vox_heads<<<fb, 256, 0, st>>>(ph->keys_alt.as<unsigned>(), n_finite, ph->flags.as<unsigned>());
+  PHCHK(c, hipcub::DeviceScan::ExclusiveSum(ph->sort_tmp.p, tmp2, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), n_finite, st));
+  k_vox_starts<<<fb, 256, 0, st>>>(ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), n_finite, ph->starts.as<unsigned>(), ph->scalars.as<unsigned>() + 8);
+  unsigned n_seg = 0;
+  PHCHK(c, hipMemcpyAsync(&n_seg, ph->scalars.as<unsigned>() + 8, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipStreamSynchronize(st));
+  PHCHK(c, out.buf.ensure(sizeof(float) * 3 * (size_t)n_seg));
+  out.n = (int)n_seg;
+  float* o = out.buf.as<float>();
+  k_vox_centroids<<<((int)n_seg + 127) / 128, 128, 0, st>>>(x, y, z, ph->vals_alt.as<unsigned>(), ph->starts.as<unsigned>(), (int)n_seg, n_finite, o,
+                                                             o + n_seg, o + 2 * (size_t)n_seg);
+  PHCHK(c, hipGetLastError());
+  return HOP_OK;
+}
+
+}  // namespace
+
+// ================================================================================================ C-ABI
+extern "C" {
+
+int hop_sdf_register_mesh(hop_ctx* c, int mesh_id, const float* V, int nv, const int32_t* F, int nf, const float* pose16) {
+  if (!c || mesh_id < 0 || mesh_id >= MAX_MESHES || nv < 0 || nf < 0 || (nv > 0 && !V) || (nf > 0 && !F)) return HOP_E_INVALID;
+  for (int i = 0; i < 3 * nf; ++i)
+    if (F[i] < 0 || F[i] >= nv) return HOP_E_INVALID;
+  PHCHK(c, hipSetDevice(hop_ctx_device(c)));
+  Physics* ph = physics(c);
+  hipStream_t st = hop_ctx_stream(c);
+  HostMesh hm;
+  prepare_mesh(hm, V, nv, F, nf, pose16);
+  TreeBuilder tb(hm);
+  if (nf > 0) tb.build(0, nf, 0);
+  if (3 * tb.max_depth + 1 > SDF_STACK || tb.nodes.size() >= (size_t)(1u << SDF_NODE_BITS)) {
+    hop_ctx_set_error(c, "mesh too large for the traversal stack");
+    return HOP_E_CAPACITY;
+  }
+  OrderTree ot(hm);
+  std::vector<float4> tri(3 * (size_t)nf), nrm(7 * (size_t)nf);
+  for (int s = 0; s < nf; ++s) {
+    const int f = tb.slot_face[s];
+    const V3 P[3] = {hm.V[F[3 * f]], hm.V[F[3 * f + 1]], hm.V[F[3 * f + 2]]};
+    const double area = sdf_doublearea(P[0], P[1], P[2]);
+    int fbits = f;
+    float fw;
+    std::memcpy(&fw, &fbits, 4);
+    tri[3 * (size_t)s] = make_float4(P[0].x, P[0].y, P[0].z, area > 1e-4 ? 1.f : 0.f);
+    tri[3 * (size_t)s + 1] = make_float4(P[1].x, P[1].y, P[1].z, fw);
+    tri[3 * (size_t)s + 2] = make_float4(P[2].x, P[2].y, P[2].z, 0.f);
+    auto put = [&](int k, V3 n) { nrm[7 * (size_t)s + k] = make_float4(n.x, n.y, n.z, 0.f); };
+    put(0, hm.FN[f]);
+    for (int e = 0; e < 3; ++e) put(1 + e, hm.EN[hm.EMAP[(size_t)e * nf + f]]);
+    for (int v = 0; v < 3; ++v) put(4 + v, hm.VN[F[3 * f + v]]);
+  }
+  MeshStore& ms = ph->mesh[mesh_id];
+  PHCHK(c, hipStreamSynchronize(st));  // a previous frame may still read the old buffers
+  PHCHK(c, ms.tri_d.ensure(std::max<size_t>(sizeof(float4) * tri.size(), 16)));
+  PHCHK(c, ms.nrm_d.ensure(std::max<size_t>(sizeof(float4) * nrm.size(), 16)));
+  PHCHK(c, ms.nodes_d.ensure(std::max<size_t>(sizeof(SdfNode) * tb.nodes.size(), 128)));
+  PHCHK(c, ms.order_d.ensure(std::max<size_t>(sizeof(SdfOrderNode) * ot.nodes.size(), 32)));
+  PHCHK(c, ms.leaf_d.ensure(std::max<size_t>(sizeof(int) * (size_t)nf, 16)));
+  if (nf > 0) {
+    PHCHK(c, hipMemcpyAsync(ms.tri_d.p, tri.data(), sizeof(float4) * tri.size(), hipMemcpyHostToDevice, st));
+    PHCHK(c, hipMemcpyAsync(ms.nrm_d.p, nrm.data(), sizeof(float4) * nrm.size(), hipMemcpyHostToDevice, st));
+    PHCHK(c, hipMemcpyAsync(ms.nodes_d.p, tb.nodes.data(), sizeof(SdfNode) * tb.nodes.size(), hipMemcpyHostToDevice, st));
+    PHCHK(c, hipMemcpyAsync(ms.order_d.p, ot.nodes.data(), sizeof(SdfOrderNode) * ot.nodes.size(), hipMemcpyHostToDevice, st));
+    PHCHK(c, hipMemcpyAsync(ms.leaf_d.p, ot.face_leaf.data(), sizeof(int) * (size_t)nf, hipMemcpyHostToDevice, st));
+  }
+  PHCHK(c, hipStreamSynchronize(st));
+  ms.dev.tri = ms.tri_d.as<float4>(), ms.dev.nrm = ms.nrm_d.as<float4>(), ms.dev.nodes = ms.nodes_d.as<SdfNode>();
+  ms.dev.order = ms.order_d.as<SdfOrderNode>(), ms.dev.face_leaf = ms.leaf_d.as<int>();
+  ms.dev.n_faces = nf, ms.dev.n_nodes = (int)tb.nodes.size();
+  ms.dev.coord_eps = 4e-7f * hm.max_abs;
+  ms.valid = true;
+  return HOP_OK;
+}
+
+int hop_sdf_signed_distance(hop_ctx* c, int mesh_id, const float* pts_xyz, int n, float* dists, int32_t* faces, float* min_dist, float* max_dist) {
+  if (!c || mesh_id < 0 || mesh_id >= MAX_MESHES || n < 0 || (n > 0 && (!pts_xyz || !dists))) return HOP_E_INVALID;
+  PHCHK(c, hipSetDevice(hop_ctx_device(c)));
+  Physics* ph = physics(c);
+  if (!ph->mesh[mesh_id].valid) return HOP_E_STATE;
+  hipStream_t st = hop_ctx_stream(c);
+  float mn = FLT_MAX, mx = -FLT_MAX;  // SDFchecker.cpp:119-120
+  if (n > 0) {
+    int rc = upload_planes(c, ph->tmp_cloud, pts_xyz, n);
+    if (rc) return rc;
+    PHCHK(c, ph->tmp_cloud2.buf.ensure(sizeof(float) * 2 * (size_t)n));
+    float* S = ph->tmp_cloud2.buf.as<float>();
+    int* I = reinterpret_cast<int*>(S + n);
+    k_sdf_query<<<(n + SDF_BLOCK - 1) / SDF_BLOCK, SDF_BLOCK, 0, st>>>(ph->mesh[mesh_id].dev, ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), n,
+                                                                       nullptr, S, I);
+    PHCHK(c, hipGetLastError());
+    PHCHK(c, hipMemcpyAsync(dists, S, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+    if (faces) PHCHK(c, hipMemcpyAsync(faces, I, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+    PHCHK(c, hipStreamSynchronize(st));
+    mn = INFINITY, mx = -INFINITY;  // S.minCoeff() / S.maxCoeff(), NaN (points on the surface) skipped
+    for (int i = 0; i < n; ++i)
+      if (dists[i] == dists[i]) mn = std::min(mn, dists[i]), mx = std::max(mx, dists[i]);
+  }
+  if (min_dist) *min_dist = mn;
+  if (max_dist) *max_dist = mx;
+  return HOP_OK;
+}
+
+int hop_voxel_downsample(hop_ctx* c, const float* xyz, int n, float leaf, float* out_xyz, int cap, int* n_out) {
+  if (!c || n < 0 || (n > 0 && !xyz) || !n_out || cap < 0) return HOP_E_INVALID;
+  PHCHK(c, hipSetDevice(hop_ctx_device(c)));
+  Physics* ph = physics(c);
+  hipStream_t st = hop_ctx_stream(c);
+  int rc = upload_planes(c, ph->tmp_cloud, xyz, n);
+  if (rc) return rc;
+  rc = voxel_downsample_device(c, ph, ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), n, leaf, ph->tmp_cloud2);
+  if (rc) return rc;
+  const int m = ph->tmp_cloud2.n;
+  *n_out = m;
+  if (m > cap) return HOP_E_CAPACITY;
+  if (m > 0 && out_xyz)
+    for (int a = 0; a < 3; ++a)
+      PHCHK(c, hipMemcpyAsync(out_xyz + (size_t)a * cap, ph->tmp_cloud2.buf.as<float>() + (size_t)a * m, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipStreamSynchronize(st));
+  return HOP_OK;
+}
+
+int hop_physics_set_frame(hop_ctx* c, const hop_physics_args* a) {
+  if (!c || !a) return HOP_E_INVALID;
+  PHCHK(c, hipSetDevice(hop_ctx_device(c)));
+  Physics* ph = physics(c);
+  hipStream_t st = hop_ctx_stream(c);
+  if (a->object_mesh < 0 || a->object_mesh >= MAX_MESHES || !ph->mesh[a->object_mesh].valid) return HOP_E_STATE;
+  for (int k = 0; k < 4; ++k)
+    if (a->finger_mesh[k] < 0 || a->finger_mesh[k] >= MAX_MESHES || !ph->mesh[a->finger_mesh[k]].valid) return HOP_E_STATE;
+  if (a->n_model < 0 || a->n_hand_cloud < 0 || a->n_cloud_without_hand < 0) return HOP_E_INVALID;
+  if (!ph->ev[0]) {
+    PHCHK(c, hipEventCreate(&ph->ev[0]));
+    PHCHK(c, hipEventCreate(&ph->ev[1]));
+  }
+  PHCHK(c, hipEventRecord(ph->ev[0], st));
+  PhysParams& P = ph->P;
+  std::memcpy(P.cam2handbase, a->cam2handbase, sizeof(P.cam2handbase));
+  std::memcpy(P.center_init, a->model_center_init, sizeof(P.center_init));
+  P.ob_diameter = a->ob_diameter;
+  P.collision_dist = std::min(-a->smallest_dim * a->collision_thres, -0.007f);  // PoseEstimator.cpp:563-564
+  P.inside_ob_dist = std::min(-a->smallest_dim / 5, -0.01f);
+  P.non_touch_dist = a->non_touch_dist;
+  P.collision_finger_dist = -a->collision_finger_dist;
+  P.volume_ratio = a->collision_finger_volume_ratio;
+  P.object_mesh = a->object_mesh;
+  P.n_model = a->n_model;
+  // finger clouds that take part in the third check (:538-551, :650-652), moved into the hand-base frame
+  int total = 0;
+  for (int k = 0; k < 4; ++k) {
+    P.finger_status[k] = a->finger_status[k] != 0;
+    P.finger_mesh[k] = a->finger_mesh[k];
+    bool act = P.finger_status[k] != 0;
+    if (!a->finger_status[0] && (k == 0 || k == 1)) act = false;
+    if (!a->finger_status[2] && (k == 2 || k == 3)) act = false;
+    if (act && (a->finger_n[k] < 0 || (a->finger_n[k] > 0 && (!a->finger_xyz[k] || !a->finger2handbase[k])))) return HOP_E_INVALID;
+    P.finger_active[k] = act;
+    P.finger_off[k] = total;
+    if (act) total += a->finger_n[k];
+  }
+  P.finger_off[4] = total;
+  PHCHK(c, ph->fingers.buf.ensure(sizeof(float) * 3 * (size_t)std::max(total, 1)));
+  ph->fingers.n = total;
+  PHCHK(c, ph->mats.ensure(sizeof(float) * 16 * 5));
+  for (int k = 0; k < 4; ++k) {
+    if (!P.finger_active[k] || a->finger_n[k] == 0) continue;
+    const int n = a->finger_n[k];
+    int rc = upload_planes(c, ph->tmp_cloud, a->finger_xyz[k], n);
+    if (rc) return rc;
+    PHCHK(c, hipMemcpyAsync(ph->mats.as<float>() + 16 * k, a->finger2handbase[k], sizeof(float) * 16, hipMemcpyHostToDevice, st));
+    float* o = ph->fingers.buf.as<float>() + P.finger_off[k];
+    k_transform_cloud<<<(n + 255) / 256, 256, 0, st>>>(ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), n, ph->mats.as<float>() + 16 * k, o, o + total,
+                                                       o + 2 * (size_t)total);
+    PHCHK(c, hipStreamSynchronize(st));  // tmp_cloud is reused by the next finger
+  }
+  // scene without the hand: hand-base frame, then the 5 mm voxel grid (:553-557)
+  {
+    const int n = a->n_cloud_without_hand;
+    int rc = upload_planes(c, ph->tmp_cloud, a->cloud_without_hand_xyz, n);
+    if (rc) return rc;
+    PHCHK(c, ph->tmp_cloud2.buf.ensure(sizeof(float) * 3 * (size_t)std::max(n, 1)));
+    ph->tmp_cloud2.n = n;
+    PHCHK(c, hipMemcpyAsync(ph->mats.as<float>() + 64, a->cam2handbase, sizeof(float) * 16, hipMemcpyHostToDevice, st));
+    if (n > 0) {
+      float* o = ph->tmp_cloud2.buf.as<float>();
+      k_transform_cloud<<<(n + 255) / 256, 256, 0, st>>>(ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), n, ph->mats.as<float>() + 64, o, o + n,
+                                                         o + 2 * (size_t)n);
+    }
+    rc = voxel_downsample_device(c, ph, ph->tmp_cloud2.x(), ph->tmp_cloud2.y(), ph->tmp_cloud2.z(), n, a->voxel_size, ph->cwh_ds);
+    if (rc) return rc;
+  }
+  int rc = upload_planes(c, ph->hand, a->hand_cloud_xyz, a->n_hand_cloud);
+  if (rc) return rc;
+  rc = upload_planes(c, ph->model, a->model_xyz, a->n_model);
+  if (rc) return rc;
+  PHCHK(c, hipEventRecord(ph->ev[1], st));
+  PHCHK(c, hipStreamSynchronize(st));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ph->ev[0], ph->ev[1]);
+  ph->ms_frame = ms;
+  ph->have_frame = true;
+  return HOP_OK;
+}
+
+int hop_reject_by_collision(hop_ctx* c, unsigned char* keep_out, float* diag8_out, int* n_in_out) {
+  if (!c) return HOP_E_INVALID;
+  PHCHK(c, hipSetDevice(hop_ctx_device(c)));
+  Physics* ph = physics(c);
+  if (!ph->have_frame) return HOP_E_STATE;
+  hipStream_t st = hop_ctx_stream(c);
+  const HopHypView hv = hop_ctx_hyp(c);
+  const int H = hv.n;
+  if (n_in_out) *n_in_out = H;
+  if (H == 0) return HOP_OK;
+  const PhysParams& P = ph->P;
+  PHCHK(c, ph->xf.ensure(sizeof(float) * XF * (size_t)H));
+  PHCHK(c, ph->stage.ensure(sizeof(int) * (size_t)H));
+  PHCHK(c, ph->fmin.ensure(sizeof(unsigned) * 12 * (size_t)H));
+  PHCHK(c, ph->diag.ensure(sizeof(float) * 8 * (size_t)H));
+  float* xf = ph->xf.as<float>();
+  int* stage = ph->stage.as<int>();
+  unsigned* fmin = ph->fmin.as<unsigned>();
+  float* diag = ph->diag.as<float>();
+  const SdfMeshDev obj = ph->mesh[P.object_mesh].dev;
+  PHCHK(c, hipEventRecord(ph->ev[0], st));
+  k_phys_prepare<<<(H + 63) / 64, 64, 0, st>>>(hv.pose, H, P, xf, stage, fmin, diag);
+  k_phys_center<<<H, 256, 0, st>>>(obj, xf, H, P, ph->cwh_ds.x(), ph->cwh_ds.y(), ph->cwh_ds.z(), ph->cwh_ds.n, ph->hand.x(), ph->hand.y(), ph->hand.z(),
+                                   ph->hand.n, stage, diag);
+  const int nfp = P.finger_off[4];
+  if (nfp > 0)
+    k_phys_fingers<<<dim3((nfp + SDF_BLOCK - 1) / SDF_BLOCK, H), SDF_BLOCK, 0, st>>>(obj, xf, P, ph->fingers.x(), ph->fingers.y(), ph->fingers.z(), stage, fmin);
+  k_phys_decide_fingers<<<(H + 63) / 64, 64, 0, st>>>(H, P, fmin, stage, diag);
+  FingerMeshes fm;
+  for (int k = 0; k < 4; ++k) fm.m[k] = ph->mesh[P.finger_mesh[k]].dev;
+  if (P.n_model > 0)
+    k_phys_model<<<dim3((P.n_model + SDF_BLOCK - 1) / SDF_BLOCK, H), SDF_BLOCK, 0, st>>>(fm, xf, P.n_model, ph->model.x(), ph->model.y(), ph->model.z(), stage,
+                                                                                         fmin);
+  k_phys_decide_model<<<(H + 63) / 64, 64, 0, st>>>(H, P, fmin, stage, diag);
+  PHCHK(c, hipGetLastError());
+  PHCHK(c, hipEventRecord(ph->ev[1], st));
+  std::vector<int> stg(H);
+  PHCHK(c, hipMemcpyAsync(stg.data(), stage, sizeof(int) * (size_t)H, hipMemcpyDeviceToHost, st));
+  if (diag8_out) PHCHK(c, hipMemcpyAsync(diag8_out, diag, sizeof(float) * 8 * (size_t)H, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipStreamSynchronize(st));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ph->ev[0], ph->ev[1]);
+  ph->ms_reject = ms;
+  // survivors keep their order (the reference's order depends on OpenMP scheduling, :730-731)
+  std::vector<int> src;
+  src.reserve(H);
+  for (int h = 0; h < H; ++h) {
+    if (keep_out) keep_out[h] = stg[h] == 0;
+    if (stg[h] == 0) src.push_back(h);
+  }
+  const int K = (int)src.size();
+  if (K < H && K > 0) {
+    PHCHK(c, ph->gather.ensure(sizeof(int) * (size_t)K));
+    PHCHK(c, ph->tmp_pose.ensure(sizeof(float) * 16 * (size_t)K));
+    PHCHK(c, ph->tmp_score.ensure(sizeof(float) * (size_t)K));
+    PHCHK(c, ph->tmp_id.ensure(sizeof(int) * (size_t)K));
+    PHCHK(c, hipMemcpyAsync(ph->gather.p, src.data(), sizeof(int) * (size_t)K, hipMemcpyHostToDevice, st));
+    k_phys_gather<<<(K * 16 + 255) / 256, 256, 0, st>>>(ph->gather.as<int>(), K, hv.pose, hv.score, hv.id, ph->tmp_pose.as<float>(), ph->tmp_score.as<float>(),
+                                                        ph->tmp_id.as<int>());
+    PHCHK(c, hipMemcpyAsync(hv.pose, ph->tmp_pose.p, sizeof(float) * 16 * (size_t)K, hipMemcpyDeviceToDevice, st));
+    PHCHK(c, hipMemcpyAsync(hv.score, ph->tmp_score.p, sizeof(float) * (size_t)K, hipMemcpyDeviceToDevice, st));
+    PHCHK(c, hipMemcpyAsync(hv.id, ph->tmp_id.p, sizeof(int) * (size_t)K, hipMemcpyDeviceToDevice, st));
+    PHCHK(c, hipStreamSynchronize(st));
+  }
+  hop_ctx_hyp_set_count(c, K);
+  return HOP_OK;
+}
+
+int hop_physics_timing(hop_ctx* c, double* ms_set_frame, double* ms_reject) {
+  if (!c) return HOP_E_INVALID;
+  Physics* ph = physics(c);
+  if (ms_set_frame) *ms_set_frame = ph->ms_frame;
+  if (ms_reject) *ms_reject = ph->ms_reject;
+  return HOP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,279 @@
+// hop_sdf.h -- triangle meshes for the physics row: what SDFchecker keeps per registered mesh
+// (SDFchecker.cpp:36-78) plus the precomputed pieces of igl::signed_distance's pseudonormal branch
+// (igl/signed_distance.cpp:88-98: per_face_normals, per_vertex_normals with angle weights, per_edge_normals with
+// uniform weights -- libigl recomputes them on every call), and a 4-wide bounding-volume tree that replaces
+// libigl's AABB tree (igl/AABB.cpp:360-452) for the closest-face search.
+//
+// Layout on the device (one registered mesh):
+//   tri   [slots][3] float4   corner A, B, C of the face in tree-leaf order; A.w = 1 when doublearea > 1e-4
+//                             (pseudonormal_test.cpp:50-62), B.w = original face index (as int bits)
+//   nrm   [slots][7] float4   face normal, the three edge pseudonormals (edge opposite corner 0,1,2), the three
+//                             vertex pseudonormals (corner 0,1,2); .w unused
+//   nodes [n_nodes]           4 children per node: boxes as SoA (lo/hi x 3 axes x 4 lanes), child index or leaf range
+//   order [2 n_faces - 1]     libigl's own AABB tree (AABB.cpp:106-200: one face per leaf), boxes and parent links only
+//   face_leaf [n_faces]       the leaf of `order` that holds each face
+// A query evaluates, for every face whose box lower bound does not exceed the best squared distance so far (plus the
+// float error of that expression), exactly the float expression of igl/point_simplex_squared_distance.cpp:43-113 and
+// keeps the minimum.  Faces at exactly the same float distance (a closest point on a shared edge or vertex: 20-30 % of
+// all queries) are ordered as libigl's depth-first walk would meet them (AABB.cpp:391-449) -- it reports the first --
+// by looking at the two children of their lowest common ancestor in `order`: the choice matters because the sign test
+// of pseudonormal_test.cpp falls back to that face's normal.
+#ifndef HOP_SDF_H_
+#define HOP_SDF_H_
+
+#include "hop_math.h"
+
+#include <stdint.h>
+
+namespace hop {
+
+constexpr int SDF_LEAF = 4;       // faces per leaf
+constexpr int SDF_STACK = 32;     // traversal stack entries per thread: a 4-wide tree of depth D needs at most 3 D + 1 (the build checks it)
+
+struct SdfNode {
+  float lo[3][4];
+  float hi[3][4];
+  int child[4];            // >= 0: inner node; < 0: leaf, first slot = -(child + 1); empty child: count 0 and lo = +inf
+  unsigned char count[4];  // faces of a leaf child (0 for inner / empty)
+  int pad[3];
+};
+static_assert(sizeof(SdfNode) == 128, "one node is one 128-byte line");
+
+struct SdfOrderNode {
+  float lo[3];
+  int parent;  // -1 for the root
+  float hi[3];
+  int info;    // depth << 1 | (1 when this node is the left child)
+};
+static_assert(sizeof(SdfOrderNode) == 32, "two nodes per 64 bytes");
+
+struct SdfMeshDev {
+  const float4* tri;
+  const float4* nrm;
+  const SdfNode* nodes;
+  const SdfOrderNode* order;
+  const int* face_leaf;
+  int n_faces, n_nodes;
+  float coord_eps;  // 4e-7 * largest |coordinate| of the mesh: float error scale of a closest point
+};
+
+#if defined(__HIPCC__)
+// ---------------------------------------------------------------------------------------------- device side
+// Ericson's closest point on a triangle, the float expression of point_simplex_squared_distance.cpp:43-113.
+__device__ __forceinline__ V3 sdf_closest_point(V3 p, V3 a, V3 b, V3 c) {
+  const V3 ab = b - a, ac = c - a, ap = p - a;
+  const float d1 = vdot(ab, ap), d2 = vdot(ac, ap);
+  if (d1 <= 0.0f && d2 <= 0.0f) return a;
+  const V3 bp = p - b;
+  const float d3 = vdot(ab, bp), d4 = vdot(ac, bp);
+  if (d3 >= 0.0f && d4 <= d3) return b;
+  const float vc = d1 * d4 - d3 * d2;
+  if (!(a.x == b.x && a.y == b.y && a.z == b.z)) {
+    if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+      const float v = d1 / (d1 - d3);
+      return a + v * ab;
+    }
+  }
+  const V3 cp = p - c;
+  const float d5 = vdot(ab, cp), d6 = vdot(ac, cp);
+  if (d6 >= 0.0f && d5 <= d6) return c;
+  const float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+    const float w = d2 / (d2 - d6);
+    return a + w * ac;
+  }
+  const float va = d3 * d6 - d5 * d4;
+  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
+    const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    return b + w * (c - b);
+  }
+  const float denom = (float)(1.0 / (double)((va + vb) + vc));  // `Scalar denom = 1.0 / (va + vb + vc)`
+  const float v = vb * denom;
+  const float w = vc * denom;
+  return (a + ab * v) + ac * w;
+}
+
+// doublearea.cpp:75-109,144-199: Kahan's Heron formula on the sorted float edge lengths, in double
+HOP_HD double sdf_doublearea(V3 A, V3 B, V3 C) {
+  double l0 = (double)vnorm(B - C), l1 = (double)vnorm(C - A), l2 = (double)vnorm(A - B), t;
+  if (l0 < l1) t = l0, l0 = l1, l1 = t;
+  if (l1 < l2) t = l1, l1 = l2, l2 = t;
+  if (l0 < l1) t = l0, l0 = l1, l1 = t;
+  const double arg = (l0 + (l1 + l2)) * (l2 - (l0 - l1)) * (l2 + (l0 - l1)) * (l0 + (l1 - l2));
+  return 2.0 * 0.25 * sqrt(arg);
+}
+
+// pseudonormal_test.cpp:24-128 for the face in `slot` with closest point c; returns +1 / -1
+__device__ inline float sdf_sign(const SdfMeshDev& m, int slot, V3 q, V3 c) {
+  const float4 A4 = m.tri[3 * slot], B4 = m.tri[3 * slot + 1], C4 = m.tri[3 * slot + 2];
+  const V3 A = v3(A4.x, A4.y, A4.z), B = v3(B4.x, B4.y, B4.z), C = v3(C4.x, C4.y, C4.z);
+  const float4* N = m.nrm + 7 * (size_t)slot;
+  int pick = 0;  // 0 face, 1..3 edge opposite corner pick-1, 4..6 vertex pick-4
+  const float epsf = (float)1e-12;
+  if (A4.w != 0.f) {
+    // barycentric_coordinates.cpp:88-100
+    const V3 v0 = B - A, v1 = C - A, v2 = c - A;
+    const float d00 = vdot(v0, v0), d01 = vdot(v0, v1), d11 = vdot(v1, v1), d20 = vdot(v2, v0), d21 = vdot(v2, v1);
+    const float denom = d00 * d11 - d01 * d01;
+    float b[3];
+    b[1] = (d11 * d20 - d01 * d21) / denom;
+    b[2] = (d00 * d21 - d01 * d20) / denom;
+    b[0] = 1.0f - (b[1] + b[2]);
+    const int type = (b[0] <= epsf) + (b[1] <= epsf) + (b[2] <= epsf);
+    if (type == 2) {
+      pick = b[0] > epsf ? 4 : (b[1] > epsf ? 5 : (b[2] > epsf ? 6 : 0));
+    } else if (type == 1) {
+      pick = b[0] <= epsf ? 1 : (b[1] <= epsf ? 2 : 3);
+    }
+  } else {
+    const V3 P[3] = {A, B, C};
+    bool found = false;
+    for (int v = 0; v < 3 && !found; ++v)
+      if ((double)vnorm(c - P[v]) < 1e-12) found = true, pick = 4 + v;
+    for (int e = 0; e < 3 && !found; ++e) {
+      // project_to_line.cpp:36-55, project_to_line_segment.cpp:27-42 (t, sqrD double; vectors float)
+      const V3 s = P[(e + 1) % 3], d = P[(e + 2) % 3];
+      const V3 DmS = d - s;
+      const double v_sqrlen = (double)vsqn(DmS);
+      const V3 SmP = s - c;
+      const float px = DmS.x * SmP.x, py = DmS.y * SmP.y, pz = DmS.z * SmP.z;
+      const double t = (double)(-(px + (py + pz))) / v_sqrlen;
+      const V3 projP = ((float)(1 - t)) * s + ((float)t) * d;
+      double sqrD = (double)vsqn(c - projP);
+      if (t < 0)
+        sqrD = (double)vsqn(c - s);
+      else if (t > 1)
+        sqrD = (double)vsqn(c - d);
+      if (sqrt(sqrD) < 1e-12) found = true, pick = 1 + e;
+    }
+  }
+  const float4 n = N[pick];
+  return vdot(q - c, v3(n.x, n.y, n.z)) >= 0 ? 1.f : -1.f;
+}
+
+// Eigen::AlignedBox::contains / squaredExteriorDistance as AABB.cpp:413-426 evaluates them
+__device__ __forceinline__ bool sdf_box_contains(const SdfOrderNode& n, V3 p) {
+  return n.lo[0] <= p.x && n.lo[1] <= p.y && n.lo[2] <= p.z && p.x <= n.hi[0] && p.y <= n.hi[1] && p.z <= n.hi[2];
+}
+__device__ __forceinline__ float sdf_box_ext(const SdfOrderNode& n, V3 p) {
+  float d2 = 0.f;
+  const float pv[3] = {p.x, p.y, p.z};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (n.lo[k] > pv[k]) {
+      const float a = n.lo[k] - pv[k];
+      d2 += a * a;
+    } else if (pv[k] > n.hi[k]) {
+      const float a = pv[k] - n.hi[k];
+      d2 += a * a;
+    }
+  }
+  return d2;
+}
+// true when libigl's walk for query p reaches face f before face g (f != g)
+__device__ inline bool sdf_precedes(const SdfMeshDev& m, V3 p, int f, int g) {
+  int a = m.face_leaf[f], b = m.face_leaf[g];
+  int da = m.order[a].info >> 1, db = m.order[b].info >> 1;
+  while (da > db) a = m.order[a].parent, --da;
+  while (db > da) b = m.order[b].parent, --db;
+  while (m.order[a].parent != m.order[b].parent) a = m.order[a].parent, b = m.order[b].parent;
+  const bool a_left = (m.order[a].info & 1) != 0;
+  const SdfOrderNode L = m.order[a_left ? a : b], R = m.order[a_left ? b : a];
+  bool left_first;
+  if (sdf_box_contains(L, p)) left_first = true;
+  else if (sdf_box_contains(R, p)) left_first = false;
+  else left_first = sdf_box_ext(L, p) < sdf_box_ext(R, p);
+  return left_first == a_left;
+}
+
+struct SdfHit {
+  float sqr_d;
+  int slot;  // -1: no face (empty mesh)
+  int face;
+  V3 c;
+};
+
+// exact closest face (see the header comment).  `stack`: SDF_STACK entries of this thread's own storage, entry k at
+// stack[k * stride] (LDS, lane-interleaved so that equal depths of a wavefront fall into different banks).  An entry
+// packs the node index (low 20 bits) with the top 12 bits of the node's lower bound (rounded towards zero, i.e. still a
+// lower bound).
+constexpr int SDF_NODE_BITS = 20;
+__device__ __forceinline__ unsigned sdf_pack(float lb, int node) {
+  return (__float_as_uint(lb) & ~((1u << SDF_NODE_BITS) - 1u)) | (unsigned)node;
+}
+__device__ inline SdfHit sdf_closest_face(const SdfMeshDev& m, V3 q, unsigned* stack, int stride) {
+  SdfHit h;
+  h.sqr_d = __builtin_inff(), h.slot = -1, h.face = 0x7fffffff, h.c = v3(0, 0, 0);
+  if (m.n_faces <= 0) return h;
+  float thr = __builtin_inff();  // prune bound: best + float slack of the triangle expression
+  const float de = m.coord_eps + 4e-7f * fmaxf(fabsf(q.x), fmaxf(fabsf(q.y), fabsf(q.z)));
+  int sp = 0;
+  stack[(sp++) * stride] = sdf_pack(0.f, 0);
+  while (sp > 0) {
+    const unsigned e = stack[(--sp) * stride];
+    if (__uint_as_float(e & ~((1u << SDF_NODE_BITS) - 1u)) > thr) continue;
+    const SdfNode& nd = m.nodes[e & ((1u << SDF_NODE_BITS) - 1u)];
+    float lb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dx = fmaxf(fmaxf(nd.lo[0][k] - q.x, q.x - nd.hi[0][k]), 0.f);
+      const float dy = fmaxf(fmaxf(nd.lo[1][k] - q.y, q.y - nd.hi[1][k]), 0.f);
+      const float dz = fmaxf(fmaxf(nd.lo[2][k] - q.z, q.z - nd.hi[2][k]), 0.f);
+      lb[k] = dx * dx + dy * dy + dz * dz;  // +inf for an empty child (lo = +inf)
+    }
+    // leaves first (they tighten the bound)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cnt = nd.count[k];
+      if (cnt == 0 || !(lb[k] <= thr)) continue;
+      const int first = -(nd.child[k] + 1);
+      for (int s = first; s < first + cnt; ++s) {
+        const float4 A4 = m.tri[3 * s], B4 = m.tri[3 * s + 1], C4 = m.tri[3 * s + 2];
+        const V3 c = sdf_closest_point(q, v3(A4.x, A4.y, A4.z), v3(B4.x, B4.y, B4.z), v3(C4.x, C4.y, C4.z));
+        const float d = vsqn(q - c);
+        const int face = __float_as_int(B4.w);
+        if (d < h.sqr_d || (d == h.sqr_d && sdf_precedes(m, q, face, h.face))) {
+          h.sqr_d = d, h.slot = s, h.face = face, h.c = c;
+          thr = d + (2.f * sqrtf(d) * de + de * de) + d * 1e-5f;
+        }
+      }
+    }
+    // inner children that can still matter, pushed farthest first so that the nearest is popped first
+    // (5-exchange sorting network on registers; key -1 marks a child that is not pushed)
+    float k0 = (nd.count[0] == 0 && nd.child[0] >= 0 && lb[0] <= thr) ? lb[0] : -1.f;
+    float k1 = (nd.count[1] == 0 && nd.child[1] >= 0 && lb[1] <= thr) ? lb[1] : -1.f;
+    float k2 = (nd.count[2] == 0 && nd.child[2] >= 0 && lb[2] <= thr) ? lb[2] : -1.f;
+    float k3 = (nd.count[3] == 0 && nd.child[3] >= 0 && lb[3] <= thr) ? lb[3] : -1.f;
+    int c0 = nd.child[0], c1 = nd.child[1], c2 = nd.child[2], c3 = nd.child[3];
+#define SDF_CX(ka, ca, kb, cb)      \
+  if (ka < kb) {                    \
+    const float tk = ka;            \
+    ka = kb, kb = tk;               \
+    const int tc = ca;              \
+    ca = cb, cb = tc;               \
+  }
+    SDF_CX(k0, c0, k1, c1) SDF_CX(k2, c2, k3, c3) SDF_CX(k0, c0, k2, c2) SDF_CX(k1, c1, k3, c3) SDF_CX(k1, c1, k2, c2)
+#undef SDF_CX
+    if (k0 >= 0.f) stack[(sp++) * stride] = sdf_pack(k0, c0);
+    if (k1 >= 0.f) stack[(sp++) * stride] = sdf_pack(k1, c1);
+    if (k2 >= 0.f) stack[(sp++) * stride] = sdf_pack(k2, c2);
+    if (k3 >= 0.f) stack[(sp++) * stride] = sdf_pack(k3, c3);
+  }
+  return h;
+}
+
+// igl::signed_distance for one point with the bounds SDFchecker passes (lower = -FLT_MAX, upper = FLT_MAX:
+// up_sqr_d = +inf, low_sqr_d = 0, signed_distance.cpp:117-156): NaN for a point at distance zero.
+__device__ inline float sdf_signed_distance(const SdfMeshDev& m, V3 q, unsigned* stack, int stride, int* face_out) {
+  const SdfHit h = sdf_closest_face(m, q, stack, stride);
+  if (h.slot < 0 || !(h.sqr_d > 0.f) || !(h.sqr_d < __builtin_inff())) {
+    if (face_out) *face_out = m.n_faces + 1;
+    return __builtin_nanf("");
+  }
+  if (face_out) *face_out = h.face;
+  return sdf_sign(m, h.slot, q, h.c) * sqrtf(h.sqr_d);
+}
+#endif  // __HIPCC__
+
+}  // namespace hop
+#endif  // HOP_SDF_H_

@@ -14,6 +14,8 @@ needs them is run on the stand-ins built here:
   at 5 mm), each rotating about its local x axis, with the reference's link names.
 * ``ellipsoid_mesh`` / ``box_mesh`` / ``torus_mesh`` / ``lshape_mesh`` -- closed, outward-oriented triangle
   meshes (row N1: the object mesh and the finger links' convex meshes the reference loads from OBJ files).
+* ``physics_case``     -- row N1: a grasp of the ellipsoid by the stand-in hand with every input of
+  ``rejectByCollisionOrNonTouching`` and hypotheses that exercise each of its checks.
 * ``replay_poses``     -- ground truth composed with bounded perturbations (rot <= 30 deg,
   trans <= 15 mm) so that scoring kernels can be timed independently of the generator.
 
@@ -472,3 +474,64 @@ def make_hand_scene(hand: HandModel, true_angles: dict, n_points: int, seed: int
     nn = np.concatenate([nrm, on.astype(np.float64)]).astype(np.float32)
     order = rng.permutation(len(xyz))
     return np.ascontiguousarray(xyz[order]), np.ascontiguousarray(nn[order])
+
+
+# --------------------------------------------------------------------------- row N1: physics rejection
+FINGER_ORDER = ("finger_1_1", "finger_1_2", "finger_2_1", "finger_2_2")
+
+
+def physics_case(n_hyp: int = 64, seed: int = 3, n_model: int = 400, n_scene: int = 3000, mesh_subdiv: int = 2,
+                 finger_status=(1, 1, 1, 1), spacing=0.005):
+    """Inputs of PoseEstimator::rejectByCollisionOrNonTouching (PoseEstimator.cpp:524-735) for a synthetic grasp.
+
+    The ellipsoid sits between the two fingers of the stand-in hand (its 40 mm semi-axis across the 68 mm gap, so the
+    true pose touches both sides); the hypotheses are the true pose under perturbations of growing size plus a few
+    targeted ones (pushed into a finger, pulled out of the hand, shifted along the fingers).
+    Returns (p, poses): ``p`` is the dict ``Context.physics_set_frame`` / ``orc.physics_args`` take (the meshes are
+    given both as arrays for the oracle and, under ``meshes``, as (id, V, F, pose) tuples to register)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    hand = t42_hand(spacing)
+    angles = {"finger_1_1": 0.0, "finger_1_2": 0.0, "finger_2_1": 0.0, "finger_2_2": 0.0}
+    Rc = rot_from_axis_angle([1.0, 0.2, -0.1], 2.6)
+    handbase_in_cam = se3(Rc, [0.03, -0.02, 0.55])
+    R_obj = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], dtype=np.float64)  # model x (40 mm) -> hand y
+    obj_in_hand = se3(R_obj, [-0.150, 0.0, 0.0])
+    gt = handbase_in_cam @ obj_in_hand
+    mx, mn_ = ellipsoid_model(n_model)
+    V, F = ellipsoid_mesh(subdiv=mesh_subdiv)
+    ext = mx.max(0) - mx.min(0)
+    # scene without the hand (camera frame): the camera-facing part of the object plus clutter behind it
+    sx, sn = ellipsoid_model(n_scene * 2)
+    sw, nw = apply(gt, sx).astype(np.float64), rotate(gt, sn).astype(np.float64)
+    vis = np.einsum("ij,ij->i", nw, sw / np.linalg.norm(sw, axis=1, keepdims=True)) < -0.05
+    obj_pts = sw[vis][: int(n_scene * 0.8)] + rng.normal(scale=0.0004, size=(min(int(n_scene * 0.8), int(vis.sum())), 3))
+    clutter = gt[:3, 3] + rng.normal(scale=0.12, size=(n_scene - len(obj_pts), 3)) + np.array([0, 0, 0.15])
+    cloud_without_hand = np.concatenate([obj_pts, clutter]).astype(np.float32)
+    cloud_without_hand = np.ascontiguousarray(cloud_without_hand[rng.permutation(len(cloud_without_hand))])
+    f2h = [hand_fk(hand, angles, name).astype(np.float32) for name in FINGER_ORDER]
+    hand_cloud = np.concatenate([apply(hand_fk(hand, angles, name) if name != "base_link" else np.eye(4), hand.clouds[name][0])
+                                 for name in ("base_link",) + FINGER_ORDER]).astype(np.float32)
+    # hypotheses
+    poses = list(replay_poses(gt, max(n_hyp - 8, 0), seed=seed + 1, max_rot_deg=25.0, max_trans=0.02))
+
+    def moved(dx, dy, dz):
+        return handbase_in_cam @ se3(np.eye(3), [dx, dy, dz]) @ obj_in_hand
+
+    poses += [gt, moved(0, 0.030, 0), moved(0, -0.028, 0), moved(-0.12, 0, 0), moved(0.02, 0, 0.05), moved(0.06, 0.0, 0.0),
+              moved(0, 0, -0.012), moved(-0.02, 0.004, 0.0)]
+    poses = np.ascontiguousarray(np.asarray(poses[-n_hyp:] if n_hyp < len(poses) else poses, dtype=np.float32))
+    p = dict(
+        object_V=V, object_F=F,
+        finger_V=[hand.meshes[n][0] for n in FINGER_ORDER], finger_F=[hand.meshes[n][1] for n in FINGER_ORDER],
+        finger_mesh_pose=f2h,
+        finger_xyz=[hand.clouds[n][0] for n in FINGER_ORDER], finger2handbase=f2h, finger_status=list(finger_status),
+        hand_cloud=hand_cloud, cloud_without_hand=cloud_without_hand,
+        cam2handbase=np.linalg.inv(handbase_in_cam).astype(np.float32),
+        model=mx, model_center_init=mx.mean(0).astype(np.float32),
+        smallest_dim=float(ext.min()), ob_diameter=float(np.linalg.norm(ext)),
+        collision_thres=0.4, non_touch_dist=0.01, collision_finger_dist=0.012, collision_finger_volume_ratio=0.25,  # config_autodataset.yaml:128-131
+        voxel_size=0.005,
+        object_mesh=0, finger_mesh=[1, 2, 3, 4],
+    )
+    p["meshes"] = [(0, V, F, None)] + [(1 + k, p["finger_V"][k], p["finger_F"][k], f2h[k]) for k in range(4)]
+    return p, poses

@@ -240,6 +240,60 @@ int hop_hand_remove_surrounding(hop_ctx* ctx, const float* scene_xyz, const floa
 int hop_model_ppf_keys(hop_ctx* ctx, const float* xyz, const float* nrm, int n, int32_t* keys4_out, int cap, int* n_keys);
 
 /* ------------------------------------------------------------------------------------------------
+ * "Next" row N1: physics rejection.
+ *   SDFchecker::registerMesh            src/perception/src/SDFchecker.cpp:36-78    -> hop_sdf_register_mesh
+ *   SDFchecker::getSignedDistanceMinMaxWithRegistered   SDFchecker.cpp:115-134      -> hop_sdf_signed_distance
+ *     (igl::signed_distance, SIGNED_DISTANCE_TYPE_PSEUDONORMAL, float, bounds -FLT_MAX / FLT_MAX as every call site
+ *      passes them: a point at distance exactly 0 yields NaN, include/igl/signed_distance.cpp:117-156)
+ *   Utils::downsamplePointCloud (pcl::VoxelGrid, xyz)   src/perception/src/Utils.cpp:334-340 -> hop_voxel_downsample
+ *   PoseEstimator::registerHandMesh / rejectByCollisionOrNonTouching   PoseEstimator.cpp:503-520, 524-735
+ *                                                                       -> hop_physics_set_frame + hop_reject_by_collision
+ * Meshes: V is nv x 3 row-major, F is nf x 3 vertex indices (triangles); pose16 (row-major, may be NULL) is applied to
+ * the vertices at registration as the reference does.  Registration prepares libigl's face / edge / vertex
+ * pseudonormals and a box tree on the host (the counterpart of loading the OBJ file); every query runs on the GPU.
+ * Clouds are SoA planes (x plane, y plane, z plane of n floats) like everywhere in this header.
+ * ---------------------------------------------------------------------------------------------- */
+#define HOP_SDF_MAX_MESHES 16
+int hop_sdf_register_mesh(hop_ctx* ctx, int mesh_id, const float* V, int nv, const int32_t* F, int nf, const float* pose16);
+/* dists[n] (NaN for points on the surface); faces[n] (may be NULL): closest face, nf + 1 where dists is NaN;
+ * *min_dist / *max_dist: S.minCoeff() / S.maxCoeff() over the non-NaN entries (FLT_MAX / -FLT_MAX when n == 0). */
+int hop_sdf_signed_distance(hop_ctx* ctx, int mesh_id, const float* pts_xyz, int n, float* dists, int32_t* faces, float* min_dist,
+                            float* max_dist);
+/* out_xyz: SoA planes with plane stride cap; centroids in ascending voxel-index order (x fastest), as pcl::VoxelGrid
+ * emits them.  HOP_E_CAPACITY when *n_out > cap or when the grid would overflow an int (PCL warns and gives up there). */
+int hop_voxel_downsample(hop_ctx* ctx, const float* xyz, int n, float leaf, float* out_xyz, int cap, int* n_out);
+typedef struct {
+  int object_mesh;    /* registered at identity: est.registerMesh(object_mesh_path, "object", I), main_realdata_auto.cpp:187 */
+  int finger_mesh[4]; /* registered at getTFHandBase(link); order finger_1_1, finger_1_2, finger_2_1, finger_2_2 */
+  /* hand->_clouds[finger] (link frame), getTFHandBase(finger), hand->_component_status[finger] */
+  const float* finger_xyz[4];
+  int finger_n[4];
+  const float* finger2handbase[4]; /* row-major 4x4 */
+  int finger_status[4];
+  const float* hand_cloud_xyz; /* hand->_hand_cloud, hand-base frame */
+  int n_hand_cloud;
+  const float* cloud_without_hand_xyz; /* _cloud_withouthand_raw, camera frame */
+  int n_cloud_without_hand;
+  float cam2handbase[16]; /* hand->_handbase_in_cam.inverse(), row-major */
+  const float* model_xyz; /* _model */
+  int n_model;
+  float model_center_init[3], smallest_dim, ob_diameter; /* PoseEstimator.cpp:12-20 */
+  float collision_thres, non_touch_dist, collision_finger_dist, collision_finger_volume_ratio; /* config_autodataset.yaml:128-131 */
+  float voxel_size; /* 0.005, PoseEstimator.cpp:556 */
+} hop_physics_args;
+/* per-frame inputs of rejectByCollisionOrNonTouching: uploads the clouds, moves the finger clouds and the scene into
+ * the hand-base frame, applies the voxel grid */
+int hop_physics_set_frame(hop_ctx* ctx, const hop_physics_args* args);
+/* filters the resident hypothesis set (hop_hypos_*) in place; survivors keep their relative order.  keep_out[H] and
+ * diag8_out[H x 8] (both may be NULL) describe the incoming set of *n_in hypotheses: diag = {deciding check (0 kept,
+ * 1 scene point inside the object, 2 hand point colliding, 3 finger cloud colliding, 4 one side not touching,
+ * 5 object inside a finger), the two single-point distances, the minimum distance of each finger cloud, the smallest
+ * object-to-finger-mesh minimum}; entries of checks that did not run are NaN. */
+int hop_reject_by_collision(hop_ctx* ctx, unsigned char* keep_out, float* diag8_out, int* n_in);
+/* device time (HIP events on the ctx stream) of the last hop_physics_set_frame / hop_reject_by_collision, in ms */
+int hop_physics_timing(hop_ctx* ctx, double* ms_set_frame, double* ms_reject);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): device time in ms of the kernels launched by the last call of the
  * named stage, measured with HIP events on the ctx stream; and launch counts.
  * ---------------------------------------------------------------------------------------------- */

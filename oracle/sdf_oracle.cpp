@@ -11,8 +11,11 @@
 //
 // Pinning: orc_sdf_signed_distance is checked against oracle/_ref/libref_sdf.so -- the reference's own libigl compiled
 // in place (oracle/ref_sdf_driver.cpp) -- by tests/test_sdf_oracle.py and the vectors of tests/golden/sdf_*.npz.
-// The closest face is found by an exhaustive scan (lowest face index on exactly equal squared distances) where libigl
-// walks an AABB tree (AABB.cpp:360-452, first-visited face on ties); distances are the same float expression.
+// The closest face is found the way libigl finds it: its AABB tree (AABB.cpp:73-200: one face per leaf, median split of
+// the barycentre ranks along the longest box axis) walked depth first (AABB.cpp:360-452: a child that contains the query
+// first, otherwise the one with the smaller exterior distance; strict improvements only), because which of several
+// faces at exactly the same float distance is reported -- and with it, for queries next to a face plane, the sign --
+// depends on that order.  Signed distance AND face index are equal to libigl's on the golden vectors.
 //
 // Plain IEEE float arithmetic, -ffp-contract=off; 3-element Eigen reductions are c0+(c1+c2) (Redux.h:91-105).
 #include "hop_oracle.h"
@@ -78,12 +81,79 @@ F3 closest_point_triangle(F3 p, F3 a, F3 b, F3 c) {
   return (a + ab * v) + ac * w;
 }
 
+struct TreeNode {
+  F3 lo, hi;
+  int left = -1, right = -1, prim = -1;
+};
 struct Mesh {
   int nv = 0, nf = 0;
   std::vector<F3> V, FN, VN, EN;
   std::vector<int> F;     // nf x 3
   std::vector<int> EMAP;  // 3*nf: EMAP[c*nf + f] = unique edge of the directed edge opposite corner c of face f
+  std::vector<TreeNode> tree;  // igl::AABB, root = 0
 };
+
+// igl::AABB<DerivedV,3>::init(V, Ele, SI, I) (AABB.cpp:106-200)
+int tree_init(Mesh& m, const std::vector<int>& SI, const std::vector<int>& I) {
+  const int idx = (int)m.tree.size();
+  m.tree.emplace_back();
+  F3 lo = f3(FLT_MAX, FLT_MAX, FLT_MAX), hi = f3(-FLT_MAX, -FLT_MAX, -FLT_MAX);  // AlignedBox::setEmpty
+  for (int f : I)
+    for (int c = 0; c < 3; ++c) {
+      const F3 v = m.V[m.F[3 * f + c]];
+      lo = f3(std::min(lo.x, v.x), std::min(lo.y, v.y), std::min(lo.z, v.z));
+      hi = f3(std::max(hi.x, v.x), std::max(hi.y, v.y), std::max(hi.z, v.z));
+    }
+  m.tree[idx].lo = lo, m.tree[idx].hi = hi;
+  if (I.size() == 1) {
+    m.tree[idx].prim = I[0];
+    return idx;
+  }
+  const float diag[3] = {hi.x - lo.x, hi.y - lo.y, hi.z - lo.z};
+  int max_d = 0;  // maxCoeff(&max_d): the first of equal maxima
+  for (int d = 1; d < 3; ++d)
+    if (diag[d] > diag[max_d]) max_d = d;
+  std::vector<int> r(I.size());
+  for (size_t i = 0; i < I.size(); ++i) r[i] = SI[3 * (size_t)I[i] + max_d];
+  std::vector<int> tmp = r;
+  const size_t n = (tmp.size() - 1) / 2;
+  std::nth_element(tmp.begin(), tmp.begin() + n, tmp.end());
+  const int med = tmp[n];
+  std::vector<int> LI, RI;
+  for (size_t i = 0; i < I.size(); ++i) (r[i] <= med ? LI : RI).push_back(I[i]);
+  if (!LI.empty()) {
+    const int l = tree_init(m, SI, LI);
+    m.tree[idx].left = l;
+  }
+  if (!RI.empty()) {
+    const int rr = tree_init(m, SI, RI);
+    m.tree[idx].right = rr;
+  }
+  return idx;
+}
+
+// AABB.cpp:73-101: barycentres (barycenter.cpp:15-33), per-axis ranks by igl::sort (sort.cpp:287-316: std::sort of an
+// index map with IndexLessThan)
+void tree_build(Mesh& m) {
+  m.tree.clear();
+  if (m.nf == 0) return;
+  std::vector<int> SI(3 * (size_t)m.nf);
+  for (int d = 0; d < 3; ++d) {
+    std::vector<float> data(m.nf);
+    for (int f = 0; f < m.nf; ++f) {
+      const F3 a = m.V[m.F[3 * f]], b = m.V[m.F[3 * f + 1]], c = m.V[m.F[3 * f + 2]];
+      const F3 bc = f3(((a.x + b.x) + c.x) / 3.0f, ((a.y + b.y) + c.y) / 3.0f, ((a.z + b.z) + c.z) / 3.0f);
+      data[f] = d == 0 ? bc.x : (d == 1 ? bc.y : bc.z);
+    }
+    std::vector<size_t> index_map(m.nf);
+    for (int f = 0; f < m.nf; ++f) index_map[f] = f;
+    std::sort(index_map.begin(), index_map.end(), [&data](size_t a, size_t b) { return data[a] < data[b]; });
+    for (int i = 0; i < m.nf; ++i) SI[3 * index_map[i] + d] = i;
+  }
+  std::vector<int> all(m.nf);
+  for (int f = 0; f < m.nf; ++f) all[f] = f;
+  tree_init(m, SI, all);
+}
 
 void mesh_normals(Mesh& m) {
   const int nf = m.nf, nv = m.nv;
@@ -142,6 +212,7 @@ void mesh_normals(Mesh& m) {
       F3& n = m.EN[m.EMAP[(size_t)c * nf + f]];
       n = n + m.FN[f];
     }
+  tree_build(m);
 }
 
 // doublearea.cpp:75-109 (three row vectors, double output) -> :144-199 (Kahan's Heron formula on sorted lengths)
@@ -218,16 +289,62 @@ float pseudonormal_sign(const Mesh& m, F3 q, int f, F3 c) {
   return dot3(q - c, n) >= 0 ? 1.f : -1.f;
 }
 
+// Eigen::AlignedBox::contains / squaredExteriorDistance (Geometry/AlignedBox.h)
+inline bool box_contains(const TreeNode& n, F3 p) {
+  return n.lo.x <= p.x && n.lo.y <= p.y && n.lo.z <= p.z && p.x <= n.hi.x && p.y <= n.hi.y && p.z <= n.hi.z;
+}
+inline float box_ext_sqdist(const TreeNode& n, F3 p) {
+  float dist2 = 0.f;
+  const float pv[3] = {p.x, p.y, p.z}, lo[3] = {n.lo.x, n.lo.y, n.lo.z}, hi[3] = {n.hi.x, n.hi.y, n.hi.z};
+  for (int k = 0; k < 3; ++k) {
+    if (lo[k] > pv[k]) {
+      const float aux = lo[k] - pv[k];
+      dist2 += aux * aux;
+    } else if (pv[k] > hi[k]) {
+      const float aux = pv[k] - hi[k];
+      dist2 += aux * aux;
+    }
+  }
+  return dist2;
+}
+// igl::AABB::squared_distance (AABB.cpp:360-452) with leaf_squared_distance / set_min (:768-833)
+void tree_squared_distance(const Mesh& m, int node, F3 p, float low_sqr_d, float& sqr_d, int& i, F3& c) {
+  const TreeNode& nd = m.tree[node];
+  if (nd.prim >= 0) {
+    if (low_sqr_d > sqr_d) {
+      sqr_d = low_sqr_d;
+      return;
+    }
+    const int f = nd.prim;
+    const F3 cc = closest_point_triangle(p, m.V[m.F[3 * f]], m.V[m.F[3 * f + 1]], m.V[m.F[3 * f + 2]]);
+    const float d = sqn3(p - cc);
+    if (d < sqr_d) sqr_d = d, i = f, c = cc;
+    return;
+  }
+  bool looked_left = false, looked_right = false;
+  auto look = [&](int child, bool& flag) {
+    // the child starts from the current bound and reports an improvement only (set_min is a strict comparison)
+    tree_squared_distance(m, child, p, low_sqr_d, sqr_d, i, c);
+    flag = true;
+  };
+  if (box_contains(m.tree[nd.left], p)) look(nd.left, looked_left);
+  if (box_contains(m.tree[nd.right], p)) look(nd.right, looked_right);
+  const float l = box_ext_sqdist(m.tree[nd.left], p), r = box_ext_sqdist(m.tree[nd.right], p);
+  if (l < r) {
+    if (!looked_left && l < sqr_d) look(nd.left, looked_left);
+    if (!looked_right && r < sqr_d) look(nd.right, looked_right);
+  } else {
+    if (!looked_right && r < sqr_d) look(nd.right, looked_right);
+    if (!looked_left && l < sqr_d) look(nd.left, looked_left);
+  }
+}
+
 // signed_distance.cpp:125-206 for one query point
 float signed_distance_point(const Mesh& m, F3 q, float low_sqr_d, float up_sqr_d, int* face_out, F3* c_out) {
   float best = up_sqr_d;  // AABB.cpp:379: sqr_d starts at up_sqr_d, strictly smaller candidates replace it
   int bi = -1;
   F3 bc = f3(0, 0, 0);
-  for (int f = 0; f < m.nf; ++f) {
-    const F3 c = closest_point_triangle(q, m.V[m.F[3 * f]], m.V[m.F[3 * f + 1]], m.V[m.F[3 * f + 2]]);
-    const float d = sqn3(q - c);
-    if (d < best) best = d, bi = f, bc = c;
-  }
+  if (m.nf > 0 && !(low_sqr_d > up_sqr_d)) tree_squared_distance(m, 0, q, low_sqr_d, best, bi, bc);
   if (face_out) *face_out = bi;
   if (c_out) *c_out = bc;
   if (best >= up_sqr_d || best <= low_sqr_d || bi < 0) {

@@ -1,0 +1,197 @@
+"""GPU parity of the physics row through the C-ABI: signed distances against the vectors the
+reference's own libigl produced and against the oracle, the voxel grid, and the collision / non-touching decision chain
+of PoseEstimator::rejectByCollisionOrNonTouching.  Run with `pytest -m gpu` on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+MESHES = ("ellipsoid", "box", "torus", "lshape")
+
+
+@pytest.fixture(scope="module")
+def api(hop):
+    from hop_amd import api as _api
+    _api.lib()  # raises if libhop.so is missing: no fallback
+    return _api
+
+
+@pytest.fixture(scope="module")
+def ctx(api):
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def synth(hop):
+    return hop.synth
+
+
+# ------------------------------------------------------------------------------------------------ signed distance
+@pytest.mark.parametrize("name", MESHES)
+def test_sdf_bit_equal_to_libigl_golden(ctx, golden_dir, name):
+    """Same frame: distance, sign and reported face equal libigl's (tests/golden/sdf_igl.npz) bit for bit."""
+    g = np.load(os.path.join(golden_dir, "sdf_igl.npz"))
+    ctx.sdf_register_mesh(5, g[f"{name}_V"], g[f"{name}_F"])
+    d, f, mn, mx = ctx.sdf_signed_distance(5, g[f"{name}_P"])
+    S = g[f"{name}_S"]
+    assert np.array_equal(d.view(np.int32), S.view(np.int32))
+    assert np.array_equal(f, g[f"{name}_I"])
+    assert mn == S.min() and mx == S.max()
+
+
+def test_sdf_posed_large_mesh_equals_oracle(ctx, orc, synth):
+    """5120 faces registered under a pose far from the origin, 20 k queries: bit-equal to the oracle."""
+    rng = np.random.default_rng(8)
+    V, F = synth.ellipsoid_mesh(subdiv=4)
+    T = synth.se3(synth.random_rotation(rng), [0.3, -0.2, 0.9]).astype(np.float32)
+    ctx.sdf_register_mesh(6, V, F, T)
+    Vt = synth.apply(T, V)
+    P = np.concatenate([Vt[rng.integers(0, len(Vt), 15000)] + rng.normal(scale=0.008, size=(15000, 3)),
+                        Vt.mean(0) + rng.normal(scale=0.3, size=(5000, 3))]).astype(np.float32)
+    d, f, _, _ = ctx.sdf_signed_distance(6, P)
+    S, I = orc.sdf_signed_distance(P, V, F, pose=T)
+    assert np.array_equal(d.view(np.int32), S.view(np.int32))
+    assert np.array_equal(f, I)
+    assert (d < 0).sum() > 3000 and (d > 0).sum() > 3000
+
+
+def test_sdf_nonconvex_sign(ctx, orc, synth):
+    V, F = synth.torus_mesh(nu=48, nv=24)
+    ctx.sdf_register_mesh(6, V, F)
+    rng = np.random.default_rng(2)
+    P = (rng.normal(size=(8000, 3)) * np.array([0.04, 0.04, 0.012])).astype(np.float32)
+    d, f, _, _ = ctx.sdf_signed_distance(6, P)
+    S, I = orc.sdf_signed_distance(P, V, F)
+    assert np.array_equal(d.view(np.int32), S.view(np.int32)) and np.array_equal(f, I)
+    exact = np.sqrt((np.linalg.norm(P[:, :2].astype(np.float64), axis=1) - 0.035) ** 2 + P[:, 2].astype(np.float64) ** 2) - 0.012
+    far = np.abs(exact) > 1.5e-3  # away from the faceting error of the 1152-face torus
+    assert np.array_equal(np.sign(d[far]), np.sign(exact[far]))
+
+
+def test_sdf_point_on_surface_and_empty(ctx):
+    V = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    F = np.array([[0, 2, 1], [0, 1, 3], [0, 3, 2], [1, 2, 3]], np.int32)
+    ctx.sdf_register_mesh(7, V, F)
+    d, f, mn, mx = ctx.sdf_signed_distance(7, np.array([[0, 0, 0], [0.1, 0.1, 0.1], [2, 2, 2]], np.float32))
+    assert np.isnan(d[0]) and f[0] == len(F) + 1  # signed_distance.cpp:150-156 with bounds of +-FLT_MAX
+    assert d[1] < 0 < d[2] and abs(d[1] + 0.1) < 1e-6
+    assert mn == d[1] and mx == d[2]
+    d, f, mn, mx = ctx.sdf_signed_distance(7, np.zeros((0, 3), np.float32))
+    assert len(d) == 0 and mn == np.finfo(np.float32).max and mx == -np.finfo(np.float32).max
+
+
+def test_sdf_bad_arguments(ctx, api):
+    V = np.zeros((3, 3), np.float32)
+    with pytest.raises(api.HopError):
+        ctx.sdf_register_mesh(99, V, np.array([[0, 1, 2]], np.int32))
+    with pytest.raises(api.HopError):
+        ctx.sdf_register_mesh(1, V, np.array([[0, 1, 3]], np.int32))  # vertex index out of range
+    with pytest.raises(api.HopError):
+        ctx.sdf_signed_distance(15, np.zeros((4, 3), np.float32))  # never registered
+
+
+# ------------------------------------------------------------------------------------------------ voxel grid
+def test_voxel_downsample_vs_oracle(ctx, orc):
+    rng = np.random.default_rng(4)
+    P = (rng.normal(size=(60000, 3)) * np.array([0.08, 0.05, 0.03]) + np.array([0.1, -0.2, 0.7])).astype(np.float32)
+    P[::997] = np.nan  # non-finite points are skipped (voxel_grid.hpp:262-270)
+    out = ctx.voxel_downsample(P, 0.005)
+    ref = orc.voxel_downsample(P, 0.005)
+    assert out.shape == ref.shape and len(out) > 5000
+    # same voxels in the same order; the centroid of a voxel is a float sum whose order pcl leaves to std::sort
+    assert np.abs(out - ref).max() < 1e-6
+    cells_out = np.floor(out.astype(np.float32) * np.float32(200.0)).astype(np.int64)
+    cells_ref = np.floor(ref.astype(np.float32) * np.float32(200.0)).astype(np.int64)
+    assert (cells_out != cells_ref).any(axis=1).mean() < 0.02  # a centroid may sit on a cell boundary
+    assert ctx.voxel_downsample(np.zeros((0, 3), np.float32), 0.005).shape == (0, 3)
+    one = ctx.voxel_downsample(np.array([[0.1, 0.2, 0.3]], np.float32), 0.005)
+    assert np.array_equal(one, np.array([[0.1, 0.2, 0.3]], np.float32))
+
+
+def test_voxel_downsample_overflow_is_an_error(ctx, api):
+    P = np.array([[0, 0, 0], [100, 100, 100]], np.float32)
+    with pytest.raises(api.HopError):
+        ctx.voxel_downsample(P, 0.001)  # 1e5^3 cells: pcl warns "integer indices would overflow" and gives up
+
+
+# ------------------------------------------------------------------------------------------------ decision chain
+def _run_case(ctx, orc, synth, p, poses):
+    for mid, V, F, T in p["meshes"]:
+        ctx.sdf_register_mesh(mid, V, F, T)
+    ctx.physics_set_frame(p)
+    scores = np.linspace(1.0, 0.5, len(poses)).astype(np.float32)
+    ctx.hypos_upload(poses, scores)
+    keep, diag = ctx.reject_by_collision()
+    keep_o, diag_o = orc.reject_by_collision(p, poses)
+    return keep, diag, keep_o, diag_o, scores
+
+
+def _check_against_oracle(keep, diag, keep_o, diag_o):
+    assert np.array_equal(diag[:, 0], diag_o[:, 0]), (diag[:, 0], diag_o[:, 0])
+    assert np.array_equal(keep, keep_o)
+    # the distances every check looked at: the oracle moves the mesh, the GPU moves the query (rounding of the motion)
+    both = np.isfinite(diag[:, 1:]) & np.isfinite(diag_o[:, 1:])
+    assert both.sum() > 0
+    assert np.abs(diag[:, 1:][both] - diag_o[:, 1:][both]).max() < 2e-6
+    # a check the oracle evaluated was evaluated here too
+    kept = keep_o
+    assert np.isfinite(diag[kept][:, 7]).all()
+
+
+def test_reject_by_collision_matches_oracle(ctx, orc, synth):
+    p, poses = synth.physics_case(96)
+    keep, diag, keep_o, diag_o, scores = _run_case(ctx, orc, synth, p, poses)
+    _check_against_oracle(keep, diag, keep_o, diag_o)
+    stages = set(diag_o[:, 0].astype(int))
+    assert {0, 1, 4, 5} <= stages, stages
+    assert 5 < keep.sum() < len(keep)
+    # the resident set is filtered in place, order and scores of the survivors preserved
+    T, sc, ids = ctx.hypos_download()
+    assert len(T) == keep.sum()
+    assert np.array_equal(T.reshape(-1, 16), poses.reshape(-1, 16)[keep])
+    assert np.array_equal(sc, scores[keep])
+    assert np.array_equal(ids, np.arange(len(poses))[keep])
+
+
+@pytest.mark.parametrize("status", [(1, 0, 1, 1), (0, 1, 1, 1), (1, 1, 0, 0), (0, 0, 0, 0)])
+def test_reject_by_collision_component_status(ctx, orc, synth, status):
+    """Fingers whose state is unknown are left out of the cloud checks (PoseEstimator.cpp:536-541, 650-652)."""
+    p, poses = synth.physics_case(48, seed=5, finger_status=status)
+    keep, diag, keep_o, diag_o, _ = _run_case(ctx, orc, synth, p, poses)
+    _check_against_oracle(keep, diag, keep_o, diag_o)
+
+
+def test_reject_by_collision_collision_stages(ctx, orc, synth):
+    """A thicker object (collision threshold reached by the finger clouds and by the hand point)."""
+    p, poses = synth.physics_case(64, seed=9)
+    p["collision_thres"] = 0.1  # collision_dist = -7 mm: pushing the object 3 cm into a finger now collides
+    p["non_touch_dist"] = 0.05
+    keep, diag, keep_o, diag_o, _ = _run_case(ctx, orc, synth, p, poses)
+    _check_against_oracle(keep, diag, keep_o, diag_o)
+    assert {2, 3} & set(diag_o[:, 0].astype(int))
+
+
+def test_reject_by_collision_dense_mesh_and_clouds(ctx, orc, synth):
+    p, poses = synth.physics_case(24, seed=13, n_model=1500, n_scene=8000, mesh_subdiv=3, spacing=0.003)
+    keep, diag, keep_o, diag_o, _ = _run_case(ctx, orc, synth, p, poses)
+    _check_against_oracle(keep, diag, keep_o, diag_o)
+
+
+def test_reject_requires_frame_and_handles_empty_set(api, synth):
+    c = api.Context(0)
+    try:
+        c.hypos_upload(np.tile(np.eye(4, dtype=np.float32), (3, 1, 1)))
+        with pytest.raises(api.HopError):
+            c.reject_by_collision()  # no hop_physics_set_frame yet
+        p, poses = synth.physics_case(8)
+        for mid, V, F, T in p["meshes"]:
+            c.sdf_register_mesh(mid, V, F, T)
+        c.physics_set_frame(p)
+        c.hypos_upload(np.zeros((0, 16), np.float32))
+        keep, diag = c.reject_by_collision()
+        assert len(keep) == 0 and c.hypos_count() == 0
+    finally:
+        c.close()

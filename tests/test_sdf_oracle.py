@@ -13,15 +13,11 @@ MESHES = ("ellipsoid", "box", "torus", "lshape")
 def test_oracle_sdf_matches_libigl_golden(orc, golden_dir, name):
     g = np.load(os.path.join(golden_dir, "sdf_igl.npz"))
     S, I = orc.sdf_signed_distance(g[f"{name}_P"], g[f"{name}_V"], g[f"{name}_F"])
-    # bit-exact signed distances (the face index may differ on exact ties: libigl reports the first face its AABB tree
-    # visits, the oracle the lowest index)
+    # bit-exact signed distances and the same face: the oracle walks libigl's AABB tree in libigl's order, which decides
+    # which of several faces at exactly the same float distance is reported (20-30 % of these queries have such ties)
     assert np.array_equal(S.view(np.int32), g[f"{name}_S"].view(np.int32))
+    assert np.array_equal(I, g[f"{name}_I"])
     assert (S < 0).sum() > 100 and (S > 0).sum() > 100
-    V, F = g[f"{name}_V"], g[f"{name}_F"]
-    differs = np.where(I != g[f"{name}_I"])[0]
-    # where the faces differ both are at the same distance: they share the closest point
-    for k in differs[:200]:
-        assert len(set(F[I[k]]) & set(F[g[f"{name}_I"][k]])) >= 1
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
@@ -35,9 +31,10 @@ def test_oracle_sdf_matches_libigl_live(orc):
     T = synth.se3(synth.random_rotation(rng), [0.1, -0.2, 0.6]).astype(np.float32)
     Vt = synth.apply(T, V)
     P = (Vt[rng.integers(0, len(Vt), 3000)] + rng.normal(scale=0.01, size=(3000, 3))).astype(np.float32)
-    S_ref, _, _ = orc.ref_signed_distance(P, Vt, F)
-    S, _ = orc.sdf_signed_distance(P, Vt, F)
+    S_ref, I_ref, _ = orc.ref_signed_distance(P, Vt, F)
+    S, I = orc.sdf_signed_distance(P, Vt, F)
     assert np.array_equal(S.view(np.int32), S_ref.view(np.int32))
+    assert np.array_equal(I, I_ref)
 
 
 def test_oracle_sdf_analytic_sphere(orc):
