@@ -550,10 +550,61 @@ class PoseEstimator:
         self.ctx.set_model(HOP_MODEL_1MM, *model001)
         self._pose_hypos = []
         self.last_stats = None
+        self._model = np.asarray(model[0], np.float32)
+        # PoseEstimator.cpp:12-20: centroid (pcl::computeCentroid sums in float, in order), bounding box of the 1 mm model
+        m1 = np.asarray(model001[0], np.float32)
+        self._model_center_init = (np.cumsum(m1, axis=0, dtype=np.float32)[-1] / np.float32(len(m1))).astype(np.float32)
+        ext = (m1.max(axis=0) - m1.min(axis=0)).astype(np.float32)
+        self._smallest_dim = np.float32(ext.min())
+        self._ob_diameter = np.float32(np.sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]))
+        self._cloud_withouthand_raw = None
+        self._mesh_ids = {}
 
-    def setCurScene(self, object_segment_xyz, object_segment_nrm, confidence):
+    def setCurScene(self, object_segment_xyz, object_segment_nrm, confidence, cloud_withouthand_raw=None):
         thres = float(self.cfg.get("pose_estimator_high_confidence_thres", 0.8))
+        if cloud_withouthand_raw is not None:
+            self._cloud_withouthand_raw = np.asarray(cloud_withouthand_raw, np.float32)
         return self.ctx.set_scene(object_segment_xyz, object_segment_nrm, confidence, thres)
+
+    # ---- physics row (N1)
+    MESH_SLOTS = {"object": 0, "finger_1_1": 1, "finger_1_2": 2, "finger_2_1": 3, "finger_2_2": 4}
+
+    def registerMesh(self, V, Fi, name, pose=None):
+        """PoseEstimator::registerMesh -> SDFchecker::registerMesh (PoseEstimator.cpp:505-508); the OBJ file of the
+        reference is passed as arrays."""
+        mid = self.MESH_SLOTS.setdefault(name, len(self.MESH_SLOTS))
+        self.ctx.sdf_register_mesh(mid, V, Fi, pose)
+        self._mesh_ids[name] = mid
+
+    def registerHandMesh(self, hand):
+        """PoseEstimator.cpp:510-520: the four finger links' convex meshes at getTFHandBase(link)."""
+        for name in ("finger_1_1", "finger_1_2", "finger_2_1", "finger_2_2"):
+            if name in hand.hand.meshes:
+                V, Fi = hand.hand.meshes[name]
+                self.registerMesh(V, Fi, name, hand.getTFHandBase(name))
+
+    def rejectByCollisionOrNonTouching(self, hand, handbase_in_cam):
+        """PoseEstimator.cpp:524-735.  Returns (keep mask, diagnostics) of the incoming hypothesis set, or None when
+        pose_estimator_use_physics is off."""
+        if not bool(self.cfg.get("pose_estimator_use_physics", True)):
+            return None
+        names = ("finger_1_1", "finger_1_2", "finger_2_1", "finger_2_2")
+        clouds = getattr(hand, "_hand_clouds", None) or hand.makeHandCloud()
+        p = dict(
+            object_mesh=self._mesh_ids["object"], finger_mesh=[self._mesh_ids[n] for n in names],
+            finger_xyz=[np.asarray(hand.hand.clouds[n][0], np.float32) for n in names],
+            finger2handbase=[hand.getTFHandBase(n) for n in names],
+            finger_status=[int(bool(hand._component_status.get(n, False))) for n in names],
+            hand_cloud=np.concatenate([clouds[n] for n in sorted(clouds)]).astype(np.float32),  # (*_hand_cloud) += ..., map order
+            cloud_without_hand=self._cloud_withouthand_raw,
+            cam2handbase=np.linalg.inv(np.asarray(handbase_in_cam, np.float64)).astype(np.float32),
+            model=self._model, model_center_init=self._model_center_init,
+            smallest_dim=self._smallest_dim, ob_diameter=self._ob_diameter,
+            collision_thres=float(self.cfg["collision_thres"]), non_touch_dist=float(self.cfg["non_touch_dist"]),
+            collision_finger_dist=float(self.cfg["collision_finger_dist"]),
+            collision_finger_volume_ratio=float(self.cfg["collision_finger_volume_ratio"]), voxel_size=0.005)
+        self.ctx.physics_set_frame(p)
+        return self.ctx.reject_by_collision()
 
     def runSuper4pcs(self, ppfs, n_trials=0, verify_mode=2):
         """PoseEstimator.cpp:62-100.  ``ppfs``: (n,4) int key table (the reference passes a std::map whose

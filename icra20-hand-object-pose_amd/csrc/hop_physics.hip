@@ -175,6 +175,7 @@ struct TreeBuilder {
     for (int k = 0; k < 4; ++k) {
       for (int a = 0; a < 3; ++a) nd.lo[a][k] = INFINITY, nd.hi[a][k] = -INFINITY;
       nd.child[k] = -1, nd.count[k] = 0;
+
     }
     for (int k = 0; k < nc; ++k) {
       const int cb = cuts[k], ce = cuts[k + 1];
@@ -197,7 +198,8 @@ struct TreeBuilder {
   }
 };
 
-// libigl's AABB tree over the faces (AABB.cpp:73-200): per-axis ranks of the face barycentres (igl::sort is a std::sort of
+// libigl's AABB tree over the faces (AABB.cpp:73-200), nodes in heap order (root 1, children 2 i and 2 i + 1; the
+// median split leaves ceil(n/2) faces on the left, so the depth is ceil(log2 n)): per-axis ranks of the face barycentres (igl::sort is a std::sort of
 // an index map, sort.cpp:287-316), nodes split at the median rank along the longest box axis, one face per leaf.  Only
 // what sdf_precedes needs is kept.
 struct OrderTree {
@@ -222,12 +224,11 @@ struct OrderTree {
     if (nf > 0) {
       std::vector<int> all(nf);
       for (int f = 0; f < nf; ++f) all[f] = f;
-      grow(all, -1, 0, false);
+      grow(all, 1);
     }
   }
-  int grow(const std::vector<int>& I, int parent, int depth, bool is_left) {
-    const int idx = (int)nodes.size();
-    nodes.emplace_back();
+  void grow(const std::vector<int>& I, size_t heap) {
+    if (heap >= nodes.size()) nodes.resize(std::max(heap + 1, 2 * nodes.size()), SdfOrderNode{});
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int f : I)
       for (int c = 0; c < 3; ++c) {
@@ -235,13 +236,12 @@ struct OrderTree {
         const float pv[3] = {v.x, v.y, v.z};
         for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], pv[k]), hi[k] = std::max(hi[k], pv[k]);
       }
-    SdfOrderNode nd;
+    SdfOrderNode nd{};
     for (int k = 0; k < 3; ++k) nd.lo[k] = lo[k], nd.hi[k] = hi[k];
-    nd.parent = parent, nd.info = (depth << 1) | (is_left ? 1 : 0);
-    nodes[idx] = nd;
+    nodes[heap] = nd;
     if (I.size() == 1) {
-      face_leaf[I[0]] = idx;
-      return idx;
+      face_leaf[I[0]] = (int)heap;
+      return;
     }
     int ax = 0;
     for (int k = 1; k < 3; ++k)
@@ -254,9 +254,8 @@ struct OrderTree {
     const int med = t[n];
     std::vector<int> LI, RI;
     for (size_t i = 0; i < I.size(); ++i) (r[i] <= med ? LI : RI).push_back(I[i]);
-    grow(LI, idx, depth + 1, true);
-    grow(RI, idx, depth + 1, false);
-    return idx;
+    grow(LI, 2 * heap);
+    grow(RI, 2 * heap + 1);
   }
 };
 
@@ -682,7 +681,7 @@ int hop_sdf_register_mesh(hop_ctx* c, int mesh_id, const float* V, int nv, const
   prepare_mesh(hm, V, nv, F, nf, pose16);
   TreeBuilder tb(hm);
   if (nf > 0) tb.build(0, nf, 0);
-  if (3 * tb.max_depth + 1 > SDF_STACK || tb.nodes.size() >= (size_t)(1u << SDF_NODE_BITS)) {
+  if (3 * tb.max_depth + 1 > SDF_STACK || tb.nodes.size() >= (size_t)(1u << SDF_NODE_BITS) || nf > (1 << 22)) {
     hop_ctx_set_error(c, "mesh too large for the traversal stack");
     return HOP_E_CAPACITY;
   }
@@ -707,7 +706,7 @@ int hop_sdf_register_mesh(hop_ctx* c, int mesh_id, const float* V, int nv, const
   PHCHK(c, hipStreamSynchronize(st));  // a previous frame may still read the old buffers
   PHCHK(c, ms.tri_d.ensure(std::max<size_t>(sizeof(float4) * tri.size(), 16)));
   PHCHK(c, ms.nrm_d.ensure(std::max<size_t>(sizeof(float4) * nrm.size(), 16)));
-  PHCHK(c, ms.nodes_d.ensure(std::max<size_t>(sizeof(SdfNode) * tb.nodes.size(), 128)));
+  PHCHK(c, ms.nodes_d.ensure(std::max<size_t>(sizeof(SdfNode) * tb.nodes.size(), 256)));
   PHCHK(c, ms.order_d.ensure(std::max<size_t>(sizeof(SdfOrderNode) * ot.nodes.size(), 32)));
   PHCHK(c, ms.leaf_d.ensure(std::max<size_t>(sizeof(int) * (size_t)nf, 16)));
   if (nf > 0) {
@@ -923,6 +922,15 @@ int hop_reject_by_collision(hop_ctx* c, unsigned char* keep_out, float* diag8_ou
   return HOP_OK;
 }
 
+#ifdef SDF_COUNT
+int hop_sdf_counters(unsigned long long* out4, int reset) {
+  unsigned long long z[4] = {0, 0, 0, 0};
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_sdf_cnt), sizeof(z));
+  if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sdf_cnt), z, sizeof(z));
+  return 0;
+}
+#endif
 int hop_physics_timing(hop_ctx* c, double* ms_set_frame, double* ms_reject) {
   if (!c) return HOP_E_INVALID;
   Physics* ph = physics(c);

@@ -10,8 +10,8 @@
 //   nrm   [slots][7] float4   face normal, the three edge pseudonormals (edge opposite corner 0,1,2), the three
 //                             vertex pseudonormals (corner 0,1,2); .w unused
 //   nodes [n_nodes]           4 children per node: boxes as SoA (lo/hi x 3 axes x 4 lanes), child index or leaf range
-//   order [2 n_faces - 1]     libigl's own AABB tree (AABB.cpp:106-200: one face per leaf), boxes and parent links only
-//   face_leaf [n_faces]       the leaf of `order` that holds each face
+//   order [2^(depth+1)]       libigl's own AABB tree (AABB.cpp:106-200: one face per leaf), boxes only, in heap order
+//   face_leaf [n_faces]       heap index of the leaf of `order` that holds each face
 // A query evaluates, for every face whose box lower bound does not exceed the best squared distance so far (plus the
 // float error of that expression), exactly the float expression of igl/point_simplex_squared_distance.cpp:43-113 and
 // keeps the minimum.  Faces at exactly the same float distance (a closest point on a shared edge or vertex: 20-30 % of
@@ -39,11 +39,11 @@ struct SdfNode {
 };
 static_assert(sizeof(SdfNode) == 128, "one node is one 128-byte line");
 
-struct SdfOrderNode {
+struct SdfOrderNode {  // stored in heap order: root at 1, children of i at 2 i (left) and 2 i + 1 (right)
   float lo[3];
-  int parent;  // -1 for the root
+  int pad0;
   float hi[3];
-  int info;    // depth << 1 | (1 when this node is the left child)
+  int pad1;
 };
 static_assert(sizeof(SdfOrderNode) == 32, "two nodes per 64 bytes");
 
@@ -170,15 +170,17 @@ __device__ __forceinline__ float sdf_box_ext(const SdfOrderNode& n, V3 p) {
   }
   return d2;
 }
-// true when libigl's walk for query p reaches face f before face g (f != g)
+// true when libigl's walk for query p reaches face f before face g (f != g): decided at their lowest common ancestor,
+// found from the heap indices of the two leaves
 __device__ inline bool sdf_precedes(const SdfMeshDev& m, V3 p, int f, int g) {
-  int a = m.face_leaf[f], b = m.face_leaf[g];
-  int da = m.order[a].info >> 1, db = m.order[b].info >> 1;
-  while (da > db) a = m.order[a].parent, --da;
-  while (db > da) b = m.order[b].parent, --db;
-  while (m.order[a].parent != m.order[b].parent) a = m.order[a].parent, b = m.order[b].parent;
-  const bool a_left = (m.order[a].info & 1) != 0;
-  const SdfOrderNode L = m.order[a_left ? a : b], R = m.order[a_left ? b : a];
+  unsigned a = (unsigned)m.face_leaf[f], b = (unsigned)m.face_leaf[g];
+  const int da = 31 - __clz(a), db = 31 - __clz(b);
+  if (da > db) a >>= (da - db);
+  else b >>= (db - da);
+  const int k = 32 - __clz(a ^ b);  // low bits below the common ancestor
+  a >>= (k - 1);
+  const bool a_left = (a & 1u) == 0u;
+  const SdfOrderNode L = m.order[a & ~1u], R = m.order[a | 1u];
   bool left_first;
   if (sdf_box_contains(L, p)) left_first = true;
   else if (sdf_box_contains(R, p)) left_first = false;
@@ -186,6 +188,9 @@ __device__ inline bool sdf_precedes(const SdfMeshDev& m, V3 p, int f, int g) {
   return left_first == a_left;
 }
 
+#ifdef SDF_COUNT  // measurement build (tools/sdf_counters.py): nodes visited, faces tested, exact ties, queries
+__device__ unsigned long long g_sdf_cnt[4];
+#endif
 struct SdfHit {
   float sqr_d;
   int slot;  // -1: no face (empty mesh)
@@ -195,9 +200,12 @@ struct SdfHit {
 
 // exact closest face (see the header comment).  `stack`: SDF_STACK entries of this thread's own storage, entry k at
 // stack[k * stride] (LDS, lane-interleaved so that equal depths of a wavefront fall into different banks).  An entry
-// packs the node index (low 20 bits) with the top 12 bits of the node's lower bound (rounded towards zero, i.e. still a
-// lower bound).
-constexpr int SDF_NODE_BITS = 20;
+// packs the node index (low SDF_NODE_BITS bits) with the top bits of the node's lower bound (rounded towards zero, i.e.
+// still a lower bound: sign, exponent and 7 mantissa bits).
+#ifndef SDF_NODE_BITS_V
+#define SDF_NODE_BITS_V 16
+#endif
+constexpr int SDF_NODE_BITS = SDF_NODE_BITS_V;
 __device__ __forceinline__ unsigned sdf_pack(float lb, int node) {
   return (__float_as_uint(lb) & ~((1u << SDF_NODE_BITS) - 1u)) | (unsigned)node;
 }
@@ -205,6 +213,9 @@ __device__ inline SdfHit sdf_closest_face(const SdfMeshDev& m, V3 q, unsigned* s
   SdfHit h;
   h.sqr_d = __builtin_inff(), h.slot = -1, h.face = 0x7fffffff, h.c = v3(0, 0, 0);
   if (m.n_faces <= 0) return h;
+#ifdef SDF_COUNT
+  atomicAdd(&g_sdf_cnt[3], 1ull);
+#endif
   float thr = __builtin_inff();  // prune bound: best + float slack of the triangle expression
   const float de = m.coord_eps + 4e-7f * fmaxf(fabsf(q.x), fmaxf(fabsf(q.y), fabsf(q.z)));
   int sp = 0;
@@ -213,6 +224,9 @@ __device__ inline SdfHit sdf_closest_face(const SdfMeshDev& m, V3 q, unsigned* s
     const unsigned e = stack[(--sp) * stride];
     if (__uint_as_float(e & ~((1u << SDF_NODE_BITS) - 1u)) > thr) continue;
     const SdfNode& nd = m.nodes[e & ((1u << SDF_NODE_BITS) - 1u)];
+#ifdef SDF_COUNT
+    atomicAdd(&g_sdf_cnt[0], 1ull);
+#endif
     float lb[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -232,6 +246,10 @@ __device__ inline SdfHit sdf_closest_face(const SdfMeshDev& m, V3 q, unsigned* s
         const V3 c = sdf_closest_point(q, v3(A4.x, A4.y, A4.z), v3(B4.x, B4.y, B4.z), v3(C4.x, C4.y, C4.z));
         const float d = vsqn(q - c);
         const int face = __float_as_int(B4.w);
+#ifdef SDF_COUNT
+        atomicAdd(&g_sdf_cnt[1], 1ull);
+        if (d == h.sqr_d) atomicAdd(&g_sdf_cnt[2], 1ull);
+#endif
         if (d < h.sqr_d || (d == h.sqr_d && sdf_precedes(m, q, face, h.face))) {
           h.sqr_d = d, h.slot = s, h.face = face, h.c = c;
           thr = d + (2.f * sqrtf(d) * de + de * de) + d * 1e-5f;

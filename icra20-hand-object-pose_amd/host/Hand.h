@@ -89,7 +89,8 @@ class FingerProperty {
 
 class Hand {
  public:
-  Hand(ConfigParser* cfg1, hop_ctx* ctx) : cfg(cfg1), ctx_(ctx) { initPSO(); }
+  typedef Mat4 Mat;
+  Hand(ConfigParser* cfg1, hop_ctx* ctx) : _handbase_in_cam(Mat4::Identity()), cfg(cfg1), ctx_(ctx) { initPSO(); }
   virtual ~Hand() {}
 
   // Hand::addComponent (Hand.cpp:525-534); `cloud` already down-sampled to 5 mm, in the link frame
@@ -101,6 +102,9 @@ class Hand {
     _component_status[name] = false;
     if (name.find("finger") != std::string::npos) _finger_properties[name] = FingerProperty(cloud, 10);
   }
+
+  // the convex mesh of a component (Hand.cpp:526-530, loaded from an OBJ file there), link frame
+  void addConvexMesh(const std::string& name, const hop::Mesh& mesh) { _convex_meshes[name] = mesh; }
 
   // products of Hand::setCurScene (Hand.cpp:327-332), hand-base frame
   void setCurScene(const hop::Cloud& scene_hand_region_removed_noise, const hop::Cloud& scene_hand_region,
@@ -137,6 +141,42 @@ class Hand {
         for (int i = 0; i < src.n; ++i)
           dst.xyz[(size_t)k * src.n + i] = ((T.m[4 * k] * x[i] + T.m[4 * k + 1] * y[i]) + T.m[4 * k + 2] * z[i]) + T.m[4 * k + 3];
       _hand_clouds[h.first] = dst;
+    }
+    // _hand_cloud: the components appended in map order (Hand.cpp:550)
+    int total = 0;
+    for (auto& h : _hand_clouds) total += h.second.n;
+    _hand_cloud.n = total;
+    _hand_cloud.xyz.assign(3 * (size_t)total, 0.f);
+    int off = 0;
+    for (auto& h : _hand_clouds) {
+      for (int k = 0; k < 3; ++k)
+        std::copy(h.second.xyz.begin() + (size_t)k * h.second.n, h.second.xyz.begin() + (size_t)(k + 1) * h.second.n,
+                  _hand_cloud.xyz.begin() + (size_t)k * total + off);
+      off += h.second.n;
+    }
+  }
+  const hop::Cloud& handCloud() {
+    if (_hand_clouds.empty()) makeHandCloud();
+    return _hand_cloud;
+  }
+  // hand->_handbase_in_cam.inverse() (PoseEstimator.cpp:554,566): inverse of an affine matrix, adjugate in double
+  void camToHandbase(float out[16]) const {
+    const float* a = _handbase_in_cam.m;
+    double m[3][3], inv[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) m[i][j] = a[4 * i + j];
+    const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                       m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    inv[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) / det, inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det;
+    inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det, inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) / det;
+    inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det, inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
+    inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det, inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det;
+    inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+    for (int i = 0; i < 16; ++i) out[i] = (i == 15) ? 1.f : 0.f;
+    for (int i = 0; i < 3; ++i) {
+      double t = 0;
+      for (int j = 0; j < 3; ++j) out[4 * i + j] = (float)inv[i][j], t -= inv[i][j] * (double)a[4 * j + 3];
+      out[4 * i + 3] = (float)t;
     }
   }
 
@@ -271,6 +311,9 @@ class Hand {
   std::map<std::string, bool> _component_status;
   std::map<std::string, float> _finger_angles;
   std::map<std::string, hop::Cloud> _hand_clouds;  // Hand::makeHandCloud products (hand-base frame)
+  hop::Cloud _hand_cloud;                          // their concatenation
+  std::map<std::string, hop::Mesh> _convex_meshes;
+  Mat4 _handbase_in_cam;
   ConfigParser* cfg;
   hop_pso_settings _pso_settings;
 

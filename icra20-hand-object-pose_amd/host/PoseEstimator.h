@@ -1,8 +1,13 @@
 // PoseEstimator.h -- host-side mirror of the reference's PoseEstimator<PointT> for the hot-path members
 // (src/perception/include/PoseEstimator.h:12-49), forwarding to the C-ABI of include/hop.h.  PCL cloud types are
-// replaced by SoA planes (hop::Cloud).  The two rejectBy* members are "next" rows and absent.
+// replaced by SoA planes (hop::Cloud), OBJ files by vertex / face arrays (hop::Mesh).  rejectByRender is a "next" row
+//  and absent.
 #ifndef HOP_HOST_POSEESTIMATOR_H_
 #define HOP_HOST_POSEESTIMATOR_H_
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -17,6 +22,12 @@ struct Cloud {            // SoA planes, as the ABI takes them
   std::vector<float> conf; // n (optional)
   int n = 0;
 };
+struct Mesh {             // what igl::readOBJ / pcl::PolygonMesh hold: vertices (nv x 3) and triangles (nf x 3)
+  std::vector<float> V;
+  std::vector<int32_t> F;
+  int nv() const { return (int)(V.size() / 3); }
+  int nf() const { return (int)(F.size() / 3); }
+};
 inline void check(int rc, hop_ctx* c, const char* where) {
   if (rc != HOP_OK) throw std::runtime_error(std::string(where) + ": " + hop_strerror(rc) + " " + (c ? hop_last_error(c) : ""));
 }
@@ -29,12 +40,32 @@ class PoseEstimator {
     hop::check(hop_ctx_create(device, &ctx_), nullptr, "hop_ctx_create");
     hop::check(hop_set_model(ctx_, HOP_MODEL_5MM, model.xyz.data(), model.nrm.data(), model.n), ctx_, "hop_set_model(5mm)");
     hop::check(hop_set_model(ctx_, HOP_MODEL_1MM, model001.xyz.data(), model001.nrm.data(), model001.n), ctx_, "hop_set_model(1mm)");
+    _model_xyz = model.xyz;
+    _n_model = model.n;
+    // PoseEstimator.cpp:12-20: centroid (float sums in order, as pcl::computeCentroid) and bounding box of the 1 mm model
+    float s[3] = {0, 0, 0}, mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) {
+      const float* p = model001.xyz.data() + (size_t)k * model001.n;
+      for (int i = 0; i < model001.n; ++i) {
+        s[k] += p[i];
+        if (i == 0 || p[i] < mn[k]) mn[k] = p[i];
+        if (i == 0 || p[i] > mx[k]) mx[k] = p[i];
+      }
+      _model_center_init[k] = model001.n ? s[k] / (float)model001.n : 0.f;
+    }
+    const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+    _smallest_dim = std::min(std::min(ex, ey), ez);
+    _ob_diameter = std::sqrt(ex * ex + ey * ey + ez * ez);
   }
   ~PoseEstimator() { hop_ctx_destroy(ctx_); }
   PoseEstimator(const PoseEstimator&) = delete;
   PoseEstimator& operator=(const PoseEstimator&) = delete;
 
   // setCurScene (PoseEstimator.cpp:32-46): keeps points with confidence >= pose_estimator_high_confidence_thres
+  void setCurScene(const hop::Cloud& object_segment, const hop::Cloud& cloud_withouthand_raw) {
+    _cloud_withouthand_raw = cloud_withouthand_raw;
+    setCurScene(object_segment);
+  }
   void setCurScene(const hop::Cloud& object_segment) {
     hop::check(hop_set_scene(ctx_, object_segment.xyz.data(), object_segment.nrm.data(),
                              object_segment.conf.empty() ? nullptr : object_segment.conf.data(), object_segment.n,
@@ -75,6 +106,58 @@ class PoseEstimator {
     hop::check(hop_icp_refine(ctx_, &o, nullptr, nullptr), ctx_, "hop_icp_refine");
   }
 
+  // registerMesh (PoseEstimator.cpp:505-508 -> SDFchecker::registerMesh, SDFchecker.cpp:36-78)
+  void registerMesh(const hop::Mesh& mesh, const std::string& name, const float* pose16) {
+    auto it = _mesh_ids.find(name);
+    const int id = it != _mesh_ids.end() ? it->second : (int)_mesh_ids.size();
+    hop::check(hop_sdf_register_mesh(ctx_, id, mesh.V.data(), mesh.nv(), mesh.F.data(), mesh.nf(), pose16), ctx_, "hop_sdf_register_mesh");
+    _mesh_ids[name] = id;
+  }
+  // registerHandMesh (PoseEstimator.cpp:510-520): HandT is the host Hand mirror (getTFHandBase, _convex_meshes)
+  template <class HandT>
+  void registerHandMesh(HandT* hand) {
+    for (const auto& h : hand->_convex_meshes) {
+      if (!(h.first == "finger_1_1" || h.first == "finger_1_2" || h.first == "finger_2_1" || h.first == "finger_2_2")) continue;
+      typename HandT::Mat model2handbase;
+      hand->getTFHandBase(h.first, model2handbase);
+      registerMesh(h.second, h.first, model2handbase.m);
+    }
+  }
+  // rejectByCollisionOrNonTouching (PoseEstimator.cpp:524-735); cam2handbase = hand->_handbase_in_cam.inverse()
+  template <class HandT>
+  void rejectByCollisionOrNonTouching(HandT* hand) {
+    if (cfg->get("pose_estimator_use_physics") == "false") {
+      printf("Not using physics\n");
+      return;
+    }
+    static const char* names[4] = {"finger_1_1", "finger_1_2", "finger_2_1", "finger_2_2"};
+    hop_physics_args a{};
+    a.object_mesh = _mesh_ids.at("object");
+    typename HandT::Mat f2h[4];
+    for (int k = 0; k < 4; ++k) {
+      a.finger_mesh[k] = _mesh_ids.at(names[k]);
+      const hop::Cloud& fc = hand->_clouds.at(names[k]);
+      a.finger_xyz[k] = fc.xyz.data(), a.finger_n[k] = fc.n;
+      hand->getTFHandBase(names[k], f2h[k]);
+      a.finger2handbase[k] = f2h[k].m;
+      a.finger_status[k] = hand->_component_status[names[k]] ? 1 : 0;
+    }
+    const hop::Cloud& hc = hand->handCloud();
+    a.hand_cloud_xyz = hc.xyz.data(), a.n_hand_cloud = hc.n;
+    a.cloud_without_hand_xyz = _cloud_withouthand_raw.xyz.data(), a.n_cloud_without_hand = _cloud_withouthand_raw.n;
+    hand->camToHandbase(a.cam2handbase);
+    a.model_xyz = _model_xyz.data(), a.n_model = _n_model;
+    for (int k = 0; k < 3; ++k) a.model_center_init[k] = _model_center_init[k];
+    a.smallest_dim = _smallest_dim, a.ob_diameter = _ob_diameter;
+    a.collision_thres = cfg->getf("collision_thres"), a.non_touch_dist = cfg->getf("non_touch_dist");
+    a.collision_finger_dist = cfg->getf("collision_finger_dist");
+    a.collision_finger_volume_ratio = cfg->getf("collision_finger_volume_ratio");
+    a.voxel_size = 0.005f;
+    printf("collision_dist=%f, non_touch_dist=%f\n", std::min(-_smallest_dim * a.collision_thres, -0.007f), a.non_touch_dist);
+    hop::check(hop_physics_set_frame(ctx_, &a), ctx_, "hop_physics_set_frame");
+    hop::check(hop_reject_by_collision(ctx_, nullptr, nullptr, nullptr), ctx_, "hop_reject_by_collision");
+  }
+
   // selectBest (PoseEstimator.cpp:465-502)
   void selectBest(PoseHypo& best_hypo) {
     hop_lcp_opts o{cfg->getf("lcp.dist"), cfg->getf("lcp.normal_angle"), -1};  // nn_mode < 0: by size (cell lists or brute force: same bits)
@@ -90,8 +173,13 @@ class PoseEstimator {
   hop_ctx* ctx() { return ctx_; }
   ConfigParser* cfg;
   hop_s4pcs_stats last_stats{};
+  float _model_center_init[3] = {0, 0, 0}, _smallest_dim = 0, _ob_diameter = 0;
 
  private:
   hop_ctx* ctx_ = nullptr;
+  std::vector<float> _model_xyz;
+  int _n_model = 0;
+  hop::Cloud _cloud_withouthand_raw;
+  std::map<std::string, int> _mesh_ids;
 };
 #endif

@@ -10,7 +10,12 @@
 //   hand.txt                                    one line per link: name parent cloud_file 16 floats (row-major)
 //   hand_scene.bin hand_region.bin hand_swivel.bin
 //   cam_side.txt                                1 if cam_in_handbase(1,3) > 0 (main :114), else 0
-// Steps not on the hot path (adjustHandHeight, removeSurroundingPoints..., rejectBy*) are "next" rows.
+// and, optionally, the inputs of the physics rejection (main :185-187,201; all three or none):
+//   meshes.txt                                  one line per mesh: name file ("object" and the finger links' convex meshes;
+//                                               file = int32 nv, int32 nf, nv*3 float vertices, nf*3 int32 triangles)
+//   cloud_withouthand.bin                       _cloud_withouthand_raw, camera frame
+//   handbase_in_cam.txt                         16 floats, row-major
+// Steps not on the hot path (adjustHandHeight, rejectByRender) are "next" rows.
 #include <cstdint>
 #include <cstdio>
 #include <fstream>
@@ -37,6 +42,21 @@ static hop::Cloud read_cloud(const std::string& path) {
   }
   if (!f) throw std::runtime_error("short read " + path);
   return c;
+}
+
+static hop::Mesh read_mesh(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("cannot open " + path);
+  int32_t nv = 0, nf = 0;
+  f.read(reinterpret_cast<char*>(&nv), 4);
+  f.read(reinterpret_cast<char*>(&nf), 4);
+  hop::Mesh m;
+  m.V.resize(3 * (size_t)nv);
+  m.F.resize(3 * (size_t)nf);
+  f.read(reinterpret_cast<char*>(m.V.data()), sizeof(float) * m.V.size());
+  f.read(reinterpret_cast<char*>(m.F.data()), sizeof(int32_t) * m.F.size());
+  if (!f) throw std::runtime_error("short read " + path);
+  return m;
 }
 
 int main(int argc, char** argv) {
@@ -111,7 +131,25 @@ int main(int argc, char** argv) {
       match1 = hand.matchOneComponentPSO("finger_2_1", 0, 120, false, f1_d, f1_a, f1_min);
       if (match1) hand.matchOneComponentPSO("finger_2_2", 0, 90, true, f2_d, f2_a, f2_min);
     }
-    est.setCurScene(read_cloud(frame + "object_segment.bin"));
+    bool physics = false;
+    {
+      std::ifstream fm(frame + "meshes.txt"), fh(frame + "handbase_in_cam.txt");
+      if (fm && fh) {
+        physics = true;
+        for (int i = 0; i < 16; ++i) fh >> hand._handbase_in_cam.m[i];
+        std::string name, file;
+        hop::Mesh object_mesh;
+        while (fm >> name >> file) {
+          if (name == "object") object_mesh = read_mesh(frame + file);
+          else hand.addConvexMesh(name, read_mesh(frame + file));
+        }
+        hand.makeHandCloud();  // main :142
+        est.setCurScene(read_cloud(frame + "object_segment.bin"), read_cloud(frame + "cloud_withouthand.bin"));
+        est.registerHandMesh(&hand);                                         // main :186
+        est.registerMesh(object_mesh, "object", Mat4::Identity().m);         // main :187
+      }
+    }
+    if (!physics) est.setCurScene(read_cloud(frame + "object_segment.bin"));
     const bool succeed = est.runSuper4pcs(ppfs);
     PoseHypo best(-1);
     if (!succeed) {
@@ -123,6 +161,14 @@ int main(int argc, char** argv) {
     est.clusterPoses(30, 0.015, true);
     est.refineByICP();
     est.clusterPoses(5, 0.003, false);
+    if (physics) {
+      est.rejectByCollisionOrNonTouching(&hand);  // main :201
+      std::printf("hypotheses after physics: %d\n", est.numHypos());
+      if (est.numHypos() == 0) {
+        std::printf("No pose left...\n");
+        return 1;
+      }
+    }
     est.selectBest(best);
     std::ofstream ff(out_dir + "/model2scene.txt");
     ff.precision(9);

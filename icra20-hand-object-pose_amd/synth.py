@@ -481,7 +481,7 @@ FINGER_ORDER = ("finger_1_1", "finger_1_2", "finger_2_1", "finger_2_2")
 
 
 def physics_case(n_hyp: int = 64, seed: int = 3, n_model: int = 400, n_scene: int = 3000, mesh_subdiv: int = 2,
-                 finger_status=(1, 1, 1, 1), spacing=0.005):
+                 finger_status=(1, 1, 1, 1), spacing=0.005, max_rot_deg=25.0, max_trans=0.02):
     """Inputs of PoseEstimator::rejectByCollisionOrNonTouching (PoseEstimator.cpp:524-735) for a synthetic grasp.
 
     The ellipsoid sits between the two fingers of the stand-in hand (its 40 mm semi-axis across the 68 mm gap, so the
@@ -506,13 +506,15 @@ def physics_case(n_hyp: int = 64, seed: int = 3, n_model: int = 400, n_scene: in
     vis = np.einsum("ij,ij->i", nw, sw / np.linalg.norm(sw, axis=1, keepdims=True)) < -0.05
     obj_pts = sw[vis][: int(n_scene * 0.8)] + rng.normal(scale=0.0004, size=(min(int(n_scene * 0.8), int(vis.sum())), 3))
     clutter = gt[:3, 3] + rng.normal(scale=0.12, size=(n_scene - len(obj_pts), 3)) + np.array([0, 0, 0.15])
+    local = (clutter - gt[:3, 3]) @ gt[:3, :3]  # a depth camera sees no point inside (or hugging) the object
+    clutter = clutter[((local / (np.asarray(SEMI_AXES) + 0.02)) ** 2).sum(axis=1) > 1.0]
     cloud_without_hand = np.concatenate([obj_pts, clutter]).astype(np.float32)
     cloud_without_hand = np.ascontiguousarray(cloud_without_hand[rng.permutation(len(cloud_without_hand))])
     f2h = [hand_fk(hand, angles, name).astype(np.float32) for name in FINGER_ORDER]
     hand_cloud = np.concatenate([apply(hand_fk(hand, angles, name) if name != "base_link" else np.eye(4), hand.clouds[name][0])
                                  for name in ("base_link",) + FINGER_ORDER]).astype(np.float32)
     # hypotheses
-    poses = list(replay_poses(gt, max(n_hyp - 8, 0), seed=seed + 1, max_rot_deg=25.0, max_trans=0.02))
+    poses = list(replay_poses(gt, max(n_hyp - 8, 0), seed=seed + 1, max_rot_deg=max_rot_deg, max_trans=max_trans))
 
     def moved(dx, dy, dz):
         return handbase_in_cam @ se3(np.eye(3), [dx, dy, dz]) @ obj_in_hand

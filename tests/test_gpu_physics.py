@@ -195,3 +195,104 @@ def test_reject_requires_frame_and_handles_empty_set(api, synth):
         assert len(keep) == 0 and c.hypos_count() == 0
     finally:
         c.close()
+
+
+# ------------------------------------------------------------------------------------------------ host mirrors
+def _write_cloud(path, xyz, nrm=None, conf=None):
+    xyz = np.asarray(xyz, np.float32)
+    nrm = np.zeros_like(xyz) if nrm is None else np.asarray(nrm, np.float32)
+    with open(path, "wb") as f:
+        np.array([len(xyz), 0 if conf is None else 1], np.int32).tofile(f)
+        np.ascontiguousarray(xyz.T).tofile(f)
+        np.ascontiguousarray(nrm.T).tofile(f)
+        if conf is not None:
+            np.asarray(conf, np.float32).tofile(f)
+
+
+def _write_mesh(path, V, F):
+    with open(path, "wb") as f:
+        np.array([len(V), len(F)], np.int32).tofile(f)
+        np.ascontiguousarray(V, np.float32).tofile(f)
+        np.ascontiguousarray(F, np.int32).tofile(f)
+
+
+def test_cpp_host_app_with_physics_equals_python_mirror(api, hop, synth, tmp_path):
+    """main_realdata_auto.cpp:185-204 with registerHandMesh / registerMesh / rejectByCollisionOrNonTouching between the
+    second clusterPoses and selectBest: the C++ host and the Python mirror keep the same hypotheses and pick the same
+    pose."""
+    import math
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg_path = os.path.join(root, "icra20-hand-object-pose_amd", "config", "config_autodataset.yaml")
+    from hop_amd import config as hop_config
+    cfg = hop_config.load_config(cfg_path)
+    exe = os.path.join(root, "icra20-hand-object-pose_amd", "lib", "main_realdata_auto")
+    mx5, mn5 = synth.ellipsoid_model_spacing(0.005)
+    mx1, mn1 = synth.ellipsoid_model(4000)
+    keys = synth.ppf_key_table()
+    sc = synth.make_scene(1200, seed=7)
+    hand = synth.t42_hand()
+    true = {"finger_1_1": math.radians(10), "finger_1_2": math.radians(6), "finger_2_1": math.radians(12), "finger_2_2": math.radians(5)}
+    hxyz, hnrm = synth.make_hand_scene(hand, true, 4000, seed=5)
+    swivel = hxyz[hxyz[:, 0] < -0.1]
+    # the hand holds the object: object pose in the hand-base frame as in synth.physics_case
+    R_obj = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], dtype=np.float64)
+    obj_in_hand = synth.se3(R_obj, [-0.150, 0.0, 0.0])
+    handbase_in_cam = (sc.gt_pose.astype(np.float64) @ np.linalg.inv(obj_in_hand)).astype(np.float32)
+    V, F = synth.ellipsoid_mesh(subdiv=3)
+    frame, out = tmp_path / "frame", tmp_path / "out"
+    frame.mkdir()
+    out.mkdir()
+    _write_cloud(frame / "model.bin", mx5, mn5)
+    _write_cloud(frame / "model001.bin", mx1, mn1)
+    _write_cloud(frame / "object_segment.bin", sc.xyz, sc.nrm, sc.conf)
+    _write_cloud(frame / "cloud_withouthand.bin", sc.xyz, sc.nrm)
+    with open(frame / "ppf_keys.bin", "wb") as f:
+        np.array([len(keys)], np.int32).tofile(f)
+        np.ascontiguousarray(keys, np.int32).tofile(f)
+    with open(frame / "hand.txt", "w") as f:
+        for name in hand.clouds:
+            if name == "base_link":
+                continue
+            x, n = hand.clouds[name]
+            _write_cloud(frame / f"{name}.bin", x, n)
+            f.write(f"{name} {hand.parents[name]} {name}.bin " + " ".join(repr(float(v)) for v in hand.tf_in_parent[name].reshape(16)) + "\n")
+    with open(frame / "meshes.txt", "w") as f:
+        _write_mesh(frame / "object.mesh", V, F)
+        f.write("object object.mesh\n")
+        for name in synth.FINGER_ORDER:
+            _write_mesh(frame / f"{name}.mesh", *hand.meshes[name])
+            f.write(f"{name} {name}.mesh\n")
+    (frame / "handbase_in_cam.txt").write_text(" ".join(repr(float(v)) for v in handbase_in_cam.reshape(16)) + "\n")
+    _write_cloud(frame / "hand_scene.bin", hxyz)
+    _write_cloud(frame / "hand_region.bin", hxyz, hnrm)
+    _write_cloud(frame / "hand_swivel.bin", swivel)
+    (frame / "cam_side.txt").write_text("1\n")
+    r = subprocess.run([exe, cfg_path, str(frame), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cpp_pose = np.loadtxt(out / "model2scene.txt").astype(np.float32)
+    cpp_left = int([ln for ln in r.stdout.splitlines() if ln.startswith("hypotheses after physics:")][0].split(":")[1])
+
+    est = api.PoseEstimator(cfg, (mx5, mn5), (mx1, mn1))
+    h = api.HandT42(cfg, hand, ctx=est.ctx)
+    ext = np.abs(mx1.min(axis=0) - mx1.max(axis=0))
+    h.gripper_min_dist = 0.8 * float(ext.min())
+    h.setCurScene(hxyz, hnrm, swivel)
+    hm = cfg["hand_match"]
+    for first, second in (("finger_2_1", "finger_2_2"), ("finger_1_1", "finger_1_2")):
+        if h.matchOneComponentPSO(first, 0, 120, False, hm["finger1_dist_thres"], hm["finger1_normal_angle"], hm["finger1_min_match"]):
+            h.matchOneComponentPSO(second, 0, 90, True, hm["finger2_dist_thres"], hm["finger2_normal_angle"], hm["finger2_min_match"])
+    h.makeHandCloud()
+    est.setCurScene(sc.xyz, sc.nrm, sc.conf, cloud_withouthand_raw=sc.xyz)
+    est.registerHandMesh(h)
+    est.registerMesh(V, F, "object")
+    assert est.runSuper4pcs(keys)
+    est.clusterPoses(30, 0.015, True)
+    est.refineByICP()
+    est.clusterPoses(5, 0.003, False)
+    n_before = est.ctx.hypos_count()
+    keep, diag = est.rejectByCollisionOrNonTouching(h, handbase_in_cam)
+    assert len(keep) == n_before and est.ctx.hypos_count() == keep.sum() == cpp_left
+    assert 0 < keep.sum()
+    best = est.selectBest()
+    assert np.abs(cpp_pose - best._pose).max() < 1e-6
