@@ -50,6 +50,8 @@ def parse():
                     "frame overlaps the device work of the others; 1 = strictly one frame at a time")
     ap.add_argument("--no-serial-frame", action="store_true", help="skip the extra undisturbed frame used for per-kernel timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the separate measurement of the physics rejection (SURVEY 8f N1)")
+    ap.add_argument("--physics-hyps", type=int, default=2048)
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     return ap.parse_args()
 
@@ -134,6 +136,64 @@ class Workload:
         return dict(h=hh, h_gen=st.n_hypotheses, n_cand=st.n_candidates, n_bases=st.n_bases, best=best, score=score,
                     icp_hyp_iters=int(np.sum(it)), n_pairs=st.n_pairs, n_quads=st.n_quads, rows=rows,
                     t_frame=t0 - tf, t_pso=t1 - t0, t_gen=t2 - t1, t_icp=t3 - t2, t_lcp=t4 - t3, ms_select=st.ms_select)
+
+
+def _load_oracle():
+    """TEST INFRASTRUCTURE: only the cpu_baseline legs import it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    orc.build()
+    return orc
+
+
+def physics_row(w, args, with_cpu):
+    """SURVEY.md 8(f) N1, measured on its own after the timed region (it does not enter `value`): hypotheses within
+    8 deg / 4 mm of a grasp of the ellipsoid (so that most of them pass the early checks and reach the mesh checks)
+    through hop_reject_by_collision; the oracle on a bounded sample of the same hypotheses beside it."""
+    synth = w.hop.synth
+    p, poses = synth.physics_case(args.physics_hyps, seed=21, n_model=args.model, n_scene=args.scene, mesh_subdiv=4, spacing=0.003,
+                                  max_rot_deg=8.0, max_trans=0.004)
+    c = w.ctx
+    t0 = time.perf_counter()
+    for mid, V, Fi, T in p["meshes"]:
+        c.sdf_register_mesh(mid, V, Fi, T)
+    ms_register = 1e3 * (time.perf_counter() - t0)
+    ms_frame, ms_reject, wall = [], [], []
+    keep = None
+    for it in range(6):
+        c.physics_set_frame(p)
+        c.hypos_upload(poses)
+        t0 = time.perf_counter()
+        keep, diag = c.reject_by_collision()
+        wall.append(1e3 * (time.perf_counter() - t0))
+        a, b = c.physics_timing()
+        ms_frame.append(a), ms_reject.append(b)
+    ms_frame, ms_reject, wall = ms_frame[1:], ms_reject[1:], wall[1:]
+    H = len(poses)
+    out = {"row": "N1 rejectByCollisionOrNonTouching (PoseEstimator.cpp:524-735)",
+           "hypotheses": H, "object_faces": int(len(p["object_F"])), "finger_faces": [int(len(f)) for f in p["finger_F"]],
+           "finger_points": [int(len(x)) for x in p["finger_xyz"]], "model_points": int(len(p["model"])),
+           "scene_points": int(len(p["cloud_without_hand"])),
+           "kept": int(keep.sum()), "decided_by_check": np.bincount(diag[:, 0].astype(int), minlength=6).tolist(),
+           "device_ms_reject": float(np.mean(ms_reject)), "device_ms_set_frame": float(np.mean(ms_frame)), "wall_ms_reject": float(np.mean(wall)),
+           "host_ms_register_meshes": ms_register,
+           "value": H / (float(np.mean(wall)) * 1e-3), "unit": "hypotheses/s",
+           "bound": "VALU issue and L1/L2 latency of a per-query tree walk (meshes are cache resident: no HBM or MFMA roofline applies)"}
+    if with_cpu:
+        orc = _load_oracle()
+        n = min(H, 64)
+        t0 = time.perf_counter()
+        ko, _ = orc.reject_by_collision(p, poses[:n])
+        dt = time.perf_counter() - t0
+        while dt < 2.0 and n < H:   # grow the sample until it takes a couple of seconds
+            n = min(H, n * 4)
+            t0 = time.perf_counter()
+            ko, _ = orc.reject_by_collision(p, poses[:n])
+            dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / dt, "unit": "hypotheses/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"first {n} of the {H} hypotheses, oracle (libigl restatement, OpenMP over hypotheses)",
+                               "decisions_equal": bool(np.array_equal(ko, keep[:n]))}
+    return out
 
 
 def cpu_baseline(w, budget_s):
@@ -392,6 +452,11 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget_s)
             except Exception as e:  # the baseline is reported, never required for the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "hypotheses/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        if not args.no_next_rows and world == 1:
+            try:
+                out["next_rows"] = {"n1_physics": physics_row(w, args, not args.no_cpu_baseline)}
+            except Exception as e:
+                out["next_rows"] = {"n1_physics": {"value": None, "error": str(e)}}
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
