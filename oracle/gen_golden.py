@@ -168,11 +168,36 @@ def sdf_query_points(rng, V, Fi, n_box=1200, n_far=300, n_vert=250, n_edge=250):
     ]).astype(np.float32)
 
 
+def sdf_special_meshes():
+    """Edge cases: one triangle, an open bumpy sheet, a closed box with a zero-area face, a duplicated vertex and an
+    unreferenced vertex, and two disconnected components."""
+    rng = np.random.default_rng(77)
+    single = (np.array([[0, 0, 0], [0.03, 0, 0], [0, 0.02, 0.01]], np.float32), np.array([[0, 1, 2]], np.int32))
+    g = np.linspace(-0.03, 0.03, 7)
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    Z = 0.004 * np.sin(40 * X) * np.cos(30 * Y)
+    Vs = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1).astype(np.float32)
+    Fs = []
+    for i in range(6):
+        for j in range(6):
+            a, b, c, d = i * 7 + j, (i + 1) * 7 + j, (i + 1) * 7 + j + 1, i * 7 + j + 1
+            Fs += [(a, b, c), (a, c, d)]
+    sheet = (Vs, np.asarray(Fs, np.int32))
+    Vb, Fb = synth.box_mesh((-0.01, -0.02, -0.015), (0.01, 0.02, 0.015), (1, 2, 1))
+    Vd = np.concatenate([Vb, Vb[:1], [[0.5, 0.5, 0.5]]]).astype(np.float32)  # duplicate of vertex 0, an unused vertex
+    Fd = np.concatenate([Fb, [[0, 1, 1]], [[len(Vb), 2, 3]]]).astype(np.int32)  # zero-area face, a face on the duplicate
+    degenerate = (Vd, Fd)
+    V1, F1 = synth.ellipsoid_mesh((0.01, 0.01, 0.01), subdiv=1)
+    two = (np.concatenate([V1, V1 + np.float32([0.05, 0, 0])]).astype(np.float32), np.concatenate([F1, F1 + len(V1)]).astype(np.int32))
+    return {"single": single, "sheet": sheet, "degenerate": degenerate, "two_parts": two}
+
+
 def gen_sdf():
     """Row N1: signed distances of the reference's own libigl (oracle/_ref/libref_sdf.so) on the synthetic meshes."""
     rng = np.random.default_rng(2024)
     meshes = {"ellipsoid": synth.ellipsoid_mesh(subdiv=2), "box": synth.box_mesh((0, 0, 0), (0.02, 0.012, 0.06)),
               "torus": synth.torus_mesh(), "lshape": synth.lshape_mesh()}
+    meshes.update(sdf_special_meshes())
     data = {}
     for name, (V, Fi) in meshes.items():
         P = sdf_query_points(rng, V, Fi)

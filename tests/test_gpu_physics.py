@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-MESHES = ("ellipsoid", "box", "torus", "lshape")
+MESHES = ("ellipsoid", "box", "torus", "lshape", "single", "sheet", "degenerate", "two_parts")
 
 
 @pytest.fixture(scope="module")

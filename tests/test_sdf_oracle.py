@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-MESHES = ("ellipsoid", "box", "torus", "lshape")
+MESHES = ("ellipsoid", "box", "torus", "lshape", "single", "sheet", "degenerate", "two_parts")
 
 
 @pytest.mark.parametrize("name", MESHES)
@@ -17,7 +17,7 @@ def test_oracle_sdf_matches_libigl_golden(orc, golden_dir, name):
     # which of several faces at exactly the same float distance is reported (20-30 % of these queries have such ties)
     assert np.array_equal(S.view(np.int32), g[f"{name}_S"].view(np.int32))
     assert np.array_equal(I, g[f"{name}_I"])
-    assert (S < 0).sum() > 100 and (S > 0).sum() > 100
+    assert (S < 0).sum() > 100 and (S > 0).sum() > 100  # open meshes: 'inside' is the side the normals point away from
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
