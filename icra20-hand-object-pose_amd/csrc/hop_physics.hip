@@ -107,6 +107,7 @@ struct TreeBuilder {
   std::vector<V3> cen, lo, hi; // per face
   std::vector<SdfNode> nodes;
   std::vector<int> slot_face;  // leaf order
+  std::vector<int> leaf_first; // slot range of every leaf (n_leaves + 1 entries)
   int max_depth = 0;
 
   explicit TreeBuilder(const HostMesh& mesh) : m(mesh) {
@@ -174,8 +175,7 @@ struct TreeBuilder {
     std::memset(&nd, 0, sizeof(nd));
     for (int k = 0; k < 4; ++k) {
       for (int a = 0; a < 3; ++a) nd.lo[a][k] = INFINITY, nd.hi[a][k] = -INFINITY;
-      nd.child[k] = -1, nd.count[k] = 0;
-
+      nd.child[k] = SDF_NO_CHILD;
     }
     for (int k = 0; k < nc; ++k) {
       const int cb = cuts[k], ce = cuts[k + 1];
@@ -185,8 +185,9 @@ struct TreeBuilder {
       nd.lo[0][k] = blo.x, nd.lo[1][k] = blo.y, nd.lo[2][k] = blo.z;
       nd.hi[0][k] = bhi.x, nd.hi[1][k] = bhi.y, nd.hi[2][k] = bhi.z;
       if (ce - cb <= SDF_LEAF) {
-        nd.child[k] = -((int)slot_face.size() + 1);
-        nd.count[k] = (unsigned char)(ce - cb);
+        max_depth = std::max(max_depth, depth + 1);
+        nd.child[k] = (int)(SDF_LEAF_BASE + (unsigned)leaf_first.size());
+        leaf_first.push_back((int)slot_face.size());
         std::sort(order.begin() + cb, order.begin() + ce);
         for (int i = cb; i < ce; ++i) slot_face.push_back(order[i]);
       } else {
@@ -260,10 +261,10 @@ struct OrderTree {
 };
 
 struct MeshStore {
-  DevBuf tri_d, nrm_d, nodes_d, order_d, leaf_d;
+  DevBuf tri_d, nrm_d, nodes_d, order_d, leaf_d, leaf_first_d;
   SdfMeshDev dev{};
   bool valid = false;
-  void release() { tri_d.release(), nrm_d.release(), nodes_d.release(), order_d.release(), leaf_d.release(), valid = false; }
+  void release() { tri_d.release(), nrm_d.release(), nodes_d.release(), order_d.release(), leaf_d.release(), leaf_first_d.release(), valid = false; }
 };
 
 struct Cloud3 {
@@ -681,7 +682,8 @@ int hop_sdf_register_mesh(hop_ctx* c, int mesh_id, const float* V, int nv, const
   prepare_mesh(hm, V, nv, F, nf, pose16);
   TreeBuilder tb(hm);
   if (nf > 0) tb.build(0, nf, 0);
-  if (3 * tb.max_depth + 1 > SDF_STACK || tb.nodes.size() >= (size_t)(1u << SDF_NODE_BITS) || nf > (1 << 22)) {
+  tb.leaf_first.push_back((int)tb.slot_face.size());
+  if (3 * tb.max_depth + 1 > SDF_STACK || tb.nodes.size() >= (size_t)SDF_LEAF_BASE || tb.leaf_first.size() > (size_t)SDF_LEAF_BASE || nf > (1 << 22)) {
     hop_ctx_set_error(c, "mesh too large for the traversal stack");
     return HOP_E_CAPACITY;
   }
@@ -709,6 +711,8 @@ int hop_sdf_register_mesh(hop_ctx* c, int mesh_id, const float* V, int nv, const
   PHCHK(c, ms.nodes_d.ensure(std::max<size_t>(sizeof(SdfNode) * tb.nodes.size(), 256)));
   PHCHK(c, ms.order_d.ensure(std::max<size_t>(sizeof(SdfOrderNode) * ot.nodes.size(), 32)));
   PHCHK(c, ms.leaf_d.ensure(std::max<size_t>(sizeof(int) * (size_t)nf, 16)));
+  PHCHK(c, ms.leaf_first_d.ensure(sizeof(int) * tb.leaf_first.size()));
+  PHCHK(c, hipMemcpyAsync(ms.leaf_first_d.p, tb.leaf_first.data(), sizeof(int) * tb.leaf_first.size(), hipMemcpyHostToDevice, st));
   if (nf > 0) {
     PHCHK(c, hipMemcpyAsync(ms.tri_d.p, tri.data(), sizeof(float4) * tri.size(), hipMemcpyHostToDevice, st));
     PHCHK(c, hipMemcpyAsync(ms.nrm_d.p, nrm.data(), sizeof(float4) * nrm.size(), hipMemcpyHostToDevice, st));
@@ -718,7 +722,7 @@ int hop_sdf_register_mesh(hop_ctx* c, int mesh_id, const float* V, int nv, const
   }
   PHCHK(c, hipStreamSynchronize(st));
   ms.dev.tri = ms.tri_d.as<float4>(), ms.dev.nrm = ms.nrm_d.as<float4>(), ms.dev.nodes = ms.nodes_d.as<SdfNode>();
-  ms.dev.order = ms.order_d.as<SdfOrderNode>(), ms.dev.face_leaf = ms.leaf_d.as<int>();
+  ms.dev.order = ms.order_d.as<SdfOrderNode>(), ms.dev.face_leaf = ms.leaf_d.as<int>(), ms.dev.leaf_first = ms.leaf_first_d.as<int>();
   ms.dev.n_faces = nf, ms.dev.n_nodes = (int)tb.nodes.size();
   ms.dev.coord_eps = 4e-7f * hm.max_abs;
   ms.valid = true;

@@ -9,7 +9,8 @@
 //                             (pseudonormal_test.cpp:50-62), B.w = original face index (as int bits)
 //   nrm   [slots][7] float4   face normal, the three edge pseudonormals (edge opposite corner 0,1,2), the three
 //                             vertex pseudonormals (corner 0,1,2); .w unused
-//   nodes [n_nodes]           4 children per node: boxes as SoA (lo/hi x 3 axes x 4 lanes), child index or leaf range
+//   nodes [n_nodes]           4 children per node: boxes as SoA (lo/hi x 3 axes x 4 lanes), child ids
+//   leaf_first [n_leaves+1]   slot range of every leaf
 //   order [2^(depth+1)]       libigl's own AABB tree (AABB.cpp:106-200: one face per leaf), boxes only, in heap order
 //   face_leaf [n_faces]       heap index of the leaf of `order` that holds each face
 // A query evaluates, for every face whose box lower bound does not exceed the best squared distance so far (plus the
@@ -28,14 +29,14 @@
 namespace hop {
 
 constexpr int SDF_LEAF = 4;       // faces per leaf
-constexpr int SDF_STACK = 32;     // traversal stack entries per thread: a 4-wide tree of depth D needs at most 3 D + 1 (the build checks it)
+constexpr int SDF_STACK = 32;     // traversal stack entries per thread: a 4-wide tree of depth D (leaves included) needs at most 3 D + 1 (the build checks it)
+constexpr int SDF_NO_CHILD = -1;
 
 struct SdfNode {
   float lo[3][4];
   float hi[3][4];
-  int child[4];            // >= 0: inner node; < 0: leaf, first slot = -(child + 1); empty child: count 0 and lo = +inf
-  unsigned char count[4];  // faces of a leaf child (0 for inner / empty)
-  int pad[3];
+  int child[4];  // stack id of the child: inner node index, SDF_LEAF_BASE + leaf index, or SDF_NO_CHILD (lo = +inf)
+  int pad[4];
 };
 static_assert(sizeof(SdfNode) == 128, "one node is one 128-byte line");
 
@@ -53,6 +54,7 @@ struct SdfMeshDev {
   const SdfNode* nodes;
   const SdfOrderNode* order;
   const int* face_leaf;
+  const int* leaf_first;  // n_leaves + 1: slots of leaf l are [leaf_first[l], leaf_first[l + 1])
   int n_faces, n_nodes;
   float coord_eps;  // 4e-7 * largest |coordinate| of the mesh: float error scale of a closest point
 };
@@ -60,6 +62,8 @@ struct SdfMeshDev {
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------------------------------------- device side
 // Ericson's closest point on a triangle, the float expression of point_simplex_squared_distance.cpp:43-113.
+// (Evaluating all seven region tests up front and sharing one division between the edge regions was tried: most tests
+// leave through the first two exits after two to four dot products, and the early exits are cheaper.)
 __device__ __forceinline__ V3 sdf_closest_point(V3 p, V3 a, V3 b, V3 c) {
   const V3 ab = b - a, ac = c - a, ap = p - a;
   const float d1 = vdot(ab, ap), d2 = vdot(ac, ap);
@@ -188,7 +192,7 @@ __device__ inline bool sdf_precedes(const SdfMeshDev& m, V3 p, int f, int g) {
   return left_first == a_left;
 }
 
-#ifdef SDF_COUNT  // measurement build (tools/sdf_counters.py): nodes visited, faces tested, exact ties, queries
+#ifdef SDF_COUNT  // measurement build (tools/physics_profile.py --counters): nodes visited, faces tested, exact ties, queries
 __device__ unsigned long long g_sdf_cnt[4];
 #endif
 struct SdfHit {
@@ -198,71 +202,79 @@ struct SdfHit {
   V3 c;
 };
 
-// exact closest face (see the header comment).  `stack`: SDF_STACK entries of this thread's own storage, entry k at
-// stack[k * stride] (LDS, lane-interleaved so that equal depths of a wavefront fall into different banks).  An entry
-// packs the node index (low SDF_NODE_BITS bits) with the top bits of the node's lower bound (rounded towards zero, i.e.
-// still a lower bound: sign, exponent and 7 mantissa bits).
-#ifndef SDF_NODE_BITS_V
-#define SDF_NODE_BITS_V 16
-#endif
-constexpr int SDF_NODE_BITS = SDF_NODE_BITS_V;
-__device__ __forceinline__ unsigned sdf_pack(float lb, int node) {
-  return (__float_as_uint(lb) & ~((1u << SDF_NODE_BITS) - 1u)) | (unsigned)node;
+// ---- exact closest face (see the header comment) as a resumable walk: one call of sdf_walk_step handles one stack
+// entry, either an inner node (four child boxes) or a leaf (up to SDF_LEAF faces), so that a kernel can keep every lane
+// busy with its own query and hand a lane its next query as soon as its stack runs empty.
+// `stack`: SDF_STACK entries of this thread's own storage, entry k at stack[k * stride] (LDS, lane-interleaved so that
+// equal depths of a wavefront fall into different banks).  An entry packs an id (low SDF_ID_BITS bits: inner node index,
+// or SDF_LEAF_BASE + leaf index) with the top 14 bits of the entry's lower bound (8 exponent + 6 mantissa bits, rounded
+// towards zero, i.e. still a lower bound).
+constexpr int SDF_ID_BITS = 18;
+constexpr unsigned SDF_LEAF_BASE = 1u << (SDF_ID_BITS - 1);
+__device__ __forceinline__ unsigned sdf_pack(float lb, unsigned id) {
+  return ((__float_as_uint(lb) >> 17) << SDF_ID_BITS) | id;
 }
-__device__ inline SdfHit sdf_closest_face(const SdfMeshDev& m, V3 q, unsigned* stack, int stride) {
+__device__ __forceinline__ float sdf_unpack_bound(unsigned e) { return __uint_as_float((e >> SDF_ID_BITS) << 17); }
+
+struct SdfWalk {
+  V3 q;
   SdfHit h;
-  h.sqr_d = __builtin_inff(), h.slot = -1, h.face = 0x7fffffff, h.c = v3(0, 0, 0);
-  if (m.n_faces <= 0) return h;
+  float thr, de;
+  int sp;
+};
+__device__ __forceinline__ void sdf_walk_begin(SdfWalk& w, const SdfMeshDev& m, V3 q, unsigned* stack, int stride) {
+  w.q = q;
+  w.h.sqr_d = __builtin_inff(), w.h.slot = -1, w.h.face = 0x7fffffff, w.h.c = v3(0, 0, 0);
+  w.thr = __builtin_inff();  // prune bound: best + float slack of the triangle expression
+  w.de = m.coord_eps + 4e-7f * fmaxf(fabsf(q.x), fmaxf(fabsf(q.y), fabsf(q.z)));
+  w.sp = 0;
+  if (m.n_faces > 0) stack[(w.sp++) * stride] = sdf_pack(0.f, 0u);
 #ifdef SDF_COUNT
   atomicAdd(&g_sdf_cnt[3], 1ull);
 #endif
-  float thr = __builtin_inff();  // prune bound: best + float slack of the triangle expression
-  const float de = m.coord_eps + 4e-7f * fmaxf(fabsf(q.x), fmaxf(fabsf(q.y), fabsf(q.z)));
-  int sp = 0;
-  stack[(sp++) * stride] = sdf_pack(0.f, 0);
-  while (sp > 0) {
-    const unsigned e = stack[(--sp) * stride];
-    if (__uint_as_float(e & ~((1u << SDF_NODE_BITS) - 1u)) > thr) continue;
-    const SdfNode& nd = m.nodes[e & ((1u << SDF_NODE_BITS) - 1u)];
+}
+__device__ inline void sdf_walk_step(SdfWalk& w, const SdfMeshDev& m, unsigned* stack, int stride) {
+  const unsigned e = stack[(--w.sp) * stride];
+  if (sdf_unpack_bound(e) > w.thr) return;
+  const unsigned id = e & ((1u << SDF_ID_BITS) - 1u);
+  if (id >= SDF_LEAF_BASE) {
+    const int first = m.leaf_first[id - SDF_LEAF_BASE], end = m.leaf_first[id - SDF_LEAF_BASE + 1];
+    for (int s = first; s < end; ++s) {
+      const float4 A4 = m.tri[3 * s], B4 = m.tri[3 * s + 1], C4 = m.tri[3 * s + 2];
+      const V3 c = sdf_closest_point(w.q, v3(A4.x, A4.y, A4.z), v3(B4.x, B4.y, B4.z), v3(C4.x, C4.y, C4.z));
+      const float d = vsqn(w.q - c);
+      const int face = __float_as_int(B4.w);
 #ifdef SDF_COUNT
-    atomicAdd(&g_sdf_cnt[0], 1ull);
+      atomicAdd(&g_sdf_cnt[1], 1ull);
+      if (d == w.h.sqr_d) atomicAdd(&g_sdf_cnt[2], 1ull);
 #endif
-    float lb[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float dx = fmaxf(fmaxf(nd.lo[0][k] - q.x, q.x - nd.hi[0][k]), 0.f);
-      const float dy = fmaxf(fmaxf(nd.lo[1][k] - q.y, q.y - nd.hi[1][k]), 0.f);
-      const float dz = fmaxf(fmaxf(nd.lo[2][k] - q.z, q.z - nd.hi[2][k]), 0.f);
-      lb[k] = dx * dx + dy * dy + dz * dz;  // +inf for an empty child (lo = +inf)
-    }
-    // leaves first (they tighten the bound)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int cnt = nd.count[k];
-      if (cnt == 0 || !(lb[k] <= thr)) continue;
-      const int first = -(nd.child[k] + 1);
-      for (int s = first; s < first + cnt; ++s) {
-        const float4 A4 = m.tri[3 * s], B4 = m.tri[3 * s + 1], C4 = m.tri[3 * s + 2];
-        const V3 c = sdf_closest_point(q, v3(A4.x, A4.y, A4.z), v3(B4.x, B4.y, B4.z), v3(C4.x, C4.y, C4.z));
-        const float d = vsqn(q - c);
-        const int face = __float_as_int(B4.w);
-#ifdef SDF_COUNT
-        atomicAdd(&g_sdf_cnt[1], 1ull);
-        if (d == h.sqr_d) atomicAdd(&g_sdf_cnt[2], 1ull);
-#endif
-        if (d < h.sqr_d || (d == h.sqr_d && sdf_precedes(m, q, face, h.face))) {
-          h.sqr_d = d, h.slot = s, h.face = face, h.c = c;
-          thr = d + (2.f * sqrtf(d) * de + de * de) + d * 1e-5f;
-        }
+      if (d < w.h.sqr_d || (d == w.h.sqr_d && sdf_precedes(m, w.q, face, w.h.face))) {
+        w.h.sqr_d = d, w.h.slot = s, w.h.face = face, w.h.c = c;
+        w.thr = d + (2.f * sqrtf(d) * w.de + w.de * w.de) + d * 1e-5f;
       }
     }
-    // inner children that can still matter, pushed farthest first so that the nearest is popped first
-    // (5-exchange sorting network on registers; key -1 marks a child that is not pushed)
-    float k0 = (nd.count[0] == 0 && nd.child[0] >= 0 && lb[0] <= thr) ? lb[0] : -1.f;
-    float k1 = (nd.count[1] == 0 && nd.child[1] >= 0 && lb[1] <= thr) ? lb[1] : -1.f;
-    float k2 = (nd.count[2] == 0 && nd.child[2] >= 0 && lb[2] <= thr) ? lb[2] : -1.f;
-    float k3 = (nd.count[3] == 0 && nd.child[3] >= 0 && lb[3] <= thr) ? lb[3] : -1.f;
-    int c0 = nd.child[0], c1 = nd.child[1], c2 = nd.child[2], c3 = nd.child[3];
+    return;
+  }
+  const SdfNode& nd = m.nodes[id];
+#ifdef SDF_COUNT
+  atomicAdd(&g_sdf_cnt[0], 1ull);
+#endif
+  const int child[4] = {nd.child[0], nd.child[1], nd.child[2], nd.child[3]};
+  float lb[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float dx = fmaxf(fmaxf(nd.lo[0][k] - w.q.x, w.q.x - nd.hi[0][k]), 0.f);
+    const float dy = fmaxf(fmaxf(nd.lo[1][k] - w.q.y, w.q.y - nd.hi[1][k]), 0.f);
+    const float dz = fmaxf(fmaxf(nd.lo[2][k] - w.q.z, w.q.z - nd.hi[2][k]), 0.f);
+    lb[k] = dx * dx + dy * dy + dz * dz;  // +inf for an empty child (lo = +inf)
+  }
+  // children that can still matter, pushed farthest first so that the nearest is popped first
+  // (5-exchange sorting network on registers; key -1 marks a child that is not pushed)
+  float k0 = (child[0] != SDF_NO_CHILD && lb[0] <= w.thr) ? lb[0] : -1.f;
+  float k1 = (child[1] != SDF_NO_CHILD && lb[1] <= w.thr) ? lb[1] : -1.f;
+  float k2 = (child[2] != SDF_NO_CHILD && lb[2] <= w.thr) ? lb[2] : -1.f;
+  float k3 = (child[3] != SDF_NO_CHILD && lb[3] <= w.thr) ? lb[3] : -1.f;
+  int c0 = child[0], c1 = child[1], c2 = child[2], c3 = child[3];
 #define SDF_CX(ka, ca, kb, cb)      \
   if (ka < kb) {                    \
     const float tk = ka;            \
@@ -270,26 +282,30 @@ __device__ inline SdfHit sdf_closest_face(const SdfMeshDev& m, V3 q, unsigned* s
     const int tc = ca;              \
     ca = cb, cb = tc;               \
   }
-    SDF_CX(k0, c0, k1, c1) SDF_CX(k2, c2, k3, c3) SDF_CX(k0, c0, k2, c2) SDF_CX(k1, c1, k3, c3) SDF_CX(k1, c1, k2, c2)
+  SDF_CX(k0, c0, k1, c1) SDF_CX(k2, c2, k3, c3) SDF_CX(k0, c0, k2, c2) SDF_CX(k1, c1, k3, c3) SDF_CX(k1, c1, k2, c2)
 #undef SDF_CX
-    if (k0 >= 0.f) stack[(sp++) * stride] = sdf_pack(k0, c0);
-    if (k1 >= 0.f) stack[(sp++) * stride] = sdf_pack(k1, c1);
-    if (k2 >= 0.f) stack[(sp++) * stride] = sdf_pack(k2, c2);
-    if (k3 >= 0.f) stack[(sp++) * stride] = sdf_pack(k3, c3);
-  }
-  return h;
+  if (k0 >= 0.f) stack[(w.sp++) * stride] = sdf_pack(k0, (unsigned)c0);
+  if (k1 >= 0.f) stack[(w.sp++) * stride] = sdf_pack(k1, (unsigned)c1);
+  if (k2 >= 0.f) stack[(w.sp++) * stride] = sdf_pack(k2, (unsigned)c2);
+  if (k3 >= 0.f) stack[(w.sp++) * stride] = sdf_pack(k3, (unsigned)c3);
 }
 
 // igl::signed_distance for one point with the bounds SDFchecker passes (lower = -FLT_MAX, upper = FLT_MAX:
 // up_sqr_d = +inf, low_sqr_d = 0, signed_distance.cpp:117-156): NaN for a point at distance zero.
-__device__ inline float sdf_signed_distance(const SdfMeshDev& m, V3 q, unsigned* stack, int stride, int* face_out) {
-  const SdfHit h = sdf_closest_face(m, q, stack, stride);
+__device__ inline float sdf_walk_finish(const SdfWalk& w, const SdfMeshDev& m, int* face_out) {
+  const SdfHit& h = w.h;
   if (h.slot < 0 || !(h.sqr_d > 0.f) || !(h.sqr_d < __builtin_inff())) {
     if (face_out) *face_out = m.n_faces + 1;
     return __builtin_nanf("");
   }
   if (face_out) *face_out = h.face;
-  return sdf_sign(m, h.slot, q, h.c) * sqrtf(h.sqr_d);
+  return sdf_sign(m, h.slot, w.q, h.c) * sqrtf(h.sqr_d);
+}
+__device__ inline float sdf_signed_distance(const SdfMeshDev& m, V3 q, unsigned* stack, int stride, int* face_out) {
+  SdfWalk w;
+  sdf_walk_begin(w, m, q, stack, stride);
+  while (w.sp > 0) sdf_walk_step(w, m, stack, stride);
+  return sdf_walk_finish(w, m, face_out);
 }
 #endif  // __HIPCC__
 
