@@ -144,6 +144,7 @@ SIGNATURES = {
     "hop_sdf_register_mesh": (C.c_int, [_vp, C.c_int, fp, C.c_int, ip, C.c_int, fp]),
     "hop_sdf_signed_distance": (C.c_int, [_vp, C.c_int, fp, C.c_int, fp, ip, fp, fp]),
     "hop_voxel_downsample": (C.c_int, [_vp, fp, C.c_int, C.c_float, fp, C.c_int, ip]),
+    "hop_scene_from_depth": (C.c_int, [_vp, C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_double, fp, fp, fp, C.c_float, fp, fp, fp, C.c_int, ip, ip]),
     "hop_physics_set_frame": (C.c_int, [_vp, C.POINTER(PhysicsArgs)]),
     "hop_reject_by_collision": (C.c_int, [_vp, C.POINTER(C.c_ubyte), fp, ip]),
     "hop_physics_timing": (C.c_int, [_vp, dp, dp]),
@@ -334,6 +335,23 @@ class Context:
         k = C.c_int(0)
         self._chk(self.L.hop_voxel_downsample(self.h, F(X), n, leaf, F(out), max(n, 1), C.byref(k)), "hop_voxel_downsample")
         return out[:, :k.value].T.copy()
+
+    def scene_from_depth(self, depth_raw, depth_unit, K, cam_in_handbase, handbase_in_cam, leaf=0.001,
+                         crop_min=(-0.25, -0.2, -0.12), crop_max=(-0.07, 0.2, 0.05)):
+        """main_realdata_auto.cpp:54-96 (no colours, no normals): (xyz (n,3) camera frame, counts[valid px, voxels, cropped])."""
+        d = np.ascontiguousarray(depth_raw, np.uint16)
+        H, W = d.shape
+        K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+        A = np.ascontiguousarray(cam_in_handbase, np.float32).reshape(16)
+        B = np.ascontiguousarray(handbase_in_cam, np.float32).reshape(16)
+        lo, hi = np.ascontiguousarray(crop_min, np.float32), np.ascontiguousarray(crop_max, np.float32)
+        cap = H * W
+        out = np.zeros((3, cap), np.float32)
+        n = C.c_int(0)
+        counts = np.zeros(3, np.int32)
+        self._chk(self.L.hop_scene_from_depth(self.h, d.ctypes.data_as(C.POINTER(C.c_ushort)), H, W, depth_unit, F(K9), F(A), F(B), leaf, F(lo), F(hi),
+                                              F(out), cap, C.byref(n), I(counts)), "hop_scene_from_depth")
+        return out[:, :n.value].T.copy(), counts
 
     def physics_set_frame(self, p):
         """p: dict -- object_mesh, finger_mesh[4] (registered ids), finger_xyz[4] ((n,3), link frame), finger2handbase[4],

@@ -581,6 +581,49 @@ __global__ void k_phys_gather(const int* __restrict__ src, int n, const float* _
   if (e == 0) oscore[k] = score[s], oid[k] = id[s];
 }
 
+// ---- scene front end (main_realdata_auto.cpp:54-96 without colours and normals)
+// readDepthImage + convert3dOrganizedRGB + the z pass-through: one thread per pixel, NaN for a dropped pixel (the voxel
+// grid skips non-finite points, as pcl::VoxelGrid does); valid pixels are counted
+__global__ void k_depth_to_cloud(const unsigned short* __restrict__ depth, int H, int W, double unit, float cx, float fx, float cy, float fy,
+                                 float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz, unsigned* __restrict__ n_valid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * W) return;
+  const int u = i / W, v = i - u * W;
+  float d = (float)((double)(float)depth[i] * unit);  // Utils.cpp:44
+  if (d > 2.0 || d < 0.1) d = 0.0f;                   // Utils.cpp:45 (double literals)
+  const float nan = __builtin_nanf("");
+  float x = nan, y = nan, z = nan;
+  if (d > 0.1 && d < 2.0) {  // Utils.cpp:96-100
+    const float px = (float)(((float)v - cx) * d / fx), py = (float)(((float)u - cy) * d / fy);
+    if (!(d < 0.1f || d > 2.0f)) x = px, y = py, z = d;  // PassThrough "z" in [0.1, 2.0] (main :64-70)
+  }
+  ox[i] = x, oy[i] = y, oz[i] = z;
+  if (z == z) atomicAdd(n_valid, 1u);
+}
+// transform into the hand-base frame, the three pass-through filters (z, x, y; inclusive limits), transform back; flag
+__global__ void k_crop_handbase(const float* __restrict__ ix, const float* __restrict__ iy, const float* __restrict__ iz, int n, const float* __restrict__ A,
+                                const float* __restrict__ B, float3 lo, float3 hi, float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz,
+                                unsigned* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 q = m4_point(A, v3(ix[i], iy[i], iz[i]));
+  const bool keep = isfinite(q.x) && isfinite(q.y) && isfinite(q.z) && !(q.z < lo.z || q.z > hi.z) && !(q.x < lo.x || q.x > hi.x) && !(q.y < lo.y || q.y > hi.y);
+  const V3 r = m4_point(B, q);
+  ox[i] = r.x, oy[i] = r.y, oz[i] = r.z;
+  flag[i] = keep ? 1u : 0u;
+}
+__global__ void k_compact3(const float* __restrict__ ix, const float* __restrict__ iy, const float* __restrict__ iz, const unsigned* __restrict__ flag,
+                           const unsigned* __restrict__ pos, int n, float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz, int stride,
+                           unsigned* __restrict__ n_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (flag[i]) {
+    const unsigned k = pos[i];
+    ox[k] = ix[i], oy[k] = iy[i], oz[k] = iz[i];
+  }
+  if (i == n - 1) *n_out = pos[i] + flag[i];
+}
+
 // ------------------------------------------------------------------------------------------------ host helpers
 int upload_planes(hop_ctx* c, Cloud3& dst, const float* planes, int n) {
   hipStream_t st = hop_ctx_stream(c);
@@ -774,6 +817,59 @@ int hop_voxel_downsample(hop_ctx* c, const float* xyz, int n, float leaf, float*
       PHCHK(c, hipMemcpyAsync(out_xyz + (size_t)a * cap, ph->tmp_cloud2.buf.as<float>() + (size_t)a * m, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
   PHCHK(c, hipStreamSynchronize(st));
   return HOP_OK;
+}
+
+int hop_scene_from_depth(hop_ctx* c, const uint16_t* depth_raw, int H, int W, double depth_unit, const float K9[9], const float cam_in_handbase[16],
+                         const float handbase_in_cam[16], float leaf, const float crop_min[3], const float crop_max[3], float* out_xyz, int cap,
+                         int* n_out, int* counts3) {
+  if (!c || !depth_raw || H <= 0 || W <= 0 || !K9 || !cam_in_handbase || !handbase_in_cam || !crop_min || !crop_max || !n_out || cap < 0) return HOP_E_INVALID;
+  PHCHK(c, hipSetDevice(hop_ctx_device(c)));
+  Physics* ph = physics(c);
+  hipStream_t st = hop_ctx_stream(c);
+  const int n = H * W;
+  PHCHK(c, ph->keys_alt.ensure(sizeof(uint16_t) * (size_t)n));  // staging of the raw image
+  PHCHK(c, hipMemcpyAsync(ph->keys_alt.p, depth_raw, sizeof(uint16_t) * (size_t)n, hipMemcpyHostToDevice, st));
+  PHCHK(c, ph->tmp_cloud.buf.ensure(sizeof(float) * 3 * (size_t)n));
+  ph->tmp_cloud.n = n;
+  PHCHK(c, ph->scalars.ensure(sizeof(unsigned) * 16));
+  PHCHK(c, hipMemsetAsync(ph->scalars.as<unsigned>() + 12, 0, sizeof(unsigned) * 2, st));
+  float* t = ph->tmp_cloud.buf.as<float>();
+  k_depth_to_cloud<<<(n + 255) / 256, 256, 0, st>>>(ph->keys_alt.as<unsigned short>(), H, W, depth_unit, K9[2], K9[0], K9[5], K9[4], t, t + n, t + 2 * (size_t)n,
+                                                     ph->scalars.as<unsigned>() + 12);
+  PHCHK(c, hipStreamSynchronize(st));  // keys_alt is reused by the voxel grid
+  int rc = voxel_downsample_device(c, ph, ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), n, leaf, ph->tmp_cloud2);
+  if (rc) return rc;
+  const int m = ph->tmp_cloud2.n;
+  unsigned n_valid = 0, kept = 0;
+  PHCHK(c, hipMemcpyAsync(&n_valid, ph->scalars.as<unsigned>() + 12, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  if (m > 0) {
+    PHCHK(c, ph->mats.ensure(sizeof(float) * 16 * 5));
+    PHCHK(c, hipMemcpyAsync(ph->mats.as<float>(), cam_in_handbase, sizeof(float) * 16, hipMemcpyHostToDevice, st));
+    PHCHK(c, hipMemcpyAsync(ph->mats.as<float>() + 16, handbase_in_cam, sizeof(float) * 16, hipMemcpyHostToDevice, st));
+    PHCHK(c, ph->tmp_cloud.buf.ensure(sizeof(float) * 6 * (size_t)m));
+    PHCHK(c, ph->flags.ensure(sizeof(unsigned) * (size_t)m));
+    PHCHK(c, ph->pos.ensure(sizeof(unsigned) * (size_t)m));
+    float* a = ph->tmp_cloud.buf.as<float>();
+    float* b = a + 3 * (size_t)m;
+    k_crop_handbase<<<(m + 255) / 256, 256, 0, st>>>(ph->tmp_cloud2.x(), ph->tmp_cloud2.y(), ph->tmp_cloud2.z(), m, ph->mats.as<float>(), ph->mats.as<float>() + 16,
+                                                    make_float3(crop_min[0], crop_min[1], crop_min[2]), make_float3(crop_max[0], crop_max[1], crop_max[2]), a,
+                                                    a + m, a + 2 * (size_t)m, ph->flags.as<unsigned>());
+    size_t tmp = 0;
+    PHCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), m, st));
+    PHCHK(c, ph->sort_tmp.ensure(tmp + 16));
+    PHCHK(c, hipcub::DeviceScan::ExclusiveSum(ph->sort_tmp.p, tmp, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), m, st));
+    k_compact3<<<(m + 255) / 256, 256, 0, st>>>(a, a + m, a + 2 * (size_t)m, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), m, b, b + m, b + 2 * (size_t)m, m,
+                                               ph->scalars.as<unsigned>() + 13);
+    PHCHK(c, hipMemcpyAsync(&kept, ph->scalars.as<unsigned>() + 13, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    PHCHK(c, hipStreamSynchronize(st));
+    if ((int)kept <= cap && out_xyz)
+      for (int k = 0; k < 3; ++k)
+        PHCHK(c, hipMemcpyAsync(out_xyz + (size_t)k * cap, b + (size_t)k * m, sizeof(float) * (size_t)kept, hipMemcpyDeviceToHost, st));
+  }
+  PHCHK(c, hipStreamSynchronize(st));
+  *n_out = (int)kept;
+  if (counts3) counts3[0] = (int)n_valid, counts3[1] = m, counts3[2] = (int)kept;
+  return (int)kept > cap ? HOP_E_CAPACITY : HOP_OK;
 }
 
 int hop_physics_set_frame(hop_ctx* c, const hop_physics_args* a) {

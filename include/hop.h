@@ -294,6 +294,19 @@ int hop_reject_by_collision(hop_ctx* ctx, unsigned char* keep_out, float* diag8_
 int hop_physics_timing(hop_ctx* ctx, double* ms_set_frame, double* ms_reject);
 
 /* ------------------------------------------------------------------------------------------------
+ * "Next" row N3b: the scene front end of src/perception/src/app/main_realdata_auto.cpp:54-96 without
+ * colours and normals -- Utils::readDepthImage (Utils.cpp:36-55, depth_unit = SR300_DEPTH_UNIT), Utils::convert3dOrganizedRGB
+ * (Utils.cpp:79-115, K9 = cam_intrinsic row-major), the z pass-through [0.1, 2.0], the voxel grid at `leaf` (0.001),
+ * the move into the hand-base frame (cam_in_handbase = handbase_in_cam.inverse()), the three pass-through filters on
+ * z, x, y (crop_min / crop_max as x, y, z; main :79-94: x [-0.25,-0.07], y [-0.2,0.2], z [-0.12,0.05]) and the move back.
+ * out_xyz: SoA planes with plane stride cap, voxel order; counts3 (may be NULL): valid pixels, points after the voxel
+ * grid, points after the crop.
+ * ---------------------------------------------------------------------------------------------- */
+int hop_scene_from_depth(hop_ctx* ctx, const uint16_t* depth_raw, int H, int W, double depth_unit, const float K9[9],
+                         const float cam_in_handbase[16], const float handbase_in_cam[16], float leaf, const float crop_min[3],
+                         const float crop_max[3], float* out_xyz, int cap, int* n_out, int* counts3);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): device time in ms of the kernels launched by the last call of the
  * named stage, measured with HIP events on the ctx stream; and launch counts.
  * ---------------------------------------------------------------------------------------------- */

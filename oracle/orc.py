@@ -155,6 +155,7 @@ def lib():
         L.orc_hand_remove_surrounding.argtypes = [fp, fp, C.c_int, fp, C.POINTER(fp), ip, fp, C.c_int, fp, fp, C.c_float, fp, fp, fp, ip]
         L.orc_sdf_signed_distance.argtypes = [fp, C.c_int, fp, C.c_int, ip, C.c_int, fp, C.c_float, C.c_float, fp, ip]
         L.orc_voxel_downsample.argtypes = [fp, C.c_int, C.c_float, fp, C.c_int, ip]
+        L.orc_scene_from_depth.argtypes = [C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_double, fp, fp, fp, C.c_float, fp, fp, fp, C.c_int, ip, ip]
         L.orc_reject_by_collision.argtypes = [C.POINTER(PhysicsArgs), fp, C.c_int, C.POINTER(C.c_ubyte), fp]
         L.orc_compute_ppf.argtypes = [fp, fp, fp, fp, ip]
         L.orc_pair_ppf_is_good.argtypes = [fp, fp, fp, fp]
@@ -468,3 +469,19 @@ def reject_by_collision(p, poses):
     diag = np.zeros((len(T), 8), np.float32)
     lib().orc_reject_by_collision(C.byref(a), F(T), len(T), out.ctypes.data_as(C.POINTER(C.c_ubyte)), F(diag))
     return out.astype(bool), diag
+
+
+def scene_from_depth(depth_raw, depth_unit, K, cam_in_handbase, handbase_in_cam, leaf, crop_min, crop_max):
+    """Returns (xyz (n,3), counts[valid pixels, after voxel grid, after crop])."""
+    d = np.ascontiguousarray(depth_raw, np.uint16)
+    H, W = d.shape
+    K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+    A = np.ascontiguousarray(cam_in_handbase, np.float32).reshape(16)
+    B = np.ascontiguousarray(handbase_in_cam, np.float32).reshape(16)
+    lo, hi = np.ascontiguousarray(crop_min, np.float32), np.ascontiguousarray(crop_max, np.float32)
+    cap = H * W
+    out = np.zeros((3, cap), np.float32)
+    n = C.c_int(0)
+    counts = np.zeros(4, np.int32)
+    lib().orc_scene_from_depth(d.ctypes.data_as(C.POINTER(C.c_ushort)), H, W, depth_unit, F(K9), F(A), F(B), leaf, F(lo), F(hi), F(out), cap, C.byref(n), I(counts))
+    return out[:, :n.value].T.copy(), counts[:3].copy()

@@ -495,6 +495,45 @@ int orc_voxel_downsample(const float* xyz_planes, int n, float leaf, float* out_
   return (int)out.size() > cap ? -1 : 0;
 }
 
+// Scene front end of main_realdata_auto.cpp:54-96 without colours and normals:
+//   Utils::readDepthImage (Utils.cpp:36-55), Utils::convert3dOrganizedRGB (Utils.cpp:79-115), PassThrough z in
+//   [0.1, 2.0] (main :64-70), VoxelGrid at `leaf` (main :74), transform into the hand-base frame (main :76-77), three
+//   PassThrough filters z, x, y (main :79-94; pcl::PassThrough keeps lo <= v <= hi and drops non-finite points),
+//   transform back (main :96).  counts4: valid pixels, after the voxel grid, after the crop, (unused).
+int orc_scene_from_depth(const unsigned short* depth_raw, int H, int W, double depth_unit, const float* K9, const float* cam_in_handbase16,
+                         const float* handbase_in_cam16, float leaf, const float* crop_min3, const float* crop_max3, float* out_planes,
+                         int cap, int* n_out, int* counts4) {
+  std::vector<F3> cloud;
+  cloud.reserve((size_t)H * W);
+  for (int u = 0; u < H; ++u)
+    for (int v = 0; v < W; ++v) {
+      float depth = (float)((double)(float)depth_raw[(size_t)u * W + v] * depth_unit);  // `(float)depthShort * SR300_DEPTH_UNIT`, a double literal
+      if (depth > 2.0 || depth < 0.1) depth = 0.0f;  // readDepthImage compares against double literals
+      F3 p = f3(0, 0, 0);                             // bad_point
+      if (depth > 0.1 && depth < 2.0) p = f3((float)((v - K9[2]) * depth / K9[0]), (float)((u - K9[5]) * depth / K9[4]), depth);
+      if (p.z < 0.1f || p.z > 2.0f) continue;         // PassThrough on z
+      cloud.push_back(p);
+    }
+  counts4[0] = (int)cloud.size();
+  std::vector<F3> ds;
+  voxel_grid(cloud, leaf, ds);
+  counts4[1] = (int)ds.size();
+  std::vector<F3> out;
+  for (const F3& p : ds) {
+    const F3 q = xform(cam_in_handbase16, p);
+    if (!std::isfinite(q.x) || !std::isfinite(q.y) || !std::isfinite(q.z)) continue;
+    if (q.z < crop_min3[2] || q.z > crop_max3[2]) continue;
+    if (q.x < crop_min3[0] || q.x > crop_max3[0]) continue;
+    if (q.y < crop_min3[1] || q.y > crop_max3[1]) continue;
+    out.push_back(xform(handbase_in_cam16, q));
+  }
+  counts4[2] = (int)out.size(), counts4[3] = 0;
+  *n_out = (int)out.size();
+  const int m = std::min((int)out.size(), cap);
+  for (int i = 0; i < m; ++i) out_planes[i] = out[i].x, out_planes[(size_t)cap + i] = out[i].y, out_planes[2 * (size_t)cap + i] = out[i].z;
+  return (int)out.size() > cap ? -1 : 0;
+}
+
 // PoseEstimator::rejectByCollisionOrNonTouching (PoseEstimator.cpp:524-735).  keep[i] = 1 for the hypotheses the
 // reference pushes back into _pose_hypos.  diag (optional, H x 8): stage that decided (0 kept, 1 scene point inside,
 // 2 hand point colliding, 3 finger cloud colliding, 4 one side not touching, 5 model inside finger), the two single-

@@ -296,3 +296,35 @@ def test_cpp_host_app_with_physics_equals_python_mirror(api, hop, synth, tmp_pat
     assert 0 < keep.sum()
     best = est.selectBest()
     assert np.abs(cpp_pose - best._pose).max() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ scene front end (N3b)
+def test_scene_from_depth_on_the_reference_example_frame(ctx, orc, golden_dir):
+    """main_realdata_auto.cpp:54-96 on the reference's example/depth7.png (tests/golden/depth7_raw.npz): 68 600 valid
+    pixels -> 1 mm voxel grid -> hand-base crop; same voxels and points as the oracle."""
+    g = np.load(os.path.join(golden_dir, "depth7_raw.npz"))
+    lo, hi = (-0.25, -0.2, -0.12), (-0.07, 0.2, 0.05)
+    xyz, counts = ctx.scene_from_depth(g["depth"], 0.001, g["K"], g["cam_in_handbase"], g["handbase_in_cam"], 0.001, lo, hi)
+    ref, counts_o = orc.scene_from_depth(g["depth"], 0.001, g["K"], g["cam_in_handbase"], g["handbase_in_cam"], 0.001, lo, hi)
+    assert counts[0] == 68600 and np.array_equal(counts, counts_o)
+    assert xyz.shape == ref.shape and len(xyz) > 5000
+    assert np.abs(xyz - ref).max() < 1e-6  # voxel centroids: float sums whose order pcl leaves to std::sort
+    # every survivor lies in the crop box of the hand-base frame
+    hb = xyz.astype(np.float64) @ g["cam_in_handbase"][:3, :3].T.astype(np.float64) + g["cam_in_handbase"][:3, 3]
+    assert (hb >= np.array(lo) - 1e-5).all() and (hb <= np.array(hi) + 1e-5).all()
+
+
+def test_scene_from_depth_limits_and_empty(ctx, orc):
+    K = np.array([[600, 0, 320], [0, 600, 240], [0, 0, 1]], np.float32)
+    I4 = np.eye(4, dtype=np.float32)
+    d = np.zeros((480, 640), np.uint16)
+    xyz, counts = ctx.scene_from_depth(d, 0.001, K, I4, I4, 0.001, (-1, -1, 0), (1, 1, 3))
+    assert len(xyz) == 0 and counts.tolist() == [0, 0, 0]
+    d[100:140, 200:260] = 100     # exactly 0.1 m: kept by every test of the chain (float 0.1f against the double literal 0.1)
+    d[300:310, 300:310] = 2000    # exactly 2.0 m: `depth < 2.0` fails in convert3dOrganizedRGB
+    d[10:20, 10:20] = 99
+    d[400:420, 500:520] = 1500
+    xyz, counts = ctx.scene_from_depth(d, 0.001, K, I4, I4, 0.005, (-1, -1, 0), (1, 1, 3))
+    ref, counts_o = orc.scene_from_depth(d, 0.001, K, I4, I4, 0.005, (-1, -1, 0), (1, 1, 3))
+    assert counts[0] == 40 * 60 + 20 * 20 and np.array_equal(counts, counts_o)
+    assert np.abs(xyz - ref).max() < 1e-6

@@ -71,3 +71,21 @@ def test_oracle_voxel_grid_small(orc):
     np.testing.assert_allclose(out[2], pts[2], atol=1e-7)
     np.testing.assert_allclose(out[3], pts[3], atol=1e-7)
     assert orc.voxel_downsample(np.zeros((0, 3), np.float32), 0.01).shape == (0, 3)
+
+
+def test_oracle_scene_front_end(orc, golden_dir):
+    """main_realdata_auto.cpp:54-96 restated: one pixel by hand, then the reference's example frame."""
+    K = np.array([[600, 0, 320], [0, 600, 240], [0, 0, 1]], np.float32)
+    I4 = np.eye(4, dtype=np.float32)
+    d = np.zeros((480, 640), np.uint16)
+    d[240, 380] = 1500  # v - cx = 60 px at 1.5 m: x = 60 * 1.5 / 600 = 0.15, y = 0
+    d[0, 0] = 50        # below 0.1 m: dropped
+    xyz, counts = orc.scene_from_depth(d, 0.001, K, I4, I4, 0.001, (-1, -1, 0), (1, 1, 3))
+    assert counts.tolist() == [1, 1, 1]
+    np.testing.assert_allclose(xyz[0], [0.15, 0.0, 1.5], atol=1e-7)
+    xyz, counts = orc.scene_from_depth(d, 0.001, K, I4, I4, 0.001, (-1, -1, 0), (0.1, 1, 3))  # x crop removes it
+    assert counts.tolist() == [1, 1, 0] and len(xyz) == 0
+    g = np.load(os.path.join(golden_dir, "depth7_raw.npz"))
+    xyz, counts = orc.scene_from_depth(g["depth"], 0.001, g["K"], g["cam_in_handbase"], g["handbase_in_cam"], 0.001,
+                                       (-0.25, -0.2, -0.12), (-0.07, 0.2, 0.05))
+    assert counts[0] == 68600 and 30000 < counts[1] < 40000 and 6000 < counts[2] < 10000  # SURVEY.md 8(d) counted 68 600 valid pixels

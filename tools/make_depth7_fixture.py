@@ -78,6 +78,12 @@ def main():
     out = os.path.join(ROOT, "tests", "golden", "depth7_hand_region.npz")
     np.savez_compressed(out, xyz=cam.astype(np.float32), nrm=nrm.astype(np.float32), handbase_in_cam=handbase_in_cam.astype(np.float32),
                         counts=np.array([n_valid, n_1mm, n_crop, len(cam)], np.int64))
+    # the raw frame itself (data of the reference's example/ directory) for the scene front end (hop_scene_from_depth)
+    raw = np.array(Image.open(os.path.join(REF, "example", "depth7.png"))).astype(np.uint16)
+    out_raw = os.path.join(ROOT, "tests", "golden", "depth7_raw.npz")
+    np.savez_compressed(out_raw, depth=raw, K=K.astype(np.float32), handbase_in_cam=handbase_in_cam.astype(np.float32),
+                        cam_in_handbase=np.linalg.inv(handbase_in_cam).astype(np.float32))
+    print("raw depth written", out_raw, os.path.getsize(out_raw), "bytes")
     print("valid px", n_valid, "-> 1 mm", n_1mm, "-> crop", n_crop, "-> 3 mm", len(cam), "written", out, os.path.getsize(out), "bytes")
 
 
