@@ -145,6 +145,7 @@ SIGNATURES = {
     "hop_sdf_signed_distance": (C.c_int, [_vp, C.c_int, fp, C.c_int, fp, ip, fp, fp]),
     "hop_voxel_downsample": (C.c_int, [_vp, fp, C.c_int, C.c_float, fp, C.c_int, ip]),
     "hop_scene_from_depth": (C.c_int, [_vp, C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_double, fp, fp, fp, C.c_float, fp, fp, fp, C.c_int, ip, ip]),
+    "hop_object_segment": (C.c_int, [_vp, fp, fp, fp, C.c_int, C.c_float, fp, fp, fp, C.c_int, ip]),
     "hop_physics_set_frame": (C.c_int, [_vp, C.POINTER(PhysicsArgs)]),
     "hop_reject_by_collision": (C.c_int, [_vp, C.POINTER(C.c_ubyte), fp, ip]),
     "hop_physics_timing": (C.c_int, [_vp, dp, dp]),
@@ -352,6 +353,17 @@ class Context:
         self._chk(self.L.hop_scene_from_depth(self.h, d.ctypes.data_as(C.POINTER(C.c_ushort)), H, W, depth_unit, F(K9), F(A), F(B), leaf, F(lo), F(hi),
                                               F(out), cap, C.byref(n), I(counts)), "hop_scene_from_depth")
         return out[:, :n.value].T.copy(), counts
+
+    def object_segment(self, xyz, nrm, conf, leaf=0.003):
+        """main_realdata_auto.cpp:156-177: (xyz, nrm, conf) of the generator's input cloud."""
+        X, Nn = soa(xyz), soa(nrm)
+        cf = np.ascontiguousarray(conf, np.float32)
+        n = X.shape[1]
+        cap = max(n, 1)
+        ox, on, oc = np.zeros((3, cap), np.float32), np.zeros((3, cap), np.float32), np.zeros(cap, np.float32)
+        k = C.c_int(0)
+        self._chk(self.L.hop_object_segment(self.h, F(X), F(Nn), F(cf), n, leaf, F(ox), F(on), F(oc), cap, C.byref(k)), "hop_object_segment")
+        return ox[:, :k.value].T.copy(), on[:, :k.value].T.copy(), oc[:k.value].copy()
 
     def physics_set_frame(self, p):
         """p: dict -- object_mesh, finger_mesh[4] (registered ids), finger_xyz[4] ((n,3), link frame), finger2handbase[4],

@@ -288,7 +288,7 @@ struct PhysParams {
 
 struct Physics : HopExt {
   MeshStore mesh[MAX_MESHES];
-  Cloud3 fingers, cwh_ds, hand, model, tmp_cloud, tmp_cloud2;
+  Cloud3 fingers, cwh_ds, hand, model, tmp_cloud, tmp_cloud2, tmp_nrm, tmp_nrm2;
   DevBuf keys, keys_alt, vals, vals_alt, flags, pos, starts, sort_tmp, scalars, xf, stage, fmin, diag, gather, tmp_pose, tmp_score, tmp_id, mats;
   PhysParams P{};
   bool have_frame = false;
@@ -296,7 +296,7 @@ struct Physics : HopExt {
   double ms_frame = 0, ms_reject = 0;
   ~Physics() override {
     for (auto& m : mesh) m.release();
-    DevBuf* bufs[] = {&fingers.buf, &cwh_ds.buf, &hand.buf, &model.buf, &tmp_cloud.buf, &tmp_cloud2.buf, &keys, &keys_alt, &vals, &vals_alt, &flags, &pos,
+    DevBuf* bufs[] = {&fingers.buf, &cwh_ds.buf, &hand.buf, &model.buf, &tmp_cloud.buf, &tmp_cloud2.buf, &tmp_nrm.buf, &tmp_nrm2.buf, &keys, &keys_alt, &vals, &vals_alt, &flags, &pos,
                       &starts, &sort_tmp, &scalars, &xf, &stage, &fmin, &diag, &gather, &tmp_pose, &tmp_score, &tmp_id, &mats};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : ev)
@@ -391,19 +391,51 @@ __global__ void k_vox_starts(const unsigned* __restrict__ flags, const unsigned*
   if (i == n - 1) *n_seg = pos[i] + flags[i];
 }
 // one thread per voxel: CentroidPoint sums xyz in float in the (stable) sorted order and divides by the count
+// nx..: optional normal planes: AccumulatorNormal sums them and returns normal.normalized()
 __global__ void k_vox_centroids(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const unsigned* __restrict__ vals,
                                 const unsigned* __restrict__ starts, int n_seg, int n_finite, float* __restrict__ ox, float* __restrict__ oy,
-                                float* __restrict__ oz) {
+                                float* __restrict__ oz, const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz,
+                                float* __restrict__ onx, float* __restrict__ ony, float* __restrict__ onz) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_seg) return;
   const int b = (int)starts[s], e = s + 1 < n_seg ? (int)starts[s + 1] : n_finite;
   float sx = 0, sy = 0, sz = 0;
+  V3 sn = v3(0, 0, 0);
   for (int j = b; j < e; ++j) {
     const unsigned p = vals[j];
     sx += x[p], sy += y[p], sz += z[p];
+    if (nx) sn = sn + v3(nx[p], ny[p], nz[p]);
   }
   const float cnt = (float)(e - b);
   ox[s] = sx / cnt, oy[s] = sy / cnt, oz[s] = sz / cnt;
+  if (nx) {
+    sn = vnormalized(sn);
+    onx[s] = sn.x, ony[s] = sn.y, onz[s] = sn.z;
+  }
+}
+// main_realdata_auto.cpp:160-177: normal towards the viewpoint (0,0,0), confidence of the nearest point of the dense
+// cloud (FLANN's squared distance, lowest index on ties); one wavefront per output point
+__global__ void __launch_bounds__(256) k_segment_finish(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, int m,
+                                                        float* __restrict__ nx, float* __restrict__ ny, float* __restrict__ nz, const float* __restrict__ dx,
+                                                        const float* __restrict__ dy, const float* __restrict__ dz, const float* __restrict__ dconf, int n,
+                                                        float* __restrict__ conf) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= m) return;
+  const V3 p = v3(px[i], py[i], pz[i]);
+  unsigned long long best = ~0ull;
+  for (int j = lane; j < n; j += 64) {
+    const unsigned long long v = ((unsigned long long)__float_as_uint(sqdist_flann(p, v3(dx[j], dy[j], dz[j]))) << 32) | (unsigned)j;
+    best = v < best ? v : best;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_down(best, o);
+    best = t < best ? t : best;
+  }
+  if (lane != 0) return;
+  conf[i] = n > 0 ? dconf[(int)(best & 0xffffffffu)] : 0.f;
+  const float vx = 0.f - p.x, vy = 0.f - p.y, vz = 0.f - p.z;
+  const float cos_theta = (vx * nx[i] + vy * ny[i]) + vz * nz[i];
+  if (cos_theta < 0) nx[i] *= -1, ny[i] *= -1, nz[i] *= -1;
 }
 
 // ---- rejectByCollisionOrNonTouching
@@ -634,7 +666,8 @@ int upload_planes(hop_ctx* c, Cloud3& dst, const float* planes, int n) {
 }
 
 // pcl::VoxelGrid on a device cloud (planes x,y,z of n); result into `out`
-int voxel_downsample_device(hop_ctx* c, Physics* ph, const float* x, const float* y, const float* z, int n, float leaf, Cloud3& out) {
+int voxel_downsample_device(hop_ctx* c, Physics* ph, const float* x, const float* y, const float* z, int n, float leaf, Cloud3& out,
+                            const float* nrm = nullptr, Cloud3* out_nrm = nullptr) {
   hipStream_t st = hop_ctx_stream(c);
   out.n = 0;
   PHCHK(c, out.buf.ensure(sizeof(float) * 3));
@@ -703,8 +736,16 @@ int voxel_downsample_device(hop_ctx* c, Physics* ph, const float* x, const float
   PHCHK(c, out.buf.ensure(sizeof(float) * 3 * (size_t)n_seg));
   out.n = (int)n_seg;
   float* o = out.buf.as<float>();
+  float* on = nullptr;
+  if (nrm && out_nrm) {
+    PHCHK(c, out_nrm->buf.ensure(sizeof(float) * 3 * (size_t)n_seg));
+    out_nrm->n = (int)n_seg;
+    on = out_nrm->buf.as<float>();
+  }
   k_vox_centroids<<<((int)n_seg + 127) / 128, 128, 0, st>>>(x, y, z, ph->vals_alt.as<unsigned>(), ph->starts.as<unsigned>(), (int)n_seg, n_finite, o,
-                                                             o + n_seg, o + 2 * (size_t)n_seg);
+                                                             o + n_seg, o + 2 * (size_t)n_seg, on ? nrm : nullptr, on ? nrm + n : nullptr,
+                                                             on ? nrm + 2 * (size_t)n : nullptr, on, on ? on + n_seg : nullptr,
+                                                             on ? on + 2 * (size_t)n_seg : nullptr);
   PHCHK(c, hipGetLastError());
   return HOP_OK;
 }
@@ -870,6 +911,40 @@ int hop_scene_from_depth(hop_ctx* c, const uint16_t* depth_raw, int H, int W, do
   *n_out = (int)kept;
   if (counts3) counts3[0] = (int)n_valid, counts3[1] = m, counts3[2] = (int)kept;
   return (int)kept > cap ? HOP_E_CAPACITY : HOP_OK;
+}
+
+int hop_object_segment(hop_ctx* c, const float* xyz, const float* nrm, const float* conf, int n, float leaf, float* out_xyz, float* out_nrm,
+                       float* out_conf, int cap, int* n_out) {
+  if (!c || n < 0 || (n > 0 && (!xyz || !nrm || !conf)) || !n_out || cap < 0) return HOP_E_INVALID;
+  PHCHK(c, hipSetDevice(hop_ctx_device(c)));
+  Physics* ph = physics(c);
+  hipStream_t st = hop_ctx_stream(c);
+  *n_out = 0;
+  if (n == 0) return HOP_OK;
+  int rc = upload_planes(c, ph->tmp_cloud, xyz, n);
+  if (rc) return rc;
+  rc = upload_planes(c, ph->tmp_nrm, nrm, n);
+  if (rc) return rc;
+  PHCHK(c, ph->gather.ensure(sizeof(float) * (size_t)n));
+  PHCHK(c, hipMemcpyAsync(ph->gather.p, conf, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, st));
+  rc = voxel_downsample_device(c, ph, ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), n, leaf, ph->tmp_cloud2, ph->tmp_nrm.buf.as<float>(), &ph->tmp_nrm2);
+  if (rc) return rc;
+  const int m = ph->tmp_cloud2.n;
+  *n_out = m;
+  if (m == 0) return HOP_OK;
+  if (m > cap) return HOP_E_CAPACITY;
+  PHCHK(c, ph->tmp_pose.ensure(sizeof(float) * (size_t)m));
+  float* on = ph->tmp_nrm2.buf.as<float>();
+  k_segment_finish<<<(m + 3) / 4, 256, 0, st>>>(ph->tmp_cloud2.x(), ph->tmp_cloud2.y(), ph->tmp_cloud2.z(), m, on, on + m, on + 2 * (size_t)m, ph->tmp_cloud.x(),
+                                               ph->tmp_cloud.y(), ph->tmp_cloud.z(), ph->gather.as<float>(), n, ph->tmp_pose.as<float>());
+  PHCHK(c, hipGetLastError());
+  for (int k = 0; k < 3; ++k) {
+    if (out_xyz) PHCHK(c, hipMemcpyAsync(out_xyz + (size_t)k * cap, ph->tmp_cloud2.buf.as<float>() + (size_t)k * m, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
+    if (out_nrm) PHCHK(c, hipMemcpyAsync(out_nrm + (size_t)k * cap, on + (size_t)k * m, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
+  }
+  if (out_conf) PHCHK(c, hipMemcpyAsync(out_conf, ph->tmp_pose.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipStreamSynchronize(st));
+  return HOP_OK;
 }
 
 int hop_physics_set_frame(hop_ctx* c, const hop_physics_args* a) {

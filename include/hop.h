@@ -306,6 +306,13 @@ int hop_scene_from_depth(hop_ctx* ctx, const uint16_t* depth_raw, int H, int W, 
                          const float cam_in_handbase[16], const float handbase_in_cam[16], float leaf, const float crop_min[3],
                          const float crop_max[3], float* out_xyz, int cap, int* n_out, int* counts3);
 
+/* "Next" row N3c: the generator's input cloud from the dense hand-free cloud (main_realdata_auto.cpp:156-177): voxel grid at
+ * `leaf` (0.003) over xyz and normals (pcl::VoxelGrid / CentroidPoint: xyz averaged, normals summed and normalised),
+ * removeAllNaNFromPointCloud, pcl::flipNormalTowardsViewpoint(0,0,0), confidence of the nearest dense point (1-NN).
+ * Inputs: the dense cloud after Utils::calNormalMLS (SoA planes) with its confidences; outputs with plane stride cap. */
+int hop_object_segment(hop_ctx* ctx, const float* xyz, const float* nrm, const float* conf, int n, float leaf, float* out_xyz,
+                       float* out_nrm, float* out_conf, int cap, int* n_out);
+
 /* ------------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): device time in ms of the kernels launched by the last call of the
  * named stage, measured with HIP events on the ctx stream; and launch counts.

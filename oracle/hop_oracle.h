@@ -149,6 +149,9 @@ int orc_sdf_signed_distance(const float* P, int np, const float* V, int nv, cons
                             float lower, float upper, float* S_out, int* I_out);
 /* pcl::VoxelGrid (Utils::downsamplePointCloud, Utils.cpp:334-340), xyz only; SoA planes in (stride n) and out (stride cap) */
 int orc_voxel_downsample(const float* xyz_planes, int n, float leaf, float* out_planes, int cap, int* n_out);
+/* main_realdata_auto.cpp:156-177: 3 mm voxel grid over xyz + normals, normals towards the camera, nearest-point confidence */
+int orc_object_segment(const float* xyz_planes, const float* nrm_planes, const float* conf, int n, float leaf, float* out_xyz, float* out_nrm,
+                       float* out_conf, int cap, int* n_out);
 /* scene front end of main_realdata_auto.cpp:54-96 (depth -> cloud, z pass-through, voxel grid, hand-base crop) */
 int orc_scene_from_depth(const unsigned short* depth_raw, int H, int W, double depth_unit, const float* K9, const float* cam_in_handbase16,
                          const float* handbase_in_cam16, float leaf, const float* crop_min3, const float* crop_max3, float* out_planes,

@@ -156,6 +156,7 @@ def lib():
         L.orc_sdf_signed_distance.argtypes = [fp, C.c_int, fp, C.c_int, ip, C.c_int, fp, C.c_float, C.c_float, fp, ip]
         L.orc_voxel_downsample.argtypes = [fp, C.c_int, C.c_float, fp, C.c_int, ip]
         L.orc_scene_from_depth.argtypes = [C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_double, fp, fp, fp, C.c_float, fp, fp, fp, C.c_int, ip, ip]
+        L.orc_object_segment.argtypes = [fp, fp, fp, C.c_int, C.c_float, fp, fp, fp, C.c_int, ip]
         L.orc_reject_by_collision.argtypes = [C.POINTER(PhysicsArgs), fp, C.c_int, C.POINTER(C.c_ubyte), fp]
         L.orc_compute_ppf.argtypes = [fp, fp, fp, fp, ip]
         L.orc_pair_ppf_is_good.argtypes = [fp, fp, fp, fp]
@@ -485,3 +486,14 @@ def scene_from_depth(depth_raw, depth_unit, K, cam_in_handbase, handbase_in_cam,
     counts = np.zeros(4, np.int32)
     lib().orc_scene_from_depth(d.ctypes.data_as(C.POINTER(C.c_ushort)), H, W, depth_unit, F(K9), F(A), F(B), leaf, F(lo), F(hi), F(out), cap, C.byref(n), I(counts))
     return out[:, :n.value].T.copy(), counts[:3].copy()
+
+
+def object_segment(xyz, nrm, conf, leaf=0.003):
+    X, Nn = soa(xyz), soa(nrm)
+    cf = np.ascontiguousarray(conf, np.float32)
+    n = X.shape[1]
+    cap = max(n, 1)
+    ox, on, oc = np.zeros((3, cap), np.float32), np.zeros((3, cap), np.float32), np.zeros(cap, np.float32)
+    k = C.c_int(0)
+    lib().orc_object_segment(F(X), F(Nn), F(cf), n, leaf, F(ox), F(on), F(oc), cap, C.byref(k))
+    return ox[:, :k.value].T.copy(), on[:, :k.value].T.copy(), oc[:k.value].copy()

@@ -534,6 +534,76 @@ int orc_scene_from_depth(const unsigned short* depth_raw, int H, int W, double d
   return (int)out.size() > cap ? -1 : 0;
 }
 
+// main_realdata_auto.cpp:156-177: the generator's input cloud from the dense hand-free cloud `object1` (with its MLS
+// normals and its confidences): VoxelGrid at `leaf` over all fields (CentroidPoint: xyz averaged, normals summed and
+// normalised, confidence has no accumulator), removeAllNaNFromPointCloud, flipNormalTowardsViewpoint(0,0,0), confidence
+// of the nearest point of object1 (pcl::KdTreeFLANN, 1-NN).
+int orc_object_segment(const float* xyz_planes, const float* nrm_planes, const float* conf, int n, float leaf, float* out_xyz, float* out_nrm,
+                       float* out_conf, int cap, int* n_out) {
+  const std::vector<F3> P = planes_to_pts(xyz_planes, n), N = planes_to_pts(nrm_planes, n);
+  *n_out = 0;
+  if (n == 0) return 0;
+  // the voxel grid again, carrying the normals (same index arithmetic and std::sort as voxel_grid above)
+  const float inv = 1.0f / leaf;
+  F3 mn = f3(FLT_MAX, FLT_MAX, FLT_MAX), mx = f3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+  bool any = false;
+  for (const F3& p : P) {
+    if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+    any = true;
+    mn = f3(std::min(mn.x, p.x), std::min(mn.y, p.y), std::min(mn.z, p.z));
+    mx = f3(std::max(mx.x, p.x), std::max(mx.y, p.y), std::max(mx.z, p.z));
+  }
+  if (!any) return 0;
+  const int minb[3] = {(int)std::floor(mn.x * inv), (int)std::floor(mn.y * inv), (int)std::floor(mn.z * inv)};
+  const int maxb[3] = {(int)std::floor(mx.x * inv), (int)std::floor(mx.y * inv), (int)std::floor(mx.z * inv)};
+  const int div[3] = {maxb[0] - minb[0] + 1, maxb[1] - minb[1] + 1, maxb[2] - minb[2] + 1};
+  const int mul[3] = {1, div[0], div[0] * div[1]};
+  struct Idx {
+    unsigned idx, pt;
+    bool operator<(const Idx& o) const { return idx < o.idx; }
+  };
+  std::vector<Idx> v;
+  for (int i = 0; i < n; ++i) {
+    const F3& p = P[i];
+    if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+    const int i0 = (int)std::floor(p.x * inv) - minb[0], i1 = (int)std::floor(p.y * inv) - minb[1], i2 = (int)std::floor(p.z * inv) - minb[2];
+    v.push_back({(unsigned)(i0 * mul[0] + i1 * mul[1] + i2 * mul[2]), (unsigned)i});
+  }
+  std::sort(v.begin(), v.end());
+  std::vector<F3> ox, on;
+  size_t k = 0;
+  while (k < v.size()) {
+    size_t e = k + 1;
+    while (e < v.size() && v[e].idx == v[k].idx) ++e;
+    F3 s = f3(0, 0, 0), sn = f3(0, 0, 0);
+    for (size_t j = k; j < e; ++j) s = s + P[v[j].pt], sn = sn + N[v[j].pt];
+    const float cnt = (float)(e - k);
+    const F3 c = f3(s.x / cnt, s.y / cnt, s.z / cnt);
+    const float z = sqn3(sn);  // AccumulatorNormal::get: normal.normalized()
+    if (z > 0.f) {
+      const float r = std::sqrt(z);
+      sn = f3(sn.x / r, sn.y / r, sn.z / r);
+    }
+    if (std::isfinite(c.x) && std::isfinite(c.y) && std::isfinite(c.z)) ox.push_back(c), on.push_back(sn);  // Utils.cpp:477-497
+    k = e;
+  }
+  *n_out = (int)ox.size();
+  const int m = std::min((int)ox.size(), cap);
+  for (int i = 0; i < m; ++i) {
+    F3 nn = on[i];
+    // pcl::flipNormalTowardsViewpoint (features/normal_3d.h): vp - point, flip when the cosine is negative
+    const float vx = 0.f - ox[i].x, vy = 0.f - ox[i].y, vz = 0.f - ox[i].z;
+    const float cos_theta = (vx * nn.x + vy * nn.y + vz * nn.z);
+    if (cos_theta < 0) nn = f3(nn.x * -1, nn.y * -1, nn.z * -1);
+    float sq;
+    const int j = nearest(P, ox[i], &sq);
+    out_xyz[i] = ox[i].x, out_xyz[(size_t)cap + i] = ox[i].y, out_xyz[2 * (size_t)cap + i] = ox[i].z;
+    out_nrm[i] = nn.x, out_nrm[(size_t)cap + i] = nn.y, out_nrm[2 * (size_t)cap + i] = nn.z;
+    out_conf[i] = j >= 0 ? conf[j] : 0.f;
+  }
+  return (int)ox.size() > cap ? -1 : 0;
+}
+
 // PoseEstimator::rejectByCollisionOrNonTouching (PoseEstimator.cpp:524-735).  keep[i] = 1 for the hypotheses the
 // reference pushes back into _pose_hypos.  diag (optional, H x 8): stage that decided (0 kept, 1 scene point inside,
 // 2 hand point colliding, 3 finger cloud colliding, 4 one side not touching, 5 model inside finger), the two single-

@@ -328,3 +328,23 @@ def test_scene_from_depth_limits_and_empty(ctx, orc):
     ref, counts_o = orc.scene_from_depth(d, 0.001, K, I4, I4, 0.005, (-1, -1, 0), (1, 1, 3))
     assert counts[0] == 40 * 60 + 20 * 20 and np.array_equal(counts, counts_o)
     assert np.abs(xyz - ref).max() < 1e-6
+
+
+def test_object_segment_vs_oracle(ctx, orc, synth):
+    """main_realdata_auto.cpp:156-177 on a dense synthetic cloud: same voxels, normals (towards the camera) and
+    nearest-point confidences as the oracle."""
+    sc = synth.make_scene(30000, seed=3)
+    nrm = sc.nrm.copy()
+    nrm[sc.xyz[:, 0] > np.median(sc.xyz[:, 0])] *= -1  # half of the cloud points away from the camera: the flip has work to do
+    # (whole regions, not single points: opposite normals inside one voxel nearly cancel, and the sum order inside a
+    # voxel is the one thing pcl leaves open)
+    xyz, n2, cf = ctx.object_segment(sc.xyz, nrm, sc.conf, 0.003)
+    ox, on, oc = orc.object_segment(sc.xyz, nrm, sc.conf, 0.003)
+    assert xyz.shape == ox.shape and 1000 < len(xyz) < len(sc.xyz)
+    assert np.abs(xyz - ox).max() < 1e-6
+    assert (np.abs(n2 - on).max(axis=1) < 1e-5).mean() > 0.995  # voxels that straddle the flipped boundary may differ
+    assert (cf == oc).mean() > 0.999  # a centroid that moves by 1e-7 can change its nearest dense point
+    assert np.abs(np.linalg.norm(n2, axis=1) - 1).max() < 1e-5
+    assert (np.einsum("ij,ij->i", n2, -xyz) >= -1e-9).all()
+    e = ctx.object_segment(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros(0, np.float32))
+    assert len(e[0]) == 0

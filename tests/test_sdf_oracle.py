@@ -89,3 +89,16 @@ def test_oracle_scene_front_end(orc, golden_dir):
     xyz, counts = orc.scene_from_depth(g["depth"], 0.001, g["K"], g["cam_in_handbase"], g["handbase_in_cam"], 0.001,
                                        (-0.25, -0.2, -0.12), (-0.07, 0.2, 0.05))
     assert counts[0] == 68600 and 30000 < counts[1] < 40000 and 6000 < counts[2] < 10000  # SURVEY.md 8(d) counted 68 600 valid pixels
+
+
+def test_oracle_object_segment_small(orc):
+    xyz = np.array([[0.0002, 0.0005, 0.5], [0.0014, 0.0005, 0.5], [0.0026, 0.0005, 0.5], [0.0105, 0.0005, 0.5]], np.float32)
+    nrm = np.array([[0, 0, 1], [0, 0.6, 0.8], [0, 0, 0], [0, 0, -1]], np.float32)
+    conf = np.array([0.2, 0.9, 0.3, 0.5], np.float32)
+    ox, on, oc = orc.object_segment(xyz, nrm, conf, 0.003)
+    assert ox.shape == (2, 3)
+    np.testing.assert_allclose(ox[0], [0.0014, 0.0005, 0.5], atol=1e-7)  # the first three points share a voxel
+    s = np.array([0, 0.6, 1.8]) / np.linalg.norm([0, 0.6, 1.8])
+    np.testing.assert_allclose(on[0], -s, atol=1e-6)                       # summed, normalised, flipped towards the origin
+    np.testing.assert_allclose(on[1], [0, 0, -1], atol=1e-7)               # already facing the camera
+    assert oc[0] == np.float32(0.9) and oc[1] == np.float32(0.5)          # nearest dense point of each centroid
