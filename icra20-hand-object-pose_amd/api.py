@@ -146,6 +146,7 @@ SIGNATURES = {
     "hop_voxel_downsample": (C.c_int, [_vp, fp, C.c_int, C.c_float, fp, C.c_int, ip]),
     "hop_scene_from_depth": (C.c_int, [_vp, C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_double, fp, fp, fp, C.c_float, fp, fp, fp, C.c_int, ip, ip]),
     "hop_object_segment": (C.c_int, [_vp, fp, fp, fp, C.c_int, C.c_float, fp, fp, fp, C.c_int, ip]),
+    "hop_hand_scene_filters": (C.c_int, [_vp, fp, fp, C.c_int, fp, fp, fp, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]),
     "hop_physics_set_frame": (C.c_int, [_vp, C.POINTER(PhysicsArgs)]),
     "hop_reject_by_collision": (C.c_int, [_vp, C.POINTER(C.c_ubyte), fp, ip]),
     "hop_physics_timing": (C.c_int, [_vp, dp, dp]),
@@ -364,6 +365,17 @@ class Context:
         k = C.c_int(0)
         self._chk(self.L.hop_object_segment(self.h, F(X), F(Nn), F(cf), n, leaf, F(ox), F(on), F(oc), cap, C.byref(k)), "hop_object_segment")
         return ox[:, :k.value].T.copy(), on[:, :k.value].T.copy(), oc[:k.value].copy()
+
+    def hand_scene_filters(self, xyz, nrm, cam_in_handbase):
+        """Hand::setCurScene (Hand.cpp:289-321): (xyz, nrm in the hand-base frame, keep flags of removed_noise, of remove_swivel)."""
+        X, Nn = soa(xyz), soa(nrm)
+        n = X.shape[1]
+        T = np.ascontiguousarray(cam_in_handbase, np.float32).reshape(16)
+        hx, hn = np.zeros((3, max(n, 1)), np.float32), np.zeros((3, max(n, 1)), np.float32)
+        k1, k2 = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint8)
+        self._chk(self.L.hop_hand_scene_filters(self.h, F(X), F(Nn), n, F(T), F(hx), F(hn), k1.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                                k2.ctypes.data_as(C.POINTER(C.c_ubyte))), "hop_hand_scene_filters")
+        return hx[:, :n].T.copy(), hn[:, :n].T.copy(), k1[:n].astype(bool), k2[:n].astype(bool)
 
     def physics_set_frame(self, p):
         """p: dict -- object_mesh, finger_mesh[4] (registered ids), finger_xyz[4] ((n,3), link frame), finger2handbase[4],
@@ -733,6 +745,15 @@ class HandT42:
     def setCurScene(self, scene_removed_noise_xyz, scene_hand_region_nrm, scene_remove_swivel_xyz):
         """Products of Hand::setCurScene (Hand.cpp:327-332), all in the hand-base frame."""
         self.ctx.hand_set_scene(scene_removed_noise_xyz, scene_hand_region_nrm, scene_remove_swivel_xyz)
+
+    def setCurSceneFromRegion(self, region_xyz_cam, region_nrm_cam, handbase_in_cam):
+        """Hand::setCurScene from the 3 mm hand-region cloud in the camera frame (Hand.cpp:289-332, after handbaseICP):
+        hand-base transform, the two radius outlier filters, the statistical outlier filter and the x pass-through run on
+        the GPU (hop_hand_scene_filters); the three products go to hop_hand_set_scene.  Returns their sizes."""
+        cam_in_handbase = np.linalg.inv(np.asarray(handbase_in_cam, np.float64)).astype(np.float32)
+        hx, hn, keep, swivel = self.ctx.hand_scene_filters(region_xyz_cam, region_nrm_cam, cam_in_handbase)
+        self.setCurScene(hx[keep], hn, hx[swivel])
+        return int(keep.sum()), len(hx), int(swivel.sum())
 
     def makeHandCloud(self):
         """Hand::makeHandCloud (Hand.cpp:537-556): every component cloud in the hand-base frame at the current finger

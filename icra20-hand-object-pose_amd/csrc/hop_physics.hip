@@ -656,6 +656,81 @@ __global__ void k_compact3(const float* __restrict__ ix, const float* __restrict
   if (i == n - 1) *n_out = pos[i] + flag[i];
 }
 
+// ---- Hand::setCurScene filters (Hand.cpp:289-321), hand-base frame
+__global__ void k_transform_cloud_nrm(const float* __restrict__ ix, const float* __restrict__ iy, const float* __restrict__ iz, const float* __restrict__ inx,
+                                      const float* __restrict__ iny, const float* __restrict__ inz, int n, const float* __restrict__ T, float* __restrict__ o,
+                                      float* __restrict__ on) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 p = m4_point(T, v3(ix[i], iy[i], iz[i])), m = m4_dir(T, v3(inx[i], iny[i], inz[i]));
+  o[i] = p.x, o[n + i] = p.y, o[2 * (size_t)n + i] = p.z;
+  on[i] = m.x, on[n + i] = m.y, on[2 * (size_t)n + i] = m.z;
+}
+// pcl::RadiusOutlierRemoval: a live point stays when more than min_pts live points (itself included) are strictly
+// within the radius (FLANN RadiusResultSet: dist < r^2)
+__global__ void __launch_bounds__(256) k_radius_outlier(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
+                                                        const unsigned char* __restrict__ live, float r2, int min_pts, unsigned char* __restrict__ out) {
+  __shared__ float4 tile[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const V3 p = i < n ? v3(x[i], y[i], z[i]) : v3(0, 0, 0);
+  int k = 0;
+  for (int base = 0; base < n; base += 256) {
+    const int j = base + threadIdx.x;
+    tile[threadIdx.x] = (j < n && live[j]) ? make_float4(x[j], y[j], z[j], 1.f) : make_float4(0, 0, 0, 0.f);
+    __syncthreads();
+    const int m = min(256, n - base);
+    for (int t = 0; t < m; ++t) {
+      const float4 q = tile[t];
+      if (q.w != 0.f && sqdist_flann(p, v3(q.x, q.y, q.z)) < r2) ++k;
+    }
+    __syncthreads();
+  }
+  if (i < n) out[i] = (live[i] && k > min_pts) ? 1 : 0;
+}
+// pcl::StatisticalOutlierRemoval, first pass: mean distance to the mean_k nearest live neighbours (the 21 smallest
+// squared distances include the point itself, which is skipped); per-thread sorted list in LDS
+constexpr int SOR_K = 20;
+__global__ void __launch_bounds__(128) k_sor_mean(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
+                                                  const unsigned char* __restrict__ live, float* __restrict__ dist) {
+  __shared__ float top[(SOR_K + 1) * 128];
+  __shared__ float4 tile[128];
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  const V3 p = i < n ? v3(x[i], y[i], z[i]) : v3(0, 0, 0);
+  float* mine = top + threadIdx.x;
+  for (int k = 0; k <= SOR_K; ++k) mine[k * 128] = __builtin_inff();
+  float worst = __builtin_inff();
+  for (int base = 0; base < n; base += 128) {
+    const int j = base + threadIdx.x;
+    tile[threadIdx.x] = (j < n && live[j]) ? make_float4(x[j], y[j], z[j], 1.f) : make_float4(0, 0, 0, 0.f);
+    __syncthreads();
+    const int m = min(128, n - base);
+    for (int t = 0; t < m; ++t) {
+      const float4 q = tile[t];
+      if (q.w == 0.f) continue;
+      const float d = sqdist_flann(p, v3(q.x, q.y, q.z));
+      if (d < worst) {  // insert into the ascending list
+        int k = SOR_K;
+        while (k > 0 && mine[(k - 1) * 128] > d) mine[k * 128] = mine[(k - 1) * 128], --k;
+        mine[k * 128] = d;
+        worst = mine[SOR_K * 128];
+      }
+    }
+    __syncthreads();
+  }
+  if (i >= n) return;
+  double sum = 0.0;
+  for (int k = 1; k <= SOR_K; ++k) sum += (double)sqrtf(mine[k * 128]);
+  dist[i] = live[i] ? (float)(sum / SOR_K) : 0.f;
+}
+__global__ void k_sor_apply(const float* __restrict__ x, int n, const unsigned char* __restrict__ live, const float* __restrict__ dist, double thr, int use_sor,
+                            unsigned char* __restrict__ keep_noise, unsigned char* __restrict__ keep_swivel) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool k = live[i] && (!use_sor || !((double)dist[i] > thr));
+  keep_noise[i] = k;
+  keep_swivel[i] = k && !(x[i] < -0.25f || x[i] > -0.1f);  // pass-through x (Hand.cpp:316-320)
+}
+
 // ------------------------------------------------------------------------------------------------ host helpers
 int upload_planes(hop_ctx* c, Cloud3& dst, const float* planes, int n) {
   hipStream_t st = hop_ctx_stream(c);
@@ -943,6 +1018,62 @@ int hop_object_segment(hop_ctx* c, const float* xyz, const float* nrm, const flo
     if (out_nrm) PHCHK(c, hipMemcpyAsync(out_nrm + (size_t)k * cap, on + (size_t)k * m, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
   }
   if (out_conf) PHCHK(c, hipMemcpyAsync(out_conf, ph->tmp_pose.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipStreamSynchronize(st));
+  return HOP_OK;
+}
+
+int hop_hand_scene_filters(hop_ctx* c, const float* xyz, const float* nrm, int n, const float cam_in_handbase[16], float* hb_xyz, float* hb_nrm,
+                           unsigned char* keep_noise, unsigned char* keep_swivel) {
+  if (!c || n < 0 || (n > 0 && (!xyz || !nrm || !hb_xyz || !hb_nrm || !keep_noise || !keep_swivel)) || !cam_in_handbase) return HOP_E_INVALID;
+  PHCHK(c, hipSetDevice(hop_ctx_device(c)));
+  Physics* ph = physics(c);
+  hipStream_t st = hop_ctx_stream(c);
+  if (n == 0) return HOP_OK;
+  int rc = upload_planes(c, ph->tmp_cloud, xyz, n);
+  if (rc) return rc;
+  rc = upload_planes(c, ph->tmp_nrm, nrm, n);
+  if (rc) return rc;
+  PHCHK(c, ph->mats.ensure(sizeof(float) * 16 * 5));
+  PHCHK(c, hipMemcpyAsync(ph->mats.p, cam_in_handbase, sizeof(float) * 16, hipMemcpyHostToDevice, st));
+  PHCHK(c, ph->tmp_cloud2.buf.ensure(sizeof(float) * 3 * (size_t)n));
+  PHCHK(c, ph->tmp_nrm2.buf.ensure(sizeof(float) * 3 * (size_t)n));
+  ph->tmp_cloud2.n = n;
+  float* hb = ph->tmp_cloud2.buf.as<float>();
+  float* hbn = ph->tmp_nrm2.buf.as<float>();
+  k_transform_cloud_nrm<<<(n + 255) / 256, 256, 0, st>>>(ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), ph->tmp_nrm.buf.as<float>(),
+                                                        ph->tmp_nrm.buf.as<float>() + n, ph->tmp_nrm.buf.as<float>() + 2 * (size_t)n, n, ph->mats.as<float>(), hb, hbn);
+  PHCHK(c, ph->flags.ensure(4 * (size_t)n + 16));  // four byte masks
+  unsigned char* live0 = ph->flags.as<unsigned char>();
+  unsigned char *live1 = live0 + n, *live2 = live1 + n, *sw = live2 + n;
+  PHCHK(c, hipMemsetAsync(live0, 1, (size_t)n, st));
+  k_radius_outlier<<<(n + 255) / 256, 256, 0, st>>>(hb, hb + n, hb + 2 * (size_t)n, n, live0, 0.02f * 0.02f, 30, live1);   // Hand.cpp:293-299
+  k_radius_outlier<<<(n + 255) / 256, 256, 0, st>>>(hb, hb + n, hb + 2 * (size_t)n, n, live1, 0.04f * 0.04f, 100, live2);  // :300-306
+  PHCHK(c, ph->pos.ensure(sizeof(float) * (size_t)n));
+  float* dist = ph->pos.as<float>();
+  k_sor_mean<<<(n + 127) / 128, 128, 0, st>>>(hb, hb + n, hb + 2 * (size_t)n, n, live2, dist);  // :307-313
+  std::vector<float> dh(n);
+  std::vector<unsigned char> lh(n);
+  PHCHK(c, hipMemcpyAsync(dh.data(), dist, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipMemcpyAsync(lh.data(), live2, (size_t)n, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipStreamSynchronize(st));
+  // mean and standard deviation of the per-point mean distances, in double, in point order (statistical_outlier_removal.hpp)
+  double sum = 0, sq_sum = 0;
+  int m = 0;
+  for (int i = 0; i < n; ++i)
+    if (lh[i]) sum += dh[i], sq_sum += (double)dh[i] * dh[i], ++m;
+  const int use_sor = m > SOR_K;
+  double thr = 0;
+  if (use_sor) {
+    const double mean = sum / (double)m;
+    const double variance = (sq_sum - sum * sum / (double)m) / ((double)m - 1);
+    thr = mean + 2.0 * std::sqrt(variance);
+  }
+  k_sor_apply<<<(n + 255) / 256, 256, 0, st>>>(hb, n, live2, dist, thr, use_sor, live0, sw);
+  PHCHK(c, hipGetLastError());
+  PHCHK(c, hipMemcpyAsync(hb_xyz, hb, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipMemcpyAsync(hb_nrm, hbn, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipMemcpyAsync(keep_noise, live0, (size_t)n, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipMemcpyAsync(keep_swivel, sw, (size_t)n, hipMemcpyDeviceToHost, st));
   PHCHK(c, hipStreamSynchronize(st));
   return HOP_OK;
 }

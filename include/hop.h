@@ -313,6 +313,15 @@ int hop_scene_from_depth(hop_ctx* ctx, const uint16_t* depth_raw, int H, int W, 
 int hop_object_segment(hop_ctx* ctx, const float* xyz, const float* nrm, const float* conf, int n, float leaf, float* out_xyz,
                        float* out_nrm, float* out_conf, int cap, int* n_out);
 
+/* "Next" row N3d: what Hand::setCurScene derives from the 3 mm hand-region cloud after handbaseICP (src/perception/src/Hand.cpp:289-321):
+ * the cloud moved into the hand-base frame (pcl::transformPointCloudWithNormals by cam_in_handbase), two
+ * pcl::RadiusOutlierRemoval passes (0.02 m / 30 neighbours, 0.04 m / 100), pcl::StatisticalOutlierRemoval (mean_k 20,
+ * 2 sigma) and the x pass-through [-0.25, -0.1].  hb_xyz / hb_nrm: `scene_in_handbase` (SoA planes, stride n);
+ * keep_noise[i] / keep_swivel[i]: whether input point i is in scene_hand_region_removed_noise / scene_remove_swivel
+ * (the three clouds hop_hand_set_scene takes: removed_noise xyz, the normals of scene_in_handbase, remove_swivel xyz). */
+int hop_hand_scene_filters(hop_ctx* ctx, const float* xyz, const float* nrm, int n, const float cam_in_handbase[16], float* hb_xyz,
+                           float* hb_nrm, unsigned char* keep_noise, unsigned char* keep_swivel);
+
 /* ------------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): device time in ms of the kernels launched by the last call of the
  * named stage, measured with HIP events on the ctx stream; and launch counts.

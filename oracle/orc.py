@@ -157,6 +157,7 @@ def lib():
         L.orc_voxel_downsample.argtypes = [fp, C.c_int, C.c_float, fp, C.c_int, ip]
         L.orc_scene_from_depth.argtypes = [C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_double, fp, fp, fp, C.c_float, fp, fp, fp, C.c_int, ip, ip]
         L.orc_object_segment.argtypes = [fp, fp, fp, C.c_int, C.c_float, fp, fp, fp, C.c_int, ip]
+        L.orc_hand_scene_filters.argtypes = [fp, fp, C.c_int, fp, fp, fp, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]
         L.orc_reject_by_collision.argtypes = [C.POINTER(PhysicsArgs), fp, C.c_int, C.POINTER(C.c_ubyte), fp]
         L.orc_compute_ppf.argtypes = [fp, fp, fp, fp, ip]
         L.orc_pair_ppf_is_good.argtypes = [fp, fp, fp, fp]
@@ -497,3 +498,14 @@ def object_segment(xyz, nrm, conf, leaf=0.003):
     k = C.c_int(0)
     lib().orc_object_segment(F(X), F(Nn), F(cf), n, leaf, F(ox), F(on), F(oc), cap, C.byref(k))
     return ox[:, :k.value].T.copy(), on[:, :k.value].T.copy(), oc[:k.value].copy()
+
+
+def hand_scene_filters(xyz, nrm, cam_in_handbase):
+    """Hand::setCurScene (Hand.cpp:289-321): (xyz, nrm in the hand-base frame, keep flags of removed_noise, of remove_swivel)."""
+    X, Nn = soa(xyz), soa(nrm)
+    n = X.shape[1]
+    T = np.ascontiguousarray(cam_in_handbase, np.float32).reshape(16)
+    hx, hn = np.zeros((3, max(n, 1)), np.float32), np.zeros((3, max(n, 1)), np.float32)
+    k1, k2 = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint8)
+    lib().orc_hand_scene_filters(F(X), F(Nn), n, F(T), F(hx), F(hn), k1.ctypes.data_as(C.POINTER(C.c_ubyte)), k2.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return hx[:, :n].T.copy(), hn[:, :n].T.copy(), k1[:n].astype(bool), k2[:n].astype(bool)

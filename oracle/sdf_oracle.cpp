@@ -604,6 +604,76 @@ int orc_object_segment(const float* xyz_planes, const float* nrm_planes, const f
   return (int)ox.size() > cap ? -1 : 0;
 }
 
+// Hand::setCurScene after handbaseICP (Hand.cpp:289-321): the 3 mm hand-region cloud moved into the hand-base frame
+// (pcl::transformPointCloudWithNormals), RadiusOutlierRemoval (0.02 m / 30, then 0.04 m / 100: a point stays when the
+// radius search -- which finds the point itself too, squared distance strictly below r^2 as FLANN's RadiusResultSet
+// tests it -- returns more than min_pts), StatisticalOutlierRemoval (mean distance to the 20 nearest neighbours, kept
+// when <= mean + 2 stddev, statistical_outlier_removal.hpp), pass-through x in [-0.25, -0.1].
+// keep_noise[n] / keep_swivel[n]: flags of the input points in scene_hand_region_removed_noise / scene_remove_swivel.
+static void radius_filter(const std::vector<F3>& in, float radius, int min_pts, std::vector<F3>& out, std::vector<int>& idx_io) {
+  std::vector<F3> res;
+  std::vector<int> ridx;
+  const float r2 = radius * radius;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < (int)in.size(); ++i) {
+    int k = 0;
+    for (size_t j = 0; j < in.size(); ++j)
+      if (sqdist_flann(in[i], in[j]) < r2) ++k;
+    if (!(k > min_pts)) idx_io[i] = -1;
+  }
+  for (size_t i = 0; i < in.size(); ++i)
+    if (idx_io[i] >= 0) res.push_back(in[i]), ridx.push_back(idx_io[i]);
+  out.swap(res);
+  idx_io.swap(ridx);
+}
+int orc_hand_scene_filters(const float* xyz_planes, const float* nrm_planes, int n, const float* cam_in_handbase16, float* hb_xyz, float* hb_nrm,
+                           unsigned char* keep_noise, unsigned char* keep_swivel) {
+  std::vector<F3> P = planes_to_pts(xyz_planes, n), N = planes_to_pts(nrm_planes, n);
+  const float* T = cam_in_handbase16;
+  for (int i = 0; i < n; ++i) {
+    P[i] = xform(T, P[i]);
+    const F3 m = N[i];  // rotation part only (pcl::transformPointCloudWithNormals)
+    N[i] = f3((T[0] * m.x + T[1] * m.y) + T[2] * m.z, (T[4] * m.x + T[5] * m.y) + T[6] * m.z, (T[8] * m.x + T[9] * m.y) + T[10] * m.z);
+    hb_xyz[i] = P[i].x, hb_xyz[(size_t)n + i] = P[i].y, hb_xyz[2 * (size_t)n + i] = P[i].z;
+    hb_nrm[i] = N[i].x, hb_nrm[(size_t)n + i] = N[i].y, hb_nrm[2 * (size_t)n + i] = N[i].z;
+    keep_noise[i] = keep_swivel[i] = 0;
+  }
+  std::vector<F3> cur = P;
+  std::vector<int> idx(n);
+  for (int i = 0; i < n; ++i) idx[i] = i;
+  radius_filter(cur, 0.02f, 30, cur, idx);
+  radius_filter(cur, 0.04f, 100, cur, idx);
+  // StatisticalOutlierRemoval, mean_k 20, std_mul 2
+  const int mean_k = 20, m = (int)cur.size();
+  std::vector<float> distances(m, 0.f);
+  if (m > mean_k) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < m; ++i) {
+      std::vector<float> d(m);
+      for (int j = 0; j < m; ++j) d[j] = sqdist_flann(cur[i], cur[j]);
+      std::partial_sort(d.begin(), d.begin() + mean_k + 1, d.end());
+      double dist_sum = 0.0;
+      for (int k = 1; k < mean_k + 1; ++k) dist_sum += std::sqrt(d[k]);  // k = 0 is the query point
+      distances[i] = (float)(dist_sum / mean_k);
+    }
+    double sum = 0, sq_sum = 0;
+    for (int i = 0; i < m; ++i) sum += distances[i], sq_sum += (double)distances[i] * distances[i];
+    const double mean = sum / (double)m;
+    const double variance = (sq_sum - sum * sum / (double)m) / ((double)m - 1);
+    const double thr = mean + 2.0 * std::sqrt(variance);
+    std::vector<F3> res;
+    std::vector<int> ridx;
+    for (int i = 0; i < m; ++i)
+      if (!(distances[i] > thr)) res.push_back(cur[i]), ridx.push_back(idx[i]);
+    cur.swap(res), idx.swap(ridx);
+  }
+  for (size_t i = 0; i < cur.size(); ++i) {
+    keep_noise[idx[i]] = 1;
+    if (!(cur[i].x < -0.25f || cur[i].x > -0.1f)) keep_swivel[idx[i]] = 1;
+  }
+  return 0;
+}
+
 // PoseEstimator::rejectByCollisionOrNonTouching (PoseEstimator.cpp:524-735).  keep[i] = 1 for the hypotheses the
 // reference pushes back into _pose_hypos.  diag (optional, H x 8): stage that decided (0 kept, 1 scene point inside,
 // 2 hand point colliding, 3 finger cloud colliding, 4 one side not touching, 5 model inside finger), the two single-

@@ -348,3 +348,49 @@ def test_object_segment_vs_oracle(ctx, orc, synth):
     assert (np.einsum("ij,ij->i", n2, -xyz) >= -1e-9).all()
     e = ctx.object_segment(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros(0, np.float32))
     assert len(e[0]) == 0
+
+
+def test_hand_scene_filters_vs_oracle(ctx, orc, synth, api, hop):
+    """Hand::setCurScene (Hand.cpp:289-321): hand-base transform, radius / statistical outlier filters, swivel pass-through.
+    The scene is the synthetic hand region plus isolated specks and a sparse halo; flags equal to the oracle's."""
+    import math
+    hand = synth.t42_hand()
+    true = {"finger_1_1": math.radians(10), "finger_1_2": math.radians(6), "finger_2_1": math.radians(12), "finger_2_2": math.radians(5)}
+    hxyz, hnrm = synth.make_hand_scene(hand, true, 6000, seed=5)
+    rng = np.random.default_rng(3)
+    specks = np.array([-0.15, 0.0, 0.0]) + rng.normal(scale=0.08, size=(300, 3))          # isolated: radius filters
+    halo = hxyz[rng.integers(0, len(hxyz), 400)] + rng.normal(scale=0.012, size=(400, 3))  # sparse fringe: statistical filter
+    xyz_h = np.concatenate([hxyz, specks, halo]).astype(np.float32)
+    nrm_h = np.concatenate([hnrm, rng.normal(size=(700, 3))]).astype(np.float32)
+    T = synth.se3(synth.rot_from_axis_angle([1.0, 0.2, -0.1], 2.6), [0.03, -0.02, 0.55])  # handbase_in_cam
+    xyz_c, nrm_c = synth.apply(T, xyz_h), synth.rotate(T, nrm_h)
+    cam_in_handbase = np.linalg.inv(T).astype(np.float32)
+    hx, hn, keep, swivel = ctx.hand_scene_filters(xyz_c, nrm_c, cam_in_handbase)
+    ox, on, keep_o, swivel_o = orc.hand_scene_filters(xyz_c, nrm_c, cam_in_handbase)
+    assert np.array_equal(hx.view(np.int32), ox.view(np.int32)) and np.array_equal(hn.view(np.int32), on.view(np.int32))
+    assert np.array_equal(keep, keep_o) and np.array_equal(swivel, swivel_o)
+    assert keep[:6000].mean() > 0.9 and keep[6000:6300].mean() < 0.2 and 0 < swivel.sum() < keep.sum()
+    assert keep[6300:].mean() < keep[:6000].mean()
+    # mirror: the products feed the hand-state search
+    from hop_amd import config as hop_config
+    cfg = hop_config.load_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "icra20-hand-object-pose_amd", "config",
+                                              "config_autodataset.yaml"))
+    h = api.HandT42(cfg, hand, ctx=ctx)
+    h.gripper_min_dist = 0.0144
+    n_noise, n_region, n_swivel = h.setCurSceneFromRegion(xyz_c, nrm_c, T)
+    assert (n_noise, n_region, n_swivel) == (int(keep.sum()), len(xyz_c), int(swivel.sum()))
+    hm = cfg["hand_match"]
+    assert h.matchOneComponentPSO("finger_2_1", 0, 120, False, hm["finger1_dist_thres"], hm["finger1_normal_angle"], hm["finger1_min_match"])
+    assert abs(h.last_angle - true["finger_2_1"]) < math.radians(6)  # 200-particle search on a 6 k-point noisy scene
+
+
+def test_hand_scene_filters_small_inputs(ctx, orc):
+    I4 = np.eye(4, dtype=np.float32)
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 15, 150):
+        x = (rng.normal(size=(n, 3)) * 0.005 + np.array([-0.15, 0, 0])).astype(np.float32)
+        nn = rng.normal(size=(n, 3)).astype(np.float32)
+        hx, hn, keep, swivel = ctx.hand_scene_filters(x, nn, I4)
+        ox, on, keep_o, swivel_o = orc.hand_scene_filters(x, nn, I4)
+        assert np.array_equal(keep, keep_o) and np.array_equal(swivel, swivel_o)
+        assert keep.sum() == (0 if n <= 100 else keep_o.sum())  # fewer than 101 points can never pass the 0.04 m / 100 filter

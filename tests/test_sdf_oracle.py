@@ -102,3 +102,22 @@ def test_oracle_object_segment_small(orc):
     np.testing.assert_allclose(on[0], -s, atol=1e-6)                       # summed, normalised, flipped towards the origin
     np.testing.assert_allclose(on[1], [0, 0, -1], atol=1e-7)               # already facing the camera
     assert oc[0] == np.float32(0.9) and oc[1] == np.float32(0.5)          # nearest dense point of each centroid
+
+
+def test_oracle_hand_scene_filters_small(orc):
+    """Hand.cpp:289-321 on a case that can be checked by counting: a dense 11 x 11 x 2 block (242 points, 1 mm pitch)
+    survives both radius filters; a speck 10 cm away has no neighbour and goes with the first one."""
+    g = np.arange(11) * 0.001
+    X, Y, Z = np.meshgrid(g, g, np.arange(2) * 0.001, indexing="ij")
+    block = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1) + np.array([-0.15, 0.0, 0.0])
+    xyz = np.concatenate([block, [[-0.15, 0.1, 0.0]]]).astype(np.float32)
+    nrm = np.tile(np.float32([0, 0, 1]), (len(xyz), 1))
+    hx, hn, keep, swivel = orc.hand_scene_filters(xyz, nrm, np.eye(4, dtype=np.float32))
+    assert np.array_equal(hx, xyz) and np.array_equal(hn, nrm)
+    assert not keep[-1]
+    # the regular block: every point has 20 neighbours within about 2 mm, so the mean distances vary little and only
+    # the statistical filter can remove points (corners of the block: largest mean distance)
+    assert keep[:-1].sum() > 200 and np.array_equal(swivel, keep)  # x = -0.15 .. -0.14 lies inside [-0.25, -0.1]
+    moved = xyz + np.float32([0.1, 0, 0])                          # x = -0.05 .. -0.04: outside the swivel pass-through
+    _, _, keep2, swivel2 = orc.hand_scene_filters(moved, nrm, np.eye(4, dtype=np.float32))
+    assert keep2[:-1].sum() > 200 and swivel2.sum() == 0
