@@ -28,9 +28,10 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
 def adi(model, est, gt):
-    a = model @ est[:3, :3].T + est[:3, 3]
-    b = model @ gt[:3, :3].T + gt[:3, 3]
-    return float(cKDTree(b).query(a)[0].mean())
+    """scripts/eval_utils.py:181-200: mean distance from every ground-truth model point to the nearest estimated one."""
+    pts_est = model @ est[:3, :3].T + est[:3, 3]
+    pts_gt = model @ gt[:3, :3].T + gt[:3, 3]
+    return float(cKDTree(pts_est).query(pts_gt, k=1)[0].mean())
 
 
 def rot_err_deg(A, B):
