@@ -147,6 +147,8 @@ SIGNATURES = {
     "hop_scene_from_depth": (C.c_int, [_vp, C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_double, fp, fp, fp, C.c_float, fp, fp, fp, C.c_int, ip, ip]),
     "hop_object_segment": (C.c_int, [_vp, fp, fp, fp, C.c_int, C.c_float, fp, fp, fp, C.c_int, ip]),
     "hop_hand_scene_filters": (C.c_int, [_vp, fp, fp, C.c_int, fp, fp, fp, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]),
+    "hop_voxel_downsample_normals": (C.c_int, [_vp, fp, fp, C.c_int, C.c_float, fp, fp, C.c_int, ip]),
+    "hop_handbase_region": (C.c_int, [_vp, fp, fp, C.c_int, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp, fp, C.POINTER(C.c_ubyte)]),
     "hop_physics_set_frame": (C.c_int, [_vp, C.POINTER(PhysicsArgs)]),
     "hop_reject_by_collision": (C.c_int, [_vp, C.POINTER(C.c_ubyte), fp, ip]),
     "hop_physics_timing": (C.c_int, [_vp, dp, dp]),
@@ -376,6 +378,25 @@ class Context:
         self._chk(self.L.hop_hand_scene_filters(self.h, F(X), F(Nn), n, F(T), F(hx), F(hn), k1.ctypes.data_as(C.POINTER(C.c_ubyte)),
                                                 k2.ctypes.data_as(C.POINTER(C.c_ubyte))), "hop_hand_scene_filters")
         return hx[:, :n].T.copy(), hn[:, :n].T.copy(), k1[:n].astype(bool), k2[:n].astype(bool)
+
+    def voxel_downsample_normals(self, xyz, nrm, leaf):
+        X, Nn = soa(xyz), soa(nrm)
+        n = X.shape[1]
+        cap = max(n, 1)
+        ox, on = np.zeros((3, cap), np.float32), np.zeros((3, cap), np.float32)
+        k = C.c_int(0)
+        self._chk(self.L.hop_voxel_downsample_normals(self.h, F(X), F(Nn), n, leaf, F(ox), F(on), cap, C.byref(k)), "hop_voxel_downsample_normals")
+        return ox[:, :k.value].T.copy(), on[:, :k.value].T.copy()
+
+    def handbase_region(self, xyz, nrm, cam_in_handbase, y1, z1, y2, z2):
+        X, Nn = soa(xyz), soa(nrm)
+        n = X.shape[1]
+        T = np.ascontiguousarray(cam_in_handbase, np.float32).reshape(16)
+        hx, hn = np.zeros((3, max(n, 1)), np.float32), np.zeros((3, max(n, 1)), np.float32)
+        k = np.zeros(max(n, 1), np.uint8)
+        self._chk(self.L.hop_handbase_region(self.h, F(X), F(Nn), n, F(T), y1, z1, y2, z2, F(hx), F(hn), k.ctypes.data_as(C.POINTER(C.c_ubyte))),
+                  "hop_handbase_region")
+        return hx[:, :n].T.copy(), hn[:, :n].T.copy(), k[:n].astype(bool)
 
     def physics_set_frame(self, p):
         """p: dict -- object_mesh, finger_mesh[4] (registered ids), finger_xyz[4] ((n,3), link frame), finger2handbase[4],
@@ -713,6 +734,16 @@ def finger_property(xyz, num_division=10):
     return dict(min=mn, max=mx, stride_z=stride, hist=hist, num_division=num_division)
 
 
+def euler_zyx_pitch(R):
+    """Second angle of Eigen's R.eulerAngles(2,1,0) (Geometry/EulerAngles.h:36-108)."""
+    R = np.asarray(R, np.float64)
+    a0 = math.atan2(R[1, 0], R[0, 0])
+    c2 = math.hypot(R[2, 2], R[2, 1])
+    if a0 < 0:
+        return math.atan2(-R[2, 0], -c2)
+    return math.atan2(-R[2, 0], c2)
+
+
 class HandT42:
     """Mirror of Hand/HandT42 for the hand-state search (Hand.h:29-92).
 
@@ -745,6 +776,39 @@ class HandT42:
     def setCurScene(self, scene_removed_noise_xyz, scene_hand_region_nrm, scene_remove_swivel_xyz):
         """Products of Hand::setCurScene (Hand.cpp:327-332), all in the hand-base frame."""
         self.ctx.hand_set_scene(scene_removed_noise_xyz, scene_hand_region_nrm, scene_remove_swivel_xyz)
+
+    def handbaseICP(self, scene_xyz_cam, scene_nrm_cam, handbase_in_cam):
+        """Hand::handbaseICP (Hand.cpp:677-777): corrects handbase_in_cam by a point-to-plane ICP of the scene around the
+        palm against the base_link cloud.  Returns (new handbase_in_cam, cam2handbase_offset)."""
+        c = self.ctx
+        handbase_in_cam = np.asarray(handbase_in_cam, np.float32)
+        cam_in_handbase = np.linalg.inv(handbase_in_cam.astype(np.float64)).astype(np.float32)
+        sx, sn = c.voxel_downsample_normals(scene_xyz_cam, scene_nrm_cam, 0.005)
+        t1, t2 = self.hand.tf_in_parent["finger_1_1"], self.hand.tf_in_parent["finger_2_1"]
+        hx, hn, keep = c.handbase_region(sx, sn, cam_in_handbase, float(t1[1, 3]), float(t1[2, 3]), float(t2[1, 3]), float(t2[2, 3]))
+        offset = np.eye(4, dtype=np.float32)
+        if keep.sum() > 0:
+            bx, bn = self.hand.clouds["base_link"]
+            c.set_scene(hx[keep], hn[keep], None, 0.0)          # Utils::runICP source (pclSegment)
+            c.set_model(HOP_MODEL_5MM, bx, bn)                   # target (pclModel)
+            c.hypos_upload(np.eye(4, dtype=np.float32)[None])
+            c.icp_refine(50, 30.0, 0.03, nn_mode=0)
+            pose, _, _ = c.hypos_download()
+            offset = np.linalg.inv(pose[0].astype(np.float64)).astype(np.float32)  # source -> target
+        translation = float(np.linalg.norm(offset[:3, 3]))
+        if translation >= 0.05:                                   # :740-745
+            offset = np.eye(4, dtype=np.float32)
+        R = offset[:3, :3].astype(np.float64)
+        rot_diff = math.degrees(math.acos(max(-1.0, min(1.0, (np.trace(R) - 1) / 2.0))))
+        pitch = euler_zyx_pitch(offset[:3, :3])
+        pitch = min(abs(pitch), abs(math.pi - pitch))
+        pitch = min(abs(pitch), abs(math.pi + pitch))
+        if rot_diff >= 10 or abs(pitch) >= 10 / 180.0 * math.pi:  # :752-756
+            offset = np.eye(4, dtype=np.float32)
+        if not np.array_equal(offset, np.eye(4, dtype=np.float32)):
+            self._component_status["handbase"] = True
+        new = (handbase_in_cam.astype(np.float64) @ np.linalg.inv(offset.astype(np.float64))).astype(np.float32)
+        return new, offset
 
     def setCurSceneFromRegion(self, region_xyz_cam, region_nrm_cam, handbase_in_cam):
         """Hand::setCurScene from the 3 mm hand-region cloud in the camera frame (Hand.cpp:289-332, after handbaseICP):

@@ -731,6 +731,26 @@ __global__ void k_sor_apply(const float* __restrict__ x, int n, const unsigned c
   keep_swivel[i] = k && !(x[i] < -0.25f || x[i] > -0.1f);  // pass-through x (Hand.cpp:316-320)
 }
 
+// Hand::handbaseICP source cloud (Hand.cpp:685-729): hand-base transform, two pass-throughs, finger connections removed
+__global__ void k_handbase_region(const float* __restrict__ ix, const float* __restrict__ iy, const float* __restrict__ iz, const float* __restrict__ inx,
+                                  const float* __restrict__ iny, const float* __restrict__ inz, int n, const float* __restrict__ T, float y1, float z1,
+                                  float y2, float z2, float* __restrict__ o, float* __restrict__ on, unsigned char* __restrict__ keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 pt = m4_point(T, v3(ix[i], iy[i], iz[i])), m = m4_dir(T, v3(inx[i], iny[i], inz[i]));
+  o[i] = pt.x, o[n + i] = pt.y, o[2 * (size_t)n + i] = pt.z;
+  on[i] = m.x, on[n + i] = m.y, on[2 * (size_t)n + i] = m.z;
+  bool k = isfinite(pt.x) && isfinite(pt.y) && isfinite(pt.z) && !(pt.x < -0.07f || pt.x > 0.03f) && !(pt.z < -0.18f || pt.z > 0.01f);
+  if (k) {
+    const float sq_dist1 = (pt.z - z1) * (pt.z - z1) + (pt.y - y1) * (pt.y - y1);
+    const float sq_dist2 = (pt.z - z2) * (pt.z - z2) + (pt.y - y2) * (pt.y - y2);
+    if (sq_dist1 <= 0.015 * 0.015) k = false;
+    else if (sq_dist2 <= 0.015 * 0.015) k = false;
+    else if (((pt.y >= y1 && pt.y <= y2) || (pt.y >= y2 && pt.y <= y1)) && fabsf(pt.z - z1) <= 0.01) k = false;  // :718-724 tests z1 twice
+  }
+  keep[i] = k;
+}
+
 // ------------------------------------------------------------------------------------------------ host helpers
 int upload_planes(hop_ctx* c, Cloud3& dst, const float* planes, int n) {
   hipStream_t st = hop_ctx_stream(c);
@@ -1074,6 +1094,57 @@ int hop_hand_scene_filters(hop_ctx* c, const float* xyz, const float* nrm, int n
   PHCHK(c, hipMemcpyAsync(hb_nrm, hbn, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
   PHCHK(c, hipMemcpyAsync(keep_noise, live0, (size_t)n, hipMemcpyDeviceToHost, st));
   PHCHK(c, hipMemcpyAsync(keep_swivel, sw, (size_t)n, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipStreamSynchronize(st));
+  return HOP_OK;
+}
+
+int hop_voxel_downsample_normals(hop_ctx* c, const float* xyz, const float* nrm, int n, float leaf, float* out_xyz, float* out_nrm, int cap, int* n_out) {
+  if (!c || n < 0 || (n > 0 && (!xyz || !nrm)) || !n_out || cap < 0) return HOP_E_INVALID;
+  PHCHK(c, hipSetDevice(hop_ctx_device(c)));
+  Physics* ph = physics(c);
+  hipStream_t st = hop_ctx_stream(c);
+  *n_out = 0;
+  if (n == 0) return HOP_OK;
+  int rc = upload_planes(c, ph->tmp_cloud, xyz, n);
+  if (rc) return rc;
+  rc = upload_planes(c, ph->tmp_nrm, nrm, n);
+  if (rc) return rc;
+  rc = voxel_downsample_device(c, ph, ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), n, leaf, ph->tmp_cloud2, ph->tmp_nrm.buf.as<float>(), &ph->tmp_nrm2);
+  if (rc) return rc;
+  const int m = ph->tmp_cloud2.n;
+  *n_out = m;
+  if (m > cap) return HOP_E_CAPACITY;
+  for (int k = 0; k < 3 && m > 0; ++k) {
+    if (out_xyz) PHCHK(c, hipMemcpyAsync(out_xyz + (size_t)k * cap, ph->tmp_cloud2.buf.as<float>() + (size_t)k * m, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
+    if (out_nrm) PHCHK(c, hipMemcpyAsync(out_nrm + (size_t)k * cap, ph->tmp_nrm2.buf.as<float>() + (size_t)k * m, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
+  }
+  PHCHK(c, hipStreamSynchronize(st));
+  return HOP_OK;
+}
+
+int hop_handbase_region(hop_ctx* c, const float* xyz, const float* nrm, int n, const float cam_in_handbase[16], float y1, float z1, float y2, float z2,
+                        float* hb_xyz, float* hb_nrm, unsigned char* keep) {
+  if (!c || n < 0 || (n > 0 && (!xyz || !nrm || !hb_xyz || !hb_nrm || !keep)) || !cam_in_handbase) return HOP_E_INVALID;
+  PHCHK(c, hipSetDevice(hop_ctx_device(c)));
+  Physics* ph = physics(c);
+  hipStream_t st = hop_ctx_stream(c);
+  if (n == 0) return HOP_OK;
+  int rc = upload_planes(c, ph->tmp_cloud, xyz, n);
+  if (rc) return rc;
+  rc = upload_planes(c, ph->tmp_nrm, nrm, n);
+  if (rc) return rc;
+  PHCHK(c, ph->mats.ensure(sizeof(float) * 16 * 5));
+  PHCHK(c, hipMemcpyAsync(ph->mats.p, cam_in_handbase, sizeof(float) * 16, hipMemcpyHostToDevice, st));
+  PHCHK(c, ph->tmp_cloud2.buf.ensure(sizeof(float) * 3 * (size_t)n));
+  PHCHK(c, ph->tmp_nrm2.buf.ensure(sizeof(float) * 3 * (size_t)n));
+  PHCHK(c, ph->flags.ensure((size_t)n + 16));
+  const float* nn = ph->tmp_nrm.buf.as<float>();
+  k_handbase_region<<<(n + 255) / 256, 256, 0, st>>>(ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), nn, nn + n, nn + 2 * (size_t)n, n, ph->mats.as<float>(), y1, z1,
+                                                    y2, z2, ph->tmp_cloud2.buf.as<float>(), ph->tmp_nrm2.buf.as<float>(), ph->flags.as<unsigned char>());
+  PHCHK(c, hipGetLastError());
+  PHCHK(c, hipMemcpyAsync(hb_xyz, ph->tmp_cloud2.buf.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipMemcpyAsync(hb_nrm, ph->tmp_nrm2.buf.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipMemcpyAsync(keep, ph->flags.p, (size_t)n, hipMemcpyDeviceToHost, st));
   PHCHK(c, hipStreamSynchronize(st));
   return HOP_OK;
 }

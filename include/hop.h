@@ -322,6 +322,21 @@ int hop_object_segment(hop_ctx* ctx, const float* xyz, const float* nrm, const f
 int hop_hand_scene_filters(hop_ctx* ctx, const float* xyz, const float* nrm, int n, const float cam_in_handbase[16], float* hb_xyz,
                            float* hb_nrm, unsigned char* keep_noise, unsigned char* keep_swivel);
 
+/* "Next" row N3e: the pieces of Hand::handbaseICP (src/perception/src/Hand.cpp:677-777) that touch clouds.
+ *   hop_voxel_downsample_normals  Utils::downsamplePointCloud on a cloud with normals (:680, leaf 0.005): centroids and the
+ *                                 normalised normal sums (pcl CentroidPoint), ascending voxel order
+ *   hop_handbase_region           the ICP source (:685-729): hand-base transform, pass-through x [-0.07, 0.03] and
+ *                                 z [-0.18, 0.01], finger connections removed (y1,z1 / y2,z2 = translation of finger_1_1 /
+ *                                 finger_2_1 in their parent); hb_xyz / hb_nrm: every input point in the hand-base frame
+ *                                 (planes, stride n), keep[i]: whether it belongs to the source cloud
+ * The ICP itself is Utils::runICP (Utils.cpp:188-229), the function refineByICP calls: hop_set_scene (source) /
+ * hop_set_model (target: the base_link cloud) / hop_hypos_upload (identity) / hop_icp_refine {50, 30, 0.03}; the offset
+ * is the inverse of the refined pose.  The acceptance rules of :740-772 are host logic (host/Hand.h, api.py). */
+int hop_voxel_downsample_normals(hop_ctx* ctx, const float* xyz, const float* nrm, int n, float leaf, float* out_xyz, float* out_nrm,
+                                 int cap, int* n_out);
+int hop_handbase_region(hop_ctx* ctx, const float* xyz, const float* nrm, int n, const float cam_in_handbase[16], float y1, float z1,
+                        float y2, float z2, float* hb_xyz, float* hb_nrm, unsigned char* keep);
+
 /* ------------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): device time in ms of the kernels launched by the last call of the
  * named stage, measured with HIP events on the ctx stream; and launch counts.

@@ -155,6 +155,10 @@ int orc_object_segment(const float* xyz_planes, const float* nrm_planes, const f
 /* Hand::setCurScene (Hand.cpp:289-321): hand-base transform, two radius outlier filters, statistical outlier filter, x pass-through */
 int orc_hand_scene_filters(const float* xyz_planes, const float* nrm_planes, int n, const float* cam_in_handbase16, float* hb_xyz, float* hb_nrm,
                            unsigned char* keep_noise, unsigned char* keep_swivel);
+/* pcl::VoxelGrid over xyz + normals; Hand::handbaseICP's source cloud (Hand.cpp:685-729) */
+int orc_voxel_downsample_normals(const float* xyz_planes, const float* nrm_planes, int n, float leaf, float* out_xyz, float* out_nrm, int cap, int* n_out);
+int orc_handbase_region(const float* xyz_planes, const float* nrm_planes, int n, const float* cam_in_handbase16, float y1, float z1, float y2, float z2,
+                        float* hb_xyz, float* hb_nrm, unsigned char* keep);
 /* scene front end of main_realdata_auto.cpp:54-96 (depth -> cloud, z pass-through, voxel grid, hand-base crop) */
 int orc_scene_from_depth(const unsigned short* depth_raw, int H, int W, double depth_unit, const float* K9, const float* cam_in_handbase16,
                          const float* handbase_in_cam16, float leaf, const float* crop_min3, const float* crop_max3, float* out_planes,

@@ -158,6 +158,8 @@ def lib():
         L.orc_scene_from_depth.argtypes = [C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_double, fp, fp, fp, C.c_float, fp, fp, fp, C.c_int, ip, ip]
         L.orc_object_segment.argtypes = [fp, fp, fp, C.c_int, C.c_float, fp, fp, fp, C.c_int, ip]
         L.orc_hand_scene_filters.argtypes = [fp, fp, C.c_int, fp, fp, fp, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]
+        L.orc_voxel_downsample_normals.argtypes = [fp, fp, C.c_int, C.c_float, fp, fp, C.c_int, ip]
+        L.orc_handbase_region.argtypes = [fp, fp, C.c_int, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp, fp, C.POINTER(C.c_ubyte)]
         L.orc_reject_by_collision.argtypes = [C.POINTER(PhysicsArgs), fp, C.c_int, C.POINTER(C.c_ubyte), fp]
         L.orc_compute_ppf.argtypes = [fp, fp, fp, fp, ip]
         L.orc_pair_ppf_is_good.argtypes = [fp, fp, fp, fp]
@@ -509,3 +511,23 @@ def hand_scene_filters(xyz, nrm, cam_in_handbase):
     k1, k2 = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint8)
     lib().orc_hand_scene_filters(F(X), F(Nn), n, F(T), F(hx), F(hn), k1.ctypes.data_as(C.POINTER(C.c_ubyte)), k2.ctypes.data_as(C.POINTER(C.c_ubyte)))
     return hx[:, :n].T.copy(), hn[:, :n].T.copy(), k1[:n].astype(bool), k2[:n].astype(bool)
+
+
+def voxel_downsample_normals(xyz, nrm, leaf):
+    X, Nn = soa(xyz), soa(nrm)
+    n = X.shape[1]
+    cap = max(n, 1)
+    ox, on = np.zeros((3, cap), np.float32), np.zeros((3, cap), np.float32)
+    k = C.c_int(0)
+    lib().orc_voxel_downsample_normals(F(X), F(Nn), n, leaf, F(ox), F(on), cap, C.byref(k))
+    return ox[:, :k.value].T.copy(), on[:, :k.value].T.copy()
+
+
+def handbase_region(xyz, nrm, cam_in_handbase, y1, z1, y2, z2):
+    X, Nn = soa(xyz), soa(nrm)
+    n = X.shape[1]
+    T = np.ascontiguousarray(cam_in_handbase, np.float32).reshape(16)
+    hx, hn = np.zeros((3, max(n, 1)), np.float32), np.zeros((3, max(n, 1)), np.float32)
+    k = np.zeros(max(n, 1), np.uint8)
+    lib().orc_handbase_region(F(X), F(Nn), n, F(T), y1, z1, y2, z2, F(hx), F(hn), k.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return hx[:, :n].T.copy(), hn[:, :n].T.copy(), k[:n].astype(bool)

@@ -674,6 +674,91 @@ int orc_hand_scene_filters(const float* xyz_planes, const float* nrm_planes, int
   return 0;
 }
 
+// pcl::VoxelGrid over xyz + normals (Utils::downsamplePointCloud on a PointXYZRGBNormal cloud): centroids and the
+// normalised normal sums, in ascending voxel order
+int orc_voxel_downsample_normals(const float* xyz_planes, const float* nrm_planes, int n, float leaf, float* out_xyz, float* out_nrm, int cap, int* n_out) {
+  // reuse orc_object_segment's grid by giving every point confidence 0 and undoing nothing: the flip towards the
+  // viewpoint is not part of the grid, so the grid is restated here once more without it
+  const std::vector<F3> P = planes_to_pts(xyz_planes, n), N = planes_to_pts(nrm_planes, n);
+  *n_out = 0;
+  std::vector<F3> cen;
+  voxel_grid(P, leaf, cen);
+  if (cen.empty()) return 0;
+  // second walk in the same order for the normals: same index arithmetic as voxel_grid
+  const float inv = 1.0f / leaf;
+  F3 mn = f3(FLT_MAX, FLT_MAX, FLT_MAX), mx = f3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+  for (const F3& p : P) {
+    if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+    mn = f3(std::min(mn.x, p.x), std::min(mn.y, p.y), std::min(mn.z, p.z));
+    mx = f3(std::max(mx.x, p.x), std::max(mx.y, p.y), std::max(mx.z, p.z));
+  }
+  const int minb[3] = {(int)std::floor(mn.x * inv), (int)std::floor(mn.y * inv), (int)std::floor(mn.z * inv)};
+  const int maxb[3] = {(int)std::floor(mx.x * inv), (int)std::floor(mx.y * inv), (int)std::floor(mx.z * inv)};
+  const int div[3] = {maxb[0] - minb[0] + 1, maxb[1] - minb[1] + 1, maxb[2] - minb[2] + 1};
+  const int mul[3] = {1, div[0], div[0] * div[1]};
+  struct Idx {
+    unsigned idx, pt;
+    bool operator<(const Idx& o) const { return idx < o.idx; }
+  };
+  std::vector<Idx> v;
+  for (int i = 0; i < n; ++i) {
+    const F3& p = P[i];
+    if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+    const int i0 = (int)std::floor(p.x * inv) - minb[0], i1 = (int)std::floor(p.y * inv) - minb[1], i2 = (int)std::floor(p.z * inv) - minb[2];
+    v.push_back({(unsigned)(i0 * mul[0] + i1 * mul[1] + i2 * mul[2]), (unsigned)i});
+  }
+  std::sort(v.begin(), v.end());
+  std::vector<F3> nn;
+  size_t k = 0;
+  while (k < v.size()) {
+    size_t e = k + 1;
+    while (e < v.size() && v[e].idx == v[k].idx) ++e;
+    F3 sn = f3(0, 0, 0);
+    for (size_t j = k; j < e; ++j) sn = sn + N[v[j].pt];
+    const float z = sqn3(sn);
+    if (z > 0.f) {
+      const float r = std::sqrt(z);
+      sn = f3(sn.x / r, sn.y / r, sn.z / r);
+    }
+    nn.push_back(sn);
+    k = e;
+  }
+  *n_out = (int)cen.size();
+  const int m = std::min((int)cen.size(), cap);
+  for (int i = 0; i < m; ++i) {
+    out_xyz[i] = cen[i].x, out_xyz[(size_t)cap + i] = cen[i].y, out_xyz[2 * (size_t)cap + i] = cen[i].z;
+    out_nrm[i] = nn[i].x, out_nrm[(size_t)cap + i] = nn[i].y, out_nrm[2 * (size_t)cap + i] = nn[i].z;
+  }
+  return (int)cen.size() > cap ? -1 : 0;
+}
+
+// Hand::handbaseICP, the source cloud (Hand.cpp:685-729): the 5 mm scene moved into the hand-base frame, pass-through
+// x in [-0.07, 0.03] and z in [-0.18, 0.01], the finger connections removed (y1,z1 / y2,z2: translation of finger_1_1 /
+// finger_2_1 in their parent).  keep[i]: whether input point i survives; hb_xyz / hb_nrm: all points in the hand-base frame.
+int orc_handbase_region(const float* xyz_planes, const float* nrm_planes, int n, const float* cam_in_handbase16, float y1, float z1, float y2, float z2,
+                        float* hb_xyz, float* hb_nrm, unsigned char* keep) {
+  const std::vector<F3> P = planes_to_pts(xyz_planes, n), N = planes_to_pts(nrm_planes, n);
+  const float* T = cam_in_handbase16;
+  for (int i = 0; i < n; ++i) {
+    const F3 pt = xform(T, P[i]);
+    const F3 m = N[i];
+    const F3 nn = f3((T[0] * m.x + T[1] * m.y) + T[2] * m.z, (T[4] * m.x + T[5] * m.y) + T[6] * m.z, (T[8] * m.x + T[9] * m.y) + T[10] * m.z);
+    hb_xyz[i] = pt.x, hb_xyz[(size_t)n + i] = pt.y, hb_xyz[2 * (size_t)n + i] = pt.z;
+    hb_nrm[i] = nn.x, hb_nrm[(size_t)n + i] = nn.y, hb_nrm[2 * (size_t)n + i] = nn.z;
+    bool k = std::isfinite(pt.x) && std::isfinite(pt.y) && std::isfinite(pt.z);
+    k = k && !(pt.x < -0.07f || pt.x > 0.03f) && !(pt.z < -0.18f || pt.z > 0.01f);
+    if (k) {
+      const float sq_dist1 = (pt.z - z1) * (pt.z - z1) + (pt.y - y1) * (pt.y - y1);
+      const float sq_dist2 = (pt.z - z2) * (pt.z - z2) + (pt.y - y2) * (pt.y - y2);
+      if (sq_dist1 <= 0.015 * 0.015) k = false;
+      else if (sq_dist2 <= 0.015 * 0.015) k = false;
+      else if (((pt.y >= y1 && pt.y <= y2) || (pt.y >= y2 && pt.y <= y1)) && std::abs(pt.z - z1) <= 0.01) k = false;  // :718-724 (both operands test z1)
+    }
+    keep[i] = k;
+  }
+  return 0;
+}
+
 // PoseEstimator::rejectByCollisionOrNonTouching (PoseEstimator.cpp:524-735).  keep[i] = 1 for the hypotheses the
 // reference pushes back into _pose_hypos.  diag (optional, H x 8): stage that decided (0 kept, 1 scene point inside,
 // 2 hand point colliding, 3 finger cloud colliding, 4 one side not touching, 5 model inside finger), the two single-

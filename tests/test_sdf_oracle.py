@@ -121,3 +121,25 @@ def test_oracle_hand_scene_filters_small(orc):
     moved = xyz + np.float32([0.1, 0, 0])                          # x = -0.05 .. -0.04: outside the swivel pass-through
     _, _, keep2, swivel2 = orc.hand_scene_filters(moved, nrm, np.eye(4, dtype=np.float32))
     assert keep2[:-1].sum() > 200 and swivel2.sum() == 0
+
+
+def test_oracle_handbase_region_and_voxel_normals(orc):
+    """Hand.cpp:685-729 on hand-picked points; pcl::VoxelGrid with normals on two points of one voxel."""
+    I4 = np.eye(4, dtype=np.float32)
+    y1, z1, y2, z2 = -0.04, 0.0, 0.04, 0.0
+    pts = np.array([[-0.03, 0.0, -0.05],    # inside both pass-throughs, between the fingers but |z - z1| = 0.05 > 0.01: kept
+                    [-0.03, 0.0, 0.005],    # between y1 and y2 and |z - z1| <= 0.01: removed
+                    [-0.03, -0.045, 0.004], # 6.4 mm from finger 1's connection: removed
+                    [-0.03, 0.045, -0.02],  # 20.6 mm from finger 2's connection, outside [y1, y2]: kept
+                    [0.05, 0.0, -0.05],     # x above 0.03: removed
+                    [-0.03, 0.0, -0.2]], np.float32)  # z below -0.18: removed
+    nrm = np.tile(np.float32([0, 0, 1]), (len(pts), 1))
+    hx, hn, keep = orc.handbase_region(pts, nrm, I4, y1, z1, y2, z2)
+    assert np.array_equal(hx, pts) and keep.tolist() == [True, False, False, True, False, False]
+    x = np.array([[0.0011, 0.001, 0.5], [0.0039, 0.004, 0.5], [0.02, 0.0, 0.5]], np.float32)
+    n = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    ox, on = orc.voxel_downsample_normals(x, n, 0.005)
+    assert len(ox) == 2
+    np.testing.assert_allclose(ox[0], [0.0025, 0.0025, 0.5], atol=1e-7)
+    np.testing.assert_allclose(on[0], [2 ** -0.5, 2 ** -0.5, 0], atol=1e-6)
+    np.testing.assert_allclose(on[1], [0, 0, 1], atol=1e-7)
