@@ -160,8 +160,8 @@ class Hand {
     return _hand_cloud;
   }
   // hand->_handbase_in_cam.inverse() (PoseEstimator.cpp:554,566): inverse of an affine matrix, adjugate in double
-  void camToHandbase(float out[16]) const {
-    const float* a = _handbase_in_cam.m;
+  void camToHandbase(float out[16]) const { affineInverse(_handbase_in_cam.m, out); }
+  static void affineInverse(const float* a, float out[16]) {
     double m[3][3], inv[3][3];
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) m[i][j] = a[4 * i + j];
@@ -178,6 +178,84 @@ class Hand {
       for (int j = 0; j < 3; ++j) out[4 * i + j] = (float)inv[i][j], t -= inv[i][j] * (double)a[4 * j + 3];
       out[4 * i + 3] = (float)t;
     }
+  }
+
+  // ---- Hand::setCurScene from the clouds of the frame (Hand.cpp:279-334), camera frame in, products to the device
+  // rows of a cloud selected by a byte mask
+  static hop::Cloud selectRows(const std::vector<float>& xyz, const std::vector<float>& nrm, int n, const std::vector<unsigned char>& keep) {
+    hop::Cloud r;
+    for (int i = 0; i < n; ++i) r.n += keep[i] ? 1 : 0;
+    r.xyz.resize(3 * (size_t)r.n), r.nrm.resize(3 * (size_t)r.n);
+    int o = 0;
+    for (int i = 0; i < n; ++i) {
+      if (!keep[i]) continue;
+      for (int k = 0; k < 3; ++k) r.xyz[(size_t)k * r.n + o] = xyz[(size_t)k * n + i], r.nrm[(size_t)k * r.n + o] = nrm[(size_t)k * n + i];
+      ++o;
+    }
+    return r;
+  }
+  // Hand::handbaseICP (Hand.cpp:677-777): scene_organized with its normals, camera frame; corrects _handbase_in_cam
+  void handbaseICP(const hop::Cloud& scene_organized, const hop::Cloud& base_link_cloud) {
+    float cam_in_handbase[16];
+    camToHandbase(cam_in_handbase);
+    std::vector<float> sx(3 * (size_t)scene_organized.n), sn(3 * (size_t)scene_organized.n);
+    int m = 0;
+    hop::check(hop_voxel_downsample_normals(ctx_, scene_organized.xyz.data(), scene_organized.nrm.data(), scene_organized.n, 0.005f, sx.data(), sn.data(),
+                                            scene_organized.n, &m),
+               ctx_, "hop_voxel_downsample_normals");
+    std::vector<float> vx(3 * (size_t)m), vn(3 * (size_t)m);
+    for (int k = 0; k < 3; ++k)
+      for (int i = 0; i < m; ++i) vx[(size_t)k * m + i] = sx[(size_t)k * scene_organized.n + i], vn[(size_t)k * m + i] = sn[(size_t)k * scene_organized.n + i];
+    const Mat4 &t1 = _tf_in_parent["finger_1_1"], &t2 = _tf_in_parent["finger_2_1"];
+    std::vector<float> hx(3 * (size_t)m), hn(3 * (size_t)m);
+    std::vector<unsigned char> keep(m);
+    hop::check(hop_handbase_region(ctx_, vx.data(), vn.data(), m, cam_in_handbase, t1.m[7], t1.m[11], t2.m[7], t2.m[11], hx.data(), hn.data(), keep.data()), ctx_,
+               "hop_handbase_region");
+    const hop::Cloud src = selectRows(hx, hn, m, keep);
+    Mat4 offset = Mat4::Identity();
+    if (src.n > 0) {  // Utils::runICP(scene_handbase, handbase, offset, 50, 30, 0.03, 1e-4), :734
+      hop::check(hop_set_scene(ctx_, src.xyz.data(), src.nrm.data(), nullptr, src.n, 0.f), ctx_, "hop_set_scene");
+      hop::check(hop_set_model(ctx_, HOP_MODEL_5MM, base_link_cloud.xyz.data(), base_link_cloud.nrm.data(), base_link_cloud.n), ctx_, "hop_set_model");
+      const Mat4 I = Mat4::Identity();
+      hop::check(hop_hypos_upload(ctx_, I.m, nullptr, 1), ctx_, "hop_hypos_upload");
+      hop_icp_opts o{50, 30.f, 0.03f, 0, 0};
+      hop::check(hop_icp_refine(ctx_, &o, nullptr, nullptr), ctx_, "hop_icp_refine");
+      Mat4 pose;
+      int got = 0;
+      hop::check(hop_hypos_download(ctx_, pose.m, nullptr, nullptr, 1, &got), ctx_, "hop_hypos_download");
+      affineInverse(pose.m, offset.m);  // offset = refined_pose.inverse(): source -> target
+    }
+    const float translation = std::sqrt(offset.m[3] * offset.m[3] + offset.m[7] * offset.m[7] + offset.m[11] * offset.m[11]);
+    if (translation >= 0.05) offset = Mat4::Identity();  // :740-745
+    const double tr = (double)offset.m[0] + offset.m[5] + offset.m[10];
+    const float rot_diff = (float)(std::acos(std::max(-1.0, std::min(1.0, (tr - 1) / 2.0))) / M_PI * 180.0);
+    // R.eulerAngles(2,1,0)(1) (Eigen Geometry/EulerAngles.h:36-108)
+    const float a0 = std::atan2(offset.m[4], offset.m[0]);
+    const float c2 = std::sqrt(offset.m[10] * offset.m[10] + offset.m[9] * offset.m[9]);
+    float pitch = a0 < 0.f ? std::atan2(-offset.m[8], -c2) : std::atan2(-offset.m[8], c2);
+    pitch = std::min(std::abs(pitch), std::abs(static_cast<float>(M_PI) - pitch));
+    pitch = std::min(std::abs(pitch), std::abs(static_cast<float>(M_PI) + pitch));
+    if (rot_diff >= 10 || std::abs(pitch) >= 10 / 180.0 * M_PI) offset = Mat4::Identity();  // :752-756
+    bool is_identity = true;
+    for (int i = 0; i < 16; ++i) is_identity = is_identity && offset.m[i] == ((i % 5 == 0) ? 1.f : 0.f);
+    if (!is_identity) _component_status["handbase"] = true;
+    Mat4 offset_inv;
+    affineInverse(offset.m, offset_inv.m);
+    _handbase_in_cam = _handbase_in_cam * offset_inv;  // :771
+  }
+  // the filters of Hand::setCurScene (Hand.cpp:289-332) on the 3 mm hand-region cloud (camera frame, with normals)
+  void setCurSceneFromRegion(const hop::Cloud& scene_hand_region) {
+    float cam_in_handbase[16];
+    camToHandbase(cam_in_handbase);
+    const int n = scene_hand_region.n;
+    std::vector<float> hx(3 * (size_t)n), hn(3 * (size_t)n);
+    std::vector<unsigned char> keep(n), swivel(n);
+    hop::check(hop_hand_scene_filters(ctx_, scene_hand_region.xyz.data(), scene_hand_region.nrm.data(), n, cam_in_handbase, hx.data(), hn.data(), keep.data(),
+                                      swivel.data()),
+               ctx_, "hop_hand_scene_filters");
+    hop::Cloud in_handbase;
+    in_handbase.n = n, in_handbase.xyz = hx, in_handbase.nrm = hn;
+    setCurScene(selectRows(hx, hn, n, keep), in_handbase, selectRows(hx, hn, n, swivel));
   }
 
   // HandT42::removeSurroundingPointsAndAssignProbability (Hand.cpp:779-888); dist_thres is the SQUARED near_hand_dist,
