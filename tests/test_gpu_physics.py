@@ -447,3 +447,19 @@ def test_handbase_icp_pieces_and_mirror(ctx, orc, synth, api):
     new2, off2 = h2.handbaseICP(scene_xyz, scene_nrm, far)
     assert np.array_equal(off2, np.eye(4, dtype=np.float32)) and np.allclose(new2, far, atol=1e-6)
     assert not h2._component_status.get("handbase", False)
+
+
+# ------------------------------------------------------------------------------------------------ dataset runner (N4)
+def test_run_real_all_two_shards(hop, tmp_path):
+    """run_real_all.cpp:70-273 / eval_all.py: eight synthetic frames processed as two shards (frame f -> rank f mod 2),
+    predictions written in the reference's layout, ADI recall from the files."""
+    from hop_amd import run_real_all as rr
+    rec = str(tmp_path / "ellipse" / "record0")
+    rr.write_synthetic_dataset(rec, 8, scene_points=1500)
+    done0 = rr.run(rec, rank=0, world=2)
+    assert done0 == [0, 2, 4, 6] and not os.path.exists(os.path.join(rec, "predict", "1"))
+    done1 = rr.run(rec, rank=1, world=2)
+    assert done1 == [1, 3, 5, 7]
+    r = rr.eval_all(rec, hop.synth.ellipsoid_model(4000)[0])
+    assert r["total"] == 8 and r["recall_5mm"] == 1.0 and r["recall_10mm"] == 1.0
+    assert max(r["errs"].values()) < 0.002
