@@ -40,6 +40,7 @@ def test_library_contains_gfx950_code_object(api):
     blob = open(api.LIB_PATH, "rb").read()
     assert b"gfx950" in blob, "no gfx950 code object embedded"
     assert b"k_verify_brute" in blob and b"k_icp_nn" in blob and b"k_lcp_forward" in blob
+    assert b"k_phys_fingers" in blob and b"k_sdf_query" in blob and b"k_sor_mean" in blob
     assert out.returncode == 0
 
 
@@ -47,7 +48,7 @@ def test_struct_layouts_match_header(api, tmp_path):
     """sizeof() of every ABI struct as plain C (gcc) sees include/hop.h == the ctypes mirror."""
     names = {"hop_s4pcs_opts": api.S4pcsOpts, "hop_s4pcs_stats": api.S4pcsStats, "hop_icp_opts": api.IcpOpts,
              "hop_lcp_opts": api.LcpOpts, "hop_finger_args": api.FingerArgs, "hop_pso_settings": api.PsoSettings,
-             "hop_timing": api.Timing}
+             "hop_timing": api.Timing, "hop_physics_args": api.PhysicsArgs, "hop_hand_link": api.HandLink}
     src = tmp_path / "sz.c"
     body = "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in names)
     src.write_text('#include <stdio.h>\n#include "hop.h"\nint main(void) {\n' + body + "  return 0;\n}\n")
