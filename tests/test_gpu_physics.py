@@ -463,3 +463,39 @@ def test_run_real_all_two_shards(hop, tmp_path):
     r = rr.eval_all(rec, hop.synth.ellipsoid_model(4000)[0])
     assert r["total"] == 8 and r["recall_5mm"] == 1.0 and r["recall_10mm"] == 1.0
     assert max(r["errs"].values()) < 0.002
+
+
+# ------------------------------------------------------------------------------------------------ properties at size
+def test_sdf_rigid_invariance_at_size(ctx, synth):
+    """20 480 faces, 200 k queries (beyond what the oracle scans in seconds): a rigid motion of mesh and queries leaves the
+    signed distance unchanged up to the rounding of the motion, and the sphere's analytic distance bounds the result."""
+    V, F = synth.ellipsoid_mesh((0.05, 0.05, 0.05), subdiv=5)
+    assert len(F) == 20480
+    rng = np.random.default_rng(12)
+    P = (rng.normal(size=(200000, 3)) * 0.04).astype(np.float32)
+    ctx.sdf_register_mesh(8, V, F)
+    d0, f0, _, _ = ctx.sdf_signed_distance(8, P)
+    T = synth.se3(synth.random_rotation(rng), [0.2, -0.1, 0.7]).astype(np.float32)
+    ctx.sdf_register_mesh(9, V, F, T)
+    d1, f1, _, _ = ctx.sdf_signed_distance(9, synth.apply(T, P))
+    ok = np.isfinite(d0) & np.isfinite(d1)
+    assert ok.mean() > 0.9999
+    assert np.abs(np.abs(d0[ok]) - np.abs(d1[ok])).max() < 2e-6
+    clear = ok & (np.abs(d0) > 5e-6)
+    assert np.array_equal(np.sign(d0[clear]), np.sign(d1[clear]))
+    exact = np.linalg.norm(P.astype(np.float64), axis=1) - 0.05
+    assert np.abs(d0[ok] - exact[ok]).max() < 7e-5          # faceting error of the 20 480-face sphere (sagitta of a 2.4 mm edge)
+    assert (d0[ok] >= exact[ok] - 1e-6).all()               # the inscribed polyhedron is never farther inside than the sphere
+
+
+def test_reject_by_collision_is_idempotent(ctx, synth):
+    p, poses = synth.physics_case(512, seed=31, n_model=2000, n_scene=6000, mesh_subdiv=3, max_rot_deg=10.0, max_trans=0.006)
+    for mid, V, F, T in p["meshes"]:
+        ctx.sdf_register_mesh(mid, V, F, T)
+    ctx.physics_set_frame(p)
+    ctx.hypos_upload(poses)
+    keep, diag = ctx.reject_by_collision()
+    assert 0 < keep.sum() < len(keep)
+    again, diag2 = ctx.reject_by_collision()
+    assert again.all() and len(again) == keep.sum()
+    assert np.array_equal(diag2[:, 1:], diag[keep][:, 1:], equal_nan=True)
