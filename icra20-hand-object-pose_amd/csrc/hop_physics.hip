@@ -108,6 +108,7 @@ struct TreeBuilder {
   std::vector<SdfNode> nodes;
   std::vector<int> slot_face;  // leaf order
   std::vector<int> leaf_first; // slot range of every leaf (n_leaves + 1 entries)
+  std::vector<float4> leaf_obb; // 3 per leaf (hop_sdf.h)
   int max_depth = 0;
 
   explicit TreeBuilder(const HostMesh& mesh) : m(mesh) {
@@ -147,6 +148,59 @@ struct TreeBuilder {
       mx = v3(std::max(mx.x, h.x), std::max(mx.y, h.y), std::max(mx.z, h.z));
     }
     *blo = mn, *bhi = mx;
+  }
+  // oriented box of a leaf: n = area-weighted mean normal, u = direction of the longest edge made orthogonal to n,
+  // v = n x u rebuilt in float as the kernel does (vcross(u, v) is then the normal axis); extents of the vertices,
+  // widened by the float error of the projections.  No box (w = 0) when the patch has no normal or when the oriented box
+  // is not clearly smaller than the axis-aligned one (flat, axis-aligned patches).
+  void leaf_box(int b, int e, V3 blo, V3 bhi) {
+    float4 o[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    double nx = 0, ny = 0, nz = 0, best_len = -1;
+    V3 edge = v3(1, 0, 0);
+    for (int i = b; i < e; ++i) {
+      const int f = order[i];
+      const V3 P[3] = {m.V[m.F[3 * f]], m.V[m.F[3 * f + 1]], m.V[m.F[3 * f + 2]]};
+      const V3 n = vcross(P[1] - P[0], P[2] - P[0]);
+      nx += n.x, ny += n.y, nz += n.z;
+      for (int c = 0; c < 3; ++c) {
+        const V3 d = P[(c + 1) % 3] - P[c];
+        const double l = (double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z;
+        if (l > best_len) best_len = l, edge = d;
+      }
+    }
+    const double nl = std::sqrt(nx * nx + ny * ny + nz * nz);
+    if (nl > 0 && best_len > 0) {
+      const double n[3] = {nx / nl, ny / nl, nz / nl};
+      double u[3] = {edge.x, edge.y, edge.z};
+      const double un = u[0] * n[0] + u[1] * n[1] + u[2] * n[2];
+      for (int k = 0; k < 3; ++k) u[k] -= un * n[k];
+      const double ul = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+      if (ul > 1e-12) {
+        const V3 uf = v3((float)(u[0] / ul), (float)(u[1] / ul), (float)(u[2] / ul));
+        // v = n x u in double, then float; the kernel's third axis is vcross(uf, vf)
+        const double vd[3] = {n[1] * u[2] / ul - n[2] * u[1] / ul, n[2] * u[0] / ul - n[0] * u[2] / ul, n[0] * u[1] / ul - n[1] * u[0] / ul};
+        const V3 vf = v3((float)vd[0], (float)vd[1], (float)vd[2]);
+        const V3 nf = vcross(uf, vf);
+        float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = b; i < e; ++i)
+          for (int c = 0; c < 3; ++c) {
+            const V3 p = m.V[m.F[3 * order[i] + c]];
+            const float s3[3] = {vdot(uf, p), vdot(vf, p), vdot(nf, p)};
+            for (int a = 0; a < 3; ++a) lo3[a] = std::min(lo3[a], s3[a]), hi3[a] = std::max(hi3[a], s3[a]);
+          }
+        const float pad = 4e-6f * (m.max_abs + 1e-3f);
+        for (int a = 0; a < 3; ++a) lo3[a] -= pad, hi3[a] += pad;
+        const double vol_o = (double)(hi3[0] - lo3[0]) * (hi3[1] - lo3[1]) * (hi3[2] - lo3[2]);
+        const double vol_a = (double)(bhi.x - blo.x + 2 * pad) * (bhi.y - blo.y + 2 * pad) * (bhi.z - blo.z + 2 * pad);
+        if (vol_o < 0.6 * vol_a) {
+          const float half = 0.5f * (hi3[2] - lo3[2]) + pad, centre = 0.5f * (hi3[2] + lo3[2]);
+          o[0] = make_float4(uf.x, uf.y, uf.z, half);
+          o[1] = make_float4(vf.x, vf.y, vf.z, lo3[0]);
+          o[2] = make_float4(hi3[0], lo3[1], hi3[1], centre);
+        }
+      }
+    }
+    leaf_obb.push_back(o[0]), leaf_obb.push_back(o[1]), leaf_obb.push_back(o[2]);
   }
   // builds the node for order[b,e) (e - b > SDF_LEAF or the root) and returns its index
   int build(int b, int e, int depth) {
@@ -189,6 +243,7 @@ struct TreeBuilder {
         nd.child[k] = (int)(SDF_LEAF_BASE + (unsigned)leaf_first.size());
         leaf_first.push_back((int)slot_face.size());
         std::sort(order.begin() + cb, order.begin() + ce);
+        leaf_box(cb, ce, blo, bhi);
         for (int i = cb; i < ce; ++i) slot_face.push_back(order[i]);
       } else {
         nd.child[k] = build(cb, ce, depth + 1);
@@ -261,10 +316,10 @@ struct OrderTree {
 };
 
 struct MeshStore {
-  DevBuf tri_d, nrm_d, nodes_d, order_d, leaf_d, leaf_first_d;
+  DevBuf tri_d, nrm_d, nodes_d, order_d, leaf_d, leaf_first_d, leaf_obb_d;
   SdfMeshDev dev{};
   bool valid = false;
-  void release() { tri_d.release(), nrm_d.release(), nodes_d.release(), order_d.release(), leaf_d.release(), leaf_first_d.release(), valid = false; }
+  void release() { tri_d.release(), nrm_d.release(), nodes_d.release(), order_d.release(), leaf_d.release(), leaf_first_d.release(), leaf_obb_d.release(), valid = false; }
 };
 
 struct Cloud3 {
@@ -892,6 +947,8 @@ int hop_sdf_register_mesh(hop_ctx* c, int mesh_id, const float* V, int nv, const
   PHCHK(c, ms.leaf_d.ensure(std::max<size_t>(sizeof(int) * (size_t)nf, 16)));
   PHCHK(c, ms.leaf_first_d.ensure(sizeof(int) * tb.leaf_first.size()));
   PHCHK(c, hipMemcpyAsync(ms.leaf_first_d.p, tb.leaf_first.data(), sizeof(int) * tb.leaf_first.size(), hipMemcpyHostToDevice, st));
+  PHCHK(c, ms.leaf_obb_d.ensure(std::max<size_t>(sizeof(float4) * tb.leaf_obb.size(), 16)));
+  if (!tb.leaf_obb.empty()) PHCHK(c, hipMemcpyAsync(ms.leaf_obb_d.p, tb.leaf_obb.data(), sizeof(float4) * tb.leaf_obb.size(), hipMemcpyHostToDevice, st));
   if (nf > 0) {
     PHCHK(c, hipMemcpyAsync(ms.tri_d.p, tri.data(), sizeof(float4) * tri.size(), hipMemcpyHostToDevice, st));
     PHCHK(c, hipMemcpyAsync(ms.nrm_d.p, nrm.data(), sizeof(float4) * nrm.size(), hipMemcpyHostToDevice, st));
@@ -901,7 +958,7 @@ int hop_sdf_register_mesh(hop_ctx* c, int mesh_id, const float* V, int nv, const
   }
   PHCHK(c, hipStreamSynchronize(st));
   ms.dev.tri = ms.tri_d.as<float4>(), ms.dev.nrm = ms.nrm_d.as<float4>(), ms.dev.nodes = ms.nodes_d.as<SdfNode>();
-  ms.dev.order = ms.order_d.as<SdfOrderNode>(), ms.dev.face_leaf = ms.leaf_d.as<int>(), ms.dev.leaf_first = ms.leaf_first_d.as<int>();
+  ms.dev.order = ms.order_d.as<SdfOrderNode>(), ms.dev.face_leaf = ms.leaf_d.as<int>(), ms.dev.leaf_first = ms.leaf_first_d.as<int>(), ms.dev.leaf_obb = ms.leaf_obb_d.as<float4>();
   ms.dev.n_faces = nf, ms.dev.n_nodes = (int)tb.nodes.size();
   ms.dev.coord_eps = 4e-7f * hm.max_abs;
   ms.valid = true;

@@ -46,6 +46,8 @@ def main():
     api = importlib.import_module("icra20-hand-object-pose_amd.api")
     if a.counters:
         api.LIB_PATH = a.counting_lib or build_counting_library()
+    elif os.environ.get("HOP_LIB"):
+        api.LIB_PATH = os.environ["HOP_LIB"]  # an alternative build of libhop.so (experiments)
     p, poses = synth.physics_case(a.hyps, seed=21, n_model=5000, n_scene=20000, mesh_subdiv=4, spacing=0.003, max_rot_deg=8.0, max_trans=0.004)
     c = api.Context(0)
     for mid, V, F, T in p["meshes"]:
