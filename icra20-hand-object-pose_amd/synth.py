@@ -481,7 +481,7 @@ FINGER_ORDER = ("finger_1_1", "finger_1_2", "finger_2_1", "finger_2_2")
 
 
 def physics_case(n_hyp: int = 64, seed: int = 3, n_model: int = 400, n_scene: int = 3000, mesh_subdiv: int = 2,
-                 finger_status=(1, 1, 1, 1), spacing=0.005, max_rot_deg=25.0, max_trans=0.02):
+                 finger_status=(1, 1, 1, 1), spacing=0.005, max_rot_deg=25.0, max_trans=0.02, finger_angles=None):
     """Inputs of PoseEstimator::rejectByCollisionOrNonTouching (PoseEstimator.cpp:524-735) for a synthetic grasp.
 
     The ellipsoid sits between the two fingers of the stand-in hand (its 40 mm semi-axis across the 68 mm gap, so the
@@ -492,6 +492,7 @@ def physics_case(n_hyp: int = 64, seed: int = 3, n_model: int = 400, n_scene: in
     rng = np.random.Generator(np.random.PCG64(seed))
     hand = t42_hand(spacing)
     angles = {"finger_1_1": 0.0, "finger_1_2": 0.0, "finger_2_1": 0.0, "finger_2_2": 0.0}
+    angles.update(finger_angles or {})
     Rc = rot_from_axis_angle([1.0, 0.2, -0.1], 2.6)
     handbase_in_cam = se3(Rc, [0.03, -0.02, 0.55])
     R_obj = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], dtype=np.float64)  # model x (40 mm) -> hand y

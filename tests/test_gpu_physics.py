@@ -174,6 +174,17 @@ def test_reject_by_collision_collision_stages(ctx, orc, synth):
     assert {2, 3} & set(diag_o[:, 0].astype(int))
 
 
+def test_reject_by_collision_tilted_fingers(ctx, orc, synth):
+    """Finger links at non-zero joint angles: their meshes and clouds are no longer axis aligned in the hand-base frame
+    (oriented leaf boxes and general rigid motions on every path)."""
+    import math
+    ang = {"finger_1_1": math.radians(14), "finger_1_2": math.radians(9), "finger_2_1": math.radians(-11), "finger_2_2": math.radians(17)}
+    p, poses = synth.physics_case(96, seed=17, finger_angles=ang, mesh_subdiv=3, n_model=800)
+    keep, diag, keep_o, diag_o, _ = _run_case(ctx, orc, synth, p, poses)
+    _check_against_oracle(keep, diag, keep_o, diag_o)
+    assert 0 < keep.sum() < len(keep)
+
+
 def test_reject_by_collision_dense_mesh_and_clouds(ctx, orc, synth):
     p, poses = synth.physics_case(24, seed=13, n_model=1500, n_scene=8000, mesh_subdiv=3, spacing=0.003)
     keep, diag, keep_o, diag_o, _ = _run_case(ctx, orc, synth, p, poses)
