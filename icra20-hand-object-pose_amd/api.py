@@ -779,7 +779,9 @@ class HandT42:
 
     def handbaseICP(self, scene_xyz_cam, scene_nrm_cam, handbase_in_cam):
         """Hand::handbaseICP (Hand.cpp:677-777): corrects handbase_in_cam by a point-to-plane ICP of the scene around the
-        palm against the base_link cloud.  Returns (new handbase_in_cam, cam2handbase_offset)."""
+        palm against the base_link cloud.  Returns (new handbase_in_cam, cam2handbase_offset).  Uses the context's scene,
+        5 mm model and hypothesis slots for the ICP (Utils::runICP is the function refineByICP calls): run it before the
+        PoseEstimator of the frame is set up, as main_realdata_auto.cpp does (:99 vs :183)."""
         c = self.ctx
         handbase_in_cam = np.asarray(handbase_in_cam, np.float32)
         cam_in_handbase = np.linalg.inv(handbase_in_cam.astype(np.float64)).astype(np.float32)

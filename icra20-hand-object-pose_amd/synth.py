@@ -538,3 +538,62 @@ def physics_case(n_hyp: int = 64, seed: int = 3, n_model: int = 400, n_scene: in
     )
     p["meshes"] = [(0, V, F, None)] + [(1 + k, p["finger_V"][k], p["finger_F"][k], f2h[k]) for k in range(4)]
     return p, poses
+
+
+# --------------------------------------------------------------------------- a whole frame: hand + grasped object, one camera
+def _look_at(eye, target, up=(0.0, 1.0, 0.0)):
+    """Camera pose (camera -> world) with +z towards the target, +x right, +y down (OpenCV convention)."""
+    eye, target = np.asarray(eye, np.float64), np.asarray(target, np.float64)
+    z = target - eye
+    z /= np.linalg.norm(z)
+    x = np.cross(z, np.asarray(up, np.float64))
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    T = np.eye(4)
+    T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3] = x, y, z, eye
+    return T
+
+
+def grasp_frame(seed: int = 2, n_object: int = 9000, hand_spacing=0.0013, noise=0.0003):
+    """One synthetic frame of the whole pipeline (main_realdata_auto.cpp:54-205): the stand-in hand at given finger
+    angles holding the ellipsoid, seen by one camera.  Returns a dict with the dense scene in the camera frame (points and
+    normals towards the camera, as the integral-image estimator leaves them), the true hand-base pose and a perturbed
+    one (what the robot reports), the object's true pose, the hand model with its angles, and the meshes."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    hand = t42_hand()
+    angles = {"finger_1_1": math.radians(4), "finger_1_2": math.radians(3), "finger_2_1": math.radians(5), "finger_2_2": math.radians(2)}
+    cam_in_handbase = _look_at([-0.34, 0.22, 0.30], [-0.09, 0.0, 0.0], up=(0.0, 0.0, -1.0))  # oblique: top and two sides of every link
+    handbase_in_cam = np.linalg.inv(cam_in_handbase)
+    eye = cam_in_handbase[:3, 3]
+    R_obj = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], dtype=np.float64)  # model x (40 mm) across the fingers
+    obj_in_hand = se3(R_obj, [-0.150, 0.0, 0.0])
+    pts, nrm, is_obj = [], [], []
+    dense = t42_hand(spacing=hand_spacing)
+    for name in dense.clouds:
+        Tl = np.eye(4) if name == "base_link" else hand_fk(hand, angles, name)
+        x, n = apply(Tl, dense.clouds[name][0]).astype(np.float64), rotate(Tl, dense.clouds[name][1]).astype(np.float64)
+        view = x - eye
+        view /= np.linalg.norm(view, axis=1, keepdims=True)
+        vis = np.einsum("ij,ij->i", n, view) < -0.15
+        pts.append(x[vis]), nrm.append(n[vis]), is_obj.append(np.zeros(int(vis.sum()), bool))
+    ox, on = ellipsoid_model(int(n_object * 2.6))
+    x, n = apply(obj_in_hand, ox).astype(np.float64), rotate(obj_in_hand, on).astype(np.float64)
+    view = x - eye
+    view /= np.linalg.norm(view, axis=1, keepdims=True)
+    vis = np.einsum("ij,ij->i", n, view) < -0.1
+    # the fingers hide what lies behind them from this camera: drop object points inside a finger box footprint
+    for name in FINGER_NAMES:
+        Tl = np.linalg.inv(hand_fk(hand, angles, name))
+        loc = x @ Tl[:3, :3].T + Tl[:3, 3]
+        lo, hi = hand.clouds[name][0].min(0) - 0.001, hand.clouds[name][0].max(0) + 0.001
+        vis &= ~((loc >= lo) & (loc <= hi)).all(axis=1)
+    pts.append(x[vis][:n_object]), nrm.append(n[vis][:n_object]), is_obj.append(np.ones(min(int(vis.sum()), n_object), bool))
+    pts, nrm, is_obj = np.concatenate(pts), np.concatenate(nrm), np.concatenate(is_obj)
+    pts = pts + rng.normal(scale=noise, size=pts.shape)
+    order = rng.permutation(len(pts))
+    pts, nrm, is_obj = pts[order], nrm[order], is_obj[order]
+    D = se3(rot_from_axis_angle([0.3, 1.0, 0.2], math.radians(2.0)), [0.003, -0.002, 0.002])
+    V, F = ellipsoid_mesh(subdiv=3)
+    return dict(scene_xyz=apply(handbase_in_cam, pts.astype(np.float32)), scene_nrm=rotate(handbase_in_cam, nrm.astype(np.float32)), is_object=is_obj,
+                handbase_in_cam=handbase_in_cam.astype(np.float32), handbase_in_cam_reported=(handbase_in_cam @ D).astype(np.float32),
+                object_in_cam=(handbase_in_cam @ obj_in_hand).astype(np.float32), hand=hand, angles=angles, object_V=V, object_F=F)

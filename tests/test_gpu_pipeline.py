@@ -1,0 +1,82 @@
+"""The whole driver above the C-ABI on one synthetic frame (hand + grasped object, one camera), in the call order of
+src/perception/src/app/main_realdata_auto.cpp:54-205 minus the two PCL normal estimators (the frame comes with normals)
+and rejectByRender: handbaseICP -> Hand::setCurScene filters -> finger PSO -> hand-point removal with confidences ->
+generator input cloud -> runSuper4pcs -> clusterPoses -> refineByICP -> clusterPoses -> rejectByCollisionOrNonTouching ->
+selectBest.  Every step runs through libhop.so; the result is judged against the frame's ground truth."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_whole_frame_pipeline(hop):
+    from hop_amd import api, config as hop_config
+    from hop_amd import run_real_all as rr
+    synth = hop.synth
+    cfg = hop_config.load_config(os.path.join(ROOT, "icra20-hand-object-pose_amd", "config", "config_autodataset.yaml"))
+    g = synth.grasp_frame(seed=2)
+    hand = g["hand"]
+    mx5, mn5 = synth.ellipsoid_model_spacing(0.005)
+    mx1, mn1 = synth.ellipsoid_model(4000)
+    ctx = api.Context(0)
+    h = api.HandT42(cfg, hand, ctx=ctx)
+    ext = np.abs(mx1.min(axis=0) - mx1.max(axis=0))
+    h.gripper_min_dist = 0.8 * float(ext.min())                                      # main :41-45
+    scene_xyz, scene_nrm = g["scene_xyz"], g["scene_nrm"]
+
+    # Hand::setCurScene: handbaseICP corrects the reported hand-base pose (Hand.cpp:287, 677-777)
+    handbase_in_cam, offset = h.handbaseICP(scene_xyz, scene_nrm, g["handbase_in_cam_reported"])
+    err_t = np.linalg.norm(handbase_in_cam[:3, 3] - g["handbase_in_cam"][:3, 3])
+    assert err_t < 2.5e-3 and h._component_status["handbase"]
+
+    # the hand region: crop in the hand-base frame (main :79-94), 3 mm voxel grid (Hand.cpp:285), filters (Hand.cpp:289-321)
+    cam_in_handbase = np.linalg.inv(handbase_in_cam.astype(np.float64))
+    hb = scene_xyz.astype(np.float64) @ cam_in_handbase[:3, :3].T + cam_in_handbase[:3, 3]
+    crop = (hb[:, 2] >= -0.12) & (hb[:, 2] <= 0.05) & (hb[:, 0] >= -0.25) & (hb[:, 0] <= -0.07) & (hb[:, 1] >= -0.2) & (hb[:, 1] <= 0.2)
+    rx, rn = ctx.voxel_downsample_normals(scene_xyz[crop], scene_nrm[crop], 0.003)
+    n_noise, n_region, n_swivel = h.setCurSceneFromRegion(rx, rn, handbase_in_cam)
+    assert n_noise > 0.8 * n_region and n_swivel > 100
+
+    # finger states (main :114-139, camera on the finger-2 side: cam_in_handbase(1,3) > 0)
+    hm = cfg["hand_match"]
+    assert cam_in_handbase[1, 3] > 0
+    angles = {}
+    for first, second in (("finger_2_1", "finger_2_2"), ("finger_1_1", "finger_1_2")):
+        if h.matchOneComponentPSO(first, 0, 120, False, hm["finger1_dist_thres"], hm["finger1_normal_angle"], hm["finger1_min_match"]):
+            angles[first] = h.last_angle
+            if h.matchOneComponentPSO(second, 0, 90, True, hm["finger2_dist_thres"], hm["finger2_normal_angle"], hm["finger2_min_match"]):
+                angles[second] = h.last_angle
+    assert len(angles) == 4, angles
+    for name, a in angles.items():
+        assert abs(a - g["angles"][name]) < math.radians(4), (name, math.degrees(a))
+
+    # hand points removed, confidences assigned (main :142-151); generator input (main :156-177)
+    h.makeHandCloud()
+    near = float(cfg["near_hand_dist"]) if "near_hand_dist" in cfg else 0.003
+    ox, on, oc, idx = h.removeSurroundingPointsAndAssignProbability(scene_xyz, scene_nrm, handbase_in_cam, near * near)
+    kept_obj = g["is_object"][idx].mean()
+    assert kept_obj > 0.9 and len(ox) < len(scene_xyz)           # what remains is mostly the object
+    sx, sn, sc = ctx.object_segment(ox, on, oc, 0.003)
+    assert len(sx) > 300
+
+    # pose estimation (main :183-204); as there, the estimator is constructed after the hand steps (handbaseICP used the
+    # context's scene / model slots for its own ICP)
+    est = api.PoseEstimator(cfg, (mx5, mn5), (mx1, mn1), ctx=ctx)
+    est.setCurScene(sx, sn, sc, cloud_withouthand_raw=ox)
+    est.registerHandMesh(h)
+    est.registerMesh(g["object_V"], g["object_F"], "object")
+    assert est.runSuper4pcs(synth.ppf_key_table())
+    est.clusterPoses(30, 0.015, True)
+    est.refineByICP()
+    est.clusterPoses(5, 0.003, False)
+    n_before = ctx.hypos_count()
+    keep, diag = est.rejectByCollisionOrNonTouching(h, handbase_in_cam)
+    assert 0 < keep.sum() <= n_before
+    best = est.selectBest()
+    gt = g["object_in_cam"].astype(np.float64)
+    e = rr.adi(best._pose[:3, :3].astype(np.float64), best._pose[:3, 3].astype(np.float64), gt[:3, :3], gt[:3, 3], mx1.astype(np.float64))
+    assert e < 0.005, e   # the authors' recall threshold (scripts/eval_all.py:77)
