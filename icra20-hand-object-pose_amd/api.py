@@ -142,6 +142,7 @@ SIGNATURES = {
     "hop_pso_default_settings": (None, [C.POINTER(PsoSettings)]),
     "hop_hand_pso_search": (C.c_int, [_vp, C.POINTER(PsoSettings), dp, dp]),
     "hop_sdf_register_mesh": (C.c_int, [_vp, C.c_int, fp, C.c_int, ip, C.c_int, fp]),
+    "hop_sdf_set_mesh_pose": (C.c_int, [_vp, C.c_int, fp]),
     "hop_sdf_signed_distance": (C.c_int, [_vp, C.c_int, fp, C.c_int, fp, ip, fp, fp]),
     "hop_voxel_downsample": (C.c_int, [_vp, fp, C.c_int, C.c_float, fp, C.c_int, ip]),
     "hop_scene_from_depth": (C.c_int, [_vp, C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_double, fp, fp, fp, C.c_float, fp, fp, fp, C.c_int, ip, ip]),
@@ -322,6 +323,10 @@ class Context:
         T = None if pose is None else np.ascontiguousarray(pose, np.float32).reshape(16)
         self._chk(self.L.hop_sdf_register_mesh(self.h, mesh_id, F(V), len(V), I(Fi), len(Fi), F(T) if T is not None else None),
                   "hop_sdf_register_mesh")
+
+    def sdf_set_mesh_pose(self, mesh_id, pose=None):
+        T = None if pose is None else np.ascontiguousarray(pose, np.float32).reshape(16)
+        self._chk(self.L.hop_sdf_set_mesh_pose(self.h, mesh_id, F(T) if T is not None else None), "hop_sdf_set_mesh_pose")
 
     def sdf_signed_distance(self, mesh_id, pts):
         """SDFchecker::getSignedDistanceMinMaxWithRegistered: (dists, faces, min_dist, max_dist)."""

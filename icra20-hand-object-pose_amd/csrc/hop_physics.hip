@@ -22,6 +22,7 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <utility>
@@ -316,10 +317,10 @@ struct OrderTree {
 };
 
 struct MeshStore {
-  DevBuf tri_d, nrm_d, nodes_d, order_d, leaf_d, leaf_first_d, leaf_obb_d;
+  DevBuf tri_d, nrm_d, nodes_d, order_d, leaf_d, leaf_first_d, leaf_obb_d, cell_start_d, cell_faces_d;
   SdfMeshDev dev{};
   bool valid = false;
-  void release() { tri_d.release(), nrm_d.release(), nodes_d.release(), order_d.release(), leaf_d.release(), leaf_first_d.release(), leaf_obb_d.release(), valid = false; }
+  void release() { tri_d.release(), nrm_d.release(), nodes_d.release(), order_d.release(), leaf_d.release(), leaf_first_d.release(), leaf_obb_d.release(), cell_start_d.release(), cell_faces_d.release(), valid = false; }
 };
 
 struct Cloud3 {
@@ -349,6 +350,8 @@ struct Physics : HopExt {
   bool have_frame = false;
   hipEvent_t ev[2] = {nullptr, nullptr};
   double ms_frame = 0, ms_reject = 0;
+  long long last_cells_total = 0;
+  int last_cells_voxels = 0;
   ~Physics() override {
     for (auto& m : mesh) m.release();
     DevBuf* bufs[] = {&fingers.buf, &cwh_ds.buf, &hand.buf, &model.buf, &tmp_cloud.buf, &tmp_cloud2.buf, &tmp_nrm.buf, &tmp_nrm2.buf, &keys, &keys_alt, &vals, &vals_alt, &flags, &pos,
@@ -806,6 +809,146 @@ __global__ void k_handbase_region(const float* __restrict__ ix, const float* __r
   keep[i] = k;
 }
 
+// ---- face cells: for every voxel of a grid around a mesh, the faces that can be closest for a query inside it
+// One wavefront per voxel (centre c, half diagonal r of the voxel grown by the rounding of the voxel index):
+//   1. d0 = distance from c to the mesh (all faces, the float expression the queries use);
+//   2. band: a face can be closest for some x of the voxel only if dist(c, f) <= d0 + 2 r  (distance to a set is
+//      1-Lipschitz: dist(x, f) >= dist(c, f) - r and dist(x, mesh) <= d0 + r);
+//   3. a band face f is dropped when one of the FC_PIVOTS band faces nearest to c, f', is closer over the whole voxel:
+//      dist(x, f') <= |x - y'| with y' the point of f' closest to c, and dist(x, f) >= n . (x - c_f) with c_f the point
+//      of f closest to c and n = (c - c_f) / |c - c_f| (f is convex: the plane through c_f normal to n supports it).
+//      |x - y'| - n . (x - c_f) is convex in x, so its maximum over the voxel is at a corner: eight evaluations; f goes
+//      when the maximum is below -FC_MARGIN (a strict margin above the float error of every distance involved: a dropped
+//      face can neither win nor tie).
+// Survivors are written in ascending slot order.  A voxel whose band exceeds FC_CAND gets no list (tree walk instead).
+constexpr int FC_CAND = 768, FC_PIVOTS = 8;
+constexpr float FC_MARGIN = 2e-6f;
+struct FaceGrid {
+  float ox, oy, oz, s;
+  int nx, ny, nz;
+};
+template <bool WRITE>
+__global__ void __launch_bounds__(64) k_face_cells(SdfMeshDev m, FaceGrid g, float margin, int* __restrict__ count, const int* __restrict__ start,
+                                                   int* __restrict__ faces) {
+  __shared__ int c_slot[FC_CAND];
+  __shared__ float c_d[FC_CAND];
+  __shared__ float c_x[FC_CAND], c_y[FC_CAND], c_z[FC_CAND];
+  __shared__ int n_cand;
+  __shared__ int piv[FC_PIVOTS];
+  const int v = blockIdx.x, lane = threadIdx.x;
+  const int ix = v % g.nx, iy = (v / g.nx) % g.ny, iz = v / (g.nx * g.ny);
+  const V3 c = v3(g.ox + (ix + 0.5f) * g.s, g.oy + (iy + 0.5f) * g.s, g.oz + (iz + 0.5f) * g.s);
+  const float h = 0.5f * g.s + margin;  // half edge, grown: the voxel index of a query is computed in float
+  const float r = 1.7320508f * h;
+  // 1. distance of the centre
+  float dmin = __builtin_inff();
+  for (int s = lane; s < m.n_faces; s += 64) {
+    const float4 A4 = m.tri[3 * s], B4 = m.tri[3 * s + 1], C4 = m.tri[3 * s + 2];
+    const V3 p = sdf_closest_point(c, v3(A4.x, A4.y, A4.z), v3(B4.x, B4.y, B4.z), v3(C4.x, C4.y, C4.z));
+    dmin = fminf(dmin, vsqn(c - p));
+  }
+  for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o));
+  const float d0 = sqrtf(dmin);
+  const float band = d0 + 2.f * r + margin;
+  const float band2 = band * band * 1.00001f;
+  // 2. the band, in slot order
+  if (lane == 0) n_cand = 0;
+  __syncthreads();
+  bool overflow = false;
+  for (int base = 0; base < m.n_faces; base += 64) {
+    const int s = base + lane;
+    bool in = false;
+    V3 p = v3(0, 0, 0);
+    float d2 = 0;
+    if (s < m.n_faces) {
+      const float4 A4 = m.tri[3 * s], B4 = m.tri[3 * s + 1], C4 = m.tri[3 * s + 2];
+      p = sdf_closest_point(c, v3(A4.x, A4.y, A4.z), v3(B4.x, B4.y, B4.z), v3(C4.x, C4.y, C4.z));
+      d2 = vsqn(c - p);
+      in = d2 <= band2;
+    }
+    const unsigned long long mask = __ballot(in);
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    const int at = n_cand + before;
+    if (in && at < FC_CAND) c_slot[at] = s, c_d[at] = sqrtf(d2), c_x[at] = p.x, c_y[at] = p.y, c_z[at] = p.z;
+    __syncthreads();
+    if (lane == 0) n_cand += __popcll(mask);
+    __syncthreads();
+    if (n_cand > FC_CAND) {
+      overflow = true;
+      break;
+    }
+  }
+  if (overflow) {
+    if (!WRITE && lane == 0) count[v] = -1;
+    return;
+  }
+  const int n = n_cand;
+  // 3a. the FC_PIVOTS band faces nearest to the centre (ties: lowest position)
+  for (int k = 0; k < FC_PIVOTS; ++k) {
+    unsigned long long best = ~0ull;
+    for (int i = lane; i < n; i += 64) {
+      bool taken = false;
+      for (int j = 0; j < k; ++j) taken = taken || piv[j] == i;
+      if (taken) continue;
+      const unsigned long long key = ((unsigned long long)__float_as_uint(c_d[i]) << 32) | (unsigned)i;
+      best = key < best ? key : best;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long t = __shfl_xor(best, o);
+      best = t < best ? t : best;
+    }
+    if (lane == 0) piv[k] = best == ~0ull ? -1 : (int)(best & 0xffffffffu);
+    __syncthreads();
+  }
+  // 3b. domination
+  int kept_before = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    bool keep = false;
+    if (i < n) {
+      keep = true;
+      const V3 cf = v3(c_x[i], c_y[i], c_z[i]);
+      const float di = c_d[i];
+      if (di > 0.f) {
+        const V3 nf = (c - cf) / di;
+        for (int k = 0; k < FC_PIVOTS && keep; ++k) {
+          const int j = piv[k];
+          if (j < 0 || j == i) continue;
+          if (!(c_d[j] < di)) continue;  // only a face that is nearer at the centre can win everywhere
+          const V3 y = v3(c_x[j], c_y[j], c_z[j]);
+          float worst = -__builtin_inff();
+#pragma unroll
+          for (int corner = 0; corner < 8; ++corner) {
+            const V3 x = v3(c.x + ((corner & 1) ? h : -h), c.y + ((corner & 2) ? h : -h), c.z + ((corner & 4) ? h : -h));
+            worst = fmaxf(worst, vnorm(x - y) - vdot(nf, x - cf));
+          }
+          if (worst < -FC_MARGIN - margin) keep = false;
+        }
+      }
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (WRITE) {
+      if (keep) faces[start[v] + kept_before + __popcll(mask & ((1ull << lane) - 1ull))] = c_slot[i];
+    }
+    kept_before += __popcll(mask);
+  }
+  if (!WRITE && lane == 0) count[v] = kept_before;
+}
+// turns the counts (-1: no list) into cell_start: exclusive scan of max(count, 0), complemented where there is no list
+__global__ void k_face_cells_pack(const int* __restrict__ count, const unsigned* __restrict__ scan, int nvox, int* __restrict__ cell_start) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > nvox) return;
+  if (v == nvox) {
+    cell_start[v] = (int)scan[v];
+    return;
+  }
+  cell_start[v] = count[v] < 0 ? ~(int)scan[v] : (int)scan[v];
+}
+__global__ void k_face_cells_clamp(const int* __restrict__ count, int nvox, unsigned* __restrict__ pos) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v <= nvox) pos[v] = (v < nvox && count[v] > 0) ? (unsigned)count[v] : 0u;
+}
+
 // ------------------------------------------------------------------------------------------------ host helpers
 int upload_planes(hop_ctx* c, Cloud3& dst, const float* planes, int n) {
   hipStream_t st = hop_ctx_stream(c);
@@ -961,7 +1104,68 @@ int hop_sdf_register_mesh(hop_ctx* c, int mesh_id, const float* V, int nv, const
   ms.dev.order = ms.order_d.as<SdfOrderNode>(), ms.dev.face_leaf = ms.leaf_d.as<int>(), ms.dev.leaf_first = ms.leaf_first_d.as<int>(), ms.dev.leaf_obb = ms.leaf_obb_d.as<float4>();
   ms.dev.n_faces = nf, ms.dev.n_nodes = (int)tb.nodes.size();
   ms.dev.coord_eps = 4e-7f * hm.max_abs;
+  ms.dev.cell_start = nullptr, ms.dev.cell_faces = nullptr;
+  ms.dev.has_pose = 0;
   ms.valid = true;
+  // face cells for meshes that are worth it (measured: no gain on the finger links' ~100-face hulls, which are also
+  // re-registered every frame); HOP_SDF_CELLS=0 turns them off
+  const char* env = getenv("HOP_SDF_CELLS");
+  if (nf >= 256 && nf <= 65536 && !(env && env[0] == '0')) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (const V3& p : hm.V) {
+      lo[0] = std::min(lo[0], p.x), lo[1] = std::min(lo[1], p.y), lo[2] = std::min(lo[2], p.z);
+      hi[0] = std::max(hi[0], p.x), hi[1] = std::max(hi[1], p.y), hi[2] = std::max(hi[2], p.z);
+    }
+    const float pad = 0.06f;  // queries farther than this from the mesh's box use the tree
+    const float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2])) + 2 * pad;
+    FaceGrid g;
+    g.s = std::max(0.0025f, ext / 96.f);  // measured on the bench case: 1.25 / 1.5 / 2.5 / 4 mm -> 8.0 / 8.2 / 7.4 / 9.6 ms
+    g.ox = lo[0] - pad, g.oy = lo[1] - pad, g.oz = lo[2] - pad;
+    g.nx = (int)std::ceil((hi[0] - lo[0] + 2 * pad) / g.s), g.ny = (int)std::ceil((hi[1] - lo[1] + 2 * pad) / g.s), g.nz = (int)std::ceil((hi[2] - lo[2] + 2 * pad) / g.s);
+    const int nvox = g.nx * g.ny * g.nz;
+    const float margin = 4e-6f * (hm.max_abs + pad + 1e-3f);
+    PHCHK(c, ph->keys.ensure(sizeof(int) * ((size_t)nvox + 1)));
+    PHCHK(c, ph->pos.ensure(sizeof(unsigned) * ((size_t)nvox + 1)));
+    PHCHK(c, ph->starts.ensure(sizeof(unsigned) * ((size_t)nvox + 1)));
+    PHCHK(c, ms.cell_start_d.ensure(sizeof(int) * ((size_t)nvox + 1)));
+    int* count = ph->keys.as<int>();
+    k_face_cells<false><<<nvox, 64, 0, st>>>(ms.dev, g, margin, count, nullptr, nullptr);
+    k_face_cells_clamp<<<(nvox + 256) / 256, 256, 0, st>>>(count, nvox, ph->pos.as<unsigned>());
+    size_t tmp = 0;
+    PHCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, ph->pos.as<unsigned>(), ph->starts.as<unsigned>(), nvox + 1, st));
+    PHCHK(c, ph->sort_tmp.ensure(tmp + 16));
+    PHCHK(c, hipcub::DeviceScan::ExclusiveSum(ph->sort_tmp.p, tmp, ph->pos.as<unsigned>(), ph->starts.as<unsigned>(), nvox + 1, st));
+    k_face_cells_pack<<<(nvox + 256) / 256, 256, 0, st>>>(count, ph->starts.as<unsigned>(), nvox, ms.cell_start_d.as<int>());
+    unsigned total = 0;
+    PHCHK(c, hipMemcpyAsync(&total, ph->starts.as<unsigned>() + nvox, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    PHCHK(c, hipStreamSynchronize(st));
+    PHCHK(c, ms.cell_faces_d.ensure(sizeof(int) * std::max<size_t>(total, 4)));
+    k_face_cells<true><<<nvox, 64, 0, st>>>(ms.dev, g, margin, nullptr, reinterpret_cast<const int*>(ph->starts.as<unsigned>()), ms.cell_faces_d.as<int>());
+    PHCHK(c, hipGetLastError());
+    PHCHK(c, hipStreamSynchronize(st));
+    ms.dev.cell_start = ms.cell_start_d.as<int>(), ms.dev.cell_faces = ms.cell_faces_d.as<int>();
+    ms.dev.cell_ox = g.ox, ms.dev.cell_oy = g.oy, ms.dev.cell_oz = g.oz, ms.dev.cell_inv = 1.0f / g.s;
+    ms.dev.cell_nx = g.nx, ms.dev.cell_ny = g.ny, ms.dev.cell_nz = g.nz;
+    ph->last_cells_total = (long long)total, ph->last_cells_voxels = nvox;
+  }
+  return HOP_OK;
+}
+
+int hop_sdf_set_mesh_pose(hop_ctx* c, int mesh_id, const float* pose16) {
+  if (!c || mesh_id < 0 || mesh_id >= MAX_MESHES) return HOP_E_INVALID;
+  Physics* ph = physics(c);
+  MeshStore& ms = ph->mesh[mesh_id];
+  if (!ms.valid) return HOP_E_STATE;
+  PHCHK(c, hipStreamSynchronize(hop_ctx_stream(c)));  // kernels in flight carry the old pose by value; nothing to wait for on the device, kept for symmetry with register
+  if (!pose16) {
+    ms.dev.has_pose = 0;
+    return HOP_OK;
+  }
+  M4 T;
+  for (int i = 0; i < 16; ++i) T.m[i] = pose16[i];
+  const M4 inv = m4_inverse_affine(T);
+  for (int i = 0; i < 12; ++i) ms.dev.pose_inv[i] = inv.m[i];
+  ms.dev.has_pose = 1;
   return HOP_OK;
 }
 

@@ -59,6 +59,17 @@ struct SdfMeshDev {
   const float4* leaf_obb;  // n_leaves x 3: an oriented box around the leaf's faces (see sdf_walk_step), w of the first = 0: none
   int n_faces, n_nodes;
   float coord_eps;  // 4e-7 * largest |coordinate| of the mesh: float error scale of a closest point
+  // face cells (meshes of 256 .. 65536 faces): a voxel grid around the mesh; cell_start[v] .. cell_start[v + 1] index
+  // cell_faces, the slots of every face that can be the closest one (or tie for it) for some query inside voxel v.
+  // cell_start[v] < 0 marks a voxel whose list was not built (too many candidates): the tree walk answers there.
+  const int* cell_start;
+  const int* cell_faces;
+  float cell_ox, cell_oy, cell_oz, cell_inv;
+  int cell_nx, cell_ny, cell_nz;
+  // SDFchecker::transformMesh without touching the vertices: queries are moved by the inverse of the mesh's current pose
+  // (hop_sdf_set_mesh_pose), so a mesh that only moves rigidly keeps its tree and its face cells
+  int has_pose;
+  float pose_inv[12];
 };
 
 #if defined(__HIPCC__)
@@ -317,10 +328,37 @@ __device__ inline float sdf_walk_finish(const SdfWalk& w, const SdfMeshDev& m, i
   if (face_out) *face_out = h.face;
   return sdf_sign(m, h.slot, w.q, h.c) * sqrtf(h.sqr_d);
 }
+// the same answer from the face cells when the query lies in a voxel with a list: every face that can attain the minimum
+// for a query of that voxel is in the list (see k_face_cells in hop_physics.hip), so the scan below is the exhaustive scan
+// restricted to the faces that matter, with the same tie rule
+__device__ inline bool sdf_cells_closest(SdfWalk& w, const SdfMeshDev& m) {
+  if (m.cell_start == nullptr) return false;
+  const float fx = (w.q.x - m.cell_ox) * m.cell_inv, fy = (w.q.y - m.cell_oy) * m.cell_inv, fz = (w.q.z - m.cell_oz) * m.cell_inv;
+  if (!(fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)m.cell_nx && fy < (float)m.cell_ny && fz < (float)m.cell_nz)) return false;
+  const int v = ((int)fz * m.cell_ny + (int)fy) * m.cell_nx + (int)fx;
+  const int b = m.cell_start[v];
+  if (b < 0) return false;
+  const int e = m.cell_start[v + 1] < 0 ? ~m.cell_start[v + 1] : m.cell_start[v + 1];
+  for (int i = b; i < e; ++i) {
+    const int s = m.cell_faces[i];
+    const float4 A4 = m.tri[3 * s], B4 = m.tri[3 * s + 1], C4 = m.tri[3 * s + 2];
+    const V3 c = sdf_closest_point(w.q, v3(A4.x, A4.y, A4.z), v3(B4.x, B4.y, B4.z), v3(C4.x, C4.y, C4.z));
+    const float d = vsqn(w.q - c);
+    const int face = __float_as_int(B4.w);
+#ifdef SDF_COUNT
+    atomicAdd(&g_sdf_cnt[1], 1ull);
+    if (d == w.h.sqr_d) atomicAdd(&g_sdf_cnt[2], 1ull);
+#endif
+    if (d < w.h.sqr_d || (d == w.h.sqr_d && sdf_precedes(m, w.q, face, w.h.face))) w.h.sqr_d = d, w.h.slot = s, w.h.face = face, w.h.c = c;
+  }
+  return true;
+}
 __device__ inline float sdf_signed_distance(const SdfMeshDev& m, V3 q, unsigned* stack, int stride, int* face_out) {
+  if (m.has_pose) q = m4_point(m.pose_inv, q);
   SdfWalk w;
   sdf_walk_begin(w, m, q, stack, stride);
-  while (w.sp > 0) sdf_walk_step(w, m, stack, stride);
+  if (!sdf_cells_closest(w, m))
+    while (w.sp > 0) sdf_walk_step(w, m, stack, stride);
   return sdf_walk_finish(w, m, face_out);
 }
 #endif  // __HIPCC__

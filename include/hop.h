@@ -255,6 +255,11 @@ int hop_model_ppf_keys(hop_ctx* ctx, const float* xyz, const float* nrm, int n, 
  * ---------------------------------------------------------------------------------------------- */
 #define HOP_SDF_MAX_MESHES 16
 int hop_sdf_register_mesh(hop_ctx* ctx, int mesh_id, const float* V, int nv, const int32_t* F, int nf, const float* pose16);
+/* SDFchecker::transformMesh (SDFchecker.cpp:81-87) as an absolute pose relative to the registered vertices: the mesh is
+ * not rebuilt, queries are moved by the inverse pose instead (distances agree with re-registering under the pose to the
+ * rounding of the motion; where libigl's sign hinges on a tie between faces, the tie can break differently).  pose16 NULL:
+ * back to the registered vertices. */
+int hop_sdf_set_mesh_pose(hop_ctx* ctx, int mesh_id, const float* pose16);
 /* dists[n] (NaN for points on the surface); faces[n] (may be NULL): closest face, nf + 1 where dists is NaN;
  * *min_dist / *max_dist: S.minCoeff() / S.maxCoeff() over the non-NaN entries (FLT_MAX / -FLT_MAX when n == 0). */
 int hop_sdf_signed_distance(hop_ctx* ctx, int mesh_id, const float* pts_xyz, int n, float* dists, int32_t* faces, float* min_dist,

@@ -118,9 +118,20 @@ def test_voxel_downsample_overflow_is_an_error(ctx, api):
 
 
 # ------------------------------------------------------------------------------------------------ decision chain
-def _run_case(ctx, orc, synth, p, poses):
+def _register(ctx, p, posed=False):
+    """Default: the pose is applied to the vertices at registration, as SDFchecker::registerMesh does (the finger meshes are
+    then bit-equal to the oracle's, and so is every tie between faces).  posed: geometry registered at identity and the
+    pose set afterwards (queries are moved instead)."""
     for mid, V, F, T in p["meshes"]:
-        ctx.sdf_register_mesh(mid, V, F, T)
+        if posed:
+            ctx.sdf_register_mesh(mid, V, F, None)
+            ctx.sdf_set_mesh_pose(mid, T)
+        else:
+            ctx.sdf_register_mesh(mid, V, F, T)
+
+
+def _run_case(ctx, orc, synth, p, poses, posed=False):
+    _register(ctx, p, posed)
     ctx.physics_set_frame(p)
     scores = np.linspace(1.0, 0.5, len(poses)).astype(np.float32)
     ctx.hypos_upload(poses, scores)
@@ -183,6 +194,46 @@ def test_reject_by_collision_tilted_fingers(ctx, orc, synth):
     keep, diag, keep_o, diag_o, _ = _run_case(ctx, orc, synth, p, poses)
     _check_against_oracle(keep, diag, keep_o, diag_o)
     assert 0 < keep.sum() < len(keep)
+
+
+def test_mesh_pose_equals_registration_under_the_pose(ctx, orc, synth):
+    """hop_sdf_set_mesh_pose (queries moved by the inverse pose) against registering the posed vertices: same signed
+    distances to the rounding of the motion, same faces; and the posed mesh answers like the oracle's posed mesh."""
+    rng = np.random.default_rng(21)
+    V, F = synth.torus_mesh(nu=40, nv=20)
+    T = synth.se3(synth.random_rotation(rng), [0.12, -0.3, 0.8]).astype(np.float32)
+    Vt = synth.apply(T, V)
+    P = (Vt[rng.integers(0, len(Vt), 6000)] + rng.normal(scale=0.01, size=(6000, 3))).astype(np.float32)
+    ctx.sdf_register_mesh(10, V, F, T)
+    d_baked, f_baked, _, _ = ctx.sdf_signed_distance(10, P)
+    ctx.sdf_register_mesh(11, V, F, None)
+    ctx.sdf_set_mesh_pose(11, T)
+    d_posed, f_posed, _, _ = ctx.sdf_signed_distance(11, P)
+    S, I = orc.sdf_signed_distance(P, V, F, pose=T)
+    assert np.array_equal(d_baked.view(np.int32), S.view(np.int32)) and np.array_equal(f_baked, I)
+    assert np.abs(np.abs(d_posed) - np.abs(S)).max() < 2e-6
+    clear = np.abs(S) > 5e-6
+    assert np.array_equal(np.sign(d_posed[clear]), np.sign(S[clear]))
+    differ = np.where(f_posed != I)[0]      # ties between faces (a closest point on a shared edge or vertex) can resolve
+    assert len(differ) < 0.3 * len(I)       # differently after the motion: then the two faces share that edge or vertex
+    for k in differ[:300]:
+        assert len(set(F[f_posed[k]]) & set(F[I[k]])) >= 1
+    ctx.sdf_set_mesh_pose(11, None)
+    d_rest, _, _, _ = ctx.sdf_signed_distance(11, P)
+    S0, _ = orc.sdf_signed_distance(P, V, F)
+    assert np.array_equal(d_rest.view(np.int32), S0.view(np.int32))
+
+
+def test_reject_by_collision_with_posed_finger_meshes(ctx, orc, synth):
+    """Finger meshes registered once in their link frames and posed by hop_sdf_set_mesh_pose: the distances every check
+    looks at agree with the oracle to the rounding of the motion; a decision may differ only where libigl's sign is decided
+    by a tie between faces (physics rejection), which moving the query can break differently."""
+    p, poses = synth.physics_case(96)
+    keep, diag, keep_o, diag_o, _ = _run_case(ctx, orc, synth, p, poses, posed=True)
+    same = diag[:, 0] == diag_o[:, 0]
+    assert same.mean() > 0.9
+    both = np.isfinite(diag[same][:, 1:7]) & np.isfinite(diag_o[same][:, 1:7])
+    assert np.abs(diag[same][:, 1:7][both] - diag_o[same][:, 1:7][both]).max() < 2e-6
 
 
 def test_reject_by_collision_dense_mesh_and_clouds(ctx, orc, synth):
@@ -501,8 +552,7 @@ def test_sdf_rigid_invariance_at_size(ctx, synth):
 
 def test_reject_by_collision_is_idempotent(ctx, synth):
     p, poses = synth.physics_case(512, seed=31, n_model=2000, n_scene=6000, mesh_subdiv=3, max_rot_deg=10.0, max_trans=0.006)
-    for mid, V, F, T in p["meshes"]:
-        ctx.sdf_register_mesh(mid, V, F, T)
+    _register(ctx, p)
     ctx.physics_set_frame(p)
     ctx.hypos_upload(poses)
     keep, diag = ctx.reject_by_collision()
