@@ -560,3 +560,23 @@ def test_reject_by_collision_is_idempotent(ctx, synth):
     again, diag2 = ctx.reject_by_collision()
     assert again.all() and len(again) == keep.sum()
     assert np.array_equal(diag2[:, 1:], diag[keep][:, 1:], equal_nan=True)
+
+
+def test_face_cells_with_degenerate_faces_far_from_origin(ctx, orc, synth):
+    """A 340-face mesh (enough for face cells) with zero-area faces and a duplicated vertex, registered 2.5 m from the
+    origin: queries inside the voxel grid, beyond it and on the grid boundary all equal the oracle bit for bit."""
+    rng = np.random.default_rng(33)
+    V, F = synth.ellipsoid_mesh((0.03, 0.02, 0.015), subdiv=2)
+    V = np.concatenate([V, V[:1]]).astype(np.float32)
+    F = np.concatenate([F, [[0, 1, 1], [5, 5, 5], [len(V) - 1, 2, 3]], F[:17][:, [0, 2, 1]]]).astype(np.int32)  # degenerate, duplicate vertex, flipped copies
+    assert len(F) >= 256
+    T = synth.se3(synth.random_rotation(rng), [1.5, -1.2, 1.6]).astype(np.float32)
+    ctx.sdf_register_mesh(12, V, F, T)
+    Vt = synth.apply(T, V)
+    c = Vt.mean(0)
+    P = np.concatenate([c + rng.normal(scale=0.02, size=(6000, 3)),          # inside the grid
+                        c + rng.normal(scale=0.15, size=(2000, 3)),          # mostly beyond it (tree walk)
+                        c + np.array([0.03 + 0.06, 0, 0]) + rng.normal(scale=1e-4, size=(500, 3))]).astype(np.float32)  # at the grid's face
+    d, f, _, _ = ctx.sdf_signed_distance(12, P)
+    S, I = orc.sdf_signed_distance(P, V, F, pose=T)
+    assert np.array_equal(d.view(np.int32), S.view(np.int32)) and np.array_equal(f, I)
