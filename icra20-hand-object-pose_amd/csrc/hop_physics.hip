@@ -725,60 +725,67 @@ __global__ void k_transform_cloud_nrm(const float* __restrict__ ix, const float*
   on[i] = m.x, on[n + i] = m.y, on[2 * (size_t)n + i] = m.z;
 }
 // pcl::RadiusOutlierRemoval: a live point stays when more than min_pts live points (itself included) are strictly
-// within the radius (FLANN RadiusResultSet: dist < r^2)
+// within the radius (FLANN RadiusResultSet: dist < r^2).  One wavefront per point, lanes stride over the cloud, so that a
+// cloud of a few thousand points still fills the GPU; a point is settled as soon as its count passes min_pts.
 __global__ void __launch_bounds__(256) k_radius_outlier(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
                                                         const unsigned char* __restrict__ live, float r2, int min_pts, unsigned char* __restrict__ out) {
-  __shared__ float4 tile[256];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const V3 p = i < n ? v3(x[i], y[i], z[i]) : v3(0, 0, 0);
-  int k = 0;
-  for (int base = 0; base < n; base += 256) {
-    const int j = base + threadIdx.x;
-    tile[threadIdx.x] = (j < n && live[j]) ? make_float4(x[j], y[j], z[j], 1.f) : make_float4(0, 0, 0, 0.f);
-    __syncthreads();
-    const int m = min(256, n - base);
-    for (int t = 0; t < m; ++t) {
-      const float4 q = tile[t];
-      if (q.w != 0.f && sqdist_flann(p, v3(q.x, q.y, q.z)) < r2) ++k;
-    }
-    __syncthreads();
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  if (!live[i]) {
+    if (lane == 0) out[i] = 0;
+    return;
   }
-  if (i < n) out[i] = (live[i] && k > min_pts) ? 1 : 0;
+  const V3 p = v3(x[i], y[i], z[i]);
+  int k = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int j = base + lane;
+    const bool hit = j < n && live[j] && sqdist_flann(p, v3(x[j], y[j], z[j])) < r2;
+    k += __popcll(__ballot(hit));
+    if (k > min_pts) break;  // uniform across the wavefront
+  }
+  if (lane == 0) out[i] = k > min_pts ? 1 : 0;
 }
 // pcl::StatisticalOutlierRemoval, first pass: mean distance to the mean_k nearest live neighbours (the 21 smallest
-// squared distances include the point itself, which is skipped); per-thread sorted list in LDS
+// squared distances include the point itself, which is skipped).  One wavefront per point: every lane keeps the sorted
+// 21 smallest of its stripe in LDS, then the wavefront extracts the 21 smallest overall, in ascending order.
 constexpr int SOR_K = 20;
-__global__ void __launch_bounds__(128) k_sor_mean(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
+__global__ void __launch_bounds__(256) k_sor_mean(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
                                                   const unsigned char* __restrict__ live, float* __restrict__ dist) {
-  __shared__ float top[(SOR_K + 1) * 128];
-  __shared__ float4 tile[128];
-  const int i = blockIdx.x * 128 + threadIdx.x;
-  const V3 p = i < n ? v3(x[i], y[i], z[i]) : v3(0, 0, 0);
-  float* mine = top + threadIdx.x;
-  for (int k = 0; k <= SOR_K; ++k) mine[k * 128] = __builtin_inff();
-  float worst = __builtin_inff();
-  for (int base = 0; base < n; base += 128) {
-    const int j = base + threadIdx.x;
-    tile[threadIdx.x] = (j < n && live[j]) ? make_float4(x[j], y[j], z[j], 1.f) : make_float4(0, 0, 0, 0.f);
-    __syncthreads();
-    const int m = min(128, n - base);
-    for (int t = 0; t < m; ++t) {
-      const float4 q = tile[t];
-      if (q.w == 0.f) continue;
-      const float d = sqdist_flann(p, v3(q.x, q.y, q.z));
-      if (d < worst) {  // insert into the ascending list
-        int k = SOR_K;
-        while (k > 0 && mine[(k - 1) * 128] > d) mine[k * 128] = mine[(k - 1) * 128], --k;
-        mine[k * 128] = d;
-        worst = mine[SOR_K * 128];
-      }
-    }
-    __syncthreads();
-  }
+  __shared__ float top[(SOR_K + 1) * 256];
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
+  if (!live[i]) {
+    if (lane == 0) dist[i] = 0.f;
+    return;
+  }
+  const V3 p = v3(x[i], y[i], z[i]);
+  float* mine = top + threadIdx.x;
+  for (int k = 0; k <= SOR_K; ++k) mine[k * 256] = __builtin_inff();
+  float worst = __builtin_inff();
+  for (int j = lane; j < n; j += 64) {
+    if (!live[j]) continue;
+    const float d = sqdist_flann(p, v3(x[j], y[j], z[j]));
+    if (d < worst) {  // insert into this lane's ascending list
+      int k = SOR_K;
+      while (k > 0 && mine[(k - 1) * 256] > d) mine[k * 256] = mine[(k - 1) * 256], --k;
+      mine[k * 256] = d;
+      worst = mine[SOR_K * 256];
+    }
+  }
+  // merge: 21 rounds, each takes the smallest head among the 64 lists (equal values: any order gives the same sum)
+  int head = 0;
   double sum = 0.0;
-  for (int k = 1; k <= SOR_K; ++k) sum += (double)sqrtf(mine[k * 128]);
-  dist[i] = live[i] ? (float)(sum / SOR_K) : 0.f;
+  for (int round = 0; round <= SOR_K; ++round) {
+    const float mine_head = head <= SOR_K ? mine[head * 256] : __builtin_inff();
+    unsigned long long key = ((unsigned long long)__float_as_uint(mine_head) << 32) | (unsigned)lane;
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long t = __shfl_xor(key, o);
+      key = t < key ? t : key;
+    }
+    if ((int)(key & 63u) == lane) ++head;
+    if (round > 0) sum += (double)sqrtf(__uint_as_float((unsigned)(key >> 32)));  // round 0 is the query point itself
+  }
+  if (lane == 0) dist[i] = (float)(sum / SOR_K);
 }
 __global__ void k_sor_apply(const float* __restrict__ x, int n, const unsigned char* __restrict__ live, const float* __restrict__ dist, double thr, int use_sor,
                             unsigned char* __restrict__ keep_noise, unsigned char* __restrict__ keep_swivel) {
@@ -1327,11 +1334,11 @@ int hop_hand_scene_filters(hop_ctx* c, const float* xyz, const float* nrm, int n
   unsigned char* live0 = ph->flags.as<unsigned char>();
   unsigned char *live1 = live0 + n, *live2 = live1 + n, *sw = live2 + n;
   PHCHK(c, hipMemsetAsync(live0, 1, (size_t)n, st));
-  k_radius_outlier<<<(n + 255) / 256, 256, 0, st>>>(hb, hb + n, hb + 2 * (size_t)n, n, live0, 0.02f * 0.02f, 30, live1);   // Hand.cpp:293-299
-  k_radius_outlier<<<(n + 255) / 256, 256, 0, st>>>(hb, hb + n, hb + 2 * (size_t)n, n, live1, 0.04f * 0.04f, 100, live2);  // :300-306
+  k_radius_outlier<<<(n + 3) / 4, 256, 0, st>>>(hb, hb + n, hb + 2 * (size_t)n, n, live0, 0.02f * 0.02f, 30, live1);   // Hand.cpp:293-299
+  k_radius_outlier<<<(n + 3) / 4, 256, 0, st>>>(hb, hb + n, hb + 2 * (size_t)n, n, live1, 0.04f * 0.04f, 100, live2);  // :300-306
   PHCHK(c, ph->pos.ensure(sizeof(float) * (size_t)n));
   float* dist = ph->pos.as<float>();
-  k_sor_mean<<<(n + 127) / 128, 128, 0, st>>>(hb, hb + n, hb + 2 * (size_t)n, n, live2, dist);  // :307-313
+  k_sor_mean<<<(n + 3) / 4, 256, 0, st>>>(hb, hb + n, hb + 2 * (size_t)n, n, live2, dist);  // :307-313
   std::vector<float> dh(n);
   std::vector<unsigned char> lh(n);
   PHCHK(c, hipMemcpyAsync(dh.data(), dist, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
