@@ -150,6 +150,7 @@ SIGNATURES = {
     "hop_hand_scene_filters": (C.c_int, [_vp, fp, fp, C.c_int, fp, fp, fp, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]),
     "hop_voxel_downsample_normals": (C.c_int, [_vp, fp, fp, C.c_int, C.c_float, fp, fp, C.c_int, ip]),
     "hop_handbase_region": (C.c_int, [_vp, fp, fp, C.c_int, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp, fp, C.POINTER(C.c_ubyte)]),
+    "hop_hand_height_matches": (C.c_int, [_vp, fp, fp, C.c_int, fp, fp, C.c_int, fp, C.c_int, ip]),
     "hop_physics_set_frame": (C.c_int, [_vp, C.POINTER(PhysicsArgs)]),
     "hop_reject_by_collision": (C.c_int, [_vp, C.POINTER(C.c_ubyte), fp, ip]),
     "hop_physics_timing": (C.c_int, [_vp, dp, dp]),
@@ -402,6 +403,13 @@ class Context:
         self._chk(self.L.hop_handbase_region(self.h, F(X), F(Nn), n, F(T), y1, z1, y2, z2, F(hx), F(hn), k.ctypes.data_as(C.POINTER(C.c_ubyte))),
                   "hop_handbase_region")
         return hx[:, :n].T.copy(), hn[:, :n].T.copy(), k[:n].astype(bool)
+
+    def hand_height_matches(self, scene_xyz, scene_nrm, hand_xyz, hand_nrm, heights):
+        S, Sn, Hx, Hn = soa(scene_xyz), soa(scene_nrm), soa(hand_xyz), soa(hand_nrm)
+        h = np.ascontiguousarray(heights, np.float32)
+        out = np.zeros(len(h), np.int32)
+        self._chk(self.L.hop_hand_height_matches(self.h, F(S), F(Sn), S.shape[1], F(Hx), F(Hn), Hx.shape[1], F(h), len(h), I(out)), "hop_hand_height_matches")
+        return out
 
     def physics_set_frame(self, p):
         """p: dict -- object_mesh, finger_mesh[4] (registered ids), finger_xyz[4] ((n,3), link frame), finger2handbase[4],
@@ -817,6 +825,36 @@ class HandT42:
         new = (handbase_in_cam.astype(np.float64) @ np.linalg.inv(offset.astype(np.float64))).astype(np.float32)
         return new, offset
 
+    TRIAL_HEIGHTS = (-0.03, -0.025, -0.02, -0.015, -0.01, -0.005, 0, 0.005, 0.01, 0.015, 0.02, 0.025, 0.03)
+
+    def adjustHandHeight(self, region_xyz_cam, region_nrm_cam, handbase_in_cam):
+        """HandT42::adjustHandHeight (Hand.cpp:999-1051): when handbaseICP did not fix the hand base, try 13 offsets along
+        the hand-base z axis and keep the one under which most hand points find a scene point within 5 mm / 45 degrees.
+        ``region``: the 3 mm hand-region cloud (camera frame).  Returns (new handbase_in_cam, best height, counts)."""
+        clouds = self.makeHandCloud()
+        handbase_in_cam = np.asarray(handbase_in_cam, np.float32)
+        if self._component_status.get("handbase", False):
+            return handbase_in_cam, 0.0, None
+        cam_in_handbase = np.linalg.inv(handbase_in_cam.astype(np.float64)).astype(np.float32)
+        x = np.asarray(region_xyz_cam, np.float32)
+        n = np.asarray(region_nrm_cam, np.float32)
+        T = cam_in_handbase
+        sx, sn = np.empty_like(x), np.empty_like(n)
+        for k in range(3):   # pcl::transformPointCloudWithNormals in float
+            sx[:, k] = ((T[k, 0] * x[:, 0] + T[k, 1] * x[:, 1]) + T[k, 2] * x[:, 2]) + T[k, 3]
+            sn[:, k] = (T[k, 0] * n[:, 0] + T[k, 1] * n[:, 1]) + T[k, 2] * n[:, 2]
+        names = sorted(clouds)
+        hx = np.concatenate([clouds[k] for k in names]).astype(np.float32)
+        hn = np.concatenate([self._hand_cloud_normals[k] for k in names]).astype(np.float32)
+        counts = self.ctx.hand_height_matches(sx, sn, hx, hn, self.TRIAL_HEIGHTS)
+        best_height, max_match = 0.0, 0
+        for h, cnt in zip(self.TRIAL_HEIGHTS, counts):   # first strict maximum (:1042-1047)
+            if cnt > max_match:
+                max_match, best_height = int(cnt), float(h)
+        offset = np.eye(4, dtype=np.float32)
+        offset[2, 3] = best_height
+        return (handbase_in_cam @ offset).astype(np.float32), best_height, counts
+
     def setCurSceneFromRegion(self, region_xyz_cam, region_nrm_cam, handbase_in_cam):
         """Hand::setCurScene from the 3 mm hand-region cloud in the camera frame (Hand.cpp:289-332, after handbaseICP):
         hand-base transform, the two radius outlier filters, the statistical outlier filter and the x pass-through run on
@@ -829,7 +867,7 @@ class HandT42:
     def makeHandCloud(self):
         """Hand::makeHandCloud (Hand.cpp:537-556): every component cloud in the hand-base frame at the current finger
         state, keyed by name (the reference keeps a kd-tree per component; std::map order = sorted names)."""
-        out = {}
+        out, nrm = {}, {}
         for name in sorted(self.hand.clouds):
             T = self.getTFHandBase(name) if name != "base_link" else np.eye(4, dtype=np.float32)
             x = np.asarray(self.hand.clouds[name][0], np.float32)
@@ -837,7 +875,13 @@ class HandT42:
             for k in range(3):   # pcl::transformPointCloud: ((m0 x + m1 y) + m2 z) + m3 in float
                 p[:, k] = ((T[k, 0] * x[:, 0] + T[k, 1] * x[:, 1]) + T[k, 2] * x[:, 2]) + T[k, 3]
             out[name] = p
+            m = np.asarray(self.hand.clouds[name][1], np.float32)
+            q = np.empty_like(m)
+            for k in range(3):   # normals: rotation part only
+                q[:, k] = (T[k, 0] * m[:, 0] + T[k, 1] * m[:, 1]) + T[k, 2] * m[:, 2]
+            nrm[name] = q
         self._hand_clouds = out
+        self._hand_cloud_normals = nrm
         return out
 
     @staticmethod

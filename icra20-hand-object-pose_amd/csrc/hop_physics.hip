@@ -956,6 +956,32 @@ __global__ void k_face_cells_clamp(const int* __restrict__ count, int nvox, unsi
   if (v <= nvox) pos[v] = (v < nvox && count[v] > 0) ? (unsigned)count[v] : 0u;
 }
 
+// HandT42::adjustHandHeight matching loop (Hand.cpp:1010-1049): grid (hand points / 4, trial heights), one wavefront per
+// (hand point, height): nearest scene point (FLANN's squared distance, lowest index on ties), 5 mm gate, 45 degree gate
+__global__ void __launch_bounds__(256) k_hand_height(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                                                     const float* __restrict__ snx, const float* __restrict__ sny, const float* __restrict__ snz, int ns,
+                                                     const float* __restrict__ hx, const float* __restrict__ hy, const float* __restrict__ hz,
+                                                     const float* __restrict__ hnx, const float* __restrict__ hny, const float* __restrict__ hnz, int nh,
+                                                     const float* __restrict__ heights, int* __restrict__ counts) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, t = blockIdx.y;
+  if (i >= nh) return;
+  const V3 p = v3(hx[i], hy[i], hz[i] + heights[t]);
+  unsigned long long best = ~0ull;
+  for (int j = lane; j < ns; j += 64) {
+    const unsigned long long v = ((unsigned long long)__float_as_uint(sqdist_flann(p, v3(sx[j], sy[j], sz[j]))) << 32) | (unsigned)j;
+    best = v < best ? v : best;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long u = __shfl_xor(best, o);
+    best = u < best ? u : best;
+  }
+  if (lane != 0 || ns == 0) return;
+  const float sq = __uint_as_float((unsigned)(best >> 32));
+  if ((double)sq > 0.005 * 0.005) return;
+  const int j = (int)(best & 0xffffffffu);
+  if ((double)vdot(v3(hnx[i], hny[i], hnz[i]), v3(snx[j], sny[j], snz[j])) >= cos(45 / 180.0 * M_PI)) atomicAdd(&counts[t], 1);
+}
+
 // ------------------------------------------------------------------------------------------------ host helpers
 int upload_planes(hop_ctx* c, Cloud3& dst, const float* planes, int n) {
   hipStream_t st = hop_ctx_stream(c);
@@ -1413,6 +1439,39 @@ int hop_handbase_region(hop_ctx* c, const float* xyz, const float* nrm, int n, c
   PHCHK(c, hipMemcpyAsync(hb_xyz, ph->tmp_cloud2.buf.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
   PHCHK(c, hipMemcpyAsync(hb_nrm, ph->tmp_nrm2.buf.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
   PHCHK(c, hipMemcpyAsync(keep, ph->flags.p, (size_t)n, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hipStreamSynchronize(st));
+  return HOP_OK;
+}
+
+int hop_hand_height_matches(hop_ctx* c, const float* scene_xyz, const float* scene_nrm, int n_scene, const float* hand_xyz, const float* hand_nrm,
+                            int n_hand, const float* heights, int n_heights, int* counts) {
+  if (!c || n_scene < 0 || n_hand < 0 || n_heights <= 0 || n_heights > 64 || !heights || !counts || (n_scene > 0 && (!scene_xyz || !scene_nrm)) ||
+      (n_hand > 0 && (!hand_xyz || !hand_nrm)))
+    return HOP_E_INVALID;
+  PHCHK(c, hipSetDevice(hop_ctx_device(c)));
+  Physics* ph = physics(c);
+  hipStream_t st = hop_ctx_stream(c);
+  for (int t = 0; t < n_heights; ++t) counts[t] = 0;
+  if (n_hand == 0 || n_scene == 0) return HOP_OK;
+  int rc = upload_planes(c, ph->tmp_cloud, scene_xyz, n_scene);
+  if (rc) return rc;
+  rc = upload_planes(c, ph->tmp_nrm, scene_nrm, n_scene);
+  if (rc) return rc;
+  rc = upload_planes(c, ph->tmp_cloud2, hand_xyz, n_hand);
+  if (rc) return rc;
+  rc = upload_planes(c, ph->tmp_nrm2, hand_nrm, n_hand);
+  if (rc) return rc;
+  PHCHK(c, ph->scalars.ensure(sizeof(unsigned) * 16));
+  PHCHK(c, ph->mats.ensure(sizeof(float) * 16 * 5));
+  PHCHK(c, ph->gather.ensure(sizeof(int) * 64));
+  PHCHK(c, hipMemcpyAsync(ph->mats.p, heights, sizeof(float) * (size_t)n_heights, hipMemcpyHostToDevice, st));
+  PHCHK(c, hipMemsetAsync(ph->gather.p, 0, sizeof(int) * 64, st));
+  const float *sn = ph->tmp_nrm.buf.as<float>(), *hn = ph->tmp_nrm2.buf.as<float>();
+  k_hand_height<<<dim3((n_hand + 3) / 4, n_heights), 256, 0, st>>>(ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), sn, sn + n_scene, sn + 2 * (size_t)n_scene, n_scene,
+                                                                  ph->tmp_cloud2.x(), ph->tmp_cloud2.y(), ph->tmp_cloud2.z(), hn, hn + n_hand, hn + 2 * (size_t)n_hand, n_hand,
+                                                                  ph->mats.as<float>(), ph->gather.as<int>());
+  PHCHK(c, hipGetLastError());
+  PHCHK(c, hipMemcpyAsync(counts, ph->gather.p, sizeof(int) * (size_t)n_heights, hipMemcpyDeviceToHost, st));
   PHCHK(c, hipStreamSynchronize(st));
   return HOP_OK;
 }

@@ -136,10 +136,14 @@ class Hand {
       hop::Cloud dst;
       dst.n = src.n;
       dst.xyz.resize(3 * (size_t)src.n);
+      dst.nrm.resize(3 * (size_t)src.n);
       const float *x = src.xyz.data(), *y = x + src.n, *z = y + src.n;
+      const float *nx = src.nrm.data(), *ny = nx + src.n, *nz = ny + src.n;
       for (int k = 0; k < 3; ++k)
-        for (int i = 0; i < src.n; ++i)
+        for (int i = 0; i < src.n; ++i) {
           dst.xyz[(size_t)k * src.n + i] = ((T.m[4 * k] * x[i] + T.m[4 * k + 1] * y[i]) + T.m[4 * k + 2] * z[i]) + T.m[4 * k + 3];
+          dst.nrm[(size_t)k * src.n + i] = (T.m[4 * k] * nx[i] + T.m[4 * k + 1] * ny[i]) + T.m[4 * k + 2] * nz[i];
+        }
       _hand_clouds[h.first] = dst;
     }
     // _hand_cloud: the components appended in map order (Hand.cpp:550)
@@ -147,11 +151,15 @@ class Hand {
     for (auto& h : _hand_clouds) total += h.second.n;
     _hand_cloud.n = total;
     _hand_cloud.xyz.assign(3 * (size_t)total, 0.f);
+    _hand_cloud.nrm.assign(3 * (size_t)total, 0.f);
     int off = 0;
     for (auto& h : _hand_clouds) {
-      for (int k = 0; k < 3; ++k)
+      for (int k = 0; k < 3; ++k) {
         std::copy(h.second.xyz.begin() + (size_t)k * h.second.n, h.second.xyz.begin() + (size_t)(k + 1) * h.second.n,
                   _hand_cloud.xyz.begin() + (size_t)k * total + off);
+        std::copy(h.second.nrm.begin() + (size_t)k * h.second.n, h.second.nrm.begin() + (size_t)(k + 1) * h.second.n,
+                  _hand_cloud.nrm.begin() + (size_t)k * total + off);
+      }
       off += h.second.n;
     }
   }
@@ -242,6 +250,35 @@ class Hand {
     Mat4 offset_inv;
     affineInverse(offset.m, offset_inv.m);
     _handbase_in_cam = _handbase_in_cam * offset_inv;  // :771
+  }
+  // HandT42::adjustHandHeight (Hand.cpp:999-1051); scene_hand_region: the 3 mm hand-region cloud, camera frame, with normals
+  void adjustHandHeight(const hop::Cloud& scene_hand_region) {
+    makeHandCloud();
+    if (_component_status["handbase"]) return;
+    float T[16];
+    camToHandbase(T);
+    const int n = scene_hand_region.n;
+    std::vector<float> sx(3 * (size_t)n), sn(3 * (size_t)n);
+    const float *x = scene_hand_region.xyz.data(), *y = x + n, *z = y + n;
+    const float *nx = scene_hand_region.nrm.data(), *ny = nx + n, *nz = ny + n;
+    for (int k = 0; k < 3; ++k)
+      for (int i = 0; i < n; ++i) {
+        sx[(size_t)k * n + i] = ((T[4 * k] * x[i] + T[4 * k + 1] * y[i]) + T[4 * k + 2] * z[i]) + T[4 * k + 3];
+        sn[(size_t)k * n + i] = (T[4 * k] * nx[i] + T[4 * k + 1] * ny[i]) + T[4 * k + 2] * nz[i];
+      }
+    const float trial_heights[13] = {-0.03f, -0.025f, -0.02f, -0.015f, -0.01f, -0.005f, 0.f, 0.005f, 0.01f, 0.015f, 0.02f, 0.025f, 0.03f};
+    int counts[13];
+    hop::check(hop_hand_height_matches(ctx_, sx.data(), sn.data(), n, _hand_cloud.xyz.data(), _hand_cloud.nrm.data(), _hand_cloud.n, trial_heights, 13, counts),
+               ctx_, "hop_hand_height_matches");
+    int max_match = 0;
+    Mat4 best_offset = Mat4::Identity();
+    for (int i = 0; i < 13; ++i)
+      if (counts[i] > max_match) {  // :1042-1047
+        max_match = counts[i];
+        best_offset = Mat4::Identity();
+        best_offset.m[11] = trial_heights[i];
+      }
+    _handbase_in_cam = _handbase_in_cam * best_offset;  // :1050
   }
   // the filters of Hand::setCurScene (Hand.cpp:289-332) on the 3 mm hand-region cloud (camera frame, with normals)
   void setCurSceneFromRegion(const hop::Cloud& scene_hand_region) {

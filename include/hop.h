@@ -342,6 +342,14 @@ int hop_voxel_downsample_normals(hop_ctx* ctx, const float* xyz, const float* nr
 int hop_handbase_region(hop_ctx* ctx, const float* xyz, const float* nrm, int n, const float cam_in_handbase[16], float y1, float z1,
                         float y2, float z2, float* hb_xyz, float* hb_nrm, unsigned char* keep);
 
+/* "Next" row N3f: the matching loop of HandT42::adjustHandHeight (src/perception/src/Hand.cpp:1010-1049).  scene: the 3 mm
+ * hand-region cloud in the hand-base frame with normals (hb_xyz / hb_nrm of hop_hand_scene_filters); hand: Hand::_hand_cloud
+ * with normals (hand-base frame).  counts[t]: hand points whose nearest scene point, after the hand is shifted by heights[t]
+ * along z, is within 5 mm with normals within 45 degrees.  The choice of the best height (first maximum, :1042-1047) and
+ * the update of _handbase_in_cam (:1050) are host logic. */
+int hop_hand_height_matches(hop_ctx* ctx, const float* scene_xyz, const float* scene_nrm, int n_scene, const float* hand_xyz,
+                            const float* hand_nrm, int n_hand, const float* heights, int n_heights, int* counts);
+
 /* ------------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): device time in ms of the kernels launched by the last call of the
  * named stage, measured with HIP events on the ctx stream; and launch counts.

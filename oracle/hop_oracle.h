@@ -159,6 +159,9 @@ int orc_hand_scene_filters(const float* xyz_planes, const float* nrm_planes, int
 int orc_voxel_downsample_normals(const float* xyz_planes, const float* nrm_planes, int n, float leaf, float* out_xyz, float* out_nrm, int cap, int* n_out);
 int orc_handbase_region(const float* xyz_planes, const float* nrm_planes, int n, const float* cam_in_handbase16, float y1, float z1, float y2, float z2,
                         float* hb_xyz, float* hb_nrm, unsigned char* keep);
+/* HandT42::adjustHandHeight matching loop (Hand.cpp:1010-1049) */
+int orc_hand_height_matches(const float* scene_xyz, const float* scene_nrm, int n_scene, const float* hand_xyz, const float* hand_nrm, int n_hand,
+                            const float* heights, int n_heights, int* counts);
 /* scene front end of main_realdata_auto.cpp:54-96 (depth -> cloud, z pass-through, voxel grid, hand-base crop) */
 int orc_scene_from_depth(const unsigned short* depth_raw, int H, int W, double depth_unit, const float* K9, const float* cam_in_handbase16,
                          const float* handbase_in_cam16, float leaf, const float* crop_min3, const float* crop_max3, float* out_planes,

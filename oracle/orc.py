@@ -160,6 +160,7 @@ def lib():
         L.orc_hand_scene_filters.argtypes = [fp, fp, C.c_int, fp, fp, fp, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]
         L.orc_voxel_downsample_normals.argtypes = [fp, fp, C.c_int, C.c_float, fp, fp, C.c_int, ip]
         L.orc_handbase_region.argtypes = [fp, fp, C.c_int, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp, fp, C.POINTER(C.c_ubyte)]
+        L.orc_hand_height_matches.argtypes = [fp, fp, C.c_int, fp, fp, C.c_int, fp, C.c_int, ip]
         L.orc_reject_by_collision.argtypes = [C.POINTER(PhysicsArgs), fp, C.c_int, C.POINTER(C.c_ubyte), fp]
         L.orc_compute_ppf.argtypes = [fp, fp, fp, fp, ip]
         L.orc_pair_ppf_is_good.argtypes = [fp, fp, fp, fp]
@@ -531,3 +532,11 @@ def handbase_region(xyz, nrm, cam_in_handbase, y1, z1, y2, z2):
     k = np.zeros(max(n, 1), np.uint8)
     lib().orc_handbase_region(F(X), F(Nn), n, F(T), y1, z1, y2, z2, F(hx), F(hn), k.ctypes.data_as(C.POINTER(C.c_ubyte)))
     return hx[:, :n].T.copy(), hn[:, :n].T.copy(), k[:n].astype(bool)
+
+
+def hand_height_matches(scene_xyz, scene_nrm, hand_xyz, hand_nrm, heights):
+    S, Sn, Hx, Hn = soa(scene_xyz), soa(scene_nrm), soa(hand_xyz), soa(hand_nrm)
+    h = np.ascontiguousarray(heights, np.float32)
+    out = np.zeros(len(h), np.int32)
+    lib().orc_hand_height_matches(F(S), F(Sn), S.shape[1], F(Hx), F(Hn), Hx.shape[1], F(h), len(h), I(out))
+    return out

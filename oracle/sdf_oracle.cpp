@@ -759,6 +759,31 @@ int orc_handbase_region(const float* xyz_planes, const float* nrm_planes, int n,
   return 0;
 }
 
+// HandT42::adjustHandHeight, the matching loop (Hand.cpp:1010-1049): for every trial height the hand cloud (hand-base
+// frame, with normals) is shifted along z; a hand point counts when its nearest scene point (hand-base frame) is within
+// 5 mm and the two normals are within 45 degrees.  counts[t] = cur_match of trial t.
+int orc_hand_height_matches(const float* scene_xyz, const float* scene_nrm, int n_scene, const float* hand_xyz, const float* hand_nrm, int n_hand,
+                            const float* heights, int n_heights, int* counts) {
+  const std::vector<F3> S = planes_to_pts(scene_xyz, n_scene), Sn = planes_to_pts(scene_nrm, n_scene);
+  const std::vector<F3> Hd = planes_to_pts(hand_xyz, n_hand), Hn = planes_to_pts(hand_nrm, n_hand);
+  const double cos45 = std::cos(45 / 180.0 * M_PI);
+  for (int t = 0; t < n_heights; ++t) {
+    int cur = 0;
+#pragma omp parallel for reduction(+ : cur) schedule(static)
+    for (int i = 0; i < n_hand; ++i) {
+      // offset = I with (2,3) = height, applied by pcl::transformPointCloudWithNormals: x and y unchanged, z + height
+      const F3 pt = f3(Hd[i].x, Hd[i].y, Hd[i].z + heights[t]);
+      float sq;
+      const int j = nearest(S, pt, &sq);
+      if (j < 0) continue;
+      if ((double)sq > 0.005 * 0.005) continue;
+      if ((double)dot3(Hn[i], Sn[j]) >= cos45) ++cur;
+    }
+    counts[t] = cur;
+  }
+  return 0;
+}
+
 // PoseEstimator::rejectByCollisionOrNonTouching (PoseEstimator.cpp:524-735).  keep[i] = 1 for the hypotheses the
 // reference pushes back into _pose_hypos.  diag (optional, H x 8): stage that decided (0 kept, 1 scene point inside,
 // 2 hand point colliding, 3 finger cloud colliding, 4 one side not touching, 5 model inside finger), the two single-

@@ -143,3 +143,18 @@ def test_oracle_handbase_region_and_voxel_normals(orc):
     np.testing.assert_allclose(ox[0], [0.0025, 0.0025, 0.5], atol=1e-7)
     np.testing.assert_allclose(on[0], [2 ** -0.5, 2 ** -0.5, 0], atol=1e-6)
     np.testing.assert_allclose(on[1], [0, 0, 1], atol=1e-7)
+
+
+def test_oracle_hand_height_matches_small(orc):
+    """Hand.cpp:1010-1049 by hand: three hand points over a flat scene patch at z = 0.01; only the trial that lifts the hand
+    by 10 mm brings them within 5 mm, and one of them faces the wrong way."""
+    g = np.arange(-3, 4) * 0.002
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    scene = np.stack([X.ravel(), Y.ravel(), np.full(X.size, 0.01)], axis=1).astype(np.float32)
+    sn = np.tile(np.float32([0, 0, 1]), (len(scene), 1))
+    hand = np.array([[0.0, 0.0, 0.0], [0.002, 0.002, 0.001], [-0.002, 0.0, 0.0]], np.float32)
+    hn = np.array([[0, 0, 1], [0, 0.6, 0.8], [0, 0, -1]], np.float32)
+    heights = np.float32([-0.01, 0.0, 0.004, 0.01, 0.02])
+    c = orc.hand_height_matches(scene, sn, hand, hn, heights)
+    # 0.004: the points end 6 / 5 / 6 mm below the patch: the middle one is exactly at 5 mm in z but 0 laterally -> within
+    assert c.tolist() == [0, 0, 1, 2, 0]
