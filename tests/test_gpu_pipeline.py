@@ -1,6 +1,6 @@
 """The whole driver above the C-ABI on one synthetic frame (hand + grasped object, one camera), in the call order of
 src/perception/src/app/main_realdata_auto.cpp:54-205 minus the two PCL normal estimators (the frame comes with normals)
-and rejectByRender: handbaseICP -> Hand::setCurScene filters -> finger PSO -> hand-point removal with confidences ->
+and rejectByRender: handbaseICP -> Hand::setCurScene filters -> finger PSO -> adjustHandHeight -> hand-point removal with confidences ->
 generator input cloud -> runSuper4pcs -> clusterPoses -> refineByICP -> clusterPoses -> rejectByCollisionOrNonTouching ->
 selectBest.  Every step runs through libhop.so; the result is judged against the frame's ground truth."""
 import math
@@ -53,6 +53,10 @@ def test_whole_frame_pipeline(hop):
     assert len(angles) == 4, angles
     for name, a in angles.items():
         assert abs(a - g["angles"][name]) < math.radians(4), (name, math.degrees(a))
+
+    # main :141: nothing to adjust, handbaseICP already fixed the hand base (Hand.cpp:1002-1005)
+    handbase_in_cam, _, counts = h.adjustHandHeight(rx, rn, handbase_in_cam)
+    assert counts is None
 
     # hand points removed, confidences assigned (main :142-151); generator input (main :156-177)
     h.makeHandCloud()
