@@ -44,8 +44,11 @@ def parse():
     ap.add_argument("--particles", type=int, default=200)
     ap.add_argument("--hand-scene", type=int, default=20000)
     ap.add_argument("--verify-mode", type=int, default=2, help="0 brute-force LDS scan, 1 voxel grid, 2 EXIST-mode cell lists (identical counts)")
-    ap.add_argument("--nn-mode", type=int, default=3, help="ICP / computeLCP nearest neighbour: 0 brute force, 1 voxel grids, 2 NN cell lists, "
-                    "3 NN cell lists with ICP search and accumulation in one kernel (identical correspondences in all modes)")
+    ap.add_argument("--nn-mode", type=int, default=4, help="ICP nearest neighbour: 0 brute force, 1 voxel grids, 2 NN cell lists, 3 packed NN cell lists "
+                    "with search and accumulation in one kernel (identical correspondences in modes 0-3), 4 = 3 with the increments "
+                    "composed into one transform per iteration (poses equal to ~1e-6, tests/test_gpu_fullsize.py)")
+    ap.add_argument("--lcp-mode", type=int, default=3, help="computeLCP: 0 brute force, 1 voxel grids, 2 NN cell lists with the reference's ordered "
+                    "float sum (bit-equal scores in modes 0-2), 3 NN cell lists with in-wave partial sums (scores within 1e-4 relative)")
     ap.add_argument("--inflight", type=int, default=8, help="frames in flight per GPU (one context each): the host base selection of one "
                     "frame overlaps the device work of the others; 1 = strictly one frame at a time")
     ap.add_argument("--no-serial-frame", action="store_true", help="skip the extra undisturbed frame used for per-kernel timing")
@@ -130,7 +133,7 @@ class Workload:
         hh = c.hypos_count()
         it, _ = c.icp_refine(10, 45.0, 0.01, nn_mode=self.args.nn_mode, want_stats=True)
         t3 = time.perf_counter()
-        best, score, idx = c.lcp_select_best(0.001, 10.0, self.args.nn_mode)
+        best, score, idx = c.lcp_select_best(0.001, 10.0, self.args.lcp_mode)
         t4 = time.perf_counter()
         rows = c.topk_pack(topk, id_offset=id_offset)[0] if topk > 0 else None
         return dict(h=hh, h_gen=st.n_hypotheses, n_cand=st.n_candidates, n_bases=st.n_bases, best=best, score=score,
@@ -379,8 +382,8 @@ def main():
             if args.nn_mode < 2:
                 kern["k_icp_nn"] = kern.pop("k_icp_corr_cells")
                 kern.pop("k_icp_accum")
-            elif args.nn_mode == 3:
-                kern["k_icp_fused"] = kern.pop("k_icp_corr_cells")
+            elif args.nn_mode >= 3:
+                kern["k_icp_fusedq"] = kern.pop("k_icp_corr_cells")
                 kern.pop("k_icp_accum")
             return kern
 
@@ -436,7 +439,7 @@ def main():
             "config": {"workload": "C2: ellipse, 2048 Super4PCS base trials + 200-particle hand search, 20k-pt scene / 5k-pt model",
                        "scene_points": N, "model_points": M, "base_trials": args.bases, "sample_size": nq,
                        "hypotheses_scored_per_rank": H, "pso_particles": args.particles, "hand_scene_points": args.hand_scene,
-                       "verify_mode": args.verify_mode, "nn_mode": args.nn_mode, "frames_in_flight": F,
+                       "verify_mode": args.verify_mode, "nn_mode": args.nn_mode, "lcp_mode": args.lcp_mode, "frames_in_flight": F,
                        "parallelism": f"hypothesis-parallel x{world}, all-gather top-{K}"},
             "roofline": roof,
             "stage_ms_per_frame": {"frame_handover": stage("t_frame"), "pso": stage("t_pso"), "generate": stage("t_gen"),

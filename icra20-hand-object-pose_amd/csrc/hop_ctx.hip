@@ -51,12 +51,14 @@ struct GridStore {
 };
 
 struct CellListStore {
-  DevBuf start_d, pts_d, nrm_d, u2_d, count_d, work_d, keep_d, range_d;
+  DevBuf start_d, pts_d, nrm_d, u2_d, count_d, work_d, keep_d, range_d, nrm_idx_d, pts_idx_d, rec_d, qlist_d;
   hop::CellListDev c{};
   bool valid = false;
   float cell = 0, max_dist = 0, coord_mag = 0;
+  bool packed = false, pack_requested = false;
   void release() {
     start_d.release(), pts_d.release(), nrm_d.release(), u2_d.release(), count_d.release(), work_d.release(), keep_d.release(), range_d.release();
+    nrm_idx_d.release(), pts_idx_d.release(), rec_d.release(), qlist_d.release();
     valid = false;
   }
 };
@@ -93,6 +95,7 @@ struct hop_ctx {
   CloudDevice scene_unit_d, scene_sorted_unit_d;  // planes 3..5: unit normals (computeLCP on cell lists), caller / Morton order
   CloudDevice scene_sorted_d;  // scoring copy in Morton order (grid paths), + permutation back to caller order
   DevBuf scene_perm_d;
+  DevBuf scene_sorted_aos_d;  // the same Morton-ordered copy as AoS: [m] float4 points, then [m] float4 normals (fused ICP kernel)
   CloudDevice model_d[2];
 
   // PPF key set
@@ -291,7 +294,9 @@ int build_grid(hop_ctx* c, GridStore& gs, const float* x, const float* y, const 
 }
 
 // NN cell lists of a cloud (device-resident planes x,y,z), padded by max_dist: three small kernels and one scan
-int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const CloudDevice& d, float max_dist, float cell) {
+// packed: additionally the 16-byte cell records / 8-byte quantised entries of CellListDev::rec (ICP lookups, cells_nnq);
+// packing runs on the host (once per model and gating distance, like the lists themselves).
+int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const CloudDevice& d, float max_dist, float cell, bool packed = false) {
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (int i = 0; i < h.n; ++i) {
     mn[0] = std::min(mn[0], h.x[i]), mn[1] = std::min(mn[1], h.y[i]), mn[2] = std::min(mn[2], h.z[i]);
@@ -337,6 +342,63 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
   launch_cell_ranges(cs.c.start, (int)ncell, cs.range_d.as<int2>(), c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   cs.c.range = cs.range_d.as<int2>();
+  cs.c.gox = -a.ox * cs.c.inv_cell, cs.c.goy = -a.oy * cs.c.inv_cell, cs.c.goz = -a.oz * cs.c.inv_cell;
+  HIPCHK(c, cs.nrm_idx_d.ensure(sizeof(float4) * (size_t)std::max(h.n, 1)));
+  launch_soa_to_aos4(d.plane(3), d.plane(4), d.plane(5), h.n, cs.nrm_idx_d.as<float4>(), c->stream);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  cs.c.nrm_idx = cs.nrm_idx_d.as<float4>();
+  HIPCHK(c, cs.pts_idx_d.ensure(sizeof(float4) * (size_t)std::max(h.n, 1)));
+  launch_soa_to_aos4(d.plane(0), d.plane(1), d.plane(2), h.n, cs.pts_idx_d.as<float4>(), c->stream);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  cs.c.pts_idx = cs.pts_idx_d.as<float4>();
+  cs.packed = false, cs.pack_requested = packed, cs.c.rec = nullptr, cs.c.qlist = nullptr;
+  // (the empty-slot convention of cells_nnq needs the cell well below the gating distance: cell < 0.42 (max_dist + margin))
+  if (packed && h.n < 0xFFFF && cell < 0.4f * max_dist) {
+    std::vector<float4> hp(std::max<size_t>(total, 1));
+    HIPCHK(c, hipMemcpyAsync(hp.data(), cs.pts_d.p, sizeof(float4) * total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // per-cell quantisation frame: every list member lies within max_dist + margin of the cell's box on every axis
+    // (cell_list_thr2), so [corner - R, corner + cell + R] holds it
+    const double R = (double)max_dist + 2.0 * (double)a.margin;
+    const double step = ((double)cell + 2.0 * R) / 65535.0, qcs = (double)cell / step, qrs = R / step;
+    bool in_range = true;
+    std::vector<uint32_t> rec(2 * ncell), ql;
+    ql.reserve(2 * total + 4 * ncell);
+    for (size_t k = 0; k < ncell; ++k) {
+      const int ic[3] = {(int)(k % a.dx), (int)((k / a.dx) % a.dy), (int)(k / ((size_t)a.dx * a.dy))};
+      const float org[3] = {a.ox, a.oy, a.oz};
+      const int n = cnt[k], chunks = 2 * ((n + 3) / 4);  // an even number of chunks: the lookup reads two per trip
+      rec[2 * k] = (uint32_t)(ql.size() / 4), rec[2 * k + 1] = (uint32_t)chunks;
+      for (int e = 0; e < 2 * chunks; ++e) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
+        if (e < n) {
+          const float4 t = hp[(size_t)start[k] + e];
+          const float v[3] = {t.x, t.y, t.z};
+          uint32_t u[3], idx;
+          for (int ax = 0; ax < 3; ++ax) {
+            const double w = std::nearbyint((((double)v[ax] - (double)org[ax]) / (double)cell - (double)ic[ax]) * qcs + qrs);
+            if (w < 0.0 || w > 65534.0) in_range = false;
+            u[ax] = (uint32_t)std::min(65534.0, std::max(0.0, w));
+          }
+          memcpy(&idx, &t.w, 4);
+          lo = u[0] | (u[1] << 16), hi = u[2] | (idx << 16);
+        }
+        ql.push_back(lo), ql.push_back(hi);
+      }
+    }
+    if (!in_range) return HOP_E_STATE;
+    if (ql.empty()) ql.assign(4, 0xFFFFFFFFu);
+    HIPCHK(c, cs.rec_d.ensure(sizeof(uint32_t) * rec.size()));
+    HIPCHK(c, cs.qlist_d.ensure(sizeof(uint32_t) * ql.size()));
+    HIPCHK(c, hipMemcpyAsync(cs.rec_d.p, rec.data(), sizeof(uint32_t) * rec.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cs.qlist_d.p, ql.data(), sizeof(uint32_t) * ql.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    cs.c.rec = cs.rec_d.as<uint2>(), cs.c.qlist = cs.qlist_d.as<uint4>();
+    cs.c.q_cs = (float)qcs, cs.c.q_rs = (float)qrs, cs.c.q_step2 = (float)(step * step);
+    cs.c.q_eq = (float)(step * 0.9);  // sqrt(3)/2 of a step + the float evaluation of the local coordinates
+    cs.packed = true;
+    if (getenv("HOP_PROFILE_SELECT")) std::printf("packed lists: %.1f MB records + %.1f MB chunks, step %.3g m\n", rec.size() * 4e-6, ql.size() * 4e-6, step);
+  }
   cs.valid = true, cs.cell = cell, cs.max_dist = max_dist, cs.coord_mag = c->coord_mag;
   if (getenv("HOP_PROFILE_SELECT")) std::printf("cell lists: %zu cells, %zu entries (%.1f per cell), cell %.4f\n", ncell, total, (double)total / (double)ncell, cell);
   return HOP_OK;
@@ -589,7 +651,7 @@ void hop_ctx_destroy(hop_ctx* c) {
   if (c->ppf_matrix_registered) (void)hipHostUnregister(c->ppf_matrix_cached);
   std::free(c->ppf_matrix_cached);
   c->fit_queue_d.release(), c->fit_count_d.release(), c->angle_thr_d.release(), c->sur_in.release(), c->sur_ws.release(), c->sur_links.release(), c->sur_out.release();
-  DevBuf* bufs[] = {&c->scene_d.buf, &c->scene_sorted_d.buf, &c->scene_unit_d.buf, &c->scene_sorted_unit_d.buf, &c->scene_perm_d, &c->model_d[0].buf, &c->model_d[1].buf, &c->key_bitmap_d, &c->gp_d.buf, &c->gq_d.buf, &c->gq_unit_d,
+  DevBuf* bufs[] = {&c->scene_sorted_aos_d, &c->scene_d.buf, &c->scene_sorted_d.buf, &c->scene_unit_d.buf, &c->scene_sorted_unit_d.buf, &c->scene_perm_d, &c->model_d[0].buf, &c->model_d[1].buf, &c->key_bitmap_d, &c->gp_d.buf, &c->gq_d.buf, &c->gq_unit_d,
                     &c->ppf_matrix_d, &c->vp_d.buf, &c->vq_d.buf, &c->bases_d, &c->pairs1_d,
                     &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
                     &c->hyp_score, &c->hyp_id, &c->hyp_key, &c->hyp_inv, &c->tmp_pose, &c->tmp_score, &c->tmp_id, &c->sort_keys_alt,
@@ -685,6 +747,18 @@ int hop_set_scene(hop_ctx* c, const float* xyz, const float* nrm, const float* c
     }
     const int rc = upload_cloud(c, c->scene_sorted_d, sorted);
     if (rc) return rc;
+    {
+      std::vector<float> aos((size_t)8 * std::max(m, 1), 0.f);
+      for (int k = 0; k < m; ++k) {
+        float* pp = aos.data() + (size_t)4 * k;
+        float* pn = aos.data() + (size_t)4 * (m + k);
+        pp[0] = sorted.x[k], pp[1] = sorted.y[k], pp[2] = sorted.z[k];
+        pn[0] = sorted.nx[k], pn[1] = sorted.ny[k], pn[2] = sorted.nz[k];
+      }
+      HIPCHK(c, c->scene_sorted_aos_d.ensure(sizeof(float) * aos.size()));
+      HIPCHK(c, hipMemcpyAsync(c->scene_sorted_aos_d.p, aos.data(), sizeof(float) * aos.size(), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     HIPCHK(c, c->scene_perm_d.ensure(sizeof(int) * 2 * (size_t)std::max(m, 1)));
     std::vector<int> inv(std::max(m, 1));
     for (int k = 0; k < m; ++k) inv[perm[k]] = k;
@@ -1198,15 +1272,18 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     a.model_grid = gs.g;
     a.max_ring = (int)std::ceil((o->max_corr_dist + 2 * GRID_MARGIN) / cell);
   } else if (cells) {
-    float cell = o->max_corr_dist / 6.f;
+    // cells of a sixth of the gating distance for the plain lists (nn_mode 2), a seventh for the packed ones (measured:
+    // 6 / 7 / 8 / 10 / 12 -> 819 / 784 / 789 / 845 / 925 us per launch at C2)
+    float cell = o->max_corr_dist / (o->nn_mode >= 3 ? 7.f : 6.f);
     if (const char* e = getenv("HOP_ICP_CELL_DIV")) cell = o->max_corr_dist / (float)atof(e);
     CellListStore& cs = c->model_cells[HOP_MODEL_5MM];
-    if (!cs.valid || cs.cell != cell || cs.max_dist != o->max_corr_dist || cs.coord_mag < c->coord_mag) {
-      const int rc = build_cell_lists(c, cs, c->gen.model_h[HOP_MODEL_5MM], c->model_d[HOP_MODEL_5MM], o->max_corr_dist, cell);
+    const bool want_packed = o->nn_mode >= 3 && c->gen.model_h[HOP_MODEL_5MM].n < 0xFFFF;
+    if (!cs.valid || cs.cell != cell || cs.max_dist != o->max_corr_dist || cs.coord_mag < c->coord_mag || (want_packed && !cs.pack_requested)) {
+      const int rc = build_cell_lists(c, cs, c->gen.model_h[HOP_MODEL_5MM], c->model_d[HOP_MODEL_5MM], o->max_corr_dist, cell, want_packed);
       if (rc) return rc;
     }
     a.cells = cs.c;
-    if (o->nn_mode != 3) HIPCHK(c, c->icp_corr_idx.ensure(sizeof(int) * (size_t)S.n * HB));  // the fused kernel keeps no correspondence array
+    if (o->nn_mode == 2) HIPCHK(c, c->icp_corr_idx.ensure(sizeof(int) * (size_t)S.n * HB));  // the fused kernels keep no correspondence array
     HIPCHK(c, c->icp_hist.ensure(sizeof(float) * 12 * (size_t)std::max(o->max_iter, 1) * HB));
     a.corr_idx = c->icp_corr_idx.as<int>(), a.hist = c->icp_hist.as<float>();
     HIPCHK(c, c->pose_inv.ensure(sizeof(float) * 12 * (size_t)H));
@@ -1215,7 +1292,9 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     // these paths walk the scene in Morton order (the per-hypothesis sums are order-insensitive up to f64 rounding)
     const CloudDevice& Q = c->scene_sorted_d;
     a.sx = Q.plane(0), a.sy = Q.plane(1), a.sz = Q.plane(2), a.snx = Q.plane(3), a.sny = Q.plane(4), a.snz = Q.plane(5);
+    a.s_pts4 = c->scene_sorted_aos_d.as<float4>(), a.s_nrm4 = a.s_pts4 + std::max(S.n, 1);
   }
+  const bool old_fused = getenv("HOP_ICP_OLD_FUSED") != nullptr;  // experiment switch: the round-1 kernel
   for (int h0 = 0; h0 < H; h0 += HB) {
     const int hb = std::min(HB, H - h0);
     a.h0 = h0;
@@ -1224,14 +1303,15 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
       a.iter = it;
       {
         SpanGuard sg(c, T_ICP_NN);
-        if (o->nn_mode == 3) {
-          launch_icp_fused(a, hb, c->stream);
+        if (o->nn_mode >= 3) {
+          if ((old_fused && o->nn_mode == 3) || !a.cells.rec) launch_icp_fused(a, hb, c->stream);  // (models of >= 65535 points: unpacked lists)
+          else launch_icp_fusedq(a, hb, o->nn_mode == 4, c->stream);
         } else if (cells) {
           launch_icp_corr_cells(a, hb, c->stream);
         } else if (o->nn_mode == 1) launch_icp_nn_grid(a, hb, c->stream);
         else launch_icp_nn(a, hb, c->stream);
       }
-      if (cells && o->nn_mode != 3) {
+      if (o->nn_mode == 2) {
         SpanGuard sg(c, T_ICP_ACCUM);
         launch_icp_accum(a, hb, c->stream);
       }
@@ -1338,7 +1418,8 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
     a.h0 = h0;
     if (lcp_grid) {
       SpanGuard sg(c, T_LCP_FWD);
-      if (lcp_cells) launch_lcp_cells(a, hb, c->stream);
+      if (nn_mode == 3) launch_lcp_cells_fast(a, hb, c->stream);
+      else if (lcp_cells) launch_lcp_cells(a, hb, c->stream);
       else launch_lcp_grid(a, hb, c->stream);
     } else {
       {
@@ -1352,7 +1433,8 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
     }
     {
       SpanGuard sg(c, T_LCP_SUM);
-      if (lcp_cells) launch_lcp_sum_t(a, hb, c->stream);
+      if (nn_mode == 3) launch_lcp_sum_partial(a, hb, c->stream);
+      else if (lcp_cells) launch_lcp_sum_t(a, hb, c->stream);
       else launch_lcp_sum(a, hb, c->stream);
     }
     c->timing.n_lcp_launches += 1;
@@ -1884,6 +1966,16 @@ int hop_timing_reset(hop_ctx* c) {
   std::memset(&c->timing, 0, sizeof(c->timing));
   return HOP_OK;
 }
+// development aid, not part of the ABI (include/hop.h): per-query statistics of the packed ICP lookups, all zero unless
+// the library was built with -DHOP_ICP_COUNT (tools/icp_counters.py)
+int hop_debug_icp_counters(hop_ctx* c, unsigned long long* out8, int reset) {
+  if (!c || !out8) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hop::icp_counters_read(out8, reset != 0);
+  return HOP_OK;
+}
+
 int hop_timing_get(hop_ctx* c, hop_timing* out) {
   if (!c || !out) return HOP_E_INVALID;
   resolve_spans(c);

@@ -129,7 +129,20 @@ struct CellListDev {
   const int2* range;  // dx*dy*dz: (start[c], start[c+1]) side by side -- what the lookups read
   const float4* pts;  // concatenated lists; .w = original index (int bits)
   const float4* nrm;  // normals of the same entries (or null)
+  float gox, goy, goz;     // -origin * inv_cell: grid coordinate = fma(q, inv_cell, go)
+  const float4* nrm_idx;   // normals of the cloud by ORIGINAL index (AoS copy; 16 B per point, cache resident)
+  const float4* pts_idx;   // points of the cloud by original index (AoS copy)
+  // PACKED lists (ICP model lists, cells_nnq).  Entries are 8 bytes: the three coordinates quantised to 16 bits in a
+  // per-cell frame (origin = cell corner - q_R, step = (cell + 2 q_R) / 65535) and the original index in 16 bits.  Lists
+  // are stored as 16-byte chunks of two entries, an even number of chunks per list (unused slots are empty:
+  // 0xFFFFFFFF 0xFFFFFFFF, coordinates farther than any real entry); rec[cell] = (first chunk, chunks).
+  const uint2* rec;
+  const uint4* qlist;
+  float q_cs, q_rs;        // local query coordinate in steps = fma(fraction of the grid coordinate, q_cs, q_rs)
+  float q_step2;           // step^2: squared step-unit distances -> m^2
+  float q_eq;              // bound of the position error of a dequantised entry (metres)
 };
+constexpr unsigned Q_EMPTY_HI = 0xFFFF0000u;  // high word >= this: empty slot
 
 struct CellListBuildArgs {
   const float *x, *y, *z;
@@ -212,6 +225,7 @@ struct IcpArgs {
   int* corr_idx;       // nn_mode 2: [hb][ns] list position of the accepted correspondence (or -1)
   float* hist;         // nn_mode 2: [hb][max_iter][12] increments solved so far
   const float* pose_inv;  // nn_mode 2: [H][12] inverse of the input poses
+  const float4 *s_pts4, *s_nrm4;  // nn_mode 3/4: the Morton-ordered source as AoS float4 (two 16-byte loads per point)
 };
 
 struct PsoParticle {
@@ -273,6 +287,7 @@ void launch_model_ppf_keys(const float* x, const float* y, const float* z, const
 void launch_hand_surround(const SurroundArgs& a, hipStream_t s);
 void launch_hand_surround_out(const SurroundOutArgs& a, hipStream_t s);
 
+void icp_counters_read(unsigned long long* out8, bool reset);
 // launchers (hop_kernels.hip)
 void launch_ppf_matrix(const PpfMatrixArgs& a, hipStream_t s);
 void launch_pairs(const PairArgs& a, int nbases, hipStream_t s);
@@ -291,6 +306,8 @@ void launch_lcp_grid(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_sum_t(const LcpArgs& a, int hb, hipStream_t s);
 int lcp_cells_row_stride(int hb);
+void launch_lcp_cells_fast(const LcpArgs& a, int hb, hipStream_t s);
+void launch_lcp_sum_partial(const LcpArgs& a, int hb, hipStream_t s);
 void launch_cell_list_local_flag(const CellListBuildArgs& a, const GridDev& g, int* flag, hipStream_t s);
 void launch_cell_list_local_work(const int* flag, const int* flag_scan, int ncell, int* work, hipStream_t s);
 void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool write, int exist_mode, const int* work, int nwork, int* keep_buf,
@@ -310,6 +327,8 @@ void launch_icp_nn_grid(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_corr_cells(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_accum(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_fused(const IcpArgs& a, int hb, hipStream_t s);
+void launch_icp_fusedq(const IcpArgs& a, int hb, bool composed, hipStream_t s);
+void launch_soa_to_aos4(const float* x, const float* y, const float* z, int n, float4* out, hipStream_t s);
 void launch_cell_list_bounds(const CellListBuildArgs& a, hipStream_t s);
 void launch_cell_list_count(const CellListBuildArgs& a, hipStream_t s);
 void launch_cell_list_fill(const CellListBuildArgs& a, hipStream_t s);

@@ -1593,8 +1593,7 @@ __global__ __launch_bounds__(256) void k_icp_corr_cells(IcpArgs a) {
   a.corr_idx[(size_t)hl * a.ns + i] = (pos >= 0 && best <= a.max_d2) ? pos : -1;
 }
 
-template <int R>
-__global__ __launch_bounds__(256) void k_icp_accum(IcpArgs a) {
+__global__ __launch_bounds__(256) void k_icp_accum(IcpArgs a, int R) {
   __shared__ double red[4][ICP_NACC];
   const int hl = blockIdx.y, h = a.h0 + hl;
   const IcpState& st = a.state[hl];
@@ -1647,7 +1646,6 @@ __global__ __launch_bounds__(256) void k_icp_accum(IcpArgs a) {
     a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NACC + threadIdx.x] = s;
   }
 }
-template __global__ void k_icp_accum<ICP_ACCUM_R>(IcpArgs);
 
 // nn_mode 3: correspondence search and accumulation in one launch (no correspondence array in between).  Same
 // arithmetic as the split pair; R points per lane share one block-level reduction of the 32 accumulators.
@@ -1706,6 +1704,219 @@ __global__ __launch_bounds__(256) void k_icp_fused(IcpArgs a) {
   }
 }
 template __global__ void k_icp_fused<ICP_ACCUM_R>(IcpArgs);
+
+// ------------------------------------------------------------------------------------------------
+// nn_mode 3 / 4: the fused ICP kernel on PACKED model lists (CellListDev::rec / qlist).
+//
+// PMC of the round-1 kernel (profiles/r01_pmc_sq_v9.txt): SIMDs ~80 % busy issuing VALU and ~0.75 L1 tag accesses per
+// clock and CU -- 6.3 cache accesses per lookup (every lane's load is its own line: range record, four 16-byte
+// candidates, the winner's normal), HBM traffic 0.13x the algorithmic bytes.  Both limits are attacked here:
+//   * source point and normal come from an AoS copy of the Morton-ordered scene (two 16-byte loads instead of six);
+//   * rest-frame query and its grid coordinate with v_fma (the ranking part is an aid; the exact expression decides);
+//   * ONE 16-byte record per cell carries up to two candidates inline (8 bytes each: coordinates quantised to 16 bits
+//     in the cell's own frame, step 0.33 um at the ICP sizes, + the original index): no range indirection, and a
+//     list of <= 2 costs one access; longer lists are chunks of two entries per access;
+//   * a candidate costs 3 cvt + 3 sub + mul + 2 fma + and_or + med3 + min: the key is the squared distance in step
+//     units with its lowest mantissa bit replaced by the slot, v_min_u32 / v_med3_u32 keep the best two keys;
+//   * the winner's exact point (AoS by original index) is moved by the pose with the reference's expression;
+//   * lanes whose runner-up is within `tol` of the winner (ranking cannot decide: transform rounding + quantisation)
+//     re-scan their list and evaluate the exact expression for the entries within `tol` of the winner; ties go to the
+//     lower index.
+// The result is the same correspondence the linear scan finds (same argument as cells_nn above, with the
+// quantisation error q_eq of a candidate position added to `tol`).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ V3 m4_point_fma(const float* T, V3 p) {
+  return v3(__builtin_fmaf(T[0], p.x, __builtin_fmaf(T[1], p.y, __builtin_fmaf(T[2], p.z, T[3]))),
+            __builtin_fmaf(T[4], p.x, __builtin_fmaf(T[5], p.y, __builtin_fmaf(T[6], p.z, T[7]))),
+            __builtin_fmaf(T[8], p.x, __builtin_fmaf(T[9], p.y, __builtin_fmaf(T[10], p.z, T[11]))));
+}
+__device__ __forceinline__ V3 m4_dir_fma(const float* T, V3 n) {
+  return v3(__builtin_fmaf(T[0], n.x, __builtin_fmaf(T[1], n.y, T[2] * n.z)), __builtin_fmaf(T[4], n.x, __builtin_fmaf(T[5], n.y, T[6] * n.z)),
+            __builtin_fmaf(T[8], n.x, __builtin_fmaf(T[9], n.y, T[10] * n.z)));
+}
+__device__ __forceinline__ float rank_d2(V3 q, const float4& t) {
+  const float dx = q.x - t.x, dy = q.y - t.y, dz = q.z - t.z;
+  return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+}
+constexpr unsigned Q_KEY_INF = 0x7f000000u;
+// -DHOP_ICP_COUNT (tools/icp_counters.py builds such a library): per-query statistics of the packed lookups
+__device__ unsigned long long g_icp_count[8];
+#ifdef HOP_ICP_COUNT
+#define ICP_COUNT(slot, v) atomicAdd(&g_icp_count[slot], (unsigned long long)(v))
+#define ICP_COUNT_WAVE(slot) do { if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0)) == 0) atomicAdd(&g_icp_count[slot], 1ull); } while (0)
+#else
+#define ICP_COUNT(slot, v) do { } while (0)
+#define ICP_COUNT_WAVE(slot) do { } while (0)
+#endif
+void icp_counters_read(unsigned long long* out8, bool reset) {
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_icp_count), sizeof(unsigned long long) * 8);
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_icp_count), z, sizeof(z));
+  }
+}
+// squared distance (step units) of the local query l to a packed entry (lo = x | y << 16, hi = z | index << 16)
+__device__ __forceinline__ float q_rank(V3 l, unsigned lo, unsigned hi) {
+  const float dx = l.x - (float)(lo & 0xffffu), dy = l.y - (float)(lo >> 16), dz = l.z - (float)(hi & 0xffffu);
+  return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+}
+// one chunk of two entries: keys = squared distance (step units) with the lowest mantissa bit replaced by the slot.
+// Empty slots carry coordinates 0xFFFF (>= 52 000 steps from any query on the diagonal, farther than any real entry of
+// a list can be: those lie within gate + margin + the cell diagonal), so they need no test here.
+__device__ __forceinline__ void q_chunk(V3 l, const uint4& ch, unsigned& b1, unsigned& b2, unsigned& why, unsigned& whw) {
+  const unsigned k0 = __float_as_uint(q_rank(l, ch.x, ch.y)) & ~1u, k1 = __float_as_uint(q_rank(l, ch.z, ch.w)) | 1u;
+  const unsigned prev = b1;
+  b2 = umed3(b1, b2, k0);
+  b1 = min(b1, k0);
+  b2 = umed3(b1, b2, k1);
+  b1 = min(b1, k1);
+  const bool changed = b1 != prev;
+  why = changed ? ch.y : why, whw = changed ? ch.w : whw;
+}
+// exact evaluation of the entries of a chunk that the ranking cannot separate from the winner (rare path)
+__device__ __forceinline__ void q_chunk_exact(const CellListDev& c, V3 l, const uint4& ch, float lim, int widx, const float* T, V3 q, float& best,
+                                              int& bidx, V3& moved) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const unsigned lo = e ? ch.z : ch.x, hi = e ? ch.w : ch.y;
+    const int j = (int)(hi >> 16);
+    if (hi >= Q_EMPTY_HI || j == widx || !(q_rank(l, lo, hi) <= lim)) continue;
+    const float4 t = c.pts_idx[j];
+    const V3 tm = m4_point(T, v3(t.x, t.y, t.z));
+    const float d2 = sqdist_flann(q, tm);
+    if (d2 < best || (d2 == best && j < bidx)) best = d2, bidx = j, moved = tm;
+  }
+}
+
+// returns the ORIGINAL index of the nearest neighbour (or -1), its exact squared distance and the neighbour moved by T
+__device__ __forceinline__ void cells_nnq(const CellListDev& c, V3 qg, const float* T, V3 q, float& best, int& bidx, V3& moved) {
+  const float hx = __builtin_fmaf(qg.x, c.inv_cell, c.gox), hy = __builtin_fmaf(qg.y, c.inv_cell, c.goy), hz = __builtin_fmaf(qg.z, c.inv_cell, c.goz);
+  const float gx = floorf(hx), gy = floorf(hy), gz = floorf(hz);
+  const int ix = (int)gx, iy = (int)gy, iz = (int)gz;
+  if ((unsigned)ix >= (unsigned)c.dx || (unsigned)iy >= (unsigned)c.dy || (unsigned)iz >= (unsigned)c.dz) return;
+  const uint2 r = c.rec[(iz * c.dy + iy) * c.dx + ix];
+  const int nch = (int)r.y;
+  ICP_COUNT(0, 1);
+  if (nch == 0) return;
+  const V3 l = v3(__builtin_fmaf(hx - gx, c.q_cs, c.q_rs), __builtin_fmaf(hy - gy, c.q_cs, c.q_rs), __builtin_fmaf(hz - gz, c.q_cs, c.q_rs));
+  unsigned b1 = Q_KEY_INF, b2 = Q_KEY_INF;
+  unsigned why = 0xFFFFFFFFu, whw = 0xFFFFFFFFu;  // high words (index) of the chunk that holds the winner
+  const uint4* __restrict__ lp = c.qlist + r.x;
+  ICP_COUNT(2, nch);
+  for (int k = 0; k < nch; k += 2) {  // two chunks (four candidates, two loads in flight) per trip
+    ICP_COUNT_WAVE(3);
+    const uint4 ca = lp[k], cb = lp[k + 1];  // (lists hold an even number of chunks)
+    q_chunk(l, ca, b1, b2, why, whw);
+    q_chunk(l, cb, b1, b2, why, whw);
+  }
+  ICP_COUNT(1, 1);
+  const unsigned whi = (b1 & 1u) ? whw : why;
+  const float f1 = __uint_as_float(b1 & ~1u) * c.q_step2, f2 = __uint_as_float(b2 & ~1u) * c.q_step2;
+  const int widx = (int)(whi >> 16);
+  const float4 w = c.pts_idx[widx];
+  moved = m4_point(T, v3(w.x, w.y, w.z));
+  best = sqdist_flann(q, moved);
+  bidx = widx;
+  const float mag = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), 0.25f));
+  const float delta = mag * 2.0e-6f;
+  const float s1 = __builtin_amdgcn_sqrtf(f1), s2 = __builtin_amdgcn_sqrtf(fminf(f2, 1.0e30f));
+  // transform rounding as in cells_nn (1.02e-4 also covers the mantissa bit the keys gave up) + the quantisation of the
+  // two candidate positions being compared
+  const float tol = 2.002f * s1 * delta + 1.02e-4f * f1 + delta * delta + 2.1f * c.q_eq * (s1 + s2) + 2.1f * c.q_eq * c.q_eq;
+  if (f2 - f1 <= tol) {
+    ICP_COUNT(4, 1);
+    ICP_COUNT_WAVE(5);
+    const float lim = (f1 + tol) / c.q_step2;  // back to step units
+    for (int k = 0; k < nch; ++k) q_chunk_exact(c, l, lp[k], lim, widx, T, q, best, bidx, moved);
+  }
+}
+
+// COMPOSED = false (nn_mode 3): the source point at iteration k is the chain T_k(...T_1(p0)) of the solved increments,
+//   the float operations of moving a stored cloud once per iteration (what the oracle / PCL do): same bits as modes 0-2.
+// COMPOSED = true (nn_mode 4, the default of the bench): one application of the accumulated transform
+//   final_tf = T_k * ... * T_1 (IcpState, float products) with fused multiply-adds.  Positions differ from the chain by
+//   float rounding (<= 1e-7 relative), so a correspondence at an exact tie or a residual at the gate can differ:
+//   same iteration counts, poses within the tolerances tests/test_gpu_parity.py::test_icp_composed_increments states.
+#ifndef ICP_WAVES_ATTR
+#define ICP_WAVES_ATTR
+#endif
+template <bool COMPOSED>
+__global__ __launch_bounds__(256) ICP_WAVES_ATTR void k_icp_fusedq(IcpArgs a, int R) {
+  __shared__ double red[4][ICP_NACC];
+  const int hl = blockIdx.y, h = a.h0 + hl;
+  const IcpState& st = a.state[hl];
+  if (!st.active) return;
+  const float* __restrict__ pose = a.pose + (size_t)h * 16;
+  const float* __restrict__ sTi = a.pose_inv + (size_t)h * 12;
+  const float* __restrict__ hist = a.hist + (size_t)hl * a.max_iter * 12;
+  const float* __restrict__ F = st.final_tf;
+  double acc[ICP_NACC];
+#pragma unroll
+  for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
+  for (int r = 0; r < R; ++r) {
+    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    if (i >= a.ns) continue;
+    const float4 p4 = a.s_pts4[i], n4 = a.s_nrm4[i];
+    V3 q = v3(p4.x, p4.y, p4.z), qn = v3(n4.x, n4.y, n4.z);
+    if (COMPOSED) {
+      if (a.iter > 0) q = m4_point_fma(F, q), qn = m4_dir_fma(F, qn);
+    } else {
+      icp_chain_point_normal(hist, a.iter, q, qn);
+    }
+    float d2 = 3.0e38f;
+    int j = -1;
+    V3 tq;  // the correspondence moved by the pose, as the distance was measured
+    cells_nnq(a.cells, m4_point_fma(sTi, q), pose, q, d2, j, tq);
+    if (j < 0 || !(d2 <= a.max_d2)) continue;
+    const float4 tn = a.cells.nrm_idx[j];
+    const V3 nt = m4_dir(pose, v3(tn.x, tn.y, tn.z));
+    if (!(vdot(qn, nt) >= a.cos_thr)) continue;
+    ICP_COUNT(6, 1);
+    ICP_COUNT_WAVE(7);
+    const V3 c = vcross(q, nt);
+    const double J[6] = {c.x, c.y, c.z, nt.x, nt.y, nt.z};
+    const double res = (double)vdot(q - tq, nt);
+    int k = 0;
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+#pragma unroll
+      for (int v = 0; v <= u; ++v) {
+        acc[k] = fma(J[u], J[v], acc[k]);
+        ++k;
+      }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) acc[21 + u] = fma(-J[u], res, acc[21 + u]);
+    acc[27] += (double)d2;
+    acc[28] += 1.0;
+    acc[29] += (double)q.x, acc[30] += (double)q.y, acc[31] += (double)q.z;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < ICP_NACC; ++k) {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < ICP_NACC) {
+    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NACC + threadIdx.x] = s;
+  }
+}
+template __global__ void k_icp_fusedq<false>(IcpArgs, int);
+template __global__ void k_icp_fusedq<true>(IcpArgs, int);
+
+__global__ void k_soa_to_aos4(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n, float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = make_float4(x[i], y[i], z[i], 0.f);
+}
+void launch_soa_to_aos4(const float* x, const float* y, const float* z, int n, float4* out, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_soa_to_aos4, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, out);
+}
 
 __device__ bool chol6(double A[6][6], const double b[6], double x[6]) {
   double L[6][6];
@@ -1847,6 +2058,119 @@ __global__ void k_icp_init(IcpState* st, int hb) {
   s.active = 1;
   s.converged = 0;
   st[hl] = s;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// computeLCP nn_mode 3: the same lookups, but the 2N terms of a hypothesis are reduced inside the wavefront and the
+// per-(64-point tile, hypothesis) partial sums go to a small table partial[tile][hypothesis] (N/64 x H floats, 13 MB at
+// C2 instead of the 1.6 GB term table); k_lcp_sum_partial adds the tiles of a hypothesis in tile order in double.
+// The score is the reference's sum in a different association: equal to ~1e-6 relative, not bit for bit
+// (SURVEY.md 8(c) L2 asks 1e-4).  nn_mode 2 keeps the reference's order for the bit tests.
+// Forward lookup: cells_nn with fused multiply-adds in the ranking part (the exact expression still decides).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cells_nn1f(const CellListDev& c, V3 qg, const float* T, V3 q, float& best, int& bpos, V3& moved) {
+  const float gx = floorf(__builtin_fmaf(qg.x, c.inv_cell, c.gox)), gy = floorf(__builtin_fmaf(qg.y, c.inv_cell, c.goy)),
+              gz = floorf(__builtin_fmaf(qg.z, c.inv_cell, c.goz));
+  const int ix = (int)gx, iy = (int)gy, iz = (int)gz;
+  if ((unsigned)ix >= (unsigned)c.dx || (unsigned)iy >= (unsigned)c.dy || (unsigned)iz >= (unsigned)c.dz) return;
+  const int2 rg = c.range[(iz * c.dy + iy) * c.dx + ix];
+  const int beg = rg.x, end = rg.y;
+  if (beg >= end) return;
+  float b1 = 3.0e38f, b2 = 3.0e38f;
+  int k1 = beg;
+  float wx = 0.f, wy = 0.f, wz = 0.f;
+  for (int k = beg; k < end; ++k) {
+    const float4 t = c.pts[k];
+    const float d = rank_d2(qg, t);
+    b2 = __builtin_amdgcn_fmed3f(b1, b2, d);
+    const bool better = d < b1;
+    k1 = better ? k : k1;
+    wx = better ? t.x : wx, wy = better ? t.y : wy, wz = better ? t.z : wz;
+    b1 = fminf(b1, d);
+  }
+  const float mag = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), 0.25f));
+  const float delta = mag * 2.0e-6f;
+  const float tol = 2.002f * __builtin_amdgcn_sqrtf(b1) * delta + 1.0e-4f * b1 + delta * delta;
+  moved = m4_point(T, v3(wx, wy, wz));
+  best = sqdist_flann(q, moved);
+  bpos = k1;
+  if (b2 - b1 <= tol) {
+    int bj = __float_as_int(c.pts[k1].w);
+    const float lim = b1 + tol;
+    for (int k = beg; k < end; ++k) {
+      if (k == k1) continue;
+      const float4 t = c.pts[k];
+      if (!(rank_d2(qg, t) <= lim)) continue;
+      const V3 tm = m4_point(T, v3(t.x, t.y, t.z));
+      const float d2 = sqdist_flann(q, tm);
+      const int j = __float_as_int(t.w);
+      if (d2 < best || (d2 == best && j < bj)) best = d2, bj = j, bpos = k, moved = tm;
+    }
+  }
+}
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_lcp_cells_fast(LcpArgs a, int hb, int hs, int npt) {
+  const int pt = blockIdx.x % npt, ht = blockIdx.x / npt;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int k = pt * 64 + lane;
+  const bool kin = k < a.ns;
+  V3 s = v3(0, 0, 0), sn = v3(0, 0, 0);
+  if (kin) s = v3(a.qx[k], a.qy[k], a.qz[k]), sn = v3(a.qnx[k], a.qny[k], a.qnz[k]);
+  for (int j = 0; j < LCP_TH / 4; ++j) {
+    const int hh = wave * (LCP_TH / 4) + j, hl = ht * LCP_TH + hh;
+    if (hl >= hb) break;  // wave-uniform
+    float v = 0.f;
+    if (kin) {
+      const float* __restrict__ T = a.pose + (size_t)(a.h0 + hl) * 16;
+      const float* __restrict__ Ti = a.pose_inv + (size_t)(a.h0 + hl) * 12;
+      float best = 3.0e38f;
+      int pos = -1;
+      V3 pm;
+      cells_nn1f(a.model_cells, m4_point_fma(Ti, s), T, s, best, pos, pm);
+      if (pos >= 0 && best < a.dist * a.dist) {
+        const float4 mnr = a.model_cells.nrm[pos];
+        const V3 nmod = vnormalized(m4_dir(T, v3(mnr.x, mnr.y, mnr.z)));
+        const float f = lcp_term_unit(sn, nmod, best, a.dist, a.cos_thres);
+        if (f >= 0.f) v = f;
+        float rbest = 3.0e38f;
+        int rk = -1;
+        cells_nn_plain(a.scene_cells, pm, rbest, rk);
+        if (rk >= 0) {
+          const float4 rn = a.scene_cells.nrm[rk];
+          const float g = lcp_term_unit(nmod, v3(rn.x, rn.y, rn.z), rbest, a.dist, a.cos_thres);
+          if (g >= 0.f) v += g;
+        }
+      }
+    }
+    v = wave_sum_f(v);
+    if (lane == 0) a.terms[(size_t)pt * hs + hl] = v;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_lcp_sum_partial(LcpArgs a, int hb, int hs, int npt) {
+  const int hl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hl >= hb) return;
+  double cp = 0.0;
+  for (int t = 0; t < npt; ++t) cp += (double)a.terms[(size_t)t * hs + hl];
+  a.score[a.h0 + hl] = (float)cp;
+}
+void launch_lcp_cells_fast(const LcpArgs& a, int hb, hipStream_t s) {
+  const int npt = (a.ns + 63) / 64, nht = (hb + LCP_TH - 1) / LCP_TH;
+  const int hs = ((hb + LCP_TH - 1) / LCP_TH) * LCP_TH;
+  hipLaunchKernelGGL(k_lcp_cells_fast, dim3((unsigned)(npt * nht)), dim3(256), 0, s, a, hb, hs, npt);
+}
+void launch_lcp_sum_partial(const LcpArgs& a, int hb, hipStream_t s) {
+  const int npt = (a.ns + 63) / 64;
+  const int hs = ((hb + LCP_TH - 1) / LCP_TH) * LCP_TH;
+  hipLaunchKernelGGL(k_lcp_sum_partial, dim3((hb + 63) / 64), dim3(64), 0, s, a, hb, hs, npt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2161,8 +2485,17 @@ void launch_icp_corr_cells(const IcpArgs& a, int hb, hipStream_t s) {
 void launch_icp_fused(const IcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_fused<ICP_ACCUM_R>, dim3(icp_blocks_per_hyp(a.ns, true), hb), dim3(256), 0, s, a);
 }
+void launch_icp_fusedq(const IcpArgs& a, int hb, bool composed, hipStream_t s) {
+  // the same number of blocks per hypothesis as the other cell-list kernels (the partial sums are laid out for it), the
+  // points spread evenly over them: 20 000 points = 3 blocks of 27 x 256 instead of 32 x 256, 32 x 256, 14 x 256
+  const int nb = icp_blocks_per_hyp(a.ns, true);
+  const int R = (a.ns + 256 * nb - 1) / (256 * nb);
+  if (composed) hipLaunchKernelGGL((k_icp_fusedq<true>), dim3(nb, hb), dim3(256), 0, s, a, R);
+  else hipLaunchKernelGGL((k_icp_fusedq<false>), dim3(nb, hb), dim3(256), 0, s, a, R);
+}
 void launch_icp_accum(const IcpArgs& a, int hb, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_accum<ICP_ACCUM_R>, dim3(icp_blocks_per_hyp(a.ns, true), hb), dim3(256), 0, s, a);
+  const int nb = icp_blocks_per_hyp(a.ns, true);  // same partition of the points as launch_icp_fusedq: same partial sums
+  hipLaunchKernelGGL(k_icp_accum, dim3(nb, hb), dim3(256), 0, s, a, (a.ns + 256 * nb - 1) / (256 * nb));
 }
 void launch_cell_list_bounds(const CellListBuildArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_cell_list_bounds, dim3(a.dx * a.dy * a.dz), dim3(256), 0, s, a);

@@ -1,0 +1,178 @@
+"""GPU parity tests at the sizes BASELINE.json's configs name (C2: 20 000-point scene / 5 000-point model / 128-base
+batches; C5: 50 000-point scene x 8 192 hypotheses per GPU), against the CPU oracle where it finishes in seconds and
+through size-independent properties beyond that.  Run with `pytest -m gpu` on an MI355X."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def api(hop):
+    from hop_amd import api as _api
+    _api.lib()
+    return _api
+
+
+@pytest.fixture(scope="module")
+def synth(hop):
+    return hop.synth
+
+
+@pytest.fixture()
+def ctx(api):
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _rot_err_deg(Ra, Rb):
+    c = (np.trace(Ra.T.astype(np.float64) @ Rb.astype(np.float64)) - 1) / 2
+    return math.degrees(math.acos(max(-1.0, min(1.0, float(c)))))
+
+
+def test_c2_generator_full_size_matches_oracle(ctx, api, orc, synth):
+    """The generator exactly as bench.py runs it -- 20 000-point scene, 5 000-point model, sample_size 100, explicit
+    trials shipped in 128-base batches (no early stop), the threshold PPF bins and the AVX-512 selection fast path --
+    against the oracle: 256 base trials, every base, every list size, every hypothesis."""
+    sc = synth.make_scene(20000, seed=7)
+    mx, mn = synth.ellipsoid_model(5000)
+    keys = synth.ppf_key_table()
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8)
+    ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
+    ctx.set_ppf_keys(keys)
+    T = 256
+    o = ctx.default_s4pcs_opts(sample_size=100, success_quadrilaterals=T, max_time_seconds=0, n_trials=T, random_seed=5489)
+    pose, lcp, st = ctx.s4pcs_generate(o, cap=1 << 21)
+    keep = sc.conf >= 0.8
+    oo = orc.OracleS4PCS(sample_size=100, success_quadrilaterals=T, n_trials=T, random_seed=5489)
+    oo.set_keys(keys)
+    n = oo.run(sc.xyz[keep], sc.nrm[keep], sc.conf[keep], mx, mn, 1)
+    op, ol = oo.hypos()
+    # (the reference's loop leaves at i / n_trials >= 0.99, congruentSetExplorationBase.hpp:177-186: 255 of 256 trials)
+    assert st.n_trials_run >= 250 and len(lcp) == n and n > 10000
+    assert np.array_equal(ol, lcp)
+    assert np.array_equal(op[:, :3, :3], pose[:, :3, :3])
+    assert np.abs(op[:, :3, 3] - pose[:, :3, 3]).max() < 1e-6
+    ob, gb = oo.bases(), ctx.s4pcs_bases()
+    assert len(ob) == len(gb) and len(gb) > 100
+    for a, b in zip(ob, gb):
+        assert np.array_equal(a["base"], b["base"]) and np.array_equal(a["inv"], b["inv"])
+        assert len(a["pairs1"]) == b["n_pairs1"] and len(a["pairs2"]) == b["n_pairs2"] and len(a["quads"]) == b["n_quads"]
+
+
+def test_c2_icp_and_lcp_full_size_match_oracle(ctx, api, orc, synth):
+    """refineByICP and computeLCP at C2's cloud sizes on 64 hypotheses against the oracle (kd-tree NN): the default
+    modes of the bench (ICP nn_mode 4 = composed increments, computeLCP nn_mode 3 = reduced sums) within their stated
+    tolerances, the exact modes (3 / 2) bit-for-bit in iterations and scores."""
+    sc = synth.make_scene(20000, seed=7)
+    mx, mn = synth.ellipsoid_model(5000)
+    keep = sc.conf >= 0.8
+    S, Sn = sc.xyz[keep], sc.nrm[keep]
+    poses = synth.replay_poses(sc.gt_pose, 64, seed=17, max_rot_deg=12.0, max_trans=0.006)
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8)
+    ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
+    ctx.set_model(api.HOP_MODEL_1MM, mx, mn)
+    ref, rit, rcv = orc.icp_refine_batch(S, Sn, mx, mn, poses, 10, 45.0, 0.01, use_tree=True)
+    ctx.hypos_upload(poses)
+    it3, cv3 = ctx.icp_refine(10, 45.0, 0.01, nn_mode=3, want_stats=True)
+    p3, _, _ = ctx.hypos_download()
+    assert np.array_equal(it3, rit) and np.array_equal(cv3, rcv)
+    assert np.abs(p3 - ref).max() < 2e-5
+    ctx.hypos_upload(poses)
+    it4, cv4 = ctx.icp_refine(10, 45.0, 0.01, nn_mode=4, want_stats=True)
+    p4, _, _ = ctx.hypos_download()
+    assert (it4 == rit).mean() >= 0.95 and np.array_equal(cv4, rcv)
+    for a, b in zip(p4, ref):   # north_star's tolerance: 1 mm / 1 degree
+        assert np.linalg.norm(a[:3, 3] - b[:3, 3]) < 1e-3 and _rot_err_deg(a[:3, :3], b[:3, :3]) < 1.0
+    assert np.median(np.abs(p4 - ref).reshape(len(ref), -1).max(axis=1)) < 2e-5
+    # computeLCP on the refined poses
+    sref = orc.compute_lcp_batch(S, Sn, mx, mn, p3, 0.001, 10.0, use_tree=True)
+    ctx.hypos_upload(p3)
+    _, s2, i2 = ctx.lcp_select_best(0.001, 10.0, 2)
+    sc2 = ctx.hypos_download()[1].copy()
+    assert np.array_equal(sc2, sref) and sref.max() > 1000
+    ctx.hypos_upload(p3)
+    _, s3, i3 = ctx.lcp_select_best(0.001, 10.0, 3)
+    sc3 = ctx.hypos_download()[1].copy()
+    big = sref > 1.0
+    assert np.abs(sc3[big] - sref[big]).max() / sref.max() < 1e-4     # 1e-4 relative
+    assert np.all(np.abs(sc3[big] - sref[big]) <= 1e-4 * sref[big])
+    assert i3 == i2 == int(np.argmax(sref))
+
+
+def test_icp_composed_increments_close_to_chained(ctx, api, synth):
+    """nn_mode 4 applies the accumulated transform once (fused multiply-adds) instead of chaining the increments as PCL /
+    the oracle do (nn_mode 3): a wide hypothesis set must keep its iteration counts (>= 99 %) and its poses (median
+    <= 1e-6, every pose within 1 mm / 1 degree)."""
+    sc = synth.make_scene(20000, seed=7)
+    mx, mn = synth.ellipsoid_model(5000)
+    poses = synth.replay_poses(sc.gt_pose, 512, seed=23, max_rot_deg=30.0, max_trans=0.015)
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8)
+    ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
+    out = {}
+    for mode in (3, 4):
+        ctx.hypos_upload(poses)
+        it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=mode, want_stats=True)
+        out[mode] = (it.copy(), cv.copy(), ctx.hypos_download()[0].copy())
+    assert (out[3][0] == out[4][0]).mean() >= 0.99 and np.array_equal(out[3][1], out[4][1])
+    d = np.abs(out[3][2] - out[4][2]).reshape(len(poses), -1).max(axis=1)
+    assert np.median(d) <= 1e-6
+    for a, b in zip(out[3][2], out[4][2]):
+        assert np.linalg.norm(a[:3, 3] - b[:3, 3]) < 1e-3 and _rot_err_deg(a[:3, :3], b[:3, :3]) < 1.0
+
+
+def test_c5_full_size_8192_hypotheses_50k_scene(ctx, api, synth):
+    """BASELINE.json configs[4], one GPU's share: 8 192 replay hypotheses (seed 13) x 50 000-point scene x 5 000-point
+    model through ICP and computeLCP in the bench's default modes.  A 256-hypothesis subsample is compared with the
+    brute-force kernels (ICP nn_mode 0, computeLCP nn_mode 0); the whole set through properties: idempotence of the
+    scoring, the reduced sums against the ordered sums (1e-4), score order (refined poses beat their starts), and the
+    best pose within 1 mm / 1 degree of the ground truth."""
+    sc = synth.make_scene(50000, seed=13)
+    mx, mn = synth.ellipsoid_model(5000)
+    H = 8192
+    poses = synth.replay_poses(sc.gt_pose, H, seed=13, max_rot_deg=30.0, max_trans=0.015)
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.0)
+    ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
+    ctx.set_model(api.HOP_MODEL_1MM, mx, mn)
+    ctx.hypos_upload(poses)
+    it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=4, want_stats=True)
+    refined = ctx.hypos_download()[0].copy()
+    best, score, idx = ctx.lcp_select_best(0.001, 10.0, 3)
+    s3 = ctx.hypos_download()[1].copy()
+    assert cv.mean() > 0.9 and it.max() <= 10
+    # idempotence: scoring the same resident set again returns the same bits
+    best_b, score_b, idx_b = ctx.lcp_select_best(0.001, 10.0, 3)
+    assert idx_b == idx and score_b == score and np.array_equal(ctx.hypos_download()[1], s3)
+    # reduced sums vs the reference's ordered sums, all 8192
+    ctx.lcp_select_best(0.001, 10.0, 2)
+    s2 = ctx.hypos_download()[1].copy()
+    big = s2 > 1.0
+    assert np.all(np.abs(s3[big] - s2[big]) <= 1e-4 * s2[big])
+    assert int(np.argmax(s2)) == idx
+    # the winner is the ground truth (modulo the ellipsoid's 180 degree symmetries)
+    gt = sc.gt_pose.astype(np.float64)
+    flips = [np.diag(v) for v in ([1, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1])]
+    err = min(_rot_err_deg(best[:3, :3], gt[:3, :3] @ F) for F in flips)
+    assert err < 1.0 and np.linalg.norm(best[:3, 3] - gt[:3, 3]) < 1e-3
+    # score order: refinement raises the score (the starts are up to 30 degrees / 15 mm off; ICP takes nearly all of them
+    # into the basin of the ground truth, so the refined scores bunch up and only this direction is a stable property)
+    ctx.hypos_upload(poses)
+    ctx.lcp_select_best(0.001, 10.0, 3)
+    s_start = ctx.hypos_download()[1].copy()
+    assert np.mean(s3 >= s_start) > 0.95 and np.median(s3) > 4 * np.median(s_start)
+    # subsample against the brute-force kernels
+    sub = np.arange(0, H, H // 256)[:256]
+    ctx.hypos_upload(poses[sub])
+    it0, cv0 = ctx.icp_refine(10, 45.0, 0.01, nn_mode=0, want_stats=True)
+    p0 = ctx.hypos_download()[0].copy()
+    assert (it0 == it[sub]).mean() >= 0.98 and np.array_equal(cv0, cv[sub])
+    assert np.median(np.abs(p0 - refined[sub]).reshape(256, -1).max(axis=1)) < 5e-6
+    ctx.hypos_upload(refined[sub])
+    ctx.lcp_select_best(0.001, 10.0, 0)
+    s0 = ctx.hypos_download()[1].copy()
+    assert np.array_equal(s0, s2[sub])     # ordered sums: cell lists == brute force, bit for bit
