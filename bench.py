@@ -35,7 +35,7 @@ VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak, same guide
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--scene", type=int, default=20000)
     ap.add_argument("--model", type=int, default=5000)
@@ -49,6 +49,8 @@ def parse():
                     "composed into one transform per iteration (poses equal to ~1e-6, tests/test_gpu_fullsize.py)")
     ap.add_argument("--lcp-mode", type=int, default=3, help="computeLCP: 0 brute force, 1 voxel grids, 2 NN cell lists with the reference's ordered "
                     "float sum (bit-equal scores in modes 0-2), 3 NN cell lists with in-wave partial sums (scores within 1e-4 relative)")
+    ap.add_argument("--pso-sum-mode", type=int, default=1, help="outer-side penalty of objFuncPSO: 0 added in scene order (the reference's float "
+                    "sum, bit-equal), 1 block reduction (equal to ~1e-6 relative)")
     ap.add_argument("--inflight", type=int, default=8, help="frames in flight per GPU (one context each): the host base selection of one "
                     "frame overlaps the device work of the others; 1 = strictly one frame at a time")
     ap.add_argument("--no-serial-frame", action="store_true", help="skip the extra undisturbed frame used for per-kernel timing")
@@ -91,6 +93,7 @@ class Workload:
         CFG["hand_match"]["pso"]["n_pop"] = self.args.particles
         for _ in range(n_slots):
             c = api.Context(device)
+            c.hand_set_sum_mode(self.args.pso_sum_mode)
             c.set_scene(self.sc.xyz, self.sc.nrm, self.sc.conf, 0.8)
             c.set_model(api.HOP_MODEL_5MM, *self.model)
             c.set_model(api.HOP_MODEL_1MM, *self.model)
@@ -197,6 +200,57 @@ def physics_row(w, args, with_cpu):
                                "sample": f"first {n} of the {H} hypotheses, oracle (libigl restatement, OpenMP over hypotheses)",
                                "decisions_equal": bool(np.array_equal(ko, keep[:n]))}
     return out
+
+
+def host_cpp_leg(w):
+    """The C++ host above the C-ABI (icra20-hand-object-pose_amd/host/app/main_realdata_auto.cpp, the reference driver's call
+    order) on the same clouds: the AS-SHIPPED chain of config_autodataset.yaml (15+1 particles x 4 fingers, <= 30 base trials
+    with early stop, cluster, ICP on <= 100 hypotheses, cluster, selectBest), one frame at a time, wall clock per frame as the
+    application measures it.  Separate from `value` (different hypothesis counts); it shows the cost of a frame driven
+    from C++ instead of the Python mirrors."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "icra20-hand-object-pose_amd", "lib", "main_realdata_auto")
+    cfg = os.path.join(ROOT, "icra20-hand-object-pose_amd", "config", "config_autodataset.yaml")
+    if not os.path.exists(exe):
+        return {"error": "host application not built"}
+
+    def wc(path, xyz, nrm=None, conf=None):
+        xyz = np.asarray(xyz, np.float32)
+        nrm = np.zeros_like(xyz) if nrm is None else np.asarray(nrm, np.float32)
+        with open(path, "wb") as f:
+            np.array([len(xyz), 0 if conf is None else 1], np.int32).tofile(f)
+            np.ascontiguousarray(xyz.T).tofile(f)
+            np.ascontiguousarray(nrm.T).tofile(f)
+            if conf is not None:
+                np.asarray(conf, np.float32).tofile(f)
+
+    with tempfile.TemporaryDirectory() as d:
+        wc(os.path.join(d, "model.bin"), *w.model)
+        wc(os.path.join(d, "model001.bin"), *w.model)
+        wc(os.path.join(d, "object_segment.bin"), w.sc.xyz, w.sc.nrm, w.sc.conf)
+        with open(os.path.join(d, "ppf_keys.bin"), "wb") as f:
+            np.array([len(w.keys)], np.int32).tofile(f)
+            np.ascontiguousarray(w.keys, np.int32).tofile(f)
+        with open(os.path.join(d, "hand.txt"), "w") as f:
+            for name in w.hand.clouds:
+                if name == "base_link":
+                    continue
+                x, n = w.hand.clouds[name]
+                wc(os.path.join(d, f"{name}.bin"), x, n)
+                f.write(f"{name} {w.hand.parents[name]} {name}.bin " + " ".join(repr(float(v)) for v in w.hand.tf_in_parent[name].reshape(16)) + "\n")
+        wc(os.path.join(d, "hand_scene.bin"), w.hxyz)
+        wc(os.path.join(d, "hand_region.bin"), w.hxyz, w.hnrm)
+        wc(os.path.join(d, "hand_swivel.bin"), w.swivel)
+        open(os.path.join(d, "cam_side.txt"), "w").write("1\n")
+        env = dict(os.environ, HOP_APP_REPEAT="6")
+        r = subprocess.run([exe, cfg, d, d], capture_output=True, text=True, timeout=600, env=env)
+        ms = [float(ln.split()[1]) for ln in r.stdout.splitlines() if ln.startswith("frame_ms")]
+        if r.returncode != 0 or len(ms) < 2:
+            return {"error": f"rc {r.returncode}: {(r.stdout + r.stderr)[-300:]}"}
+        return {"what": "as-shipped chain (config_autodataset.yaml) driven by host/app/main_realdata_auto (C++ over the C-ABI), same C2 clouds, "
+                        "one frame at a time; first pass (model-side lists built) excluded",
+                "frame_ms_median": float(np.median(ms[1:])), "frame_ms_all": ms}
 
 
 def cpu_baseline(w, budget_s):
@@ -374,7 +428,9 @@ def main():
                 "k_icp_accum": (tmx["ms_icp_accum"], tmx["n_icp_nn_launches"], hyp_iters * bytes_per_hyp, 0.0),
                 "k_lcp_cells": (tmx["ms_lcp_fwd"] + tmx["ms_lcp_rev"], tmx["n_lcp_launches"], H * nf * bytes_per_hyp, 2.0 * H * nf * flops_per_hyp),
                 "k_lcp_sum": (tmx["ms_lcp_sum"], tmx["n_lcp_launches"], H * nf * (8 * N + 4), 0.0),
-                "k_verify_cells": (tmx["ms_verify"], tmx["n_verify_launches"], n_cand * (12 * (N + nq) + 68), n_cand * 8.0 * N * nq),
+                # Verify on EXIST-mode cell lists never streams P: per candidate it reads the transform (48 B), nq samples
+                # (12 B each, shared through L2) and per sample one 8-byte range record + at most one 16-byte entry
+                "k_verify_cells": (tmx["ms_verify"], tmx["n_verify_launches"], n_cand * (48 + nq * (12 + 8 + 16) + 4), 0.0),
                 "k_quads": (tmx["ms_quads"], tmx["n_quads_launches"],
                             sum(i["n_pairs"] for i in frames) * 8 + sum(i["n_quads"] for i in frames) * 36 + n_cand * 88, 0.0),
                 "k_ppf_matrix": (tmx["ms_ppf_matrix"], nf, nf * (24 * N + N * N / 8), 0.0),
@@ -410,7 +466,10 @@ def main():
                 traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        roof["frac_timed_region"] = roof["frac"]
         roof = {"bound": "hbm", **roof, "traffic": traffic,
+                "traffic_source": "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command taken separately "
+                                  "(MI355X_MICROARCH.md corrections applied by tools/pmc_summary.py), per launch; not measured in this run",
                 "definition": "achieved = algorithmic bytes per launch (SURVEY.md 8(d): 24*(N+M)+72 B per hypothesis and NN pass, x the "
                               "hypotheses -- for ICP the hypothesis-iterations -- one launch processes) / mean launch duration from HIP events "
                               "on the context stream over the timed region",
@@ -421,6 +480,7 @@ def main():
             roof["serial_frame"] = {"note": "same kernels measured on one extra frame run alone after the timed region "
                                             "(frames_in_flight > 1 stretches the spans above by cross-frame sharing of the device)",
                                     **roofline_of(ks, dom, [info_serial])}
+            roof["frac_serial_frame"] = roof["serial_frame"]["frac"]
         hyp_iters = sum(i["icp_hyp_iters"] for i in infos)
         stage = lambda key: 1e3 * float(np.mean([i[key] for i in infos]))
         out = {
@@ -439,12 +499,16 @@ def main():
             "config": {"workload": "C2: ellipse, 2048 Super4PCS base trials + 200-particle hand search, 20k-pt scene / 5k-pt model",
                        "scene_points": N, "model_points": M, "base_trials": args.bases, "sample_size": nq,
                        "hypotheses_scored_per_rank": H, "pso_particles": args.particles, "hand_scene_points": args.hand_scene,
-                       "verify_mode": args.verify_mode, "nn_mode": args.nn_mode, "lcp_mode": args.lcp_mode, "frames_in_flight": F,
+                       "verify_mode": args.verify_mode, "nn_mode": args.nn_mode, "lcp_mode": args.lcp_mode, "pso_sum_mode": args.pso_sum_mode, "frames_in_flight": F,
                        "parallelism": f"hypothesis-parallel x{world}, all-gather top-{K}"},
             "roofline": roof,
             "stage_ms_per_frame": {"frame_handover": stage("t_frame"), "pso": stage("t_pso"), "generate": stage("t_gen"),
                                    "generate_host_select": float(np.mean([i["ms_select"] for i in infos])),
                                    "icp": stage("t_icp"), "lcp": stage("t_lcp")},
+            "frame_latency_ms": {"note": "ms_per_step is a throughput figure (frames overlap); these are per-frame latencies, hand-over to best pose",
+                                 "with_frames_in_flight": float(np.mean([1e3 * (i["t_frame"] + i["t_pso"] + i["t_gen"] + i["t_icp"] + i["t_lcp"]) for i in infos])),
+                                 "one_frame_alone": (1e3 * (info_serial["t_frame"] + info_serial["t_pso"] + info_serial["t_gen"] + info_serial["t_icp"]
+                                                            + info_serial["t_lcp"]) if info_serial else None)},
             "device_ms_total": {k: v for k, v in tm.items() if k.startswith("ms_")},
             "icp_hypothesis_iterations_per_step": hyp_iters / steps,
             "hypotheses_generated_per_step": infos[-1]["h_gen"], "candidates_verified_per_step": infos[-1]["n_cand"],
@@ -455,6 +519,11 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget_s)
             except Exception as e:  # the baseline is reported, never required for the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "hypotheses/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        if not args.no_next_rows and world == 1:
+            try:
+                out["host_cpp_frame"] = host_cpp_leg(w)
+            except Exception as e:
+                out["host_cpp_frame"] = {"error": str(e)}
         if not args.no_next_rows and world == 1:
             try:
                 out["next_rows"] = {"n1_physics": physics_row(w, args, not args.no_cpu_baseline)}

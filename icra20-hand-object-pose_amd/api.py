@@ -138,6 +138,7 @@ SIGNATURES = {
     "hop_model_ppf_keys": (C.c_int, [_vp, fp, fp, C.c_int, ip, C.c_int, ip]),
     "hop_hand_set_finger": (C.c_int, [_vp, C.POINTER(FingerArgs)]),
     "hop_hand_remove_surrounding": (C.c_int, [_vp, fp, fp, C.c_int, fp, C.POINTER(HandLink), C.c_int, fp, fp, C.c_float, fp, fp, fp, ip, ip]),
+    "hop_hand_set_sum_mode": (C.c_int, [_vp, C.c_int]),
     "hop_hand_pso_eval_batch": (C.c_int, [_vp, dp, C.c_int, dp]),
     "hop_pso_default_settings": (None, [C.POINTER(PsoSettings)]),
     "hop_hand_pso_search": (C.c_int, [_vp, C.POINTER(PsoSettings), dp, dp]),
@@ -542,6 +543,9 @@ class Context:
 
     def hand_set_finger(self, args: "FingerArgs"):
         self._chk(self.L.hop_hand_set_finger(self.h, C.byref(args)), "hop_hand_set_finger")
+
+    def hand_set_sum_mode(self, mode):
+        self._chk(self.L.hop_hand_set_sum_mode(self.h, int(mode)), "hop_hand_set_sum_mode")
 
     def hand_pso_eval_batch(self, angles):
         a = np.ascontiguousarray(angles, dtype=np.float64)

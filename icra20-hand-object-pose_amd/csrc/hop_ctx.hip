@@ -146,6 +146,7 @@ struct hop_ctx {
   int hand_n_scene = 0, hand_n_lookup = 0, hand_n_swivel = 0;
   hop_finger_args finger{};
   std::vector<float> finger_hist;
+  int pso_sum_mode = 0;  // hop_hand_set_sum_mode
   DevBuf finger_hist_d, pso_particles_d, pso_match_d, pso_terms_d, pso_sum_d, pso_cnt_d;
   PinnedBuf pso_particles_h, pso_out_h;
   bool have_finger = false, have_hand_scene = false;
@@ -1614,6 +1615,12 @@ static void mat4_vec4(const M4& T, const float v[4], float out[4]) {
 }
 
 // objFuncPSO (Hand.cpp:10-178): scalar parts on the host, cloud parts on the device.
+int hop_hand_set_sum_mode(hop_ctx* c, int mode) {
+  if (!c || (mode != 0 && mode != 1)) return HOP_E_INVALID;
+  c->pso_sum_mode = mode;
+  return HOP_OK;
+}
+
 int hop_hand_pso_eval_batch(hop_ctx* c, const double* angles, int n, double* cost_out) {
   if (!c || !angles || !cost_out || n < 0) return HOP_E_INVALID;
   if (!c->have_finger || !c->have_hand_scene) return HOP_E_STATE;
@@ -1703,6 +1710,7 @@ int hop_hand_pso_eval_batch(hop_ctx* c, const double* angles, int n, double* cos
     pa.use_grid = 2;
   }
   pa.n_particles = n;
+  pa.sum_mode = c->pso_sum_mode;
   pa.match_count = c->pso_match_d.as<int>(), pa.outer_terms = c->pso_terms_d.as<float>();
   pa.outer_cnt = c->pso_match_d.as<int>() + n, pa.outer_sum = reinterpret_cast<float*>(c->pso_match_d.as<int>() + 2 * (size_t)n);
   {

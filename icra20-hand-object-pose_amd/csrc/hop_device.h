@@ -254,6 +254,7 @@ struct PsoArgs {
   int use_grid;             // 0 brute force, 1 ring search on scene_grid, 2 NN cell lists
   CellListDev scene_cells;  // hand scene NN cell lists (max_dist = dist_thres)
   int n_particles;
+  int sum_mode;  // 0: outer-side terms added in scene order (the reference's float sum), 1: block reduction
   int* match_count;
   float* outer_terms;  // [n_swivel][n_particles]
   float* outer_sum;

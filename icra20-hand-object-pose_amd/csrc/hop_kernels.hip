@@ -2309,6 +2309,38 @@ __global__ __launch_bounds__(64) void k_pso_outer_sum(PsoArgs a, int n_particles
   a.outer_cnt[p] = cnt;
 }
 
+
+// sum_mode 1: the outer-side term of objFuncPSO (Hand.cpp:141-152) reduced inside the block instead of added in scene
+// order: one block per particle, threads stride over the no-swivel scene, float tree reduction in a fixed order
+// (deterministic; equal to the reference's sequential float sum to ~1e-6 relative -- tests/test_gpu_parity.py).  No term
+// table, no 4-wave sequential pass.
+__global__ __launch_bounds__(256) void k_pso_outer_reduce(PsoArgs a) {
+  __shared__ float rs[4];
+  __shared__ int rc[4];
+  const int p = blockIdx.x;
+  const PsoParticle& pp = a.particles[p];
+  if (pp.skip) return;
+  const float* __restrict__ Ti = pp.Tinv;
+  float sum = 0.f;
+  int cnt = 0;
+  for (int i = threadIdx.x; i < a.n_swivel; i += 256) {
+    const V3 pt = m4_point(Ti, v3(a.wx[i], a.wy[i], a.wz[i]));
+    int bin = (int)(fmaxf(pt.z - a.fp_min_z, 0.0f) / a.fp_stride_z);
+    bin = min(max(bin, 0), a.fp_num_division - 1);
+    const float lim = a.hist_min_y[bin];
+    const float v = (pt.y >= lim) ? -1.f : fabsf(pt.y - lim);
+    if (v >= 0.f) sum += v, cnt += 1;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off), cnt += __shfl_down(cnt, off);
+  if ((threadIdx.x & 63) == 0) rs[threadIdx.x >> 6] = sum, rc[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.outer_sum[p] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    a.outer_cnt[p] = (rc[0] + rc[1]) + (rc[2] + rc[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // N4: the pair loop of the offline computePPF tool (computePPF.cpp:17-38,88-100): key of every pair i < j of the model
 // cloud, collected in the same direct-address bitmap the generator looks keys up in.
@@ -2547,6 +2579,10 @@ void launch_icp_finish(const IcpArgs& a, int hb, int* iters, int* conv, hipStrea
 void launch_pso(const PsoArgs& a, int n_particles, hipStream_t s) {
   const int R = 2;
   hipLaunchKernelGGL(k_pso_match<2>, dim3((a.nm + 256 * R - 1) / (256 * R), n_particles), dim3(256), 0, s, a);
+  if (a.sum_mode == 1) {
+    hipLaunchKernelGGL(k_pso_outer_reduce, dim3(n_particles), dim3(256), 0, s, a);
+    return;
+  }
   hipLaunchKernelGGL(k_pso_outer, dim3(max(1, min(256, (a.n_swivel + 63) / 64)), (n_particles + 255) / 256), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_pso_outer_sum, dim3((n_particles + 63) / 64), dim3(64), 0, s, a, n_particles);
 }

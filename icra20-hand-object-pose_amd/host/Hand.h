@@ -103,6 +103,16 @@ class Hand {
     if (name.find("finger") != std::string::npos) _finger_properties[name] = FingerProperty(cloud, 10);
   }
 
+  // Hand::reset (Hand.cpp:336-361): the per-frame state goes back to its initial values, the model stays
+  void reset() {
+    for (auto& c : _component_status) c.second = false;
+    for (auto& h : _finger_angles) h.second = 0;
+    _handbase_in_cam = Mat4::Identity();
+    _hand_cloud = hop::Cloud();
+    _hand_clouds.clear();
+    for (auto& t : _tf_self) t.second = Mat4::Identity();
+  }
+
   // the convex mesh of a component (Hand.cpp:526-530, loaded from an OBJ file there), link frame
   void addConvexMesh(const std::string& name, const hop::Mesh& mesh) { _convex_meshes[name] = mesh; }
 

@@ -73,6 +73,13 @@ class PoseEstimator {
                ctx_, "hop_set_scene");
   }
 
+  // reset (PoseEstimator.cpp:49-60): scene clouds and hypotheses of the frame are dropped, the models stay
+  void reset() {
+    _cloud_withouthand_raw = hop::Cloud();
+    const float none[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    hop::check(hop_hypos_upload(ctx_, none, nullptr, 0), ctx_, "hop_hypos_upload");
+  }
+
   // runSuper4pcs (PoseEstimator.cpp:62-100); ppf_keys4 = the key set of the reference's ppf map (4 ints per key)
   bool runSuper4pcs(const std::vector<int32_t>& ppf_keys4) {
     hop::check(hop_set_ppf_keys(ctx_, ppf_keys4.data(), (int)(ppf_keys4.size() / 4)), ctx_, "hop_set_ppf_keys");

@@ -2,6 +2,8 @@
 // main_realdata_auto.cpp:99-205) on top of libhop, for one frame whose clouds are given as files.
 //
 //   main_realdata_auto <config_autodataset.yaml> <frame_dir> [out_dir]
+//   HOP_APP_REPEAT=n: the frame is processed n times (hand.reset() / est.reset() in between, as run_real_all.cpp:265-266
+//   does between frames) and every pass prints "frame_ms <wall ms>": what bench.py's host_cpp leg reads.
 //
 // The reference loads meshes, a Boost PPF archive and a URDF, none of which ship with it; here the frame
 // directory holds the already prepared clouds (what Hand::setCurScene / main :54-181 would produce):
@@ -16,8 +18,10 @@
 //   cloud_withouthand.bin                       _cloud_withouthand_raw, camera frame
 //   handbase_in_cam.txt                         16 floats, row-major
 // Steps not on the hot path (adjustHandHeight, rejectByRender) are "next" rows.
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -110,7 +114,15 @@ int main(int argc, char** argv) {
         hand.addComponent(name, parent, read_cloud(frame + file), T);
       }
     }
-    hand.setCurScene(read_cloud(frame + "hand_scene.bin"), read_cloud(frame + "hand_region.bin"), read_cloud(frame + "hand_swivel.bin"));
+    const hop::Cloud hand_scene = read_cloud(frame + "hand_scene.bin"), hand_region = read_cloud(frame + "hand_region.bin"),
+                     hand_swivel = read_cloud(frame + "hand_swivel.bin"), object_segment = read_cloud(frame + "object_segment.bin");
+    const int repeat = std::getenv("HOP_APP_REPEAT") ? std::max(1, std::atoi(std::getenv("HOP_APP_REPEAT"))) : 1;
+    for (int rep = 0; rep < repeat; ++rep) {
+    const auto t_frame = std::chrono::steady_clock::now();
+    const bool last = rep + 1 == repeat;
+    hand.reset();
+    est.reset();
+    hand.setCurScene(hand_scene, hand_region, hand_swivel);
     int cam_right = 1;
     {
       std::ifstream f(frame + "cam_side.txt");
@@ -144,12 +156,12 @@ int main(int argc, char** argv) {
           else hand.addConvexMesh(name, read_mesh(frame + file));
         }
         hand.makeHandCloud();  // main :142
-        est.setCurScene(read_cloud(frame + "object_segment.bin"), read_cloud(frame + "cloud_withouthand.bin"));
+        est.setCurScene(object_segment, read_cloud(frame + "cloud_withouthand.bin"));
         est.registerHandMesh(&hand);                                         // main :186
         est.registerMesh(object_mesh, "object", Mat4::Identity().m);         // main :187
       }
     }
-    if (!physics) est.setCurScene(read_cloud(frame + "object_segment.bin"));
+    if (!physics) est.setCurScene(object_segment);
     const bool succeed = est.runSuper4pcs(ppfs);
     PoseHypo best(-1);
     if (!succeed) {
@@ -170,6 +182,8 @@ int main(int argc, char** argv) {
       }
     }
     est.selectBest(best);
+    std::printf("frame_ms %.3f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_frame).count());
+    if (!last) continue;
     std::ofstream ff(out_dir + "/model2scene.txt");
     ff.precision(9);
     std::cout << "best tf:\n";
@@ -182,6 +196,7 @@ int main(int argc, char** argv) {
     std::ofstream fa(out_dir + "/finger_angles.txt");
     fa.precision(9);
     for (auto& kv : hand._finger_angles) fa << kv.first << " " << kv.second << "\n";
+    }
     return 0;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());

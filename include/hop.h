@@ -196,6 +196,10 @@ typedef struct {
 int hop_hand_set_finger(hop_ctx* ctx, const hop_finger_args* args);
 /* objFuncPSO for n angles (radians) at once */
 int hop_hand_pso_eval_batch(hop_ctx* ctx, const double* angles, int n, double* cost_out);
+/* How the outer-side penalty of objFuncPSO (Hand.cpp:141-152, one float accumulated over the no-swivel scene) is summed:
+ * 0 (default) in scene order, bit-equal to the reference's loop; 1 by a fixed-order tree reduction on the GPU (equal to
+ * ~1e-6 relative; the order of a float sum is not part of the reference's interface).  Applies to the calls that follow. */
+int hop_hand_set_sum_mode(hop_ctx* ctx, int mode);
 
 typedef struct {
   int n_pop, n_gen, check_freq;     /* hand_match.pso.* (config_autodataset.yaml:108-114) */

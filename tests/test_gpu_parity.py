@@ -366,6 +366,15 @@ def test_pso_objective_equals_oracle(ctx, api, orc, synth, finger):
     ref = np.zeros(len(angles))
     orc.lib().orc_pso_objective_batch(C.byref(oa), orc.D(np.ascontiguousarray(angles)), len(angles), orc.D(ref))
     assert np.array_equal(got, ref), np.abs(got - ref).max()
+    # hop_hand_set_sum_mode(1): the outer-side penalty reduced in a tree instead of in scene order -- same objective to
+    # 1e-5 relative (the penalty enters through avg = sum / count and an exp), same arg-min
+    ctx.hand_set_sum_mode(1)
+    try:
+        fast = ctx.hand_pso_eval_batch(angles)
+    finally:
+        ctx.hand_set_sum_mode(0)
+    assert np.all(np.abs(fast - ref) <= 1e-5 * np.maximum(np.abs(ref), 1.0)), np.abs(fast - ref).max()
+    assert np.argmin(fast) == np.argmin(ref)
     # the objective has a real minimum near the true angle
     best = angles[np.argmin(ref)]
     assert abs(best - true[finger]) < math.radians(8.0)
