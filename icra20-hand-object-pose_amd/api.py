@@ -148,6 +148,10 @@ SIGNATURES = {
     "hop_voxel_downsample": (C.c_int, [_vp, fp, C.c_int, C.c_float, fp, C.c_int, ip]),
     "hop_scene_from_depth": (C.c_int, [_vp, C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_double, fp, fp, fp, C.c_float, fp, fp, fp, C.c_int, ip, ip]),
     "hop_object_segment": (C.c_int, [_vp, fp, fp, fp, C.c_int, C.c_float, fp, fp, fp, C.c_int, ip]),
+    "hop_normals_integral_image": (C.c_int, [_vp, fp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, fp]),
+    "hop_normals_mls": (C.c_int, [_vp, fp, C.c_int, C.c_float, C.c_int, fp, fp, fp, ip, C.c_int, ip]),
+    "hop_scene_from_depth_normals": (C.c_int, [_vp, C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_double, fp, fp, fp, C.c_float, fp, fp, C.c_float, C.c_float,
+                                              fp, fp, C.c_int, ip, ip]),
     "hop_hand_scene_filters": (C.c_int, [_vp, fp, fp, C.c_int, fp, fp, fp, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]),
     "hop_voxel_downsample_normals": (C.c_int, [_vp, fp, fp, C.c_int, C.c_float, fp, fp, C.c_int, ip]),
     "hop_handbase_region": (C.c_int, [_vp, fp, fp, C.c_int, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp, fp, C.POINTER(C.c_ubyte)]),
@@ -363,6 +367,46 @@ class Context:
         self._chk(self.L.hop_scene_from_depth(self.h, d.ctypes.data_as(C.POINTER(C.c_ushort)), H, W, depth_unit, F(K9), F(A), F(B), leaf, F(lo), F(hi),
                                               F(out), cap, C.byref(n), I(counts)), "hop_scene_from_depth")
         return out[:, :n.value].T.copy(), counts
+
+    def scene_from_depth_normals(self, depth_raw, depth_unit, K, cam_in_handbase, handbase_in_cam, leaf=0.001,
+                                 crop_min=(-0.25, -0.2, -0.12), crop_max=(-0.07, 0.2, 0.05), max_depth_change_factor=0.02, smoothing=10.0):
+        """main_realdata_auto.cpp:54-96 with the integral-image normals of :61: (xyz, nrm (n,3) camera frame, counts)."""
+        d = np.ascontiguousarray(depth_raw, np.uint16)
+        H, W = d.shape
+        K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+        A = np.ascontiguousarray(cam_in_handbase, np.float32).reshape(16)
+        B = np.ascontiguousarray(handbase_in_cam, np.float32).reshape(16)
+        lo, hi = np.ascontiguousarray(crop_min, np.float32), np.ascontiguousarray(crop_max, np.float32)
+        cap = H * W
+        out, on = np.zeros((3, cap), np.float32), np.zeros((3, cap), np.float32)
+        n = C.c_int(0)
+        counts = np.zeros(3, np.int32)
+        self._chk(self.L.hop_scene_from_depth_normals(self.h, d.ctypes.data_as(C.POINTER(C.c_ushort)), H, W, depth_unit, F(K9), F(A), F(B), leaf, F(lo), F(hi),
+                                                      max_depth_change_factor, smoothing, F(out), F(on), cap, C.byref(n), I(counts)),
+                  "hop_scene_from_depth_normals")
+        return out[:, :n.value].T.copy(), on[:, :n.value].T.copy(), counts
+
+    def normals_integral_image(self, xyz_organized, max_depth_change_factor=0.02, smoothing=10.0, depth_dependent=True):
+        """Utils::calNormalIntegralImage (Utils.cpp:293-329, method -1) on an organised cloud (H, W, 3): (H, W, 3) normals."""
+        a = np.asarray(xyz_organized, np.float32)
+        H, W = a.shape[:2]
+        planes = np.ascontiguousarray(a.reshape(H * W, 3).T)
+        out = np.zeros((3, H * W), np.float32)
+        self._chk(self.L.hop_normals_integral_image(self.h, F(planes), H, W, max_depth_change_factor, smoothing, int(bool(depth_dependent)), F(out)),
+                  "hop_normals_integral_image")
+        return out.T.reshape(H, W, 3).copy()
+
+    def normals_mls(self, xyz, radius=0.003, order=2):
+        """Utils::calNormalMLS (Utils.cpp:268-289): (projected xyz, normals, curvature, input index of every output)."""
+        X = soa(xyz)
+        n = X.shape[1]
+        cap = max(n, 1)
+        ox, on = np.zeros((3, cap), np.float32), np.zeros((3, cap), np.float32)
+        oc, ki = np.zeros(cap, np.float32), np.zeros(cap, np.int32)
+        k = C.c_int(0)
+        self._chk(self.L.hop_normals_mls(self.h, F(X), n, radius, int(order), F(ox), F(on), F(oc), I(ki), cap, C.byref(k)), "hop_normals_mls")
+        m = k.value
+        return ox[:, :m].T.copy(), on[:, :m].T.copy(), oc[:m].copy(), ki[:m].copy()
 
     def object_segment(self, xyz, nrm, conf, leaf=0.003):
         """main_realdata_auto.cpp:156-177: (xyz, nrm, conf) of the generator's input cloud."""

@@ -64,6 +64,8 @@ struct HopExt {
 };
 constexpr int HOP_EXT_SLOTS = 4;
 constexpr int HOP_EXT_PHYSICS = 0;
+constexpr int HOP_EXT_NORMALS = 1;
+constexpr int HOP_EXT_RENDER = 2;
 
 struct HopHypView {
   float* pose;   // n x 16 row-major
@@ -78,5 +80,9 @@ void hop_ctx_set_error(hop_ctx* c, const std::string& msg);
 HopExt*& hop_ctx_ext(hop_ctx* c, int slot);
 HopHypView hop_ctx_hyp(hop_ctx* c);
 void hop_ctx_hyp_set_count(hop_ctx* c, int n);
+
+// hop_normals.hip: integral-image normals of an organised device cloud (planes of H*W floats each)
+int hop_normals_ii_device(hop_ctx* c, const float* x, const float* y, const float* z, int H, int W, float max_depth_change_factor, float smoothing_size,
+                          int depth_dependent, float* nx, float* ny, float* nz);
 
 #endif  // HOP_CTX_EXT_H_

@@ -2117,7 +2117,13 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 }
 
 __global__ __launch_bounds__(256) void k_lcp_cells_fast(LcpArgs a, int hb, int hs, int npt) {
-  const int pt = blockIdx.x % npt, ht = blockIdx.x / npt;
+  // XCD-aware mapping: workgroups go to the 8 XCDs round-robin (blockIdx.x & 7) and each XCD has its own 4 MB L2; the
+  // scene lists + model lists (~18 MB at C2) do not fit one L2, an eighth of the Morton-ordered scene with the model
+  // region it meets does.  XCD k walks the point tiles [k * per, (k + 1) * per) for every hypothesis tile.
+  const int per = (npt + 7) >> 3;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int pt = xcd * per + j % per, ht = j / per;
+  if (pt >= npt) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int k = pt * 64 + lane;
@@ -2165,7 +2171,7 @@ __global__ __launch_bounds__(64) void k_lcp_sum_partial(LcpArgs a, int hb, int h
 void launch_lcp_cells_fast(const LcpArgs& a, int hb, hipStream_t s) {
   const int npt = (a.ns + 63) / 64, nht = (hb + LCP_TH - 1) / LCP_TH;
   const int hs = ((hb + LCP_TH - 1) / LCP_TH) * LCP_TH;
-  hipLaunchKernelGGL(k_lcp_cells_fast, dim3((unsigned)(npt * nht)), dim3(256), 0, s, a, hb, hs, npt);
+  hipLaunchKernelGGL(k_lcp_cells_fast, dim3((unsigned)(8 * ((npt + 7) / 8) * nht)), dim3(256), 0, s, a, hb, hs, npt);
 }
 void launch_lcp_sum_partial(const LcpArgs& a, int hb, hipStream_t s) {
   const int npt = (a.ns + 63) / 64;

@@ -1249,9 +1249,37 @@ int hop_voxel_downsample(hop_ctx* c, const float* xyz, int n, float leaf, float*
   return HOP_OK;
 }
 
+// normals through the crop: pcl::transformPointCloudWithNormals into the hand-base frame and back (main :72,94) rotates
+// them twice in float
+__global__ void k_rotate_twice(const float* __restrict__ inx, const float* __restrict__ iny, const float* __restrict__ inz, int n, const float* __restrict__ A,
+                               const float* __restrict__ B, float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 r = m4_dir(B, m4_dir(A, v3(inx[i], iny[i], inz[i])));
+  ox[i] = r.x, oy[i] = r.y, oz[i] = r.z;
+}
+
+static int scene_from_depth_impl(hop_ctx* c, const uint16_t* depth_raw, int H, int W, double depth_unit, const float K9[9], const float cam_in_handbase[16],
+                                 const float handbase_in_cam[16], float leaf, const float crop_min[3], const float crop_max[3], bool with_normals,
+                                 float max_depth_change_factor, float normal_smoothing_size, float* out_xyz, float* out_nrm, int cap, int* n_out, int* counts3);
+
 int hop_scene_from_depth(hop_ctx* c, const uint16_t* depth_raw, int H, int W, double depth_unit, const float K9[9], const float cam_in_handbase[16],
                          const float handbase_in_cam[16], float leaf, const float crop_min[3], const float crop_max[3], float* out_xyz, int cap,
                          int* n_out, int* counts3) {
+  return scene_from_depth_impl(c, depth_raw, H, W, depth_unit, K9, cam_in_handbase, handbase_in_cam, leaf, crop_min, crop_max, false, 0.f, 0.f, out_xyz, nullptr,
+                               cap, n_out, counts3);
+}
+int hop_scene_from_depth_normals(hop_ctx* c, const uint16_t* depth_raw, int H, int W, double depth_unit, const float K9[9], const float cam_in_handbase[16],
+                                 const float handbase_in_cam[16], float leaf, const float crop_min[3], const float crop_max[3], float max_depth_change_factor,
+                                 float normal_smoothing_size, float* out_xyz, float* out_nrm, int cap, int* n_out, int* counts3) {
+  if (!(normal_smoothing_size >= 1.f)) return HOP_E_INVALID;
+  return scene_from_depth_impl(c, depth_raw, H, W, depth_unit, K9, cam_in_handbase, handbase_in_cam, leaf, crop_min, crop_max, true, max_depth_change_factor,
+                               normal_smoothing_size, out_xyz, out_nrm, cap, n_out, counts3);
+}
+
+static int scene_from_depth_impl(hop_ctx* c, const uint16_t* depth_raw, int H, int W, double depth_unit, const float K9[9], const float cam_in_handbase[16],
+                                 const float handbase_in_cam[16], float leaf, const float crop_min[3], const float crop_max[3], bool with_normals,
+                                 float max_depth_change_factor, float normal_smoothing_size, float* out_xyz, float* out_nrm, int cap, int* n_out, int* counts3) {
   if (!c || !depth_raw || H <= 0 || W <= 0 || !K9 || !cam_in_handbase || !handbase_in_cam || !crop_min || !crop_max || !n_out || cap < 0) return HOP_E_INVALID;
   PHCHK(c, hipSetDevice(hop_ctx_device(c)));
   Physics* ph = physics(c);
@@ -1267,7 +1295,18 @@ int hop_scene_from_depth(hop_ctx* c, const uint16_t* depth_raw, int H, int W, do
   k_depth_to_cloud<<<(n + 255) / 256, 256, 0, st>>>(ph->keys_alt.as<unsigned short>(), H, W, depth_unit, K9[2], K9[0], K9[5], K9[4], t, t + n, t + 2 * (size_t)n,
                                                      ph->scalars.as<unsigned>() + 12);
   PHCHK(c, hipStreamSynchronize(st));  // keys_alt is reused by the voxel grid
-  int rc = voxel_downsample_device(c, ph, ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), n, leaf, ph->tmp_cloud2);
+  int rc = HOP_OK;
+  if (with_normals) {
+    // main :61: integral-image normals on the organised cloud (dropped pixels count as (0,0,0) there), before the pass-through
+    PHCHK(c, ph->tmp_nrm.buf.ensure(sizeof(float) * 3 * (size_t)n));
+    ph->tmp_nrm.n = n;
+    float* q = ph->tmp_nrm.buf.as<float>();
+    rc = hop_normals_ii_device(c, t, t + n, t + 2 * (size_t)n, H, W, max_depth_change_factor, normal_smoothing_size, 1, q, q + n, q + 2 * (size_t)n);
+    if (rc) return rc;
+    rc = voxel_downsample_device(c, ph, ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), n, leaf, ph->tmp_cloud2, q, &ph->tmp_nrm2);
+  } else {
+    rc = voxel_downsample_device(c, ph, ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), n, leaf, ph->tmp_cloud2);
+  }
   if (rc) return rc;
   const int m = ph->tmp_cloud2.n;
   unsigned n_valid = 0, kept = 0;
@@ -1295,6 +1334,15 @@ int hop_scene_from_depth(hop_ctx* c, const uint16_t* depth_raw, int H, int W, do
     if ((int)kept <= cap && out_xyz)
       for (int k = 0; k < 3; ++k)
         PHCHK(c, hipMemcpyAsync(out_xyz + (size_t)k * cap, b + (size_t)k * m, sizeof(float) * (size_t)kept, hipMemcpyDeviceToHost, st));
+    if (with_normals && out_nrm && (int)kept <= cap) {
+      PHCHK(c, hipStreamSynchronize(st));
+      const float* vn = ph->tmp_nrm2.buf.as<float>();
+      k_rotate_twice<<<(m + 255) / 256, 256, 0, st>>>(vn, vn + m, vn + 2 * (size_t)m, m, ph->mats.as<float>(), ph->mats.as<float>() + 16, a, a + m, a + 2 * (size_t)m);
+      k_compact3<<<(m + 255) / 256, 256, 0, st>>>(a, a + m, a + 2 * (size_t)m, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), m, b, b + m, b + 2 * (size_t)m, m,
+                                                 ph->scalars.as<unsigned>() + 14);
+      for (int k = 0; k < 3; ++k)
+        PHCHK(c, hipMemcpyAsync(out_nrm + (size_t)k * cap, b + (size_t)k * m, sizeof(float) * (size_t)kept, hipMemcpyDeviceToHost, st));
+    }
   }
   PHCHK(c, hipStreamSynchronize(st));
   *n_out = (int)kept;

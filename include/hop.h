@@ -315,6 +315,32 @@ int hop_scene_from_depth(hop_ctx* ctx, const uint16_t* depth_raw, int H, int W, 
                          const float cam_in_handbase[16], const float handbase_in_cam[16], float leaf, const float crop_min[3],
                          const float crop_max[3], float* out_xyz, int cap, int* n_out, int* counts3);
 
+/* "Next" row N3g: the two normal estimators of the driver (PCL 1.9, restated from its published sources: parity unpinned).
+ *   hop_normals_integral_image   Utils::calNormalIntegralImage (src/perception/src/Utils.cpp:293-329; main_realdata_auto.cpp:61 passes
+ *                                method -1 = SIMPLE_3D_GRADIENT, max_depth_change_factor 0.02, smoothing 10, depth-dependent):
+ *                                pcl::IntegralImageNormalEstimation on the ORGANISED cloud.  xyz: SoA planes of H*W floats, row-major
+ *                                pixels; a dropped pixel is (0,0,0) in the reference (Utils.cpp:92) -- non-finite values are read as 0.
+ *                                nrm_out: planes of H*W, NaN where PCL leaves the normal undefined (border of `smoothing` pixels,
+ *                                depth edges, zero gradient); normals flipped towards the origin.  H <= 1025.
+ *   hop_normals_mls              Utils::calNormalMLS (Utils.cpp:268-289; main :153 passes radius 0.003): pcl::MovingLeastSquares,
+ *                                polynomial order 2 (0 / 1: plane only), normals, SIMPLE projection, no upsampling.  Points with fewer than
+ *                                3 neighbours in the radius are dropped (mls.process + getCorrespondingIndices + ExtractIndices);
+ *                                the survivors come back PROJECTED onto the fitted surface with its normal and PCL's curvature,
+ *                                in input order (PCL's OpenMP version emits thread chunks in arrival order); keep_index[k] = input
+ *                                index of output k.  Outputs: planes with stride cap.
+ *   hop_scene_from_depth_normals hop_scene_from_depth with the integral-image normals computed on the organised cloud and carried
+ *                                through the pass-through, the voxel grid (pcl::VoxelGrid averages every field: normals summed and
+ *                                normalised per voxel, NaN if any member is NaN) and the crop: the cloud Hand::setCurScene receives
+ *                                (main_realdata_auto.cpp:54-96,100). */
+int hop_normals_integral_image(hop_ctx* ctx, const float* xyz, int H, int W, float max_depth_change_factor, float normal_smoothing_size,
+                               int depth_dependent_smoothing, float* nrm_out);
+int hop_normals_mls(hop_ctx* ctx, const float* xyz, int n, float search_radius, int polynomial_order, float* out_xyz, float* out_nrm,
+                    float* out_curvature, int* keep_index, int cap, int* n_out);
+int hop_scene_from_depth_normals(hop_ctx* ctx, const uint16_t* depth_raw, int H, int W, double depth_unit, const float K9[9],
+                                 const float cam_in_handbase[16], const float handbase_in_cam[16], float leaf, const float crop_min[3],
+                                 const float crop_max[3], float max_depth_change_factor, float normal_smoothing_size, float* out_xyz,
+                                 float* out_nrm, int cap, int* n_out, int* counts3);
+
 /* "Next" row N3c: the generator's input cloud from the dense hand-free cloud (main_realdata_auto.cpp:156-177): voxel grid at
  * `leaf` (0.003) over xyz and normals (pcl::VoxelGrid / CentroidPoint: xyz averaged, normals summed and normalised),
  * removeAllNaNFromPointCloud, pcl::flipNormalTowardsViewpoint(0,0,0), confidence of the nearest dense point (1-NN).

@@ -45,7 +45,7 @@ def soa(a):
 def build(force=False):
     """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
     if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(
-            os.path.getmtime(os.path.join(HERE, f)) for f in ("hop_oracle.cpp", "sdf_oracle.cpp", "hop_oracle.h")):
+            os.path.getmtime(os.path.join(HERE, f)) for f in ("hop_oracle.cpp", "sdf_oracle.cpp", "normals_oracle.cpp", "hop_oracle.h")):
         subprocess.check_call(["make", "-C", HERE, "_build/liboracle.so"], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
 
@@ -540,3 +540,43 @@ def hand_height_matches(scene_xyz, scene_nrm, hand_xyz, hand_nrm, heights):
     out = np.zeros(len(h), np.int32)
     lib().orc_hand_height_matches(F(S), F(Sn), S.shape[1], F(Hx), F(Hn), Hx.shape[1], F(h), len(h), I(out))
     return out
+
+
+def normals_integral_image(xyz_organized, max_depth_change_factor=0.02, smoothing=10.0, depth_dependent=True):
+    """pcl::IntegralImageNormalEstimation as Utils::calNormalIntegralImage configures it (Utils.cpp:293-329, method -1).
+    xyz_organized: (H, W, 3); returns (H, W, 3) normals, NaN where undefined."""
+    a = np.asarray(xyz_organized, np.float32)
+    H, W = a.shape[:2]
+    planes = np.ascontiguousarray(a.reshape(H * W, 3).T)
+    out = np.zeros((3, H * W), np.float32)
+    lib().orc_normals_integral_image(F(planes), H, W, C.c_float(max_depth_change_factor), C.c_float(smoothing), int(bool(depth_dependent)), F(out))
+    return out.T.reshape(H, W, 3).copy()
+
+
+def normals_mls(xyz, radius=0.003, order=2):
+    """pcl::MovingLeastSquares as Utils::calNormalMLS configures it (Utils.cpp:268-289): (projected xyz, normals, curvature,
+    input index) of the points that have >= 3 neighbours."""
+    X = soa(xyz)
+    n = X.shape[1]
+    cap = max(n, 1)
+    ox, on = np.zeros((3, cap), np.float32), np.zeros((3, cap), np.float32)
+    oc, ki = np.zeros(cap, np.float32), np.zeros(cap, np.int32)
+    k = C.c_int(0)
+    lib().orc_normals_mls(F(X), n, C.c_float(radius), int(order), F(ox), F(on), F(oc), I(ki), cap, C.byref(k))
+    m = k.value
+    return ox[:, :m].T.copy(), on[:, :m].T.copy(), oc[:m].copy(), ki[:m].copy()
+
+
+def scene_from_depth_normals(depth_raw, depth_unit, K, cam_in_handbase, handbase_in_cam, leaf, crop_min, crop_max, factor=0.02, smoothing=10.0):
+    d = np.ascontiguousarray(depth_raw, np.uint16)
+    H, W = d.shape
+    K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+    A = np.ascontiguousarray(cam_in_handbase, np.float32).reshape(16)
+    B = np.ascontiguousarray(handbase_in_cam, np.float32).reshape(16)
+    lo, hi = np.ascontiguousarray(crop_min, np.float32), np.ascontiguousarray(crop_max, np.float32)
+    cap = H * W
+    ox, on = np.zeros((3, cap), np.float32), np.zeros((3, cap), np.float32)
+    n = C.c_int(0)
+    lib().orc_scene_from_depth_normals(d.ctypes.data_as(C.POINTER(C.c_ushort)), H, W, C.c_double(depth_unit), F(K9), F(A), F(B), C.c_float(leaf), F(lo), F(hi),
+                                       C.c_float(factor), C.c_float(smoothing), F(ox), F(on), cap, C.byref(n))
+    return ox[:, :n.value].T.copy(), on[:, :n.value].T.copy()

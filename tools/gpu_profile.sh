@@ -17,3 +17,12 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INS
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE -d $OUT/pmc_sq2 -o b -- $S > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_tcp -o b -- $S > /dev/null 2>&1
 find $OUT -name "*.db" | xargs ls -la
+# summaries (the databases exceed what gpurun copies back)
+cd /root/repo
+python tools/rocprof_summary.py $OUT/stats_default/b_results.db $OUT/kernel_stats_default.txt "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-next-rows --steps 32 --warmup 8" > /dev/null
+python tools/rocprof_summary.py $OUT/stats_serial/b_results.db $OUT/kernel_stats_serial_inflight1.txt "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-next-rows --inflight 1 --steps 8 --warmup 2" > /dev/null
+python tools/pmc_summary.py $OUT/pmc_fetch/b_results.db $OUT/pmc_write/b_results.db $OUT/pmc_latest.json > $OUT/pmc_hbm.txt
+python tools/pmc_sq_summary.py $OUT/pmc_sq.txt "rocprofv3 --kernel-trace --pmc <set> -- python bench.py --no-cpu-baseline --no-next-rows --inflight 1 --steps 2 --warmup 1 (three passes: SQ x2, TCP/TCC)" $OUT/pmc_sq1/b_results.db $OUT/pmc_sq2/b_results.db $OUT/pmc_tcp/b_results.db > /dev/null
+find $OUT -name "*.db" -delete
+find $OUT -type d -empty -delete
+ls -la $OUT
