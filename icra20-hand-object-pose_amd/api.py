@@ -148,6 +148,10 @@ SIGNATURES = {
     "hop_voxel_downsample": (C.c_int, [_vp, fp, C.c_int, C.c_float, fp, C.c_int, ip]),
     "hop_scene_from_depth": (C.c_int, [_vp, C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_double, fp, fp, fp, C.c_float, fp, fp, fp, C.c_int, ip, ip]),
     "hop_object_segment": (C.c_int, [_vp, fp, fp, fp, C.c_int, C.c_float, fp, fp, fp, C.c_int, ip]),
+    "hop_render_set_frame": (C.c_int, [_vp, C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_double, fp, fp, C.c_int, ip, C.c_int]),
+    "hop_render_set_object": (C.c_int, [_vp, fp, C.c_int, ip, C.c_int]),
+    "hop_render_depth": (C.c_int, [_vp, fp, fp, C.POINTER(C.c_ubyte)]),
+    "hop_reject_by_render": (C.c_int, [_vp, C.c_float, C.c_float, C.c_int, fp, ip, ip]),
     "hop_normals_integral_image": (C.c_int, [_vp, fp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, fp]),
     "hop_normals_mls": (C.c_int, [_vp, fp, C.c_int, C.c_float, C.c_int, fp, fp, fp, ip, C.c_int, ip]),
     "hop_scene_from_depth_normals": (C.c_int, [_vp, C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_double, fp, fp, fp, C.c_float, fp, fp, C.c_float, C.c_float,
@@ -385,6 +389,40 @@ class Context:
                                                       max_depth_change_factor, smoothing, F(out), F(on), cap, C.byref(n), I(counts)),
                   "hop_scene_from_depth_normals")
         return out[:, :n.value].T.copy(), on[:, :n.value].T.copy(), counts
+
+    # ---- rejectByRender (N2)
+    def render_set_frame(self, depth_raw, depth_unit, K, hand_V, hand_F):
+        d = np.ascontiguousarray(depth_raw, np.uint16)
+        H, W = d.shape
+        K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+        V = np.ascontiguousarray(np.asarray(hand_V, np.float32).reshape(-1, 3))
+        Fi = np.ascontiguousarray(np.asarray(hand_F, np.int32).reshape(-1, 3))
+        self._render_shape = (H, W)
+        self._chk(self.L.hop_render_set_frame(self.h, d.ctypes.data_as(C.POINTER(C.c_ushort)), H, W, depth_unit, F(K9), F(V) if len(V) else None, len(V),
+                                              I(Fi) if len(Fi) else None, len(Fi)), "hop_render_set_frame")
+
+    def render_set_object(self, V, Fi):
+        V = np.ascontiguousarray(np.asarray(V, np.float32).reshape(-1, 3))
+        Fi = np.ascontiguousarray(np.asarray(Fi, np.int32).reshape(-1, 3))
+        self._chk(self.L.hop_render_set_object(self.h, F(V), len(V), I(Fi), len(Fi)), "hop_render_set_object")
+
+    def render_depth(self, pose=None):
+        """Renderer::doRender: (depth metres (H, W), owner (H, W): 0 nothing, 1 hand, 2 object)."""
+        H, W = self._render_shape
+        d = np.zeros((H, W), np.float32)
+        o = np.zeros((H, W), np.uint8)
+        T = None if pose is None else np.ascontiguousarray(pose, np.float32).reshape(16)
+        self._chk(self.L.hop_render_depth(self.h, F(T) if T is not None else None, F(d), o.ctypes.data_as(C.POINTER(C.c_ubyte))), "hop_render_depth")
+        return d, o
+
+    def reject_by_render(self, roi_weight, keep_ratio, sum_mode=0):
+        """PoseEstimator::rejectByRender on the resident set: (wrong_ratio of every hypothesis before the call, kept positions)."""
+        n = max(self.hypos_count(), 1)
+        wr = np.zeros(n, np.float32)
+        keep = np.zeros(n, np.int32)
+        nk = C.c_int(0)
+        self._chk(self.L.hop_reject_by_render(self.h, roi_weight, keep_ratio, int(sum_mode), F(wr), I(keep), C.byref(nk)), "hop_reject_by_render")
+        return wr, keep[:nk.value].copy()
 
     def normals_integral_image(self, xyz_organized, max_depth_change_factor=0.02, smoothing=10.0, depth_dependent=True):
         """Utils::calNormalIntegralImage (Utils.cpp:293-329, method -1) on an organised cloud (H, W, 3): (H, W, 3) normals."""

@@ -1,0 +1,362 @@
+// hop_render.hip -- "next" row N2: PoseEstimator::rejectByRender without OpenGL.
+//
+//   src/perception/src/PoseEstimator.cpp:345-463   scene assembly, per-hypothesis render, per-pixel score, keep the best
+//   src/perception/src/Renderer.cpp:41-81          addObject / doRender (camera axes, metres, clamp to [0.1, 2.0])
+//   src/depth_sim/src/range_likelihood.cpp:391-449 projection matrix and camera transform
+//   src/depth_sim/src/simulation_io.cpp:411-460    depth read-back (vertical flip, z-buffer -> millimetres, rounding)
+//   src/depth_sim/src/model.cpp:114-211            flat vertex colours, no culling, no lighting
+//
+// The reference renders the hand meshes (fixed) plus the object mesh under every hypothesis with a fixed-function OpenGL
+// pipeline, one hypothesis after the other, reads depth + colour back and scores every pixel on the CPU.  Here:
+//   * the camera model those files define: window x = fx X/Z + cx, window y (top-down, after the read-back flip)
+//     = fy Y/Z + (H - cy) -- the principal point ends up mirrored vertically --, one sample per pixel centre;
+//   * a z-buffer rasteriser: the hand once per frame, the object once per hypothesis (one thread per (hypothesis, face),
+//     ordered-float atomicMin per covered pixel), composed with GL_LESS in the reference's draw order (hand, then object);
+//   * depth through the read-back's float expression, rounded to whole millimetres, clamped to [0.1, 2.0] m;
+//   * the score loop of :398-440 with its always-true sub-conditions.  sum_mode 0 adds the 307 200 per-pixel terms into
+//     one float in row order like the reference (after ~1e5 background pixels worth 2.0 each, millimetre-sized terms
+//     round away: the result depends on that order); sum_mode 1 reduces them in double (block reduction);
+//   * the survivors: max(int(keep_ratio n), 10) smallest wrong ratios, ascending (the reference's priority queue).
+// Parity unpinned: no OpenGL exists here to pin pixel coverage or depth quantisation against; the CPU restatement
+// (oracle/render_oracle.cpp) is checked on hand-computed triangles.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "hop_ctx_ext.h"
+#include "hop_math.h"
+
+using namespace hop;
+
+#define RDCHK(ctx, call)                                                             \
+  do {                                                                               \
+    hipError_t _e = (call);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      hop_ctx_set_error((ctx), std::string(#call) + ": " + hipGetErrorString(_e));   \
+      return HOP_E_HIP;                                                              \
+    }                                                                                \
+  } while (0)
+
+namespace {
+
+struct RCam {
+  float fx, fy, cx, cy;
+  int H, W;
+};
+
+struct Render : HopExt {
+  DevBuf raw, real, hand_V, hand_F, hand_z, obj_V, obj_F, zbuf, terms, sums, poses, out_depth, out_owner;
+  RCam cam{};
+  int hand_nf = 0, obj_nv = 0, obj_nf = 0;
+  bool have_frame = false, have_object = false;
+  ~Render() override {
+    for (DevBuf* b : {&raw, &real, &hand_V, &hand_F, &hand_z, &obj_V, &obj_F, &zbuf, &terms, &sums, &poses, &out_depth, &out_owner}) b->release();
+  }
+};
+Render* render_ext(hop_ctx* c) {
+  HopExt*& e = hop_ctx_ext(c, HOP_EXT_RENDER);
+  if (!e) e = new Render;
+  return static_cast<Render*>(e);
+}
+
+constexpr unsigned Z_CLEAR = 0x3f800000u;  // 1.0f: glClearDepth(1.0)
+
+// Utils::readDepthImage (Utils.cpp:36-55)
+__global__ void k_real_depth(const unsigned short* __restrict__ raw, int n, double unit, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float d = (float)((double)(float)raw[i] * unit);
+  if (d > 2.0 || d < 0.1) d = 0.0f;
+  out[i] = d;
+}
+
+__device__ __forceinline__ float window_depth(double Z) { return (float)((2.0 / 1.9) * (1.0 - 0.1 / Z)); }
+__device__ __forceinline__ float readback_m(float d) {  // simulation_io.cpp:427 + Renderer.cpp:68-72
+  const float zn = 0.1f, zf = 2.0f;
+  const unsigned short mm = (unsigned short)round((double)(1000 * (-zf * zn / ((zf - zn) * (d - zf / (zf - zn))))));
+  float m = (float)mm / 1000.0f;
+  if (m > 2.0f) m = 2.0f;
+  if (m < 0.1f) m = 0.1f;
+  return m;
+}
+
+// one thread per (hypothesis, face); poses == nullptr: the vertices are used as they are (hand meshes, camera frame)
+__global__ void k_raster(const float* __restrict__ V, const int* __restrict__ F, int nf, const float* __restrict__ poses, int n_hyp, RCam c,
+                         unsigned* __restrict__ zbuf) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)nf * n_hyp) return;
+  const int hyp = (int)(t / nf), f = (int)(t - (long long)hyp * nf);
+  unsigned* zb = zbuf + (size_t)hyp * c.H * c.W;
+  double x[3], y[3], iz[3];
+  bool ok = true;
+  for (int k = 0; k < 3; ++k) {
+    const float* p = V + 3 * (size_t)F[3 * f + k];
+    V3 q = v3(p[0], p[1], p[2]);
+    if (poses) q = m4_point(poses + 16 * (size_t)hyp, q);  // Utils::transformPolygonMesh
+    if (!(q.z > 1e-6f)) ok = false;
+    x[k] = (double)c.fx * q.x / q.z + c.cx;
+    y[k] = (double)c.fy * q.y / q.z + ((double)c.H - c.cy);
+    iz[k] = 1.0 / q.z;
+  }
+  if (!ok) return;
+  const double area = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
+  if (area == 0.0) return;
+  const int w0 = max(0, (int)floor(fmin(fmin(x[0], x[1]), x[2]) - 0.5)), w1 = min(c.W - 1, (int)ceil(fmax(fmax(x[0], x[1]), x[2]) - 0.5));
+  const int h0 = max(0, (int)floor(fmin(fmin(y[0], y[1]), y[2]) - 0.5)), h1 = min(c.H - 1, (int)ceil(fmax(fmax(y[0], y[1]), y[2]) - 0.5));
+  for (int h = h0; h <= h1; ++h)
+    for (int w = w0; w <= w1; ++w) {
+      const double px = w + 0.5, py = h + 0.5;
+      const double e0 = (x[2] - x[1]) * (py - y[1]) - (y[2] - y[1]) * (px - x[1]);
+      const double e1 = (x[0] - x[2]) * (py - y[2]) - (y[0] - y[2]) * (px - x[2]);
+      const double e2 = (x[1] - x[0]) * (py - y[0]) - (y[1] - y[0]) * (px - x[0]);
+      if (!((e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0))) continue;
+      const double Z = area / (e0 * iz[0] + e1 * iz[1] + e2 * iz[2]);
+      if (!(Z >= 0.1 && Z <= 2.0)) continue;
+      atomicMin(&zb[(size_t)h * c.W + w], __float_as_uint(window_depth(Z)));  // positive floats order like their bits
+    }
+}
+
+__device__ __forceinline__ void pixel_term(float real, unsigned zh, unsigned zo, float& diff, bool& roi) {
+  // GL_LESS in draw order: the object (drawn last) owns the pixel only where it is strictly nearer than the hand
+  roi = zo < zh;
+  const float sim = readback_m(__uint_as_float(roi ? zo : zh));
+  if ((real <= 0.1 || real >= 2.0) && (sim > 0.1 || sim < 2.0)) diff = 2.0f;
+  else if ((sim <= 0.1 || sim >= 2.0) && (real > 0.1 || real < 2.0)) diff = 2.0f;
+  else diff = fabsf(sim - real);
+}
+
+// sum_mode 0, pass 1: the per-pixel term of every hypothesis, [pixel][hypothesis]; bit 31 = object pixel (diff >= 0)
+__global__ void k_score_terms(const float* __restrict__ real, const unsigned* __restrict__ hand_z, const unsigned* __restrict__ zbuf, int npx, int n_hyp,
+                              unsigned* __restrict__ terms) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)npx * n_hyp) return;
+  const int hyp = (int)(t / npx), px = (int)(t - (long long)hyp * npx);
+  float diff;
+  bool roi;
+  pixel_term(real[px], hand_z[px], zbuf[(size_t)hyp * npx + px], diff, roi);
+  terms[(size_t)px * n_hyp + hyp] = __float_as_uint(diff) | (roi ? 0x80000000u : 0u);
+}
+// sum_mode 0, pass 2: one lane per hypothesis adds its terms in row order (the reference's loop, :402-437)
+__global__ __launch_bounds__(64) void k_score_serial(const unsigned* __restrict__ terms, int npx, int n_hyp, float roi_weight, float* __restrict__ wrong) {
+  const int hyp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hyp >= n_hyp) return;
+  float roi_diff = 0, bg_diff = 0;
+  int roi_cnt = 0, bg_cnt = 0;
+  constexpr int U = 16;
+  int px = 0;
+  for (; px + U <= npx; px += U) {
+    unsigned v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = terms[(size_t)(px + u) * n_hyp + hyp];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float d = __uint_as_float(v[u] & 0x7fffffffu);
+      if (v[u] & 0x80000000u) roi_diff += d, roi_cnt++;
+      else bg_diff += d, bg_cnt++;
+    }
+  }
+  for (; px < npx; ++px) {
+    const unsigned v = terms[(size_t)px * n_hyp + hyp];
+    const float d = __uint_as_float(v & 0x7fffffffu);
+    if (v & 0x80000000u) roi_diff += d, roi_cnt++;
+    else bg_diff += d, bg_cnt++;
+  }
+  wrong[hyp] = roi_weight * roi_diff / roi_cnt + bg_diff / bg_cnt;
+}
+// sum_mode 1: one block per hypothesis, sums reduced in double
+__global__ __launch_bounds__(256) void k_score_reduce(const float* __restrict__ real, const unsigned* __restrict__ hand_z, const unsigned* __restrict__ zbuf, int npx,
+                                                      float roi_weight, float* __restrict__ wrong) {
+  __shared__ double sd[4][2];
+  __shared__ int sc[4][2];
+  const int hyp = blockIdx.x;
+  double roi_diff = 0, bg_diff = 0;
+  int roi_cnt = 0, bg_cnt = 0;
+  for (int px = threadIdx.x; px < npx; px += 256) {
+    float diff;
+    bool roi;
+    pixel_term(real[px], hand_z[px], zbuf[(size_t)hyp * npx + px], diff, roi);
+    if (roi) roi_diff += diff, roi_cnt++;
+    else bg_diff += diff, bg_cnt++;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    roi_diff += __shfl_down(roi_diff, off), bg_diff += __shfl_down(bg_diff, off);
+    roi_cnt += __shfl_down(roi_cnt, off), bg_cnt += __shfl_down(bg_cnt, off);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sd[wave][0] = roi_diff, sd[wave][1] = bg_diff, sc[wave][0] = roi_cnt, sc[wave][1] = bg_cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double r = (sd[0][0] + sd[1][0]) + (sd[2][0] + sd[3][0]), b = (sd[0][1] + sd[1][1]) + (sd[2][1] + sd[3][1]);
+    const int rc = sc[0][0] + sc[1][0] + sc[2][0] + sc[3][0], bc = sc[0][1] + sc[1][1] + sc[2][1] + sc[3][1];
+    wrong[hyp] = roi_weight * (float)r / (float)rc + (float)b / (float)bc;
+  }
+}
+
+__global__ void k_compose_image(const unsigned* __restrict__ hand_z, const unsigned* __restrict__ obj_z, int npx, float* __restrict__ depth_m,
+                                unsigned char* __restrict__ owner) {
+  const int px = blockIdx.x * blockDim.x + threadIdx.x;
+  if (px >= npx) return;
+  const unsigned zh = hand_z[px], zo = obj_z ? obj_z[px] : Z_CLEAR;
+  const bool roi = zo < zh;
+  const unsigned z = roi ? zo : zh;
+  depth_m[px] = readback_m(__uint_as_float(z));
+  owner[px] = roi ? 2 : (zh < Z_CLEAR ? 1 : 0);
+}
+
+int fill_clear(hop_ctx* c, void* p, size_t words) {
+  RDCHK(c, hipMemsetD32Async((hipDeviceptr_t)p, (int)Z_CLEAR, words, hop_ctx_stream(c)));
+  return HOP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hop_render_set_frame(hop_ctx* c, const uint16_t* depth_raw, int H, int W, double depth_unit, const float K9[9], const float* hand_V, int hand_nv,
+                         const int32_t* hand_F, int hand_nf) {
+  if (!c || !depth_raw || H <= 0 || W <= 0 || !K9 || hand_nv < 0 || hand_nf < 0 || (hand_nf > 0 && (!hand_V || !hand_F))) return HOP_E_INVALID;
+  for (int i = 0; i < 3 * hand_nf; ++i)
+    if (hand_F[i] < 0 || hand_F[i] >= hand_nv) return HOP_E_INVALID;
+  RDCHK(c, hipSetDevice(hop_ctx_device(c)));
+  Render* r = render_ext(c);
+  hipStream_t st = hop_ctx_stream(c);
+  const size_t npx = (size_t)H * W;
+  r->cam = RCam{K9[0], K9[4], K9[2], K9[5], H, W};
+  RDCHK(c, r->raw.ensure(sizeof(uint16_t) * npx));
+  RDCHK(c, r->real.ensure(sizeof(float) * npx));
+  RDCHK(c, r->hand_z.ensure(sizeof(unsigned) * npx));
+  RDCHK(c, hipMemcpyAsync(r->raw.p, depth_raw, sizeof(uint16_t) * npx, hipMemcpyHostToDevice, st));
+  k_real_depth<<<(unsigned)((npx + 255) / 256), 256, 0, st>>>(r->raw.as<unsigned short>(), (int)npx, depth_unit, r->real.as<float>());
+  int rc = fill_clear(c, r->hand_z.p, npx);
+  if (rc) return rc;
+  r->hand_nf = hand_nf;
+  if (hand_nf > 0) {
+    RDCHK(c, r->hand_V.ensure(sizeof(float) * 3 * (size_t)hand_nv));
+    RDCHK(c, r->hand_F.ensure(sizeof(int) * 3 * (size_t)hand_nf));
+    RDCHK(c, hipMemcpyAsync(r->hand_V.p, hand_V, sizeof(float) * 3 * (size_t)hand_nv, hipMemcpyHostToDevice, st));
+    RDCHK(c, hipMemcpyAsync(r->hand_F.p, hand_F, sizeof(int) * 3 * (size_t)hand_nf, hipMemcpyHostToDevice, st));
+    k_raster<<<(hand_nf + 63) / 64, 64, 0, st>>>(r->hand_V.as<float>(), r->hand_F.as<int>(), hand_nf, nullptr, 1, r->cam, r->hand_z.as<unsigned>());
+  }
+  RDCHK(c, hipGetLastError());
+  RDCHK(c, hipStreamSynchronize(st));
+  r->have_frame = true;
+  return HOP_OK;
+}
+
+int hop_render_set_object(hop_ctx* c, const float* V, int nv, const int32_t* F, int nf) {
+  if (!c || !V || !F || nv <= 0 || nf <= 0) return HOP_E_INVALID;
+  for (int i = 0; i < 3 * nf; ++i)
+    if (F[i] < 0 || F[i] >= nv) return HOP_E_INVALID;
+  RDCHK(c, hipSetDevice(hop_ctx_device(c)));
+  Render* r = render_ext(c);
+  hipStream_t st = hop_ctx_stream(c);
+  RDCHK(c, r->obj_V.ensure(sizeof(float) * 3 * (size_t)nv));
+  RDCHK(c, r->obj_F.ensure(sizeof(int) * 3 * (size_t)nf));
+  RDCHK(c, hipMemcpyAsync(r->obj_V.p, V, sizeof(float) * 3 * (size_t)nv, hipMemcpyHostToDevice, st));
+  RDCHK(c, hipMemcpyAsync(r->obj_F.p, F, sizeof(int) * 3 * (size_t)nf, hipMemcpyHostToDevice, st));
+  RDCHK(c, hipStreamSynchronize(st));
+  r->obj_nv = nv, r->obj_nf = nf, r->have_object = true;
+  return HOP_OK;
+}
+
+int hop_render_depth(hop_ctx* c, const float* pose16, float* depth_m_out, unsigned char* owner_out) {
+  if (!c || !depth_m_out) return HOP_E_INVALID;
+  Render* r = render_ext(c);
+  if (!r->have_frame || (pose16 && !r->have_object)) return HOP_E_STATE;
+  RDCHK(c, hipSetDevice(hop_ctx_device(c)));
+  hipStream_t st = hop_ctx_stream(c);
+  const size_t npx = (size_t)r->cam.H * r->cam.W;
+  RDCHK(c, r->out_depth.ensure(sizeof(float) * npx));
+  RDCHK(c, r->out_owner.ensure(npx));
+  const unsigned* oz = nullptr;
+  if (pose16) {
+    RDCHK(c, r->zbuf.ensure(sizeof(unsigned) * npx));
+    RDCHK(c, r->poses.ensure(sizeof(float) * 16));
+    RDCHK(c, hipMemcpyAsync(r->poses.p, pose16, sizeof(float) * 16, hipMemcpyHostToDevice, st));
+    int rc = fill_clear(c, r->zbuf.p, npx);
+    if (rc) return rc;
+    k_raster<<<(r->obj_nf + 63) / 64, 64, 0, st>>>(r->obj_V.as<float>(), r->obj_F.as<int>(), r->obj_nf, r->poses.as<float>(), 1, r->cam, r->zbuf.as<unsigned>());
+    oz = r->zbuf.as<unsigned>();
+  }
+  k_compose_image<<<(unsigned)((npx + 255) / 256), 256, 0, st>>>(r->hand_z.as<unsigned>(), oz, (int)npx, r->out_depth.as<float>(), r->out_owner.as<unsigned char>());
+  RDCHK(c, hipGetLastError());
+  RDCHK(c, hipMemcpyAsync(depth_m_out, r->out_depth.p, sizeof(float) * npx, hipMemcpyDeviceToHost, st));
+  if (owner_out) RDCHK(c, hipMemcpyAsync(owner_out, r->out_owner.p, npx, hipMemcpyDeviceToHost, st));
+  RDCHK(c, hipStreamSynchronize(st));
+  return HOP_OK;
+}
+
+int hop_reject_by_render(hop_ctx* c, float roi_weight, float keep_ratio, int sum_mode, float* wrong_ratio_out, int* keep_index_out, int* n_keep_out) {
+  if (!c || (sum_mode != 0 && sum_mode != 1) || !(keep_ratio >= 0)) return HOP_E_INVALID;
+  Render* r = render_ext(c);
+  if (!r->have_frame || !r->have_object) return HOP_E_STATE;
+  RDCHK(c, hipSetDevice(hop_ctx_device(c)));
+  hipStream_t st = hop_ctx_stream(c);
+  HopHypView hv = hop_ctx_hyp(c);
+  const int n = hv.n;
+  if (n_keep_out) *n_keep_out = 0;
+  if (n == 0) return HOP_OK;
+  const size_t npx = (size_t)r->cam.H * r->cam.W;
+  std::vector<float> wrong(n);
+  RDCHK(c, r->sums.ensure(sizeof(float) * (size_t)n));
+  // batches bound the z-buffers (1.2 MB per hypothesis at 640 x 480) and, in sum_mode 0, the staged terms
+  const int HB = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)1 << 30) / (sizeof(unsigned) * npx)));
+  RDCHK(c, r->zbuf.ensure(sizeof(unsigned) * npx * (size_t)HB));
+  if (sum_mode == 0) RDCHK(c, r->terms.ensure(sizeof(unsigned) * npx * (size_t)HB));
+  for (int h0 = 0; h0 < n; h0 += HB) {
+    const int hb = std::min(HB, n - h0);
+    int rc = fill_clear(c, r->zbuf.p, npx * (size_t)hb);
+    if (rc) return rc;
+    const long long work = (long long)r->obj_nf * hb;
+    k_raster<<<(unsigned)((work + 63) / 64), 64, 0, st>>>(r->obj_V.as<float>(), r->obj_F.as<int>(), r->obj_nf, hv.pose + 16 * (size_t)h0, hb, r->cam,
+                                                         r->zbuf.as<unsigned>());
+    if (sum_mode == 0) {
+      const long long t = (long long)npx * hb;
+      k_score_terms<<<(unsigned)((t + 255) / 256), 256, 0, st>>>(r->real.as<float>(), r->hand_z.as<unsigned>(), r->zbuf.as<unsigned>(), (int)npx, hb,
+                                                                r->terms.as<unsigned>());
+      k_score_serial<<<(hb + 63) / 64, 64, 0, st>>>(r->terms.as<unsigned>(), (int)npx, hb, roi_weight, r->sums.as<float>() + h0);
+    } else {
+      k_score_reduce<<<hb, 256, 0, st>>>(r->real.as<float>(), r->hand_z.as<unsigned>(), r->zbuf.as<unsigned>(), (int)npx, roi_weight, r->sums.as<float>() + h0);
+    }
+    RDCHK(c, hipGetLastError());
+  }
+  RDCHK(c, hipMemcpyAsync(wrong.data(), r->sums.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+  // the survivors, ascending wrong ratio (ties by position; NaN -- no object pixel -- last), gathered on the host: n is small
+  std::vector<float> pose((size_t)16 * n), score(n);
+  std::vector<int> id(n);
+  RDCHK(c, hipMemcpyAsync(pose.data(), hv.pose, sizeof(float) * 16 * (size_t)n, hipMemcpyDeviceToHost, st));
+  RDCHK(c, hipMemcpyAsync(score.data(), hv.score, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+  RDCHK(c, hipMemcpyAsync(id.data(), hv.id, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+  RDCHK(c, hipStreamSynchronize(st));
+  int num_to_keep = std::max((int)(keep_ratio * n), 10);
+  num_to_keep = std::min(num_to_keep, n);
+  std::vector<int> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    const float x = wrong[a], y = wrong[b];
+    if (std::isnan(x) || std::isnan(y)) return !std::isnan(x) && std::isnan(y);
+    return x < y;
+  });
+  std::vector<float> p2((size_t)16 * num_to_keep), s2(num_to_keep);
+  std::vector<int> i2(num_to_keep);
+  for (int k = 0; k < num_to_keep; ++k) {
+    std::copy(pose.begin() + 16 * (size_t)order[k], pose.begin() + 16 * (size_t)order[k] + 16, p2.begin() + 16 * (size_t)k);
+    s2[k] = score[order[k]], i2[k] = id[order[k]];
+    if (keep_index_out) keep_index_out[k] = order[k];
+  }
+  RDCHK(c, hipMemcpyAsync(hv.pose, p2.data(), sizeof(float) * 16 * (size_t)num_to_keep, hipMemcpyHostToDevice, st));
+  RDCHK(c, hipMemcpyAsync(hv.score, s2.data(), sizeof(float) * (size_t)num_to_keep, hipMemcpyHostToDevice, st));
+  RDCHK(c, hipMemcpyAsync(hv.id, i2.data(), sizeof(int) * (size_t)num_to_keep, hipMemcpyHostToDevice, st));
+  RDCHK(c, hipStreamSynchronize(st));
+  hop_ctx_hyp_set_count(c, num_to_keep);
+  if (wrong_ratio_out) std::copy(wrong.begin(), wrong.end(), wrong_ratio_out);
+  if (n_keep_out) *n_keep_out = num_to_keep;
+  return HOP_OK;
+}
+
+}  // extern "C"

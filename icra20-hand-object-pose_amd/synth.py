@@ -597,3 +597,85 @@ def grasp_frame(seed: int = 2, n_object: int = 9000, hand_spacing=0.0013, noise=
     return dict(scene_xyz=apply(handbase_in_cam, pts.astype(np.float32)), scene_nrm=rotate(handbase_in_cam, nrm.astype(np.float32)), is_object=is_obj,
                 handbase_in_cam=handbase_in_cam.astype(np.float32), handbase_in_cam_reported=(handbase_in_cam @ D).astype(np.float32),
                 object_in_cam=(handbase_in_cam @ obj_in_hand).astype(np.float32), hand=hand, angles=angles, object_V=V, object_F=F)
+
+
+# --------------------------------------------------------------------------- depth images (rows N2 / N3 / N4)
+def hand_mesh_in_cam(hand: HandModel, angles: dict, handbase_in_cam, names=None):
+    """The triangles of the hand's link meshes moved by handbase_in_cam * getTFHandBase(name): what
+    PoseEstimator::rejectByRender adds to the renderer for every matched component (PoseEstimator.cpp:362-383)."""
+    Vs, Fs, off = [], [], 0
+    for name in (names if names is not None else hand.meshes):
+        V, F = hand.meshes[name]
+        T = np.asarray(handbase_in_cam, np.float64) @ (np.eye(4) if name == "base_link" else hand_fk(hand, angles, name))
+        Vs.append(apply(T, np.asarray(V, np.float32)).astype(np.float32))
+        Fs.append(np.asarray(F, np.int32) + off)
+        off += len(V)
+    if not Vs:
+        return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32)
+    return np.concatenate(Vs), np.concatenate(Fs)
+
+
+def render_depth_numpy(V, F, K, H, W):
+    """Nearest eye depth (metres, 0 = nothing) per pixel of a triangle soup given in the camera frame: pinhole
+    u = fx X / Z + cx, v = fy Y / Z + cy sampled at integer pixels (what a depth sensor image means to
+    Utils::convert3dOrganizedRGB).  A plain z-buffer for the synthetic frames; not the reference's renderer (that is
+    hop_render_depth, with OpenGL's half-pixel and mirrored principal point)."""
+    fx, fy, cx, cy = float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2])
+    V = np.asarray(V, np.float64)
+    z = np.full((H, W), np.inf)
+    P = V[np.asarray(F)]                                   # (nf, 3, 3)
+    ok = (P[:, :, 2] > 1e-6).all(axis=1)
+    x = fx * P[:, :, 0] / np.where(P[:, :, 2] > 1e-6, P[:, :, 2], 1.0) + cx
+    y = fy * P[:, :, 1] / np.where(P[:, :, 2] > 1e-6, P[:, :, 2], 1.0) + cy
+    iz = 1.0 / np.where(P[:, :, 2] > 1e-6, P[:, :, 2], 1.0)
+    for f in np.flatnonzero(ok):
+        w0, w1 = max(0, int(math.ceil(x[f].min()))), min(W - 1, int(math.floor(x[f].max())))
+        h0, h1 = max(0, int(math.ceil(y[f].min()))), min(H - 1, int(math.floor(y[f].max())))
+        if w0 > w1 or h0 > h1:
+            continue
+        px, py = np.meshgrid(np.arange(w0, w1 + 1, dtype=np.float64), np.arange(h0, h1 + 1, dtype=np.float64))
+        area = (x[f, 1] - x[f, 0]) * (y[f, 2] - y[f, 0]) - (x[f, 2] - x[f, 0]) * (y[f, 1] - y[f, 0])
+        if area == 0:
+            continue
+        e0 = (x[f, 2] - x[f, 1]) * (py - y[f, 1]) - (y[f, 2] - y[f, 1]) * (px - x[f, 1])
+        e1 = (x[f, 0] - x[f, 2]) * (py - y[f, 2]) - (y[f, 0] - y[f, 2]) * (px - x[f, 2])
+        e2 = (x[f, 1] - x[f, 0]) * (py - y[f, 0]) - (y[f, 1] - y[f, 0]) * (px - x[f, 0])
+        inside = ((e0 >= 0) & (e1 >= 0) & (e2 >= 0)) | ((e0 <= 0) & (e1 <= 0) & (e2 <= 0))
+        if not inside.any():
+            continue
+        with np.errstate(divide="ignore", invalid="ignore"):
+            Z = area / (e0 * iz[f, 0] + e1 * iz[f, 1] + e2 * iz[f, 2])
+        sub = z[h0:h1 + 1, w0:w1 + 1]
+        upd = inside & (Z > 0) & (Z < sub)
+        sub[upd] = Z[upd]
+    z[~np.isfinite(z)] = 0.0
+    return z
+
+
+CAM_K = np.array([[615.0, 0.0, 320.0], [0.0, 615.0, 240.0], [0.0, 0.0, 1.0]], dtype=np.float32)  # SR300-like, 640 x 480
+
+
+def grasp_depth_frame(seed: int = 2, noise_mm: float = 0.3, table: bool = True):
+    """The synthetic grasp of ``grasp_frame`` as what the robot records (run_real_all.cpp:72-104): a 16-bit depth image in
+    millimetres (hand + object meshes, optionally a table plane behind them, rendered through ``CAM_K``, Gaussian depth
+    noise), the camera intrinsics, the true and the reported hand-base pose, the object's pose, the hand model with its
+    finger angles, and the meshes."""
+    g = grasp_frame(seed=seed, n_object=200)
+    rng = np.random.Generator(np.random.PCG64(seed + 77))
+    hand = g["hand"]
+    hV, hF = hand_mesh_in_cam(hand, g["angles"], g["handbase_in_cam"])
+    oV = apply(g["object_in_cam"], np.asarray(g["object_V"], np.float32))
+    V = np.concatenate([hV, oV])
+    F = np.concatenate([hF, np.asarray(g["object_F"], np.int32) + len(hV)])
+    if table:   # a plane 12 cm behind the hand, facing the camera: the background a real frame has
+        zc = float(np.concatenate([hV, oV])[:, 2].max()) + 0.12
+        q = np.array([[-0.6, -0.5, zc], [0.6, -0.5, zc], [0.6, 0.5, zc], [-0.6, 0.5, zc]], np.float32)
+        V = np.concatenate([V, q])
+        F = np.concatenate([F, np.array([[0, 1, 2], [0, 2, 3]], np.int32) + len(V) - 4])
+    H, W = 480, 640
+    z = render_depth_numpy(V, F, CAM_K, H, W)
+    mm = z * 1000.0 + np.where(z > 0, rng.normal(0.0, noise_mm, z.shape), 0.0)
+    depth = np.clip(np.rint(mm), 0, 65535).astype(np.uint16)
+    out = dict(g)
+    out.update(depth=depth, K=CAM_K.copy(), hand_mesh_cam=(hV, hF))
+    return out

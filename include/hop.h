@@ -303,6 +303,31 @@ int hop_reject_by_collision(hop_ctx* ctx, unsigned char* keep_out, float* diag8_
 int hop_physics_timing(hop_ctx* ctx, double* ms_set_frame, double* ms_reject);
 
 /* ------------------------------------------------------------------------------------------------
+ * "Next" row N2: PoseEstimator::rejectByRender (src/perception/src/PoseEstimator.cpp:345-463) without OpenGL:
+ * Renderer::addObject / doRender (src/perception/src/Renderer.cpp:41-81), the projection of
+ * src/depth_sim/src/range_likelihood.cpp:391-449 and the depth read-back of src/depth_sim/src/simulation_io.cpp:411-460
+ * restated as a z-buffer rasteriser (hop_render.hip; parity unpinned: no OpenGL exists here to pin coverage against).
+ *   hop_render_set_frame    the frame's depth image (Utils::readDepthImage: raw * depth_unit, out of [0.1, 2.0] -> 0), the camera
+ *                           intrinsics (Renderer(H, W, fx, fy, cx, cy)) and the hand: the triangles of every hand mesh whose
+ *                           component was matched, ALREADY moved by handbase_in_cam * getTFHandBase(name) (:362-383), one soup
+ *   hop_render_set_object   the object mesh in the model frame (_obj_mesh); every hypothesis moves it by its pose (:388)
+ *   hop_render_depth        Renderer::doRender for one object pose (NULL: hand only): depth in metres (millimetre-rounded,
+ *                           clamped to [0.1, 2.0], background 2.0) and owner per pixel (0 nothing, 1 hand, 2 object = the
+ *                           blue pixels of the colour image)
+ *   hop_reject_by_render    scores every resident hypothesis (_wrong_ratio = roi_weight * roi_diff / roi_cnt + bg_diff / bg_cnt,
+ *                           :398-444) and keeps the max(int(keep_ratio * n), 10) smallest, ascending (:447-461; ties by position).
+ *                           sum_mode 0: the per-pixel terms are added into one float in row order, as the reference does (the
+ *                           result depends on that order); 1: reduced in double.  wrong_ratio_out: n values in the order of
+ *                           the set before the call; keep_index_out: positions (before the call) of the survivors.
+ * ---------------------------------------------------------------------------------------------- */
+int hop_render_set_frame(hop_ctx* ctx, const uint16_t* depth_raw, int H, int W, double depth_unit, const float K9[9], const float* hand_V,
+                         int hand_nv, const int32_t* hand_F, int hand_nf);
+int hop_render_set_object(hop_ctx* ctx, const float* V, int nv, const int32_t* F, int nf);
+int hop_render_depth(hop_ctx* ctx, const float* pose16, float* depth_m_out, unsigned char* owner_out);
+int hop_reject_by_render(hop_ctx* ctx, float roi_weight, float keep_ratio, int sum_mode, float* wrong_ratio_out, int* keep_index_out,
+                         int* n_keep_out);
+
+/* ------------------------------------------------------------------------------------------------
  * "Next" row N3b: the scene front end of src/perception/src/app/main_realdata_auto.cpp:54-96 without
  * colours and normals -- Utils::readDepthImage (Utils.cpp:36-55, depth_unit = SR300_DEPTH_UNIT), Utils::convert3dOrganizedRGB
  * (Utils.cpp:79-115, K9 = cam_intrinsic row-major), the z pass-through [0.1, 2.0], the voxel grid at `leaf` (0.001),

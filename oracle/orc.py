@@ -45,7 +45,7 @@ def soa(a):
 def build(force=False):
     """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
     if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(
-            os.path.getmtime(os.path.join(HERE, f)) for f in ("hop_oracle.cpp", "sdf_oracle.cpp", "normals_oracle.cpp", "hop_oracle.h")):
+            os.path.getmtime(os.path.join(HERE, f)) for f in ("hop_oracle.cpp", "sdf_oracle.cpp", "normals_oracle.cpp", "render_oracle.cpp", "hop_oracle.h")):
         subprocess.check_call(["make", "-C", HERE, "_build/liboracle.so"], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
 
@@ -580,3 +580,43 @@ def scene_from_depth_normals(depth_raw, depth_unit, K, cam_in_handbase, handbase
     lib().orc_scene_from_depth_normals(d.ctypes.data_as(C.POINTER(C.c_ushort)), H, W, C.c_double(depth_unit), F(K9), F(A), F(B), C.c_float(leaf), F(lo), F(hi),
                                        C.c_float(factor), C.c_float(smoothing), F(ox), F(on), cap, C.byref(n))
     return ox[:, :n.value].T.copy(), on[:, :n.value].T.copy()
+
+
+def _mesh(V, Fi):
+    V = np.ascontiguousarray(np.asarray(V, np.float32).reshape(-1, 3))
+    Fi = np.ascontiguousarray(np.asarray(Fi, np.int32).reshape(-1, 3))
+    return V, Fi
+
+
+def render(hand_V, hand_F, obj_V, obj_F, K, H, W):
+    """Renderer::doRender of hand + object meshes given in the camera frame: (depth metres (H, W), owner (H, W))."""
+    hv, hf = _mesh(hand_V, hand_F)
+    ov, of = _mesh(obj_V, obj_F)
+    K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+    d = np.zeros((H, W), np.float32)
+    o = np.zeros((H, W), np.uint8)
+    lib().orc_render(F(hv), I(hf), len(hf), F(ov), I(of), len(of), F(K9), H, W, F(d), o.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return d, o
+
+
+def read_depth_image(depth_raw, unit=0.001):
+    """Utils::readDepthImage (Utils.cpp:36-55)."""
+    d = (np.asarray(depth_raw).astype(np.float32).astype(np.float64) * unit).astype(np.float32)
+    d[(d > 2.0) | (d < 0.1)] = 0
+    return d
+
+
+def reject_by_render(depth_raw, unit, K, hand_V, hand_F, obj_V, obj_F, poses, roi_weight, keep_ratio):
+    """PoseEstimator::rejectByRender: (wrong_ratio of every hypothesis, kept indices in pop order)."""
+    dm = np.ascontiguousarray(read_depth_image(depth_raw, unit))
+    H, W = dm.shape
+    hv, hf = _mesh(hand_V, hand_F)
+    ov, of = _mesh(obj_V, obj_F)
+    K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+    T = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    wr = np.zeros(max(len(T), 1), np.float32)
+    keep = np.zeros(max(len(T), 1), np.int32)
+    nk = C.c_int(0)
+    lib().orc_reject_by_render(F(dm), H, W, F(K9), F(hv), I(hf), len(hf), F(ov), len(ov), I(of), len(of), F(T), len(T), C.c_float(roi_weight), C.c_float(keep_ratio),
+                               F(wr), I(keep), C.byref(nk))
+    return wr[:len(T)].copy(), keep[:nk.value].copy()
