@@ -710,6 +710,9 @@ class PoseEstimator:
         self.ctx = ctx or Context(device)
         self.ctx.set_model(HOP_MODEL_5MM, *model)
         self.ctx.set_model(HOP_MODEL_1MM, *model001)
+        self.ctx.model_owner = self
+        self._models = ((np.asarray(model[0], np.float32), np.asarray(model[1], np.float32)),
+                        (np.asarray(model001[0], np.float32), np.asarray(model001[1], np.float32)))
         self._pose_hypos = []
         self.last_stats = None
         self._model = np.asarray(model[0], np.float32)
@@ -721,11 +724,22 @@ class PoseEstimator:
         self._ob_diameter = np.float32(np.sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]))
         self._cloud_withouthand_raw = None
         self._mesh_ids = {}
+        self._slots = dict(self.MESH_SLOTS)   # per instance: new names do not leak into other estimators
+        self._obj_mesh = None
+        self._depth_raw = self._depth_unit = self._K = None
 
-    def setCurScene(self, object_segment_xyz, object_segment_nrm, confidence, cloud_withouthand_raw=None):
+    def setCurScene(self, object_segment_xyz, object_segment_nrm, confidence, cloud_withouthand_raw=None, depth_raw=None, depth_unit=0.001, K=None):
+        """PoseEstimator::setCurScene (PoseEstimator.cpp:32-46); depth_raw / K: the frame's depth image and intrinsics
+        (_depth_meters, the constructor's K), needed by rejectByRender only."""
         thres = float(self.cfg.get("pose_estimator_high_confidence_thres", 0.8))
+        if getattr(self.ctx, "model_owner", self) is not self:   # HandT42.handbaseICP borrowed the context's model slot
+            self.ctx.set_model(HOP_MODEL_5MM, *self._models[0])
+            self.ctx.set_model(HOP_MODEL_1MM, *self._models[1])
+            self.ctx.model_owner = self
         if cloud_withouthand_raw is not None:
             self._cloud_withouthand_raw = np.asarray(cloud_withouthand_raw, np.float32)
+        if depth_raw is not None:
+            self._depth_raw, self._depth_unit, self._K = np.asarray(depth_raw, np.uint16), float(depth_unit), np.asarray(K, np.float32)
         return self.ctx.set_scene(object_segment_xyz, object_segment_nrm, confidence, thres)
 
     # ---- physics row (N1)
@@ -734,9 +748,33 @@ class PoseEstimator:
     def registerMesh(self, V, Fi, name, pose=None):
         """PoseEstimator::registerMesh -> SDFchecker::registerMesh (PoseEstimator.cpp:505-508); the OBJ file of the
         reference is passed as arrays."""
-        mid = self.MESH_SLOTS.setdefault(name, len(self.MESH_SLOTS))
+        mid = self._slots.setdefault(name, len(self._slots))
         self.ctx.sdf_register_mesh(mid, V, Fi, pose)
         self._mesh_ids[name] = mid
+        if name == "object":
+            self._obj_mesh = (np.asarray(V, np.float32), np.asarray(Fi, np.int32))   # _obj_mesh, what rejectByRender draws
+
+    def rejectByRender(self, projection_thres, hand, handbase_in_cam, sum_mode=0):
+        """PoseEstimator::rejectByRender (PoseEstimator.cpp:345-463; projection_thres is unused there as well): the meshes
+        of the matched hand components at handbase_in_cam * getTFHandBase(name), the object mesh under every hypothesis,
+        _wrong_ratio from the depth difference to the frame's depth image, the best render_keep_hypo share kept.
+        Returns (wrong ratios of the incoming set, kept positions)."""
+        if self._depth_raw is None or self._obj_mesh is None:
+            raise HopError(-5, "rejectByRender", "setCurScene(depth_raw=..., K=...) and registerMesh(..., 'object') come first")
+        Vs, Fs, off = [], [], 0
+        for name, (V, Fi) in hand.hand.meshes.items():          # hand->_meshes, map order; unmatched components are skipped (:364-365)
+            if not hand._component_status.get(name, False):
+                continue
+            T = np.asarray(handbase_in_cam, np.float32) @ hand.getTFHandBase(name)
+            V = np.asarray(V, np.float32)
+            Vs.append((V @ T[:3, :3].T + T[:3, 3]).astype(np.float32))
+            Fs.append(np.asarray(Fi, np.int32) + off)
+            off += len(V)
+        hV = np.concatenate(Vs) if Vs else np.zeros((0, 3), np.float32)
+        hF = np.concatenate(Fs) if Fs else np.zeros((0, 3), np.int32)
+        self.ctx.render_set_frame(self._depth_raw, self._depth_unit, self._K, hV, hF)
+        self.ctx.render_set_object(*self._obj_mesh)
+        return self.ctx.reject_by_render(float(self.cfg.get("render_roi_weight", 2.0)), float(self.cfg.get("render_keep_hypo", 0.3)), sum_mode)
 
     def registerHandMesh(self, hand):
         """PoseEstimator.cpp:510-520: the four finger links' convex meshes at getTFHandBase(link)."""
@@ -793,7 +831,8 @@ class PoseEstimator:
 
     def selectBest(self):
         pose, score, idx = self.ctx.lcp_select_best(float(self.cfg["lcp"]["dist"]), float(self.cfg["lcp"]["normal_angle"]), -1)
-        return PoseHypo(pose, idx, score)
+        ids = self.ctx.hypos_download()[2]     # the reference copies the winning PoseHypo: _id is the id clusterPoses assigned
+        return PoseHypo(pose, int(ids[idx]) if 0 <= idx < len(ids) else idx, score)
 
     def hypos(self):
         pose, sc, ids = self.ctx.hypos_download()
@@ -892,6 +931,7 @@ class HandT42:
             bx, bn = self.hand.clouds["base_link"]
             c.set_scene(hx[keep], hn[keep], None, 0.0)          # Utils::runICP source (pclSegment)
             c.set_model(HOP_MODEL_5MM, bx, bn)                   # target (pclModel)
+            c.model_owner = self                                 # a PoseEstimator on this context uploads its models again
             c.hypos_upload(np.eye(4, dtype=np.float32)[None])
             c.icp_refine(50, 30.0, 0.03, nn_mode=0)
             pose, _, _ = c.hypos_download()
@@ -1066,6 +1106,7 @@ class HandT42:
         self.ctx.hand_set_finger(args)
         angle, objval = self.ctx.hand_pso_search(self.pso_settings(min_angle, max_angle))
         self.last_objval = objval
+        self._hand_clouds = None   # the link moves (or resets): a cached makeHandCloud() result would be stale
         if -objval <= least_match:
             self._tf_self[model_name] = np.eye(4, dtype=np.float32)
             self._component_status[model_name] = False

@@ -115,6 +115,8 @@ class Hand {
 
   // the convex mesh of a component (Hand.cpp:526-530, loaded from an OBJ file there), link frame
   void addConvexMesh(const std::string& name, const hop::Mesh& mesh) { _convex_meshes[name] = mesh; }
+  // the visual mesh of a component (Hand.cpp:529, hand->_meshes: what rejectByRender draws), link frame
+  void addMesh(const std::string& name, const hop::Mesh& mesh) { _meshes[name] = mesh; }
 
   // products of Hand::setCurScene (Hand.cpp:327-332), hand-base frame
   void setCurScene(const hop::Cloud& scene_hand_region_removed_noise, const hop::Cloud& scene_hand_region,
@@ -437,7 +439,7 @@ class Hand {
   std::map<std::string, float> _finger_angles;
   std::map<std::string, hop::Cloud> _hand_clouds;  // Hand::makeHandCloud products (hand-base frame)
   hop::Cloud _hand_cloud;                          // their concatenation
-  std::map<std::string, hop::Mesh> _convex_meshes;
+  std::map<std::string, hop::Mesh> _convex_meshes, _meshes;
   Mat4 _handbase_in_cam;
   ConfigParser* cfg;
   hop_pso_settings _pso_settings;

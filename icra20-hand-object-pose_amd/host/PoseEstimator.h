@@ -1,7 +1,6 @@
 // PoseEstimator.h -- host-side mirror of the reference's PoseEstimator<PointT> for the hot-path members
 // (src/perception/include/PoseEstimator.h:12-49), forwarding to the C-ABI of include/hop.h.  PCL cloud types are
-// replaced by SoA planes (hop::Cloud), OBJ files by vertex / face arrays (hop::Mesh).  rejectByRender is a "next" row
-//  and absent.
+// replaced by SoA planes (hop::Cloud), OBJ files by vertex / face arrays (hop::Mesh), cv::Mat depth by a 16-bit image.
 #ifndef HOP_HOST_POSEESTIMATOR_H_
 #define HOP_HOST_POSEESTIMATOR_H_
 #include <algorithm>
@@ -119,6 +118,39 @@ class PoseEstimator {
     const int id = it != _mesh_ids.end() ? it->second : (int)_mesh_ids.size();
     hop::check(hop_sdf_register_mesh(ctx_, id, mesh.V.data(), mesh.nv(), mesh.F.data(), mesh.nf(), pose16), ctx_, "hop_sdf_register_mesh");
     _mesh_ids[name] = id;
+    if (name == "object") _obj_mesh = mesh;  // what rejectByRender draws under every hypothesis
+  }
+  // the frame's depth image and the camera (setCurScene's depth argument, the constructor's K): rejectByRender only
+  void setDepth(const std::vector<uint16_t>& depth_raw, int H, int W, double depth_unit, const float K9[9]) {
+    _depth_raw = depth_raw, _H = H, _W = W, _depth_unit = depth_unit;
+    std::copy(K9, K9 + 9, _K);
+  }
+  // rejectByRender (PoseEstimator.cpp:345-463; projection_thres is unused there as well): HandT provides _meshes (the
+  // components' meshes, link frame), _component_status, getTFHandBase and _handbase_in_cam
+  template <class HandT>
+  void rejectByRender(float /*projection_thres*/, HandT* hand, int sum_mode = 0) {
+    printf("before projection check, #hypo=%d\n", numHypos());
+    std::vector<float> V;
+    std::vector<int32_t> F;
+    for (const auto& h : hand->_meshes) {
+      if (!hand->_component_status[h.first]) continue;
+      typename HandT::Mat tf_in_base;
+      hand->getTFHandBase(h.first, tf_in_base);
+      const typename HandT::Mat T = hand->_handbase_in_cam * tf_in_base;
+      const int32_t off = (int32_t)(V.size() / 3);
+      for (int i = 0; i < h.second.nv(); ++i) {
+        const float* p = &h.second.V[3 * (size_t)i];
+        for (int r = 0; r < 3; ++r) V.push_back(((T.m[4 * r] * p[0] + T.m[4 * r + 1] * p[1]) + T.m[4 * r + 2] * p[2]) + T.m[4 * r + 3]);
+      }
+      for (int32_t f : h.second.F) F.push_back(f + off);
+    }
+    hop::check(hop_render_set_frame(ctx_, _depth_raw.data(), _H, _W, _depth_unit, _K, V.data(), (int)(V.size() / 3), F.data(), (int)(F.size() / 3)), ctx_,
+               "hop_render_set_frame");
+    hop::check(hop_render_set_object(ctx_, _obj_mesh.V.data(), _obj_mesh.nv(), _obj_mesh.F.data(), _obj_mesh.nf()), ctx_, "hop_render_set_object");
+    int kept = 0;
+    hop::check(hop_reject_by_render(ctx_, cfg->getf("render_roi_weight"), cfg->getf("render_keep_hypo"), sum_mode, nullptr, nullptr, &kept), ctx_,
+               "hop_reject_by_render");
+    printf("after projection check, #hypo=%d\n", kept);
   }
   // registerHandMesh (PoseEstimator.cpp:510-520): HandT is the host Hand mirror (getTFHandBase, _convex_meshes)
   template <class HandT>
@@ -172,7 +204,11 @@ class PoseEstimator {
     int idx = 0;
     hop::check(hop_lcp_select_best(ctx_, &o, best_hypo._pose, &score, &idx), ctx_, "hop_lcp_select_best");
     best_hypo._lcp_score = score;
-    best_hypo._id = idx;
+    // the reference copies the winning PoseHypo: _id is the id clusterPoses(..., assign_id = true) gave it
+    std::vector<int> ids((size_t)std::max(numHypos(), 1));
+    int n = 0;
+    hop::check(hop_hypos_download(ctx_, nullptr, nullptr, ids.data(), (int)ids.size(), &n), ctx_, "hop_hypos_download");
+    best_hypo._id = (idx >= 0 && idx < n) ? ids[idx] : idx;
     best_hypo.print();
   }
 
@@ -187,6 +223,11 @@ class PoseEstimator {
   std::vector<float> _model_xyz;
   int _n_model = 0;
   hop::Cloud _cloud_withouthand_raw;
+  hop::Mesh _obj_mesh;
+  std::vector<uint16_t> _depth_raw;
+  int _H = 0, _W = 0;
+  double _depth_unit = 0.001;
+  float _K[9] = {0};
   std::map<std::string, int> _mesh_ids;
 };
 #endif

@@ -17,7 +17,9 @@
 //                                               file = int32 nv, int32 nf, nv*3 float vertices, nf*3 int32 triangles)
 //   cloud_withouthand.bin                       _cloud_withouthand_raw, camera frame
 //   handbase_in_cam.txt                         16 floats, row-major
-// Steps not on the hot path (adjustHandHeight, rejectByRender) are "next" rows.
+// and, optionally on top of those, the inputs of rejectByRender (main :202):
+//   depth.bin                                   int32 H, int32 W, float64 depth unit, 9 float32 camera matrix (row-major), H*W uint16
+//                                               (the link meshes of meshes.txt double as the hand's visual meshes)
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -143,7 +145,24 @@ int main(int argc, char** argv) {
       match1 = hand.matchOneComponentPSO("finger_2_1", 0, 120, false, f1_d, f1_a, f1_min);
       if (match1) hand.matchOneComponentPSO("finger_2_2", 0, 90, true, f2_d, f2_a, f2_min);
     }
-    bool physics = false;
+    bool physics = false, render = false;
+    {
+      std::ifstream fd(frame + "depth.bin", std::ios::binary);
+      if (fd) {
+        int32_t dh = 0, dw = 0;
+        double unit = 0;
+        float K9[9];
+        fd.read(reinterpret_cast<char*>(&dh), 4);
+        fd.read(reinterpret_cast<char*>(&dw), 4);
+        fd.read(reinterpret_cast<char*>(&unit), 8);
+        fd.read(reinterpret_cast<char*>(K9), sizeof(K9));
+        std::vector<uint16_t> raw((size_t)dh * dw);
+        fd.read(reinterpret_cast<char*>(raw.data()), sizeof(uint16_t) * raw.size());
+        if (!fd) throw std::runtime_error("short read depth.bin");
+        est.setDepth(raw, dh, dw, unit, K9);
+        render = true;
+      }
+    }
     {
       std::ifstream fm(frame + "meshes.txt"), fh(frame + "handbase_in_cam.txt");
       if (fm && fh) {
@@ -153,7 +172,11 @@ int main(int argc, char** argv) {
         hop::Mesh object_mesh;
         while (fm >> name >> file) {
           if (name == "object") object_mesh = read_mesh(frame + file);
-          else hand.addConvexMesh(name, read_mesh(frame + file));
+          else {
+            const hop::Mesh m = read_mesh(frame + file);
+            hand.addConvexMesh(name, m);
+            hand.addMesh(name, m);
+          }
         }
         hand.makeHandCloud();  // main :142
         est.setCurScene(object_segment, read_cloud(frame + "cloud_withouthand.bin"));
@@ -180,6 +203,7 @@ int main(int argc, char** argv) {
         std::printf("No pose left...\n");
         return 1;
       }
+      if (render) est.rejectByRender(cfg.getf("lcp.dist"), &hand);  // main :202 (the threshold argument is unused there too)
     }
     est.selectBest(best);
     std::printf("frame_ms %.3f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_frame).count());
