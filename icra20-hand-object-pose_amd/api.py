@@ -657,6 +657,20 @@ class Context:
         self._chk(self.L.hop_synchronize(self.h), "hop_synchronize")
 
 
+def organized_cloud(depth_raw, K, depth_unit=0.001):
+    """Utils::readDepthImage + Utils::convert3dOrganizedRGB (Utils.cpp:36-55,79-115) without colours: (H, W, 3) float32, a
+    dropped pixel is (0, 0, 0) (bad_point)."""
+    K = np.asarray(K, np.float32).reshape(3, 3)
+    d = (np.asarray(depth_raw).astype(np.float32).astype(np.float64) * depth_unit).astype(np.float32)
+    d[(d > 2.0) | (d < 0.1)] = 0
+    H, W = d.shape
+    v, u = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    ok = (d > 0.1) & (d < 2.0)
+    x = ((v - K[0, 2]) * d / K[0, 0]).astype(np.float32)
+    y = ((u - K[1, 2]) * d / K[1, 1]).astype(np.float32)
+    return np.where(ok[..., None], np.stack([x, y, d], axis=-1), 0).astype(np.float32)
+
+
 def topk_merge(tables, k):
     t = np.ascontiguousarray(tables, dtype=np.float32).reshape(-1, k, TOPK_ROW_FLOATS)
     out = np.zeros((k, TOPK_ROW_FLOATS), np.float32)

@@ -84,3 +84,49 @@ def test_whole_frame_pipeline(hop):
     gt = g["object_in_cam"].astype(np.float64)
     e = rr.adi(best._pose[:3, :3].astype(np.float64), best._pose[:3, 3].astype(np.float64), gt[:3, :3], gt[:3, 3], mx1.astype(np.float64))
     assert e < 0.005, e   # the authors' recall threshold (scripts/eval_all.py:77)
+
+
+def test_whole_frame_pipeline_from_a_depth_image(hop):
+    """run_real_all.cpp:100-262 from what the robot records: a 16-bit depth image, the camera matrix and the reported
+    hand-base pose (synthetic grasp rendered to 640 x 480; the reference's own example frame has no matching hand or
+    object model).  Nothing is injected: the normals come from the integral-image and MLS estimators, the hand region from
+    the depth image, and both rejections run."""
+    from hop_amd import api, config as hop_config
+    from hop_amd import run_real_all as rr
+    synth = hop.synth
+    cfg = hop_config.load_config(os.path.join(ROOT, "icra20-hand-object-pose_amd", "config", "config_autodataset.yaml"))
+    g = synth.grasp_depth_frame(seed=2)
+    ctx = api.Context(0)
+    assets = rr.Assets()
+    info = {}
+    pose = rr.process_frame(ctx, cfg, assets, g["depth"], g["K"], g["handbase_in_cam_reported"], info=info)
+    assert info["n_valid"] > 200000 and info["n_hand_region"] > 5000
+    assert np.linalg.norm(info["handbase_in_cam"][:3, 3] - g["handbase_in_cam"][:3, 3]) < 3.5e-3     # handbaseICP: 4 mm / 2 deg off -> better
+    assert len(info["angles"]) == 4
+    for name, a in info["angles"].items():
+        assert abs(a - g["angles"][name]) < math.radians(5), (name, math.degrees(a))
+    assert info["n_object_segment"] > 200 and info["n_after_icp"] >= 1
+    assert 1 <= info["n_after_render"] <= info["n_after_physics"]
+    gt = g["object_in_cam"].astype(np.float64)
+    e = rr.adi(pose[:3, :3].astype(np.float64), pose[:3, 3].astype(np.float64), gt[:3, :3], gt[:3, 3], assets.model001[0].astype(np.float64))
+    assert e < 0.005, e
+    ctx.close()
+
+
+def test_dataset_runner_on_the_reference_layout(hop, tmp_path):
+    """run_real_all.cpp:70-273 on <base>/<model>/<record>/{rgbN.png, depthN.png, palm_in_baseN.txt, arm_left_link_7_t_N.txt},
+    results in predict/<N>/model2scene.txt, evaluated like scripts/eval_all.py; a second run resumes (skips finished frames)."""
+    from hop_amd import config as hop_config
+    from hop_amd import run_real_all as rr
+    base = str(tmp_path / "auto_collect")
+    rec = rr.write_synthetic_record(base, "ellipse", n_frames=3)
+    cfg = hop_config.load_config(os.path.join(base, "config_autodataset.yaml"))
+    done = rr.run_raw(base, cfg, rank=0, world=1)
+    assert done == {"synthetic_000": [0, 1, 2]}
+    for k in range(3):
+        assert os.path.exists(os.path.join(rec, "predict", str(k), "model2scene.txt"))
+    r = rr.eval_raw(base, "ellipse", hop.synth.ellipsoid_model(4000)[0])
+    assert r["total"] == 3 and r["recall_10mm"] >= 2 / 3 and r["recall_5mm"] >= 2 / 3, r["errs"]
+    assert rr.run_raw(base, cfg) == {"synthetic_000": []}                       # resume: nothing left to do
+    os.remove(os.path.join(rec, "predict", "1", "model2scene.txt"))
+    assert rr.run_raw(base, cfg, rank=1, world=2) == {"synthetic_000": [1]}     # frame 1 belongs to rank 1 of 2
