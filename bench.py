@@ -53,6 +53,11 @@ def parse():
                     "sum, bit-equal), 1 block reduction (equal to ~1e-6 relative)")
     ap.add_argument("--inflight", type=int, default=8, help="frames in flight per GPU (one context each): the host base selection of one "
                     "frame overlaps the device work of the others; 1 = strictly one frame at a time")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, BASELINE configs[1] 'C2' per GPU: every rank runs its own 2048 base trials) or strong (configs[4] "
+                         "'C5': a FIXED replay set of --strong-hyps hypotheses, seed 13, on a 50k-point scene, split contiguously over the ranks)")
+    ap.add_argument("--strong-hyps", type=int, default=65536)
+    ap.add_argument("--strong-scene", type=int, default=50000)
     ap.add_argument("--no-serial-frame", action="store_true", help="skip the extra undisturbed frame used for per-kernel timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the separate measurement of the physics rejection (SURVEY 8f N1)")
@@ -105,6 +110,37 @@ class Workload:
                                         n_trials=self.args.bases, random_seed=5489 + self.rank, verify_mode=self.args.verify_mode)
             self.slots.append(dict(ctx=c, hand=h, opts=opts))
         self.ctx = self.slots[0]["ctx"]
+
+    def setup_device_strong(self, device, rank, world):
+        """C5: H = 65 536 replay poses (seed 13) x 50 000-point scene x 5 000-point model; rank r owns the
+        contiguous block [r H / N, (r + 1) H / N)."""
+        api, synth = self.api, self.hop.synth
+        self.sc = synth.make_scene(self.args.strong_scene, seed=13)
+        H = self.args.strong_hyps
+        poses = synth.replay_poses(self.sc.gt_pose, H, seed=13, max_rot_deg=30.0, max_trans=0.015)
+        per = (H + world - 1) // world
+        self.h0 = rank * per
+        self.shard = np.ascontiguousarray(poses[self.h0:min(H, self.h0 + per)])
+        c = api.Context(device)
+        c.set_scene(self.sc.xyz, self.sc.nrm, self.sc.conf, 0.0)
+        c.set_model(api.HOP_MODEL_5MM, *self.model)
+        c.set_model(api.HOP_MODEL_1MM, *self.model)
+        self.slots.append(dict(ctx=c, hand=None, opts=None))
+        self.ctx = c
+
+    def step_strong(self, slot=0, topk=0, id_offset=0):
+        """One pass over this rank's block of the fixed hypothesis set: refineByICP + selectBest on all of it, top-k table."""
+        c = self.slots[slot]["ctx"]
+        tf = time.perf_counter()
+        c.hypos_upload(self.shard)          # ICP refines the resident poses in place: every step starts from the replay set
+        t2 = time.perf_counter()
+        it, _ = c.icp_refine(10, 45.0, 0.01, nn_mode=self.args.nn_mode, want_stats=True)
+        t3 = time.perf_counter()
+        best, score, idx = c.lcp_select_best(0.001, 10.0, self.args.lcp_mode)
+        t4 = time.perf_counter()
+        rows = c.topk_pack(topk, id_offset=self.h0)[0] if topk > 0 else None
+        return dict(h=len(self.shard), h_gen=0, n_cand=0, n_bases=0, best=best, score=score, icp_hyp_iters=int(np.sum(it)), n_pairs=0, n_quads=0,
+                    rows=rows, t_frame=t2 - tf, t_pso=0.0, t_gen=0.0, t_icp=t3 - t2, t_lcp=t4 - t3, ms_select=0.0)
 
     def hand_search(self, h):
         for name in h._tf_self:
@@ -314,15 +350,50 @@ def main():
     dev = torch.device("cuda", local_rank)
     xdev = dev if backend == "nccl" else torch.device("cpu")   # where the collectives run
 
-    F = max(1, args.inflight)
+    strong = args.scaling == "strong"
+    F = 1 if strong else max(1, args.inflight)
     w = Workload(args, rank)
-    w.setup_device(local_rank, F)
+    if strong:
+        w.setup_device_strong(local_rank, rank, world)
+        w.step = w.step_strong
+    else:
+        w.setup_device(local_rank, F)
     api = w.api
     K = 128  # rows of the exchanged top-k table
+
+    # The exchange runs inside the library (hop_comm_*: ncclAllGather of the k x 72-byte table from device buffers + the
+    # merge) on one RCCL communicator per rank.  Whether it is used is decided collectively -- rank 0's unique id travels
+    # with a validity byte, then every rank reports whether its communicator came up -- so that a rank that cannot load
+    # RCCL takes everybody to the torch.distributed exchange instead of leaving the others waiting.
+    comm, exchange_kind = None, ("none" if not use_dist else "torch.distributed all_gather + hop_topk_merge")
+    if use_dist and backend == "nccl" and not os.environ.get("HOP_BENCH_NO_LIB_COMM"):
+        idt = torch.zeros(129, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            try:
+                idt = torch.tensor([1] + list(api.Comm.unique_id()), dtype=torch.uint8, device=dev)
+            except Exception as e:
+                print(f"[bench] hop_comm_unique_id failed: {e}", file=sys.stderr)
+        dist.broadcast(idt, 0)
+        ok = 0
+        if int(idt[0].item()) == 1:
+            try:
+                comm = api.Comm(local_rank, bytes(idt[1:].cpu().numpy().tolist()), rank, world)
+                ok = 1
+            except Exception as e:
+                print(f"[bench] rank {rank}: hop_comm_create failed: {e}", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            exchange_kind = "hop_topk_allgather (RCCL inside libhop.so)"
+        elif comm is not None:
+            comm.close()
+            comm = None
 
     def exchange(rows):
         if not use_dist:
             return rows
+        if comm is not None:
+            return comm.topk_allgather(rows, K)[0]
         t = torch.from_numpy(rows).to(xdev)
         out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=xdev)
         dist.all_gather_into_tensor(out, t)
@@ -353,6 +424,13 @@ def main():
                 errors.append(e)
                 for ev in ready:
                     ev.set()
+                if use_dist:
+                    # the other ranks are (or will be) inside the per-frame collective: take the whole job down instead of
+                    # leaving them blocked until the RCCL timeout
+                    import traceback
+                    traceback.print_exc()
+                    sys.stderr.flush()
+                    os._exit(3)
 
         threads = [threading.Thread(target=worker, args=(s,)) for s in range(min(F, n))]
         for t in threads:
@@ -492,11 +570,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "C2: ellipse, 2048 Super4PCS base trials + 200-particle hand search, 20k-pt scene / 5k-pt model",
+            "config": {"workload": ("C5: fixed replay set of %d hypotheses (seed 13) x %d-pt scene / 5k-pt model, refineByICP + selectBest, split over the ranks"
+                                    % (args.strong_hyps, args.strong_scene)) if strong else
+                                   "C2: ellipse, 2048 Super4PCS base trials + 200-particle hand search, 20k-pt scene / 5k-pt model",
+                       "exchange": exchange_kind,
                        "scene_points": N, "model_points": M, "base_trials": args.bases, "sample_size": nq,
                        "hypotheses_scored_per_rank": H, "pso_particles": args.particles, "hand_scene_points": args.hand_scene,
                        "verify_mode": args.verify_mode, "nn_mode": args.nn_mode, "lcp_mode": args.lcp_mode, "pso_sum_mode": args.pso_sum_mode, "frames_in_flight": F,
@@ -514,11 +595,13 @@ def main():
             "hypotheses_generated_per_step": infos[-1]["h_gen"], "candidates_verified_per_step": infos[-1]["n_cand"],
             "best_lcp_score": infos[-1]["score"],
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not strong:
             try:
                 out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget_s)
             except Exception as e:  # the baseline is reported, never required for the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "hypotheses/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        if strong:
+            args.no_next_rows = True
         if not args.no_next_rows and world == 1:
             try:
                 out["host_cpp_frame"] = host_cpp_leg(w)
@@ -529,6 +612,8 @@ def main():
                 out["next_rows"] = {"n1_physics": physics_row(w, args, not args.no_cpu_baseline)}
             except Exception as e:
                 out["next_rows"] = {"n1_physics": {"value": None, "error": str(e)}}
+    if comm is not None:
+        comm.close()
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

@@ -138,6 +138,11 @@ SIGNATURES = {
     "hop_model_ppf_keys": (C.c_int, [_vp, fp, fp, C.c_int, ip, C.c_int, ip]),
     "hop_hand_set_finger": (C.c_int, [_vp, C.POINTER(FingerArgs)]),
     "hop_hand_remove_surrounding": (C.c_int, [_vp, fp, fp, C.c_int, fp, C.POINTER(HandLink), C.c_int, fp, fp, C.c_float, fp, fp, fp, ip, ip]),
+    "hop_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
+    "hop_comm_create": (C.c_int, [C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(_vp)]),
+    "hop_comm_destroy": (None, [_vp]),
+    "hop_comm_last_error": (C.c_char_p, [_vp]),
+    "hop_topk_allgather": (C.c_int, [_vp, fp, C.c_int, fp, ip]),
     "hop_hand_set_sum_mode": (C.c_int, [_vp, C.c_int]),
     "hop_hand_pso_eval_batch": (C.c_int, [_vp, dp, C.c_int, dp]),
     "hop_pso_default_settings": (None, [C.POINTER(PsoSettings)]),
@@ -669,6 +674,40 @@ def organized_cloud(depth_raw, K, depth_unit=0.001):
     x = ((v - K[0, 2]) * d / K[0, 0]).astype(np.float32)
     y = ((u - K[1, 2]) * d / K[1, 1]).astype(np.float32)
     return np.where(ok[..., None], np.stack([x, y, d], axis=-1), 0).astype(np.float32)
+
+
+class Comm:
+    """One RCCL communicator per process / GPU (hop_comm_*): the per-frame all-gather + merge of the top-k tables."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * 128)()
+        rc = lib().hop_comm_unique_id(buf)
+        if rc:
+            raise HopError(rc, "hop_comm_unique_id", (lib().hop_comm_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    def __init__(self, device, unique_id, rank, world):
+        self.L = lib()
+        self.h = _vp()
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        rc = self.L.hop_comm_create(int(device), buf, int(rank), int(world), C.byref(self.h))
+        if rc:
+            raise HopError(rc, "hop_comm_create", (self.L.hop_comm_last_error(None) or b"").decode())
+
+    def topk_allgather(self, rows, k):
+        t = np.ascontiguousarray(rows, dtype=np.float32).reshape(k, TOPK_ROW_FLOATS)
+        out = np.zeros((k, TOPK_ROW_FLOATS), np.float32)
+        n = C.c_int(0)
+        rc = self.L.hop_topk_allgather(self.h, F(t), k, F(out), C.byref(n))
+        if rc:
+            raise HopError(rc, "hop_topk_allgather", (self.L.hop_comm_last_error(self.h) or b"").decode())
+        return out, n.value
+
+    def close(self):
+        if self.h:
+            self.L.hop_comm_destroy(self.h)
+            self.h = _vp()
 
 
 def topk_merge(tables, k):

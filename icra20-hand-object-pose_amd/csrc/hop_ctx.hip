@@ -616,6 +616,7 @@ const char* hop_strerror(int s) {
     case HOP_E_STATE: return "call order / missing input";
     case HOP_E_NO_HYPOTHESIS: return "no hypothesis generated";
     case HOP_E_ALLOC: return "allocation failed";
+    case HOP_E_COMM: return "RCCL unavailable or collective failed";
   }
   return "unknown status";
 }

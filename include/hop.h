@@ -30,7 +30,8 @@ typedef enum {
   HOP_E_CAPACITY = -4,    /* caller buffer or internal capacity too small */
   HOP_E_STATE = -5,       /* call order (e.g. generate before set_scene) */
   HOP_E_NO_HYPOTHESIS = -6, /* generator produced nothing: runSuper4pcs would return false */
-  HOP_E_ALLOC = -7
+  HOP_E_ALLOC = -7,
+  HOP_E_COMM = -8         /* RCCL unavailable or a collective failed (see hop_comm_last_error) */
 } hop_status;
 
 typedef struct hop_ctx hop_ctx;
@@ -162,6 +163,20 @@ int hop_cluster_poses_host(const float* poses16, const float* scores, const int*
 int hop_topk_pack(hop_ctx* ctx, int k, int id_offset, float* rows_out /* k*18 floats */, int* n_rows_out);
 /* pure function: merge n_tables tables of k rows each (rows with id < 0 are padding) into the k best */
 int hop_topk_merge(const float* tables, int n_tables, int k, float* rows_out, int* n_rows_out);
+
+/* The exchange itself, inside the library (the reference has no multi-GPU path): one RCCL communicator per
+ * process / GPU, one ncclAllGather of the k x 72-byte table per frame from device buffers on the communicator's own
+ * stream, then hop_topk_merge -- the same k rows on every rank.  RCCL is loaded with dlopen on first use.
+ *   hop_comm_unique_id   rank 0: ncclGetUniqueId; the launcher hands the 128 bytes to the other ranks (any channel)
+ *   hop_comm_create      every rank: ncclCommInitRank on `device`
+ *   hop_topk_allgather   collective: every rank calls it once per frame, in the same order */
+#define HOP_COMM_ID_BYTES 128
+typedef struct hop_comm hop_comm;
+int hop_comm_unique_id(unsigned char id_out[HOP_COMM_ID_BYTES]);
+int hop_comm_create(int device, const unsigned char id[HOP_COMM_ID_BYTES], int rank, int world, hop_comm** out);
+void hop_comm_destroy(hop_comm* comm);
+const char* hop_comm_last_error(const hop_comm* comm /* may be NULL: why RCCL could not be loaded */);
+int hop_topk_allgather(hop_comm* comm, const float* rows_in, int k, float* merged_out, int* n_rows_out);
 
 /* ------------------------------------------------------------------------------------------------
  * Hand-state search: Hand::matchOneComponentPSO (src/perception/src/Hand.cpp:603-672) ->

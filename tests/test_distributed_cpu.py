@@ -69,3 +69,56 @@ def test_topk_allgather_merge_two_ranks(tmp_path):
     pose, score, mid = api.rows_to_hypos(m0)
     assert (np.diff(score) <= 0).all()
     assert set(mid >> 24) == {0, 1}, "both ranks contribute to the global top-k"
+
+
+def _strong_worker(rank, world, port, k, H, out_dir):
+    """bench.py --scaling strong without the kernels: every rank owns the contiguous block [r H / N, (r + 1) H / N) of ONE
+    fixed hypothesis set, packs its k best rows (ids offset by the block start) and takes part in the exchange."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import hop_loader
+    hop_loader.load()
+    from hop_amd import api
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(13)                      # the same set on every rank (seed 13, as the C5 replay set)
+    scores = rng.random(H).astype(np.float32)
+    poses = rng.normal(size=(H, 16)).astype(np.float32)
+    per = (H + world - 1) // world
+    h0, h1 = rank * per, min(H, (rank + 1) * per)
+    order = np.lexsort((np.arange(h0, h1), -scores[h0:h1]))[:k]
+    rows = np.zeros((k, api.TOPK_ROW_FLOATS), np.float32)
+    rows[:, 0] = -np.finfo(np.float32).max
+    rows[:, 1] = np.array([-1], np.int32).view(np.float32)[0]
+    m = len(order)
+    rows[:m, 0] = scores[h0:h1][order]
+    rows[:m, 1] = (order.astype(np.int32) + h0).view(np.float32)
+    rows[:m, 2:] = poses[h0:h1][order]
+    t = torch.from_numpy(rows)
+    out = torch.empty((world * k, t.shape[1]), dtype=t.dtype)
+    dist.all_gather_into_tensor(out, t)
+    merged, n = api.topk_merge(out.numpy(), k)
+    np.save(os.path.join(out_dir, f"strong_{rank}.npy"), merged)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H", [1000, 37])
+def test_strong_scaling_shards_reproduce_the_global_topk(tmp_path, H):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import hop_loader
+    hop_loader.load()
+    from hop_amd import api
+    k, world = 16, 2
+    mp.spawn(_strong_worker, args=(world, _free_port(), k, H, str(tmp_path)), nprocs=world, join=True)
+    m0, m1 = np.load(tmp_path / "strong_0.npy"), np.load(tmp_path / "strong_1.npy")
+    assert np.array_equal(m0, m1)
+    rng = np.random.default_rng(13)
+    scores = rng.random(H).astype(np.float32)
+    poses = rng.normal(size=(H, 16)).astype(np.float32)
+    best = np.lexsort((np.arange(H), -scores))[:k]      # what one GPU holding all H hypotheses would report
+    pose, score, ids = api.rows_to_hypos(m0)
+    assert np.array_equal(ids, best) and np.array_equal(score, scores[best]) and np.array_equal(pose.reshape(-1, 16), poses[best])

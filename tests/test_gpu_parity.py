@@ -753,3 +753,22 @@ def test_model_ppf_keys_equal_oracle(ctx, orc, synth):
     assert ctx.model_ppf_keys(mx[:1], mn[:1]).shape == (0, 4)
     with pytest.raises(Exception):
         ctx.model_ppf_keys(mx, mn, cap=10)                    # HOP_E_CAPACITY, not a silent truncation
+
+
+def test_library_exchange_single_rank(api, ctx, synth):
+    """hop_comm_* / hop_topk_allgather with a communicator of one rank (RCCL refuses two ranks on one device, so a single
+    GPU box can exercise no more): the all-gather + merge returns the rank's own table."""
+    uid = api.Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = api.Comm(0, uid, 0, 1)
+    sc, mx, mn, poses = _scoring_case(synth, 600, 500, 20)
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.0)
+    ctx.set_model(api.HOP_MODEL_1MM, mx, mn)
+    ctx.hypos_upload(poses)
+    ctx.lcp_select_best(0.001, 10.0, 0)
+    rows, n = ctx.topk_pack(8, id_offset=1000)
+    merged, m = comm.topk_allgather(rows, 8)
+    assert m == n == 8 and np.array_equal(merged, rows)
+    for _ in range(3):      # repeated collectives on the communicator's stream
+        assert np.array_equal(comm.topk_allgather(rows, 8)[0], rows)
+    comm.close()
