@@ -352,6 +352,17 @@ def icp_refine_batch(S, Sn, M, Mn, poses, max_iter=10, angle_deg=45.0, max_corr_
     return T.reshape(-1, 4, 4), it, cv
 
 
+def icp_refine_batch_variant(S, Sn, M, Mn, poses, max_iter=10, angle_deg=45.0, max_corr_dist=0.01, minimiser=0, strict_normal=False, relative_stop=True):
+    """run_icp with the deviations of the restatement switched (see IcpVariant in hop_oracle.cpp); kd-tree NN."""
+    Sp, Snp, Mp, Mnp = soa(S), soa(Sn), soa(M), soa(Mn)
+    T = np.ascontiguousarray(poses, np.float32).reshape(-1, 16).copy()
+    it = np.zeros(len(T), np.int32)
+    cv = np.zeros(len(T), np.int32)
+    lib().orc_icp_refine_batch_variant(F(Sp), F(Snp), Sp.shape[1], F(Mp), F(Mnp), Mp.shape[1], F(T), len(T), int(max_iter), C.c_float(angle_deg),
+                                       C.c_float(max_corr_dist), int(minimiser), int(bool(strict_normal)), int(bool(relative_stop)), I(it), I(cv))
+    return T.reshape(-1, 4, 4), it, cv
+
+
 def cluster_poses(poses, lcp, ids, angle_deg, dist, sym_deg):
     T = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
     lcp = np.ascontiguousarray(lcp, np.float32)
