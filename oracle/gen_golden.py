@@ -106,6 +106,26 @@ def gen_case(name, n_scene, seed, n_calls, sample_size, succ):
     print(name, "hypotheses", n, "bases", len(bases), "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_plain(name, n_scene, seed, n_calls, sample_size, succ):
+    """Hypotheses of the UNTOUCHED reference matcher (no tracing override of generateCongruents, oracle/ref_driver.cpp) on
+    the inputs of case `name`; must equal the traced run that produced s4pcs_<name>.npz."""
+    mx, mn = synth.ellipsoid_model_spacing(0.005)
+    keys = synth.ppf_key_table()
+    sc = synth.make_scene(n_scene, seed=seed)
+    out = {}
+    for plain in (True, False):
+        r = orc.RefS4PCS(sample_size=sample_size, success_quadrilaterals=succ, plain=plain)
+        r.set_keys(keys)
+        r.run(sc.xyz, sc.nrm, sc.conf, mx, mn, n_calls)
+        out[plain] = canonical_hypos(*r.hypos())
+    assert np.array_equal(out[True][0], out[False][0]) and np.array_equal(out[True][1], out[False][1]), "the tracing override changed the result"
+    g = np.load(os.path.join(OUT, f"s4pcs_{name}.npz"))
+    assert np.array_equal(out[True][0], g["hyp_pose"]) and np.array_equal(out[True][1], g["hyp_lcp"]), "differs from the committed traced golden"
+    path = os.path.join(OUT, f"s4pcs_plain_{name}.npz")
+    np.savez_compressed(path, hyp_pose=out[True][0], hyp_lcp=out[True][1], opts=np.array([sample_size, succ, n_calls, n_scene, seed], np.int32))
+    print("plain", name, "hypotheses", len(out[True][1]), "== traced run ->", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def gen_kats():
     """Known-answer tests of the pure functions, straight from the reference build."""
     R = orc.ref()
@@ -222,3 +242,5 @@ if __name__ == "__main__":
     for c in CASES:
         if not only or c[0] in only:
             gen_case(*c)
+    if not only or "plain" in only:
+        gen_plain(*[c for c in CASES if c[0] == "case1"][0])

@@ -280,11 +280,13 @@ class RefS4PCS(_GenBase):
     """The reference's own matcher (build container only)."""
 
     def __init__(self, sample_size=100, overlap=0.2, delta=0.003, dispersion=0.5, success_quadrilaterals=10,
-                 max_time_seconds=10 ** 9, record_pairs=True):
+                 max_time_seconds=10 ** 9, record_pairs=True, plain=False):
         self.L = ref()
         o = RefOpts(sample_size, overlap, delta, dispersion, success_quadrilaterals, max_time_seconds, -1.0, -1.0)
         self.h = C.c_void_p(self.L.ref_create(C.byref(o)))
         self.L.ref_record_pairs(self.h, 1 if record_pairs else 0)
+        self.L.ref_use_plain_matcher.argtypes = [C.c_void_p, C.c_int]
+        self.L.ref_use_plain_matcher(self.h, 1 if plain else 0)   # plain: the reference's own generateCongruents, no tracing override
 
     def _call(self, name, *a):
         return getattr(self.L, "ref_" + name)(self.h, *a)

@@ -51,12 +51,14 @@ class TracingMatcher : public RefMatcherBase {
   using Base::Base;
   std::vector<BaseTrace> trace;
   bool record_pairs = true;
+  bool plain = false;  // true: the reference's own generateCongruents runs untouched (no trace): see ref_use_plain_matcher
 
   // Same call sequence as Match4pcsBase::generateCongruents (match4pcsBase.hpp:207-281), made through the
   // reference's own member functions, so that the invariants and the two pair lists can be recorded
   // (the reference keeps them in locals).  Re-deriving the invariants afterwards is NOT possible:
   // TryQuadrilateral's permutation loop is not closed under relabelling.
   bool generateCongruents(CongruentBaseType& base, Set& quads) override {
+    if (plain) return Base::generateCongruents(base, quads);  // match4pcsBase.hpp:207-281 as written by its authors
     Scalar invariant1, invariant2;
     if (!this->SelectQuadrilateral(invariant1, invariant2, base[0], base[1], base[2], base[3])) return false;
     const auto& b0 = this->base_3D_[0];
@@ -162,6 +164,12 @@ void ref_set_ppf_keys(void* h, const int* keys4, int n) {
     c->matcher->_ppfs[k];  // membership only: the mapped lists are never read (matchBase.hpp:134,159,201)
   }
 }
+
+// The golden hypotheses normally come from "reference + the tracing override above" (the override repeats the body of
+// match4pcsBase.hpp:207-281 call for call to see its locals).  With plain = 1 the override steps aside and the reference's
+// own member runs: gen_golden.py emits one set that way (tests/golden/s4pcs_plain_case1.npz) and checks that it equals the
+// traced run, so the override is shown not to change what the reference computes.
+void ref_use_plain_matcher(void* h, int on) { static_cast<RefCtx*>(h)->matcher->plain = on != 0; }
 
 void ref_record_pairs(void* h, int on) { static_cast<RefCtx*>(h)->matcher->record_pairs = on != 0; }
 

@@ -143,3 +143,25 @@ def test_oracle_probes_against_reference_build(orc):
             L.orc_probe_quat(orc.F(n.astype(np.float32)), orc.F(b), orc.F(o1))
             R.ref_probe_quat(orc.F(n.astype(np.float32)), orc.F(b), orc.F(o2))
             assert np.array_equal(o1, o2)
+
+
+def test_golden_of_the_untouched_reference_matcher(orc, golden_dir):
+    """tests/golden/s4pcs_plain_case1.npz: hypotheses of the reference matcher run WITHOUT the tracing override of
+    generateCongruents (oracle/ref_driver.cpp, ref_use_plain_matcher; gen_golden.py `plain`).  They equal the traced golden
+    (the override changes nothing) and the oracle reproduces them."""
+    gp = np.load(os.path.join(golden_dir, "s4pcs_plain_case1.npz"))
+    g = np.load(os.path.join(golden_dir, "s4pcs_case1.npz"))
+    assert np.array_equal(gp["hyp_pose"], g["hyp_pose"]) and np.array_equal(gp["hyp_lcp"], g["hyp_lcp"])
+    sample_size, succ, n_calls = (int(v) for v in gp["opts"][:3])
+    o = orc.OracleS4PCS(sample_size=sample_size, success_quadrilaterals=succ)
+    o.set_keys(g["keys"])
+    n = o.run(g["P_xyz"], g["P_nrm"], g["P_conf"], g["Q_xyz"], g["Q_nrm"], n_calls)
+    pose, lcp = o.hypos()
+    flat = pose.reshape(n, 16)
+    rot = flat[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]]
+    order = np.lexsort(tuple(rot[:, ::-1].T) + (-lcp,))
+    assert np.array_equal(lcp[order], gp["hyp_lcp"]) and np.array_equal(pose[order][:, :3, :3], gp["hyp_pose"][:, :3, :3])
+    if orc.ref_available():   # build container: the plain matcher itself, run now
+        r = orc.RefS4PCS(sample_size=sample_size, success_quadrilaterals=succ, plain=True)
+        r.set_keys(g["keys"])
+        assert r.run(g["P_xyz"], g["P_nrm"], g["P_conf"], g["Q_xyz"], g["Q_nrm"], n_calls) == n
