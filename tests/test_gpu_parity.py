@@ -580,6 +580,50 @@ def test_c1_depth7_full_chain_within_1mm_1deg_of_oracle(ctx, api, orc, synth, go
     assert abs(score - s3.max()) <= 1e-4 * s3.max()
 
 
+def test_c1_depth7_from_the_raw_depth_image(ctx, api, orc, synth, golden_dir):
+    """The same C1 criterion, starting from the reference's raw example/depth7.png (tests/golden/depth7_raw.npz) instead of a
+    prepared cloud: depth image -> organised cloud -> integral-image normals -> 1 mm voxel grid -> hand-base crop -> 3 mm
+    voxel grid on the GPU (main_realdata_auto.cpp:54-96, Hand.cpp:285), then the as-shipped chain on the GPU and in the
+    oracle on that cloud: best pose within 1 mm / 1 degree.  The front end itself against the oracle's front end."""
+    g = np.load(os.path.join(golden_dir, "depth7_raw.npz"))
+    lo, hi = (-0.25, -0.2, -0.12), (-0.07, 0.2, 0.05)
+    sx, sn, counts = ctx.scene_from_depth_normals(g["depth"], 0.001, g["K"], g["cam_in_handbase"], g["handbase_in_cam"], 0.001, lo, hi)
+    rx, rn = orc.scene_from_depth_normals(g["depth"], 0.001, g["K"], g["cam_in_handbase"], g["handbase_in_cam"], 0.001, lo, hi)
+    assert counts[0] == 68600 and sx.shape == rx.shape and np.abs(sx - rx).max() < 1e-6
+    m = np.isfinite(sn).all(axis=1)
+    assert np.array_equal(m, np.isfinite(rn).all(axis=1)) and np.abs(sn[m] - rn[m]).max() < 5e-5
+    xyz, nrm = ctx.voxel_downsample_normals(sx[m], sn[m], 0.003)     # (points without a defined normal dropped: depth edges)
+    assert 1200 < len(xyz) < 2100
+    conf = np.ones(len(xyz), np.float32)
+    mx5, mn5 = synth.ellipsoid_model_spacing(0.005)
+    mx1, mn1 = synth.ellipsoid_model(4000)
+    keys = synth.ppf_key_table()
+    sym = [180, 180, 180]
+    ctx.set_scene(xyz, nrm, conf, 0.8)
+    ctx.set_model(api.HOP_MODEL_5MM, mx5, mn5)
+    ctx.set_model(api.HOP_MODEL_1MM, mx1, mn1)
+    ctx.set_ppf_keys(keys)
+    pose, lcp, st = ctx.s4pcs_generate(ctx.default_s4pcs_opts(max_time_seconds=0))
+    ctx.cluster_poses(30.0, 0.015, sym, True)
+    ctx.icp_refine(10, 45.0, 0.01, max_hypotheses=100, nn_mode=3)
+    ctx.cluster_poses(5.0, 0.003, sym, False)
+    best, score, idx = ctx.lcp_select_best(0.001, 10.0, 2)
+    oo = orc.OracleS4PCS()
+    oo.set_keys(keys)
+    oo.run(xyz, nrm, conf, mx5, mn5, 1)
+    op, ol = oo.hypos()
+    assert len(ol) > 500 and np.array_equal(ol, lcp)
+    keep = orc.cluster_poses(op, ol, np.arange(len(ol)), 30.0, 0.015, sym)
+    p1, l1 = op[keep][:100], ol[keep][:100]
+    p2, _, _ = orc.icp_refine_batch(xyz, nrm, mx5, mn5, p1, 10, 45.0, 0.01)
+    keep2 = orc.cluster_poses(p2, l1, np.arange(len(l1)), 5.0, 0.003, sym)
+    p3 = p2[keep2]
+    s3 = orc.compute_lcp_batch(xyz, nrm, mx1, mn1, p3, 0.001, 10.0)
+    ob = p3[int(np.flatnonzero(s3 == s3.max())[0])]
+    assert np.linalg.norm(best[:3, 3] - ob[:3, 3]) < 1e-3
+    assert _rot_err_deg(best[:3, :3].astype(np.float64), ob[:3, :3].astype(np.float64)) < 1.0
+
+
 # ------------------------------------------------------------------------------------------------ next row N3a
 def test_remove_surrounding_points_equals_oracle(api, orc, synth, hop):
     """HandT42::removeSurroundingPointsAndAssignProbability (Hand.cpp:779-888; SURVEY.md 8(f) N3): same survivors as
