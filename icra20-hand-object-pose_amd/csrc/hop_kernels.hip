@@ -1845,6 +1845,17 @@ __device__ __forceinline__ void cells_nnq(const CellListDev& c, V3 qg, const flo
 #ifndef ICP_WAVES_ATTR
 #define ICP_WAVES_ATTR
 #endif
+template <bool F32>
+struct IcpAcc {
+  typedef double type;
+};
+template <>
+struct IcpAcc<true> {
+  typedef float type;
+};
+__device__ __forceinline__ double icp_wave_sum(double v) { return wave_sum(v); }
+__device__ __forceinline__ double icp_fma(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ float icp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 template <bool COMPOSED>
 __global__ __launch_bounds__(256) ICP_WAVES_ATTR void k_icp_fusedq(IcpArgs a, int R) {
   __shared__ double red[4][ICP_NACC];
@@ -1855,9 +1866,13 @@ __global__ __launch_bounds__(256) ICP_WAVES_ATTR void k_icp_fusedq(IcpArgs a, in
   const float* __restrict__ sTi = a.pose_inv + (size_t)h * 12;
   const float* __restrict__ hist = a.hist + (size_t)hl * a.max_iter * 12;
   const float* __restrict__ F = st.final_tf;
-  double acc[ICP_NACC];
+  // nn_mode 4 keeps the 32 per-lane sums in float (a lane adds at most ~30 terms; lanes, waves and blocks are then summed in
+  // double as before): half the accumulator registers (71 instead of 107 VGPRs: 7 instead of 4 waves per SIMD).  nn_mode 3
+  // accumulates in double like the oracle.
+  typedef typename IcpAcc<COMPOSED>::type acc_t;
+  acc_t acc[ICP_NACC];
 #pragma unroll
-  for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
+  for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0;
   for (int r = 0; r < R; ++r) {
     const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
     if (i >= a.ns) continue;
@@ -1879,26 +1894,26 @@ __global__ __launch_bounds__(256) ICP_WAVES_ATTR void k_icp_fusedq(IcpArgs a, in
     ICP_COUNT(6, 1);
     ICP_COUNT_WAVE(7);
     const V3 c = vcross(q, nt);
-    const double J[6] = {c.x, c.y, c.z, nt.x, nt.y, nt.z};
-    const double res = (double)vdot(q - tq, nt);
+    const acc_t J[6] = {c.x, c.y, c.z, nt.x, nt.y, nt.z};
+    const acc_t res = (acc_t)vdot(q - tq, nt);
     int k = 0;
 #pragma unroll
     for (int u = 0; u < 6; ++u)
 #pragma unroll
       for (int v = 0; v <= u; ++v) {
-        acc[k] = fma(J[u], J[v], acc[k]);
+        acc[k] = icp_fma(J[u], J[v], acc[k]);
         ++k;
       }
 #pragma unroll
-    for (int u = 0; u < 6; ++u) acc[21 + u] = fma(-J[u], res, acc[21 + u]);
-    acc[27] += (double)d2;
-    acc[28] += 1.0;
-    acc[29] += (double)q.x, acc[30] += (double)q.y, acc[31] += (double)q.z;
+    for (int u = 0; u < 6; ++u) acc[21 + u] = icp_fma(-J[u], res, acc[21 + u]);
+    acc[27] += (acc_t)d2;
+    acc[28] += (acc_t)1;
+    acc[29] += (acc_t)q.x, acc[30] += (acc_t)q.y, acc[31] += (acc_t)q.z;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < ICP_NACC; ++k) {
-    const double s = wave_sum(acc[k]);
+    const double s = icp_wave_sum(acc[k]);
     if (lane == 0) red[wave][k] = s;
   }
   __syncthreads();

@@ -107,8 +107,9 @@ def test_c2_icp_and_lcp_full_size_match_oracle(ctx, api, orc, synth):
 
 def test_icp_composed_increments_close_to_chained(ctx, api, synth):
     """nn_mode 4 applies the accumulated transform once (fused multiply-adds) instead of chaining the increments as PCL /
-    the oracle do (nn_mode 3): a wide hypothesis set must keep its iteration counts (>= 99 %) and its poses (median
-    <= 1e-6, every pose within 1 mm / 1 degree)."""
+    the oracle do (nn_mode 3), and keeps the per-lane sums of the normal equations in float (<= ~30 terms per lane; lanes,
+    waves and blocks are summed in double): a wide hypothesis set must keep its iteration counts (>= 99 %) and its poses
+    (median <= 1e-5 -- micrometres --, every pose within 1 mm / 1 degree)."""
     sc = synth.make_scene(20000, seed=7)
     mx, mn = synth.ellipsoid_model(5000)
     poses = synth.replay_poses(sc.gt_pose, 512, seed=23, max_rot_deg=30.0, max_trans=0.015)
@@ -121,7 +122,7 @@ def test_icp_composed_increments_close_to_chained(ctx, api, synth):
         out[mode] = (it.copy(), cv.copy(), ctx.hypos_download()[0].copy())
     assert (out[3][0] == out[4][0]).mean() >= 0.99 and np.array_equal(out[3][1], out[4][1])
     d = np.abs(out[3][2] - out[4][2]).reshape(len(poses), -1).max(axis=1)
-    assert np.median(d) <= 1e-6
+    assert np.median(d) <= 1e-5
     for a, b in zip(out[3][2], out[4][2]):
         assert np.linalg.norm(a[:3, 3] - b[:3, 3]) < 1e-3 and _rot_err_deg(a[:3, :3], b[:3, :3]) < 1.0
 
@@ -171,7 +172,7 @@ def test_c5_full_size_8192_hypotheses_50k_scene(ctx, api, synth):
     it0, cv0 = ctx.icp_refine(10, 45.0, 0.01, nn_mode=0, want_stats=True)
     p0 = ctx.hypos_download()[0].copy()
     assert (it0 == it[sub]).mean() >= 0.98 and np.array_equal(cv0, cv[sub])
-    assert np.median(np.abs(p0 - refined[sub]).reshape(256, -1).max(axis=1)) < 5e-6
+    assert np.median(np.abs(p0 - refined[sub]).reshape(256, -1).max(axis=1)) < 2e-5
     ctx.hypos_upload(refined[sub])
     ctx.lcp_select_best(0.001, 10.0, 0)
     s0 = ctx.hypos_download()[1].copy()
