@@ -354,8 +354,9 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
   HIPCHK(c, hipStreamSynchronize(c->stream));
   cs.c.pts_idx = cs.pts_idx_d.as<float4>();
   cs.packed = false, cs.pack_requested = packed, cs.c.rec = nullptr, cs.c.qlist = nullptr;
-  // (the empty-slot convention of cells_nnq needs the cell well below the gating distance: cell < 0.42 (max_dist + margin))
-  if (packed && h.n < 0xFFFF && cell < 0.4f * max_dist) {
+  // (the empty-slot convention of cells_nnq needs the cell well below the gating distance: cell < 0.42 (max_dist + margin);
+  // its 32-bit integer squared distances need every coordinate difference below 37 800 steps: cell < 0.3 max_dist)
+  if (packed && h.n < 0xFFFF && cell < 0.3f * max_dist) {
     std::vector<float4> hp(std::max<size_t>(total, 1));
     HIPCHK(c, hipMemcpyAsync(hp.data(), cs.pts_d.p, sizeof(float4) * total, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -396,8 +397,9 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
     HIPCHK(c, hipMemcpyAsync(cs.qlist_d.p, ql.data(), sizeof(uint32_t) * ql.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     cs.c.rec = cs.rec_d.as<uint2>(), cs.c.qlist = cs.qlist_d.as<uint4>();
-    cs.c.q_cs = (float)qcs, cs.c.q_rs = (float)qrs, cs.c.q_step2 = (float)(step * step);
-    cs.c.q_eq = (float)(step * 0.9);  // sqrt(3)/2 of a step + the float evaluation of the local coordinates
+    cs.c.q_cs = (float)qcs, cs.c.q_rs = (float)(qrs + 0.5), cs.c.q_step2 = (float)(step * step);  // + 0.5: the lookup truncates
+    // sqrt(3)/2 of a step for the entry, as much for the query (rounded to whole steps too), the float evaluation of its local coordinate
+    cs.c.q_eq = (float)(step * 1.8);
     cs.packed = true;
     if (getenv("HOP_PROFILE_SELECT")) std::printf("packed lists: %.1f MB records + %.1f MB chunks, step %.3g m\n", rec.size() * 4e-6, ql.size() * 4e-6, step);
   }

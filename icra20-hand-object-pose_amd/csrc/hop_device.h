@@ -138,9 +138,9 @@ struct CellListDev {
   // 0xFFFFFFFF 0xFFFFFFFF, coordinates farther than any real entry); rec[cell] = (first chunk, chunks).
   const uint2* rec;
   const uint4* qlist;
-  float q_cs, q_rs;        // local query coordinate in steps = fma(fraction of the grid coordinate, q_cs, q_rs)
+  float q_cs, q_rs;        // local query coordinate in whole steps = (int)fma(fraction of the grid coordinate, q_cs, q_rs)
   float q_step2;           // step^2: squared step-unit distances -> m^2
-  float q_eq;              // bound of the position error of a dequantised entry (metres)
+  float q_eq;              // bound of the position error of a dequantised entry + that of the rounded query (metres)
 };
 constexpr unsigned Q_EMPTY_HI = 0xFFFF0000u;  // high word >= this: empty slot
 

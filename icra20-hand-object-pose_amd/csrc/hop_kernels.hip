@@ -1743,7 +1743,6 @@ __device__ __forceinline__ float rank_d2(V3 q, const float4& t) {
   const float dx = q.x - t.x, dy = q.y - t.y, dz = q.z - t.z;
   return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
 }
-constexpr unsigned Q_KEY_INF = 0x7f000000u;
 // -DHOP_ICP_COUNT (tools/icp_counters.py builds such a library): per-query statistics of the packed lookups
 __device__ unsigned long long g_icp_count[8];
 #ifdef HOP_ICP_COUNT
@@ -1760,16 +1759,27 @@ void icp_counters_read(unsigned long long* out8, bool reset) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_icp_count), z, sizeof(z));
   }
 }
-// squared distance (step units) of the local query l to a packed entry (lo = x | y << 16, hi = z | index << 16)
-__device__ __forceinline__ float q_rank(V3 l, unsigned lo, unsigned hi) {
-  const float dx = l.x - (float)(lo & 0xffffu), dy = l.y - (float)(lo >> 16), dz = l.z - (float)(hi & 0xffffu);
-  return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+// squared distance (whole steps) of the local query l (rounded to whole steps) to a packed entry (lo = x | y << 16,
+// hi = z | index << 16): three word-select subtractions and 24-bit integer multiply-adds.  Every difference is below 2^15.2
+// steps (cell < 0.3 gate, see build_cell_lists), so the sum stays below 2^32.
+struct Q3 {
+  int x, y, z;
+};
+__device__ __forceinline__ unsigned q_rank(Q3 l, unsigned lo, unsigned hi) {
+  const int dx = l.x - (int)(lo & 0xffffu), dy = l.y - (int)(lo >> 16), dz = l.z - (int)(hi & 0xffffu);
+  unsigned d = (unsigned)__mul24(dz, dz);
+  asm("v_mad_i32_i24 %0, %1, %1, %0" : "+v"(d) : "v"(dy));  // (the compiler prefers three multiplies and v_add3)
+  asm("v_mad_i32_i24 %0, %1, %1, %0" : "+v"(d) : "v"(dx));
+  return d;
 }
-// one chunk of two entries: keys = squared distance (step units) with the lowest mantissa bit replaced by the slot.
-// Empty slots carry coordinates 0xFFFF (>= 52 000 steps from any query on the diagonal, farther than any real entry of
+#define Q_L(v) (int)(v)
+#define Q_KEYF(k) (float)(k)
+#define Q_INF 0xFFFFFFFFu
+// one chunk of two entries: keys = squared distance with the lowest bit replaced by the slot.
+// Empty slots carry coordinates 0xFFFF (>= 30 000 steps from any query on every axis, farther than any real entry of
 // a list can be: those lie within gate + margin + the cell diagonal), so they need no test here.
-__device__ __forceinline__ void q_chunk(V3 l, const uint4& ch, unsigned& b1, unsigned& b2, unsigned& why, unsigned& whw) {
-  const unsigned k0 = __float_as_uint(q_rank(l, ch.x, ch.y)) & ~1u, k1 = __float_as_uint(q_rank(l, ch.z, ch.w)) | 1u;
+__device__ __forceinline__ void q_chunk(Q3 l, const uint4& ch, unsigned& b1, unsigned& b2, unsigned& why, unsigned& whw) {
+  const unsigned k0 = q_rank(l, ch.x, ch.y) & ~1u, k1 = q_rank(l, ch.z, ch.w) | 1u;
   const unsigned prev = b1;
   b2 = umed3(b1, b2, k0);
   b1 = min(b1, k0);
@@ -1779,13 +1789,13 @@ __device__ __forceinline__ void q_chunk(V3 l, const uint4& ch, unsigned& b1, uns
   why = changed ? ch.y : why, whw = changed ? ch.w : whw;
 }
 // exact evaluation of the entries of a chunk that the ranking cannot separate from the winner (rare path)
-__device__ __forceinline__ void q_chunk_exact(const CellListDev& c, V3 l, const uint4& ch, float lim, int widx, const float* T, V3 q, float& best,
+__device__ __forceinline__ void q_chunk_exact(const CellListDev& c, Q3 l, const uint4& ch, float lim, int widx, const float* T, V3 q, float& best,
                                               int& bidx, V3& moved) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const unsigned lo = e ? ch.z : ch.x, hi = e ? ch.w : ch.y;
     const int j = (int)(hi >> 16);
-    if (hi >= Q_EMPTY_HI || j == widx || !(q_rank(l, lo, hi) <= lim)) continue;
+    if (hi >= Q_EMPTY_HI || j == widx || !(Q_KEYF(q_rank(l, lo, hi)) <= lim)) continue;
     const float4 t = c.pts_idx[j];
     const V3 tm = m4_point(T, v3(t.x, t.y, t.z));
     const float d2 = sqdist_flann(q, tm);
@@ -1793,30 +1803,37 @@ __device__ __forceinline__ void q_chunk_exact(const CellListDev& c, V3 l, const 
   }
 }
 
-// returns the ORIGINAL index of the nearest neighbour (or -1), its exact squared distance and the neighbour moved by T
-__device__ __forceinline__ void cells_nnq(const CellListDev& c, V3 qg, const float* T, V3 q, float& best, int& bidx, V3& moved) {
+// DEFER: a lookup whose two best keys the ranking cannot separate is not re-scanned here; the caller is told (true) and
+// repeats it later with DEFER = false (k_icp_fusedq<true> collects such lookups per block and runs them densely packed).
+template <bool DEFER>
+__device__ __forceinline__ bool cells_nnq(const CellListDev& c, V3 qg, const float* T, V3 q, float& best, int& bidx, V3& moved) {
   const float hx = __builtin_fmaf(qg.x, c.inv_cell, c.gox), hy = __builtin_fmaf(qg.y, c.inv_cell, c.goy), hz = __builtin_fmaf(qg.z, c.inv_cell, c.goz);
   const float gx = floorf(hx), gy = floorf(hy), gz = floorf(hz);
   const int ix = (int)gx, iy = (int)gy, iz = (int)gz;
-  if ((unsigned)ix >= (unsigned)c.dx || (unsigned)iy >= (unsigned)c.dy || (unsigned)iz >= (unsigned)c.dz) return;
+  if ((unsigned)ix >= (unsigned)c.dx || (unsigned)iy >= (unsigned)c.dy || (unsigned)iz >= (unsigned)c.dz) return false;
   const uint2 r = c.rec[(iz * c.dy + iy) * c.dx + ix];
   const int nch = (int)r.y;
   ICP_COUNT(0, 1);
-  if (nch == 0) return;
-  const V3 l = v3(__builtin_fmaf(hx - gx, c.q_cs, c.q_rs), __builtin_fmaf(hy - gy, c.q_cs, c.q_rs), __builtin_fmaf(hz - gz, c.q_cs, c.q_rs));
-  unsigned b1 = Q_KEY_INF, b2 = Q_KEY_INF;
+  if (nch == 0) return false;
+  // local coordinate in whole steps (q_rs carries the + 0.5 of the rounding)
+  const Q3 l = {Q_L(__builtin_fmaf(hx - gx, c.q_cs, c.q_rs)), Q_L(__builtin_fmaf(hy - gy, c.q_cs, c.q_rs)), Q_L(__builtin_fmaf(hz - gz, c.q_cs, c.q_rs))};
+  unsigned b1 = Q_INF, b2 = Q_INF;
   unsigned why = 0xFFFFFFFFu, whw = 0xFFFFFFFFu;  // high words (index) of the chunk that holds the winner
   const uint4* __restrict__ lp = c.qlist + r.x;
+  // (32-bit byte offsets from the uniform base: one register and a 64-bit add less than a per-lane pointer; the lists of a
+  // cloud stay far below 4 GB)
+  const char* __restrict__ qbase = (const char*)c.qlist;
+  unsigned qoff = r.x * 16u;
   ICP_COUNT(2, nch);
-  for (int k = 0; k < nch; k += 2) {  // two chunks (four candidates, two loads in flight) per trip
+  for (int k = 0; k < nch; k += 2, qoff += 32u) {  // two chunks (four candidates, two loads in flight) per trip
     ICP_COUNT_WAVE(3);
-    const uint4 ca = lp[k], cb = lp[k + 1];  // (lists hold an even number of chunks)
+    const uint4 ca = *(const uint4*)(qbase + qoff), cb = *(const uint4*)(qbase + qoff + 16u);  // (lists hold an even number of chunks)
     q_chunk(l, ca, b1, b2, why, whw);
     q_chunk(l, cb, b1, b2, why, whw);
   }
   ICP_COUNT(1, 1);
   const unsigned whi = (b1 & 1u) ? whw : why;
-  const float f1 = __uint_as_float(b1 & ~1u) * c.q_step2, f2 = __uint_as_float(b2 & ~1u) * c.q_step2;
+  const float f1 = Q_KEYF(b1 & ~1u) * c.q_step2, f2 = Q_KEYF(b2 & ~1u) * c.q_step2;
   const int widx = (int)(whi >> 16);
   const float4 w = c.pts_idx[widx];
   moved = m4_point(T, v3(w.x, w.y, w.z));
@@ -1825,15 +1842,17 @@ __device__ __forceinline__ void cells_nnq(const CellListDev& c, V3 qg, const flo
   const float mag = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), 0.25f));
   const float delta = mag * 2.0e-6f;
   const float s1 = __builtin_amdgcn_sqrtf(f1), s2 = __builtin_amdgcn_sqrtf(fminf(f2, 1.0e30f));
-  // transform rounding as in cells_nn (1.02e-4 also covers the mantissa bit the keys gave up) + the quantisation of the
-  // two candidate positions being compared
-  const float tol = 2.002f * s1 * delta + 1.02e-4f * f1 + delta * delta + 2.1f * c.q_eq * (s1 + s2) + 2.1f * c.q_eq * c.q_eq;
+  // transform rounding as in cells_nn (1.02e-4 also covers the conversion of the keys to float) + the quantisation of the
+  // query and of the two candidate positions being compared (q_eq bounds their sum) + the key bit each of them gave up
+  const float tol = 2.002f * s1 * delta + 1.02e-4f * f1 + delta * delta + 2.1f * c.q_eq * (s1 + s2) + 2.1f * c.q_eq * c.q_eq + 2.f * c.q_step2;
   if (f2 - f1 <= tol) {
+    if (DEFER) return true;
     ICP_COUNT(4, 1);
     ICP_COUNT_WAVE(5);
     const float lim = (f1 + tol) / c.q_step2;  // back to step units
     for (int k = 0; k < nch; ++k) q_chunk_exact(c, l, lp[k], lim, widx, T, q, best, bidx, moved);
   }
+  return false;
 }
 
 // COMPOSED = false (nn_mode 3): the source point at iteration k is the chain T_k(...T_1(p0)) of the solved increments,
@@ -1842,8 +1861,8 @@ __device__ __forceinline__ void cells_nnq(const CellListDev& c, V3 qg, const flo
 //   final_tf = T_k * ... * T_1 (IcpState, float products) with fused multiply-adds.  Positions differ from the chain by
 //   float rounding (<= 1e-7 relative), so a correspondence at an exact tie or a residual at the gate can differ:
 //   same iteration counts, poses within the tolerances tests/test_gpu_parity.py::test_icp_composed_increments states.
-#ifndef ICP_WAVES_ATTR
-#define ICP_WAVES_ATTR
+#ifndef HOP_ICP_W
+#define HOP_ICP_W 7
 #endif
 template <bool F32>
 struct IcpAcc {
@@ -1856,12 +1875,69 @@ struct IcpAcc<true> {
 __device__ __forceinline__ double icp_wave_sum(double v) { return wave_sum(v); }
 __device__ __forceinline__ double icp_fma(double a, double b, double c) { return fma(a, b, c); }
 __device__ __forceinline__ float icp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// one source point of a hypothesis: move it, find its correspondence, gate it, add its terms to the lane's sums.
+// Returns ICP_PT_DEFERRED if the lookup was deferred (DEFER only; nothing was added), ICP_PT_ACCEPTED if terms were added.
+enum { ICP_PT_REJECTED = 0, ICP_PT_DEFERRED = 1, ICP_PT_ACCEPTED = 2 };
+template <bool COMPOSED, bool DEFER, typename acc_t>
+__device__ __forceinline__ int icp_fusedq_point(const IcpArgs& a, int i, const float* __restrict__ pose, const float* __restrict__ sTi,
+                                                 const float* __restrict__ hist, const float* __restrict__ F, acc_t (&acc)[ICP_NACC]) {
+  const float4 p4 = a.s_pts4[i];
+  V3 q = v3(p4.x, p4.y, p4.z), qn;
+  if (COMPOSED) {
+    if (a.iter > 0) q = m4_point_fma(F, q);
+  } else {
+    const float4 n4 = a.s_nrm4[i];
+    qn = v3(n4.x, n4.y, n4.z);
+    icp_chain_point_normal(hist, a.iter, q, qn);
+  }
+  float d2 = 3.0e38f;
+  int j = -1;
+  V3 tq;  // the correspondence moved by the pose, as the distance was measured
+  if (cells_nnq<DEFER>(a.cells, m4_point_fma(sTi, q), pose, q, d2, j, tq)) return ICP_PT_DEFERRED;
+  if (j < 0 || !(d2 <= a.max_d2)) return ICP_PT_REJECTED;
+  const float4 tn = a.cells.nrm_idx[j];
+  if (COMPOSED) {  // the source normal only now: three registers less across the scan of the list
+    const float4 n4 = a.s_nrm4[i];
+    qn = v3(n4.x, n4.y, n4.z);
+    if (a.iter > 0) qn = m4_dir_fma(F, qn);
+  }
+  const V3 nt = m4_dir(pose, v3(tn.x, tn.y, tn.z));
+  if (!(vdot(qn, nt) >= a.cos_thr)) return ICP_PT_REJECTED;
+  ICP_COUNT(6, 1);
+  ICP_COUNT_WAVE(7);
+  const V3 c = vcross(q, nt);
+  const acc_t J[6] = {c.x, c.y, c.z, nt.x, nt.y, nt.z};
+  const acc_t res = (acc_t)vdot(q - tq, nt);
+  int k = 0;
+#pragma unroll
+  for (int u = 0; u < 6; ++u)
+#pragma unroll
+    for (int v = 0; v <= u; ++v) {
+      acc[k] = icp_fma(J[u], J[v], acc[k]);
+      ++k;
+    }
+#pragma unroll
+  for (int u = 0; u < 6; ++u) acc[21 + u] = icp_fma(-J[u], res, acc[21 + u]);
+  acc[27] += (acc_t)d2;
+  // the count of accepted correspondences: per lane in double (nn_mode 3), by the caller per wavefront (nn_mode 4)
+  if (sizeof(acc_t) == 8) acc[28] += (acc_t)1;
+  acc[29] += (acc_t)q.x, acc[30] += (acc_t)q.y, acc[31] += (acc_t)q.z;
+  return ICP_PT_ACCEPTED;
+}
 template <bool COMPOSED>
-__global__ __launch_bounds__(256) ICP_WAVES_ATTR void k_icp_fusedq(IcpArgs a, int R) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPOSED ? HOP_ICP_W : 4))) void k_icp_fusedq(IcpArgs a, int R) {
   __shared__ double red[4][ICP_NACC];
+  // nn_mode 4: lookups that need the exact re-scan (0.4 % of them, but a fifth of the wavefronts held one) are queued per block
+  // and run afterwards densely packed, instead of every such wavefront walking its lists again for one or two lanes
+  __shared__ unsigned short defer_i[COMPOSED ? 256 * ICP_ACCUM_R : 1];
+  __shared__ int defer_n;
   const int hl = blockIdx.y, h = a.h0 + hl;
   const IcpState& st = a.state[hl];
   if (!st.active) return;
+  if (COMPOSED) {
+    if (threadIdx.x == 0) defer_n = 0;
+    __syncthreads();
+  }
   const float* __restrict__ pose = a.pose + (size_t)h * 16;
   const float* __restrict__ sTi = a.pose_inv + (size_t)h * 12;
   const float* __restrict__ hist = a.hist + (size_t)hl * a.max_iter * 12;
@@ -1873,47 +1949,26 @@ __global__ __launch_bounds__(256) ICP_WAVES_ATTR void k_icp_fusedq(IcpArgs a, in
   acc_t acc[ICP_NACC];
 #pragma unroll
   for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0;
+  int n_wave = 0;
+  const int base = blockIdx.x * (256 * R);
   for (int r = 0; r < R; ++r) {
-    const int i = blockIdx.x * (256 * R) + r * 256 + threadIdx.x;
+    const int li = r * 256 + threadIdx.x, i = base + li;
     if (i >= a.ns) continue;
-    const float4 p4 = a.s_pts4[i], n4 = a.s_nrm4[i];
-    V3 q = v3(p4.x, p4.y, p4.z), qn = v3(n4.x, n4.y, n4.z);
-    if (COMPOSED) {
-      if (a.iter > 0) q = m4_point_fma(F, q), qn = m4_dir_fma(F, qn);
-    } else {
-      icp_chain_point_normal(hist, a.iter, q, qn);
-    }
-    float d2 = 3.0e38f;
-    int j = -1;
-    V3 tq;  // the correspondence moved by the pose, as the distance was measured
-    cells_nnq(a.cells, m4_point_fma(sTi, q), pose, q, d2, j, tq);
-    if (j < 0 || !(d2 <= a.max_d2)) continue;
-    const float4 tn = a.cells.nrm_idx[j];
-    const V3 nt = m4_dir(pose, v3(tn.x, tn.y, tn.z));
-    if (!(vdot(qn, nt) >= a.cos_thr)) continue;
-    ICP_COUNT(6, 1);
-    ICP_COUNT_WAVE(7);
-    const V3 c = vcross(q, nt);
-    const acc_t J[6] = {c.x, c.y, c.z, nt.x, nt.y, nt.z};
-    const acc_t res = (acc_t)vdot(q - tq, nt);
-    int k = 0;
-#pragma unroll
-    for (int u = 0; u < 6; ++u)
-#pragma unroll
-      for (int v = 0; v <= u; ++v) {
-        acc[k] = icp_fma(J[u], J[v], acc[k]);
-        ++k;
-      }
-#pragma unroll
-    for (int u = 0; u < 6; ++u) acc[21 + u] = icp_fma(-J[u], res, acc[21 + u]);
-    acc[27] += (acc_t)d2;
-    acc[28] += (acc_t)1;
-    acc[29] += (acc_t)q.x, acc[30] += (acc_t)q.y, acc[31] += (acc_t)q.z;
+    const int res = icp_fusedq_point<COMPOSED, COMPOSED, acc_t>(a, i, pose, sTi, hist, F, acc);
+    if (res == ICP_PT_DEFERRED) defer_i[atomicAdd(&defer_n, 1)] = (unsigned short)li;
+    // (lane 0 of a wavefront is among the lanes that get here whenever any of them does: its copy is the wavefront's count)
+    if (COMPOSED) n_wave += __popcll(__ballot(res == ICP_PT_ACCEPTED));
+  }
+  if (COMPOSED) {
+    __syncthreads();
+    const int nd = defer_n;
+    for (int t = threadIdx.x; t < nd; t += 256)
+      n_wave += __popcll(__ballot(icp_fusedq_point<COMPOSED, false, acc_t>(a, base + defer_i[t], pose, sTi, hist, F, acc) == ICP_PT_ACCEPTED));
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < ICP_NACC; ++k) {
-    const double s = icp_wave_sum(acc[k]);
+    const double s = (COMPOSED && k == 28) ? (double)n_wave : icp_wave_sum(acc[k]);
     if (lane == 0) red[wave][k] = s;
   }
   __syncthreads();

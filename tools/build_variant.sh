@@ -1,0 +1,13 @@
+#!/bin/bash
+# tools/build_variant.sh <name> [extra hipcc flags]: an alternative build of libhop.so under tools/_tmp/<name>/ (A/B runs on one box:
+# HOP_LIB=tools/_tmp/<name>/libhop.so python tools/icp_bench.py ...)
+set -e
+N=$1; shift
+D=/root/repo/tools/_tmp/$N
+mkdir -p $D
+cd /root/repo/icra20-hand-object-pose_amd/csrc
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-result $*"
+for f in hop_kernels hop_ctx; do /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $D/$f.o & done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $D/hop_kernels.o $D/hop_ctx.o ../lib/obj/hop_physics.o ../lib/obj/hop_normals.o ../lib/obj/hop_render.o ../lib/obj/hop_comm.o -ldl -o $D/libhop.so
+ls -la $D/libhop.so
