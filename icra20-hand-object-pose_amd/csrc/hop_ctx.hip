@@ -57,6 +57,7 @@ struct CellListStore {
   float cell = 0, max_dist = 0, coord_mag = 0;
   bool packed = false, pack_requested = false;
   int sub = 1;  // per-frame lists: subdivision of the ring grid they were built with
+  float avg_len = 0;  // entries per voxel with candidates at the last build (chooses the lanes per voxel of the next one)
   void release() {
     start_d.release(), pts_d.release(), nrm_d.release(), u2_d.release(), count_d.release(), work_d.release(), keep_d.release(), range_d.release();
     nrm_idx_d.release(), pts_idx_d.release(), rec_d.release(), qlist_d.release();
@@ -449,7 +450,10 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   int* keep = cs.keep_d.as<int>();
   launch_cell_list_local_work(flag, scan, (int)ncell, work, c->stream);
   // stage 2: one wave per listed cell, count then write around a scan of the counts
-  launch_cell_list_local(a, g, false, exist_mode, work, nwork, keep, c->stream);
+  // lanes per voxel from the list lengths this store had last time (first build: short lists assumed)
+  static const int lanes_env = getenv("HOP_LOCAL_SUB") ? atoi(getenv("HOP_LOCAL_SUB")) : 0;
+  const int lanes = lanes_env ? lanes_env : (cs.avg_len > 5.0f ? 64 : 16);
+  launch_cell_list_local(a, g, false, exist_mode, work, nwork, keep, lanes, c->stream);
   HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->sort_tmp.p, tmp_bytes, a.count, cs.start_d.as<int>(), (int)(ncell + 1), c->stream));
   int total = 0;
   HIPCHK(c, hipMemcpyAsync(&total, cs.start_d.as<int>() + ncell, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -457,7 +461,8 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   HIPCHK(c, cs.pts_d.ensure(sizeof(float4) * (size_t)std::max(total, 1)));
   if (normals) HIPCHK(c, cs.nrm_d.ensure(sizeof(float4) * (size_t)std::max(total, 1)));
   a.start = cs.start_d.as<int>(), a.pts = cs.pts_d.as<float4>(), a.nrm = normals ? cs.nrm_d.as<float4>() : nullptr;
-  launch_cell_list_local(a, g, true, exist_mode, work, nwork, keep, c->stream);
+  cs.avg_len = nwork > 0 ? (float)total / (float)nwork : 0.f;
+  launch_cell_list_local(a, g, true, exist_mode, work, nwork, keep, lanes_env ? lanes_env : (cs.avg_len > 5.0f ? 64 : 16), c->stream);
   cs.c.ox = a.ox, cs.c.oy = a.oy, cs.c.oz = a.oz, cs.c.cell = a.cell, cs.c.inv_cell = 1.0f / a.cell;
   cs.c.dx = a.dx, cs.c.dy = a.dy, cs.c.dz = a.dz;
   cs.c.start = cs.start_d.as<int>(), cs.c.pts = cs.pts_d.as<float4>(), cs.c.nrm = normals ? cs.nrm_d.as<float4>() : nullptr;

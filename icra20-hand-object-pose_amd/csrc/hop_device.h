@@ -312,7 +312,7 @@ void launch_lcp_sum_partial(const LcpArgs& a, int hb, hipStream_t s);
 void launch_cell_list_local_flag(const CellListBuildArgs& a, const GridDev& g, int* flag, hipStream_t s);
 void launch_cell_list_local_work(const int* flag, const int* flag_scan, int ncell, int* work, hipStream_t s);
 void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool write, int exist_mode, const int* work, int nwork, int* keep_buf,
-                            hipStream_t s);
+                            int lanes, hipStream_t s);
 int cell_list_local_keep();
 void launch_pose_inverse(const float* pose, int n, float* inv12, hipStream_t s);
 void launch_unit_normals(const float* nx, const float* ny, const float* nz, int n, float* ux, float* uy, float* uz, hipStream_t s);

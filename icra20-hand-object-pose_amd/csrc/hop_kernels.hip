@@ -1026,21 +1026,26 @@ __global__ __launch_bounds__(256) void k_cell_list_local_work(const int* __restr
 // realises U(C) into an LDS list, pairwise domination among them, ballot-compacted output.  Lanes own candidate rows.
 #define LOCAL_WCAP 512
 #define LOCAL_KEEP 192  /* results of the counting pass up to this length are replayed by the writing pass */
-template <bool WRITE>
+// SUB lanes work on one voxel (256 / SUB voxels per workgroup): the candidate rows of a voxel are few (3 x 3 ring cells: 9 rows), so
+// a whole wavefront per voxel left most lanes idle in a latency-bound kernel.
+template <bool WRITE, int SUB>
 __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, GridDev g, int exist_mode, const int* __restrict__ work, int nwork,
                                                          int* __restrict__ keep_buf) {
-  __shared__ int list_s[4][LOCAL_WCAP];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wi = blockIdx.x * 4 + wave;
-  if (wi >= nwork) return;  // whole waves leave; no block-level barrier below
-  int* list = list_s[wave];
+  __shared__ int list_s[256 / SUB][LOCAL_WCAP];
+  const int grp = threadIdx.x / SUB, lane = threadIdx.x % SUB;
+  const int gsh = ((threadIdx.x & 63) / SUB) * SUB;  // this group's bits in a wavefront ballot
+  const unsigned long long gmask = SUB == 64 ? ~0ull : ((1ull << (SUB & 63)) - 1ull);
+#define GBALLOT(x) ((__ballot(x) >> gsh) & gmask)
+  const int wi = blockIdx.x * (256 / SUB) + grp;
+  if (wi >= nwork) return;  // whole groups leave; no block-level barrier below
+  int* list = list_s[grp];
   const int cidx = work[wi];
   int* keepw = keep_buf + (size_t)wi * LOCAL_KEEP;
   if (WRITE) {
     const int pos = a.start[cidx], cnt = a.start[cidx + 1] - pos;
     if (cnt == 0) return;
     if (cnt <= LOCAL_KEEP) {  // replay
-      for (int i = lane; i < cnt; i += 64) {
+      for (int i = lane; i < cnt; i += SUB) {
         const float4 m = g.pts[keepw[i]];
         a.pts[pos + i] = m;
         if (a.nrm) {
@@ -1060,7 +1065,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
   float u2 = 3.0e38f;
   int kb = 0x7fffffff;
   int maxlen = 0;
-  for (int r = lane; r < nrows; r += 64) {
+  for (int r = lane; r < nrows; r += SUB) {
     const int row = ((z0 + r / ny) * g.dy + (y0 + r % ny)) * g.dx;
     const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
     maxlen = max(maxlen, e - b);
@@ -1071,11 +1076,11 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
     }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const float ou = __shfl_xor(u2, off);
-    const int ok = __shfl_xor(kb, off);
+  for (int off = SUB / 2; off > 0; off >>= 1) {
+    const float ou = __shfl_xor(u2, off, SUB);
+    const int ok = __shfl_xor(kb, off, SUB);
     if (ou < u2 || (ou == u2 && ok < kb)) u2 = ou, kb = ok;
-    maxlen = max(maxlen, __shfl_xor(maxlen, off));
+    maxlen = max(maxlen, __shfl_xor(maxlen, off, SUB));
   }
   const int pos = WRITE ? a.start[cidx] : 0;
   const float4 best = g.pts[kb];
@@ -1094,7 +1099,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
   const double bhi[3] = {(double)hi[0] + a.margin, (double)hi[1] + a.margin, (double)hi[2] + a.margin};
   // step 2: survivors of the threshold and of `best`, in (position-in-row, row) order
   int L = 0;
-  for (int r0 = 0; r0 < nrows; r0 += 64) {
+  for (int r0 = 0; r0 < nrows; r0 += SUB) {
     const int r = r0 + lane;
     int b = 0, e = 0;
     if (r < nrows) {
@@ -1108,7 +1113,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
         const float4 t = g.pts[k];
         in = box_mindist2(lo, hi, t.x, t.y, t.z) <= thr2 && (k == kb || !dominates(best, t, blo, bhi, a.dom_eps));
       }
-      const unsigned long long m = __ballot(in);
+      const unsigned long long m = GBALLOT(in);
       if (in) {
         const int at = L + __popcll(m & ((1ull << lane) - 1ull));
         if (at < LOCAL_WCAP) list[at] = k;
@@ -1126,7 +1131,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
     for (int round = 0; round < 48 && L > 8; ++round) {
       float c2 = 3.0e38f;
       int ck = 0x7fffffff;
-      for (int i = lane; i < L; i += 64) {
+      for (int i = lane; i < L; i += SUB) {
         const int k = list[i];
         if (k < 0) continue;
         const float4 t = g.pts[k];
@@ -1135,15 +1140,15 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
         if (after && (m2 < c2 || (m2 == c2 && k < ck))) c2 = m2, ck = k;
       }
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const float oc = __shfl_xor(c2, off);
-        const int ok = __shfl_xor(ck, off);
+      for (int off = SUB / 2; off > 0; off >>= 1) {
+        const float oc = __shfl_xor(c2, off, SUB);
+        const int ok = __shfl_xor(ck, off, SUB);
         if (oc < c2 || (oc == c2 && ok < ck)) c2 = oc, ck = ok;
       }
       if (ck == 0x7fffffff) break;
       pm2 = c2, pk = ck;
       const float4 pv = g.pts[ck];
-      for (int i = lane; i < L; i += 64) {
+      for (int i = lane; i < L; i += SUB) {
         const int k = list[i];
         if (k < 0 || k == ck) continue;
         if (dominates(pv, g.pts[k], blo, bhi, a.dom_eps)) list[i] = ~k;
@@ -1152,10 +1157,10 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
     }
     // compact the survivors (order preserved)
     int L2 = 0;
-    for (int i0 = 0; i0 < L; i0 += 64) {
+    for (int i0 = 0; i0 < L; i0 += SUB) {
       const int i = i0 + lane;
       const int k = i < L ? list[i] : -1;
-      const unsigned long long m = __ballot(k >= 0);
+      const unsigned long long m = GBALLOT(k >= 0);
       __builtin_amdgcn_wave_barrier();
       if (k >= 0) list[L2 + __popcll(m & ((1ull << lane) - 1ull))] = k;
       L2 += __popcll(m);
@@ -1163,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
     }
     L = L2;
     // step 3b: pairwise domination among what is left
-    for (int i0 = 0; i0 < L; i0 += 64) {
+    for (int i0 = 0; i0 < L; i0 += SUB) {
       const int i = i0 + lane;
       bool keep = false;
       float4 m = make_float4(0, 0, 0, 0);
@@ -1177,7 +1182,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
         for (int j = 0; j < L && keep && L <= 160; ++j)
           if (j != i) keep = !dominates(g.pts[list[j]], m, blo, bhi, a.dom_eps);
       }
-      const unsigned long long kmask = __ballot(keep);
+      const unsigned long long kmask = GBALLOT(keep);
       if (keep) {
         const int n = kept + __popcll(kmask & ((1ull << lane) - 1ull));
         if (WRITE) {
@@ -1192,7 +1197,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
     }
   } else {
     // more survivors than the list holds (not seen at the sizes built here): keep them all, same order as step 2
-    for (int r0 = 0; r0 < nrows; r0 += 64) {
+    for (int r0 = 0; r0 < nrows; r0 += SUB) {
       const int r = r0 + lane;
       int b = 0, e = 0;
       if (r < nrows) {
@@ -1207,7 +1212,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
           t = g.pts[k];
           in = box_mindist2(lo, hi, t.x, t.y, t.z) <= thr2 && (k == kb || !dominates(best, t, blo, bhi, a.dom_eps));
         }
-        const unsigned long long m = __ballot(in);
+        const unsigned long long m = GBALLOT(in);
         if (WRITE && in) {
           const int at = pos + kept + __popcll(m & ((1ull << lane) - 1ull));
           a.pts[at] = t;
@@ -1223,8 +1228,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
   }
   if (!WRITE && lane == 0) a.count[cidx] = kept;
 }
-template __global__ void k_cell_list_local<false>(CellListBuildArgs, GridDev, int, const int*, int, int*);
-template __global__ void k_cell_list_local<true>(CellListBuildArgs, GridDev, int, const int*, int, int*);
+#undef GBALLOT
 
 // Scan of one cell list.  The candidates are ranked by their squared distance to the query IN THE CLOUD'S REST FRAME
 // (qg, 8 flops each); the reference's distance expression -- query against the candidate moved by T, in the query's
@@ -2622,10 +2626,17 @@ void launch_cell_list_local_work(const int* flag, const int* flag_scan, int ncel
   hipLaunchKernelGGL(k_cell_list_local_work, dim3((ncell + 255) / 256), dim3(256), 0, s, flag, flag_scan, ncell, work);
 }
 void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool write, int exist_mode, const int* work, int nwork, int* keep_buf,
-                            hipStream_t s) {
+                            int lanes, hipStream_t s) {
   if (nwork <= 0) return;
-  if (write) hipLaunchKernelGGL(k_cell_list_local<true>, dim3((nwork + 3) / 4), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
-  else hipLaunchKernelGGL(k_cell_list_local<false>, dim3((nwork + 3) / 4), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
+  // lanes per voxel: 16 for the short lists (a few candidate rows of a few points: scene and Verify lists, 1.7x faster), a whole
+  // wavefront where the lists are long (the hand scene: the pairwise pass is O(L^2) per voxel and 16 lanes make few, long waves)
+  if (lanes >= 64) {
+    if (write) hipLaunchKernelGGL((k_cell_list_local<true, 64>), dim3((nwork + 3) / 4), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
+    else hipLaunchKernelGGL((k_cell_list_local<false, 64>), dim3((nwork + 3) / 4), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
+  } else {
+    if (write) hipLaunchKernelGGL((k_cell_list_local<true, 16>), dim3((nwork + 15) / 16), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
+    else hipLaunchKernelGGL((k_cell_list_local<false, 16>), dim3((nwork + 15) / 16), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
+  }
 }
 int cell_list_local_keep() { return LOCAL_KEEP; }
 __global__ __launch_bounds__(256) void k_cell_ranges(const int* __restrict__ start, int ncell, int2* __restrict__ range) {
