@@ -157,6 +157,7 @@ struct CellListBuildArgs {
   const float *nx, *ny, *nz;  // optional normals of the cloud ...
   float4* nrm;                // ... copied next to pts (null: none)
   float dom_eps;              // domination margin on squared distances
+  int pair_max;               // per-frame lists: the pairwise pruning pass runs for at most this many survivors (longer: kept as they are)
 };
 
 struct EmitArgs {

@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, Gr
         keep = true;
         // (a few cells far from a dense cloud keep hundreds of survivors: the O(L^2) pass is skipped there -- longer
         // lists, same answers -- rather than letting a handful of waves set the kernel's duration)
-        for (int j = 0; j < L && keep && L <= 160; ++j)
+        for (int j = 0; j < L && keep && L <= a.pair_max; ++j)
           if (j != i) keep = !dominates(g.pts[list[j]], m, blo, bhi, a.dom_eps);
       }
       const unsigned long long kmask = GBALLOT(keep);
