@@ -25,8 +25,8 @@ def build():
     subprocess.check_call(["make", "-C", SRC], stdout=subprocess.DEVNULL)
     o = os.path.join(OUT, "hop_kernels_count.o")
     subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-c", os.path.join(SRC, "hop_kernels.hip"), "-o", o])
-    objs = [o, os.path.join(SRC, "..", "lib", "obj", "hop_ctx.o"), os.path.join(SRC, "..", "lib", "obj", "hop_physics.o")]
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", os.path.join(OUT, "libhop_count.so")])
+    objs = [o] + [os.path.join(SRC, "..", "lib", "obj", n + ".o") for n in ("hop_ctx", "hop_physics", "hop_normals", "hop_render", "hop_comm")]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", os.path.join(OUT, "libhop_count.so")])
 
 
 def main():
