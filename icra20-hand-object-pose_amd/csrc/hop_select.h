@@ -153,37 +153,34 @@ __attribute__((target("avx512f"))) inline int fourth_point_mask_avx512(const flo
   const __m512 one = _mm512_set1_ps(1.0f);
   __m512 bx[3], by[3], bz[3];
   for (int q = 0; q < 3; ++q) bx[q] = _mm512_set1_ps(b[q][0]), by[q] = _mm512_set1_ps(b[q][1]), bz[q] = _mm512_set1_ps(b[q][2]);
-  // every lane keeps its own running minimum and the index where it first occurred (strict '<'); the overall
-  // first minimum is the smallest index among the lanes that hold the global minimum
+  // The scalar loop keeps ONE running best and takes a candidate only if it is strictly below it.  The same here, sixteen
+  // at a time: lanes not below the running best are out before anything else is computed for them, and the three
+  // "far enough from the base points" tests -- most of the arithmetic -- run only for blocks that still hold such a lane
+  // (a few dozen of the ~900 blocks: the best falls quickly).  Within a block the lowest index among the lanes with the
+  // smallest distance wins, which is what the scalar loop does when it walks the block in order.
+  float best_distance = FLT_MAX;
+  int best = -1;
   __m512 vbest = _mm512_set1_ps(FLT_MAX);
-  __m512i vidx = _mm512_set1_epi32(-1);
-  __m512i cur = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-  const __m512i step = _mm512_set1_epi32(16);
   const int nfull = nr & ~15;
   const unsigned short* m16 = reinterpret_cast<const unsigned short*>(mask);
-  for (int k = 0; k < nfull; k += 16, cur = _mm512_add_epi32(cur, step)) {
+  for (int k = 0; k < nfull; k += 16) {
     __mmask16 ok = m16[k >> 4];
     if (!ok) continue;
     const __m512 px = _mm512_loadu_ps(X + k), py = _mm512_loadu_ps(Y + k), pz = _mm512_loadu_ps(Z + k);
+    const __m512 s = _mm512_add_ps(_mm512_add_ps(_mm512_mul_ps(vA, px), _mm512_mul_ps(vB, py)), _mm512_mul_ps(vC, pz));
+    const __m512 dist = _mm512_abs_ps(_mm512_sub_ps(s, one));
+    ok = _mm512_mask_cmp_ps_mask(ok, dist, vbest, _CMP_LT_OQ);  // false for NaN, like the scalar loop
+    if (!ok) continue;
     for (int q = 0; q < 3; ++q) {
       const __m512 dx = _mm512_sub_ps(px, bx[q]), dy = _mm512_sub_ps(py, by[q]), dz = _mm512_sub_ps(pz, bz[q]);
       const __m512 d2 = _mm512_add_ps(_mm512_mul_ps(dx, dx), _mm512_add_ps(_mm512_mul_ps(dy, dy), _mm512_mul_ps(dz, dz)));
       ok = _mm512_mask_cmp_ps_mask(ok, d2, vts, _CMP_GE_OQ);
     }
-    const __m512 s = _mm512_add_ps(_mm512_add_ps(_mm512_mul_ps(vA, px), _mm512_mul_ps(vB, py)), _mm512_mul_ps(vC, pz));
-    const __m512 dist = _mm512_abs_ps(_mm512_sub_ps(s, one));
-    const __mmask16 better = _mm512_mask_cmp_ps_mask(ok, dist, vbest, _CMP_LT_OQ);  // false for NaN, like the scalar loop
-    vbest = _mm512_mask_mov_ps(vbest, better, dist);
-    vidx = _mm512_mask_mov_epi32(vidx, better, cur);
+    if (!ok) continue;
+    best_distance = _mm512_mask_reduce_min_ps(ok, dist);
+    vbest = _mm512_set1_ps(best_distance);
+    best = k + __builtin_ctz((unsigned)_mm512_mask_cmp_ps_mask(ok, dist, vbest, _CMP_EQ_OQ));
   }
-  float lb[16];
-  int li[16];
-  _mm512_storeu_ps(lb, vbest);
-  _mm512_storeu_si512(li, vidx);
-  float best_distance = FLT_MAX;
-  int best = -1;
-  for (int q = 0; q < 16; ++q)
-    if (li[q] >= 0 && (lb[q] < best_distance || (lb[q] == best_distance && li[q] < best))) best_distance = lb[q], best = li[q];
   for (int r = nfull; r < nr; ++r) {  // tail (< 16 entries), scalar; strict '<' keeps the earlier index on ties
     if (!((mask[r >> 6] >> (r & 63)) & 1ull)) continue;
     const float px = X[r], py = Y[r], pz = Z[r];
@@ -284,6 +281,62 @@ __attribute__((target("avx512f"))) inline int count_below_off_avx512(const doubl
   int cnt = 0;
   for (int k = 0; k < n; k += 8) cnt += __builtin_popcount((unsigned)_mm512_cmp_pd_mask(_mm512_add_pd(_mm512_loadu_pd(c + k), b), t, _CMP_LT_OQ));
   return cnt;
+}
+// ---- pool without a materialised copy (AVX-512 path of the pair draws) ---------------------------------------------
+// The pool of a first point is the set bits of its matrix row; its weights are read through the row's masks straight
+// from the per-call weight array (point order), summed per 16-lane chunk, per word and in two running-sum levels above.
+// Returns the pool size; cs[4 w + c] = weight of chunk c of word w, bsum[w] = weight of word w, wstart[w] = pool rank of the
+// word's first member; *first / *last = lowest / highest member id (-1 if empty).
+__attribute__((target("avx512f"))) inline int pool_sums_avx512(const unsigned long long* row, int W, const float* weights, double* cs, double* bsum,
+                                                              int* wstart, int* first, int* last) {
+  int k = 0, lo_id = -1, hi_id = -1;
+  for (int w = 0; w < W; ++w) {
+    const unsigned long long bits = row[w];
+    wstart[w] = k;
+    if (!bits) {
+      cs[4 * w] = cs[4 * w + 1] = cs[4 * w + 2] = cs[4 * w + 3] = 0.0;
+      bsum[w] = 0.0;
+      continue;
+    }
+    if (lo_id < 0) lo_id = w * 64 + __builtin_ctzll(bits);
+    hi_id = w * 64 + 63 - __builtin_clzll(bits);
+    double tot = 0.0;
+    for (int c = 0; c < 4; ++c) {
+      const __mmask16 m = (__mmask16)(bits >> (16 * c));
+      double v = 0.0;
+      if (m) {
+        const __m512 p = _mm512_maskz_loadu_ps(m, weights + w * 64 + c * 16);
+        v = _mm512_reduce_add_pd(
+            _mm512_add_pd(_mm512_cvtps_pd(_mm512_castps512_ps256(p)), _mm512_cvtps_pd(_mm256_castpd_ps(_mm512_extractf64x4_pd(_mm512_castps_pd(p), 1)))));
+      }
+      cs[4 * w + c] = v;
+      tot += v;
+    }
+    bsum[w] = tot;
+    k += __builtin_popcountll(bits);
+  }
+  wstart[W] = k;
+  *first = lo_id, *last = hi_id;
+  return k;
+}
+// lowest set lane j of the chunk mask m with lo + (weights of the set lanes <= j) >= target, the highest set lane if none;
+// *lo_out = the cumulative weight before lane j.  w16: the 16 weights of the chunk (unset lanes are not read).
+__attribute__((target("avx512f"))) inline int chunk_scan_avx512(const float* w16, unsigned m, double lo, double target, double* lo_out) {
+  const __m512i sh1 = _mm512_setr_epi64(0, 0, 1, 2, 3, 4, 5, 6), sh2 = _mm512_setr_epi64(0, 0, 0, 1, 2, 3, 4, 5), sh4 = _mm512_setr_epi64(0, 0, 0, 0, 0, 1, 2, 3);
+  const __m512 p = _mm512_maskz_loadu_ps((__mmask16)m, w16);
+  __m512d a = _mm512_cvtps_pd(_mm512_castps512_ps256(p)), b = _mm512_cvtps_pd(_mm256_castpd_ps(_mm512_extractf64x4_pd(_mm512_castps_pd(p), 1)));
+  a = _mm512_mask_add_pd(a, 0xfe, a, _mm512_permutexvar_pd(sh1, a)), b = _mm512_mask_add_pd(b, 0xfe, b, _mm512_permutexvar_pd(sh1, b));
+  a = _mm512_mask_add_pd(a, 0xfc, a, _mm512_permutexvar_pd(sh2, a)), b = _mm512_mask_add_pd(b, 0xfc, b, _mm512_permutexvar_pd(sh2, b));
+  a = _mm512_mask_add_pd(a, 0xf0, a, _mm512_permutexvar_pd(sh4, a)), b = _mm512_mask_add_pd(b, 0xf0, b, _mm512_permutexvar_pd(sh4, b));
+  alignas(64) double incl[16];
+  _mm512_store_pd(incl, a);
+  b = _mm512_add_pd(b, _mm512_set1_pd(incl[7]));
+  _mm512_store_pd(incl + 8, b);
+  const __m512d t = _mm512_set1_pd(target), l = _mm512_set1_pd(lo);
+  const unsigned ge = ((unsigned)_mm512_cmp_pd_mask(_mm512_add_pd(a, l), t, _CMP_GE_OQ) | ((unsigned)_mm512_cmp_pd_mask(_mm512_add_pd(b, l), t, _CMP_GE_OQ) << 8)) & m;
+  const int j = ge ? __builtin_ctz(ge) : 31 - __builtin_clz(m);
+  *lo_out = j > 0 ? lo + incl[j - 1] : lo;
+  return j;
 }
 #endif
 
@@ -762,6 +815,9 @@ struct GenHost {
       bsum_.assign(W, 0.0);
       wstart_.assign(W + 1, 0);
     }
+#if defined(__x86_64__)
+    if (simd_draw_) return SelectRandomTriangleNoPool(base1, base2, base3, tp);
+#endif
     const int first_point = draw_index(fw_all_, point_probs_.data(), n);
     {
       const float old = point_probs_[first_point];
@@ -903,8 +959,187 @@ struct GenHost {
     }
     t_pairdraw += now() - tp, tp = now();
     if (base2 == -1 || base3 == -1) return false;
-    // 4th-point candidates: pool RANKS (not point ids -- the reference stores the loop index, matchBase.hpp:203) of the
-    // pool members compatible with base2 and base3, as a bit mask over [0, npool)
+    const bool ok4 = build_mask4(row, base1, base2, base3, npool);
+    t_pool4 += now() - tp;
+    return ok4;
+  }
+
+#if defined(__x86_64__)
+  // ---- AVX-512 form of the fast path: no materialised pool -------------------------------------------------------
+  // The pool members are the set bits of the first point's matrix row; draws return POINT IDS (ranks and ids order the
+  // pool identically, so every comparison the rank form makes carries over), weights are read through the row masks from
+  // wloc_ = point_probs_ with this call's drops applied (undone when the call ends), and a draw descends four levels of
+  // sums: super-blocks of 16 words, words, 16-lane chunks, lanes -- at most 16 weights are scanned per draw instead of 64.
+  std::vector<float> wloc_;
+  std::vector<double> cs_;  // per 16-lane chunk of a matrix word: weight of its pool members
+  std::vector<std::pair<int, float>> undo_;
+  int pool_first_ = -1, pool_last_ = -1;
+  const unsigned long long* row_ = nullptr;
+  struct IdDraw {
+    int id;         // point id
+    double lo, hi;  // cumulative weight before / through it when the draw was resolved (hi < lo: from the exact routine)
+    double u;
+  };
+  // the reference's own arithmetic on the pool as a vector (rare: a draw within the guard zone of a bin boundary)
+  IdDraw exact_pool_id(double u) {
+    ++n_fallbacks;
+    int k = 0;
+    for (int w = 0; w < W; ++w) {
+      unsigned long long bits = row_[w];
+      while (bits) {
+        const int i = w * 64 + __builtin_ctzll(bits);
+        bits &= bits - 1;
+        pool_ids_[k] = i, probs_[k] = wloc_[i], ++k;
+      }
+    }
+    return {pool_ids_[exact_discrete_index(probs_.data(), npool_, u)], 0.0, -1.0, u};
+  }
+  bool id_draw_ok(int id, double lo, double hi, double target, double T) const {
+    const double tol = guard_tol * T;
+    if (!(T > 0.0)) return false;
+    return (target - lo > tol && hi - target > tol) || (id == pool_first_ && target <= hi - tol) || (id == pool_last_ && target - lo > tol);
+  }
+  IdDraw draw_pool_id(double u) {
+    const double T = pool_total_, target = u * T;
+    const int sb = std::min(count_below_avx512(c0_.data(), (int)c0_.size(), target), nsb_ - 1);
+    const double base0 = sb > 0 ? c0_[sb - 1] : 0.0;
+    const int wi = count_below_off_avx512(c1_.data() + 16 * sb, 16, base0, target);
+    const int w = std::min(16 * sb + wi, W - 1);
+    const unsigned long long bits = row_[w];
+    if (!bits) return exact_pool_id(u);  // an empty word can only be hit through rounding
+    // chunk: the first whose running sum reaches the target, the last non-empty one if none does (no branches to mispredict)
+    const double* cw = cs_.data() + 4 * w;
+    double run[5];
+    run[0] = base0 + ((w & 15) > 0 ? c1_[w - 1] : 0.0);
+    run[1] = run[0] + cw[0], run[2] = run[1] + cw[1], run[3] = run[2] + cw[2], run[4] = run[3] + cw[3];
+    const int below = (run[1] < target) + (run[2] < target) + (run[3] < target) + (run[4] < target);
+    const int sel = std::min(below, 3 - (__builtin_clzll(bits) >> 4));
+    if (!((bits >> (16 * sel)) & 0xffffull)) return exact_pool_id(u);  // (an empty chunk: only through rounding)
+    const double before = run[sel];
+    double lo;
+    const int lane = chunk_scan_avx512(wloc_.data() + w * 64 + sel * 16, (unsigned)((bits >> (16 * sel)) & 0xffffull), before, target, &lo);
+    const int id = w * 64 + sel * 16 + lane;
+    const double hi = lo + (double)wloc_[id];
+    if (id_draw_ok(id, lo, hi, target, T)) return {id, lo, hi, u};
+    return exact_pool_id(u);
+  }
+  // a draw resolved before the weights of ids a and b dropped by da, db (<= 0): still the same member afterwards?
+  bool redraw_unchanged_id(IdDraw& d, int a, double da, int b, double db) const {
+    if (d.hi < d.lo) return false;
+    const double lo = d.lo + (a < d.id ? da : 0.0) + (b < d.id ? db : 0.0);
+    const double hi = lo + (double)wloc_[d.id];
+    const double T = pool_total_;
+    const bool ok = id_draw_ok(d.id, lo, hi, d.u * T, T);
+    if (ok) d.lo = lo, d.hi = hi;
+    return ok;
+  }
+  bool SelectRandomTriangleNoPool(int& base1, int& base2, int& base3, double tp) {
+    if (wloc_.size() != point_probs_.size()) {
+      wloc_ = point_probs_;
+      cs_.assign((size_t)4 * W, 0.0);
+      if (pool_ids_.size() < (size_t)n + 64) pool_ids_.resize((size_t)n + 64), probs_.resize((size_t)n + 64);
+    }
+    const int first_point = draw_index(fw_all_, point_probs_.data(), n);
+    {
+      const float old = point_probs_[first_point];
+      point_probs_[first_point] *= opt.dispersion;
+      wloc_[first_point] = point_probs_[first_point];
+      fw_all_.add(first_point, (double)point_probs_[first_point] - (double)old);
+    }
+    t_first += now() - tp, tp = now();
+    const unsigned long long* row = M + (size_t)first_point * W;
+    row_ = row;
+    const int npool = pool_sums_avx512(row, W, wloc_.data(), cs_.data(), bsum_.data(), wstart_.data(), &pool_first_, &pool_last_);
+    npool_ = npool;
+    nsb_ = (W + 15) / 16;
+    c1_.assign((size_t)nsb_ * 16, HUGE_VAL);
+    c0_.assign((size_t)((nsb_ + 7) & ~7), HUGE_VAL);
+    {
+      double tot = 0.0;
+      for (int sb = 0; sb < nsb_; ++sb) {
+        double acc = 0.0;
+        for (int w = 16 * sb; w < std::min(W, 16 * sb + 16); ++w) acc += bsum_[w], c1_[w] = acc;
+        tot += acc;
+        c0_[sb] = tot;
+      }
+      pool_total_ = tot;
+    }
+    t_pool += now() - tp, tp = now();
+    sum_pool += npool;
+    if (npool < 3) return false;
+    const float sq_max = max_base_diameter_ * max_base_diameter_;
+    const V3 p0 = ppos(first_point);
+    const size_t max_it = (size_t)npool * (size_t)npool / 4;
+    // (look-ahead queue, engine roll-back: as in the rank form above)
+    const std::mt19937 engine_before = point_index_engine_;
+    constexpr int MAXLA = 8;
+    const int LOOKAHEAD = lookahead_;
+    IdDraw q0[MAXLA + 1], q1[MAXLA + 1];
+    int qhead = 0, qlen = 0;
+    size_t drawn_pairs = 0, used_pairs = 0;
+    undo_.clear();
+    auto push_pair = [&]() {
+      const double u0 = canonical53(), u1 = canonical53();
+      ++drawn_pairs;
+      const int at = (qhead + qlen) % (LOOKAHEAD + 1);
+      q0[at] = draw_pool_id(u0), q1[at] = draw_pool_id(u1);
+      if (q0[at].id != q1[at].id) __builtin_prefetch(&M[(size_t)q0[at].id * W + (q1[at].id >> 6)], 0, 1);
+      ++qlen;
+    };
+    for (size_t it = 0; it < max_it && it < (size_t)INT_MAX; ++it) {
+      ++n_pair_iters;
+      while (qlen < LOOKAHEAD + 1 && it + (size_t)qlen < max_it) push_pair();
+      const int second = q0[qhead].id, third = q1[qhead].id;
+      qhead = (qhead + 1) % (LOOKAHEAD + 1), --qlen;
+      used_pairs = it + 1;
+      if (second == third) { ++n_same; continue; }
+      if (!bit(second, third)) { ++n_nobit; continue; }
+      ++n_geom;
+      double dlt[2];
+      int q = 0;
+      for (int id : {second, third}) {
+        const float old = wloc_[id];
+        undo_.emplace_back(id, old);
+        wloc_[id] = old * opt.dispersion;
+        const double d = (double)wloc_[id] - (double)old;
+        const int w = id >> 6;
+        cs_[4 * w + ((id >> 4) & 3)] += d;
+        bsum_[w] += d;
+        suffix_add_avx512(c1_.data() + 16 * (w >> 4), w & 15, 16, d);
+        suffix_add_avx512(c0_.data(), w >> 4, (int)c0_.size(), d);
+        pool_total_ += d;
+        dlt[q++] = d;
+      }
+      const V3 u = ppos(second) - p0;
+      const V3 w = ppos(third) - p0;
+      const float how_wide = vdot(vnormalized(u), vnormalized(w));
+      if ((double)std::fabs(how_wide) <= std::cos(45 * M_PI / 180.0) && vsqn(u) < sq_max && vsqn(w) < sq_max) {
+        base1 = first_point, base2 = second, base3 = third;
+        break;
+      }
+      for (int k = 0; k < qlen; ++k) {
+        const int at = (qhead + k) % (LOOKAHEAD + 1);
+        bool moved = false;
+        if (!redraw_unchanged_id(q0[at], second, dlt[0], third, dlt[1])) q0[at] = draw_pool_id(q0[at].u), moved = true;
+        if (!redraw_unchanged_id(q1[at], second, dlt[0], third, dlt[1])) q1[at] = draw_pool_id(q1[at].u), moved = true;
+        if (moved && q0[at].id != q1[at].id) __builtin_prefetch(&M[(size_t)q0[at].id * W + (q1[at].id >> 6)], 0, 1);
+      }
+    }
+    if (drawn_pairs != used_pairs) {
+      point_index_engine_ = engine_before;
+      point_index_engine_.discard(4ull * used_pairs);
+    }
+    for (size_t k = undo_.size(); k-- > 0;) wloc_[undo_[k].first] = undo_[k].second;  // the drops were this call's only
+    t_pairdraw += now() - tp, tp = now();
+    if (base2 == -1 || base3 == -1) return false;
+    const bool ok = build_mask4(row, base1, base2, base3, npool);
+    t_pool4 += now() - tp;
+    return ok;
+  }
+#endif
+  // 4th-point candidates: pool RANKS (not point ids -- the reference stores the loop index, matchBase.hpp:203) of the
+  // pool members compatible with base2 and base3, as a bit mask over [0, npool)
+  bool build_mask4(const unsigned long long* row, int base1, int base2, int base3, int npool) {
     const unsigned long long* r2 = M + (size_t)base2 * W;
     const unsigned long long* r3 = M + (size_t)base3 * W;
     mask4_.assign(((size_t)npool + 63) / 64 + 1, 0ull);
@@ -928,7 +1163,6 @@ struct GenHost {
       if (off) mask4_[word + 1] |= comp >> (64 - off);
     }
     n4_ = n4;
-    t_pool4 += now() - tp;
     return n4 > 0;
   }
 
