@@ -2001,6 +2001,19 @@ int hop_debug_icp_counters(hop_ctx* c, unsigned long long* out8, int reset) {
   return HOP_OK;
 }
 
+// development aid, not part of the ABI: the PPF key membership matrix of the last hop_generate (n rows of `words` 64-bit words)
+int hop_debug_ppf_matrix(hop_ctx* c, unsigned long long* out, size_t cap_words, int* n_out, int* words_out) {
+  if (!c || !n_out || !words_out) return HOP_E_INVALID;
+  const int N = c->gen.gp_h.n, W = (N + 63) / 64;
+  *n_out = N, *words_out = W;
+  if (!c->ppf_matrix_cached) return HOP_E_STATE;
+  if (out) {
+    if (cap_words < (size_t)N * W) return HOP_E_CAPACITY;
+    std::memcpy(out, c->ppf_matrix_cached, sizeof(unsigned long long) * (size_t)N * W);
+  }
+  return HOP_OK;
+}
+
 int hop_timing_get(hop_ctx* c, hop_timing* out) {
   if (!c || !out) return HOP_E_INVALID;
   resolve_spans(c);

@@ -156,6 +156,77 @@ __global__ __launch_bounds__(256) void k_ppf_matrix(PpfMatrixArgs a) {
   }
 }
 
+// The same matrix from half the pair evaluations (threshold-bin path only).  key(j -> i) shares with key(i -> j) the distance
+// bin, the unit direction up to its sign and the three dot products: (pi - pj) = -(pj - pi), a quotient and a sum of products
+// change sign exactly with their operands, and ni . nj commutes -- so the reverse key is (k0, bin(-(nj . d)), bin(-(ni . d)), k3)
+// from values already in registers, bit for bit what the direct evaluation gives.  A wave owns the 64 columns jb and walks the 64
+// rows of word ib <= jb: the forward bits of a row go out as one ballot word M[i][jb], the reverse bits accumulate per lane
+// into M[j][ib]; diagonal blocks (ib == jb) hold both orders already.
+__global__ __launch_bounds__(256) void k_ppf_matrix_sym(PpfMatrixArgs a) {
+  __shared__ float rows[PPF_ROWS][8];
+  __shared__ float sthr[32];
+  static_assert(PPF_ROWS == 64, "one matrix word of rows per block");
+  const int ib = blockIdx.y;
+  if ((int)blockIdx.x * 4 + 3 < ib) return;  // the whole block lies below the diagonal
+  if (threadIdx.x < 32) sthr[threadIdx.x] = a.angle_thr[threadIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int jb = blockIdx.x * 4 + wave;
+  const int j = jb * 64 + lane;
+  const int i0 = ib * PPF_ROWS;
+  for (int t = threadIdx.x; t < PPF_ROWS; t += blockDim.x) {
+    const int i = i0 + t;
+    if (i < a.n) {
+      rows[t][0] = a.x[i], rows[t][1] = a.y[i], rows[t][2] = a.z[i];
+      rows[t][3] = a.nx[i], rows[t][4] = a.ny[i], rows[t][5] = a.nz[i];
+    }
+  }
+  __syncthreads();
+  if (jb >= a.words || jb < ib) return;
+  const bool both = jb != ib;
+  V3 pj = v3(0, 0, 0), nj = v3(0, 0, 1);
+  const bool jvalid = j < a.n;
+  if (jvalid) {
+    pj = v3(a.x[j], a.y[j], a.z[j]);
+    nj = v3(a.nx[j], a.ny[j], a.nz[j]);
+  }
+  auto member = [&](int d, int a1, int a2, int a3) -> bool {
+    // direct-address bitmap: dist bin in [0, dist_bins), angle bins in [0, 18]
+    const unsigned bit = ((unsigned)(d * 19 + a1) * 19u + (unsigned)a2) * 19u + (unsigned)a3;
+    return (a.bitmap[bit >> 5] >> (bit & 31)) & 1u;
+  };
+  unsigned long long rev = 0ull;
+  const int rmax = min(PPF_ROWS, a.n - i0);
+  for (int r = 0; r < rmax; ++r) {
+    const V3 pi = v3(rows[r][0], rows[r][1], rows[r][2]);
+    const V3 ni = v3(rows[r][3], rows[r][4], rows[r][5]);
+    bool fwd = false, bwd = false;
+    if (jvalid && (i0 + r) != j) {
+      const float nrm = vnorm(pi - pj) * 1000.f;  // (ppf_key_thr: p1 = the row's point, p2 = the column's)
+      if (nrm < 2147483648.0f) {
+        const int k0 = ppf_closest_bin((int)nrm, 5);
+        const V3 dir = vnormalized(pj - pi);
+        const float s1 = vdot(ni, dir), s2 = vdot(nj, dir), s3 = vdot(ni, nj);
+        int b1, b2, b3;
+        if (ppf_angle_bin_thr(s1, sthr, &b1) && ppf_angle_bin_thr(s2, sthr, &b2) && ppf_angle_bin_thr(s3, sthr, &b3)) {
+          const int d = k0 / 5, a3 = b3 / 10;
+          if (k0 >= 0 && d < a.dist_bins) {
+            fwd = member(d, b1 / 10, b2 / 10, a3);
+            if (both) {
+              int c1, c2;
+              (void)ppf_angle_bin_thr(-s2, sthr, &c1), (void)ppf_angle_bin_thr(-s1, sthr, &c2);  // (|s| <= 1 holds for both already)
+              bwd = member(d, c1 / 10, c2 / 10, a3);
+            }
+          }
+        }
+      }
+    }
+    const unsigned long long word = __ballot(fwd);
+    if (lane == 0) a.out[(size_t)(i0 + r) * a.words + jb] = word;
+    rev |= (unsigned long long)bwd << r;
+  }
+  if (both && jvalid) a.out[(size_t)j * a.words + ib] = rev;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3a: pair extraction for a batch of bases (FunctorSuper4PCS::ExtractPairs + PairCreationFunctor::process
 // + AdaptivePointFilter, FunctorSuper4pcs.h:79-116, pairCreationFunctor.h:189-214, PointPairFilter.h:88-172)
@@ -1931,17 +2002,13 @@ __device__ __forceinline__ int icp_fusedq_point(const IcpArgs& a, int i, const f
 template <bool COMPOSED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPOSED ? HOP_ICP_W : 4))) void k_icp_fusedq(IcpArgs a, int R) {
   __shared__ double red[4][ICP_NACC];
-  // nn_mode 4: lookups that need the exact re-scan (0.4 % of them, but a fifth of the wavefronts held one) are queued per block
-  // and run afterwards densely packed, instead of every such wavefront walking its lists again for one or two lanes
-  __shared__ unsigned short defer_i[COMPOSED ? 256 * ICP_ACCUM_R : 1];
-  __shared__ int defer_n;
+  // nn_mode 4: lookups that need the exact re-scan (0.6 % of them, but a fifth of the wavefronts held one) are queued per
+  // wavefront and run afterwards densely packed, instead of every such wavefront walking its lists again for one or two lanes.
+  // The queue is filled by ballot (no atomics): its order, and with it every float sum, is the same in every run.
+  __shared__ unsigned short defer_i[COMPOSED ? 4 : 1][COMPOSED ? 64 * ICP_ACCUM_R : 1];
   const int hl = blockIdx.y, h = a.h0 + hl;
   const IcpState& st = a.state[hl];
   if (!st.active) return;
-  if (COMPOSED) {
-    if (threadIdx.x == 0) defer_n = 0;
-    __syncthreads();
-  }
   const float* __restrict__ pose = a.pose + (size_t)h * 16;
   const float* __restrict__ sTi = a.pose_inv + (size_t)h * 12;
   const float* __restrict__ hist = a.hist + (size_t)hl * a.max_iter * 12;
@@ -1953,23 +2020,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPOSED ? 
   acc_t acc[ICP_NACC];
 #pragma unroll
   for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0;
-  int n_wave = 0;
+  int n_wave = 0, n_def = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int base = blockIdx.x * (256 * R);
   for (int r = 0; r < R; ++r) {
     const int li = r * 256 + threadIdx.x, i = base + li;
     if (i >= a.ns) continue;
     const int res = icp_fusedq_point<COMPOSED, COMPOSED, acc_t>(a, i, pose, sTi, hist, F, acc);
-    if (res == ICP_PT_DEFERRED) defer_i[atomicAdd(&defer_n, 1)] = (unsigned short)li;
-    // (lane 0 of a wavefront is among the lanes that get here whenever any of them does: its copy is the wavefront's count)
-    if (COMPOSED) n_wave += __popcll(__ballot(res == ICP_PT_ACCEPTED));
+    // (lane 0 of a wavefront is among the lanes that get here whenever any of them does: its copies are the wavefront's counts)
+    if (COMPOSED) {
+      const unsigned long long dm = __ballot(res == ICP_PT_DEFERRED);
+      if (res == ICP_PT_DEFERRED) defer_i[wave][n_def + __popcll(dm & ((1ull << lane) - 1ull))] = (unsigned short)li;
+      n_def += __popcll(dm);
+      n_wave += __popcll(__ballot(res == ICP_PT_ACCEPTED));
+    }
   }
   if (COMPOSED) {
-    __syncthreads();
-    const int nd = defer_n;
-    for (int t = threadIdx.x; t < nd; t += 256)
-      n_wave += __popcll(__ballot(icp_fusedq_point<COMPOSED, false, acc_t>(a, base + defer_i[t], pose, sTi, hist, F, acc) == ICP_PT_ACCEPTED));
+    const int nd = __builtin_amdgcn_readfirstlane(n_def);
+    for (int t = lane; t < nd; t += 64)
+      n_wave += __popcll(__ballot(icp_fusedq_point<COMPOSED, false, acc_t>(a, base + defer_i[wave][t], pose, sTi, hist, F, acc) == ICP_PT_ACCEPTED));
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < ICP_NACC; ++k) {
     const double s = (COMPOSED && k == 28) ? (double)n_wave : icp_wave_sum(acc[k]);
@@ -2532,7 +2602,9 @@ __global__ void k_grid_cell_ids(const float* __restrict__ x, const float* __rest
 // ------------------------------------------------------------------------------------------------
 void launch_ppf_matrix(const PpfMatrixArgs& a, hipStream_t s) {
   dim3 grid((a.words + 3) / 4, (a.n + PPF_ROWS - 1) / PPF_ROWS);
-  if (a.angle_thr) hipLaunchKernelGGL(k_ppf_matrix<true>, grid, dim3(256), 0, s, a);
+  const bool sym = !getenv("HOP_PPF_NO_SYM");  // (tests compare the two kernels)
+  if (a.angle_thr && sym) hipLaunchKernelGGL(k_ppf_matrix_sym, grid, dim3(256), 0, s, a);
+  else if (a.angle_thr) hipLaunchKernelGGL(k_ppf_matrix<true>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(k_ppf_matrix<false>, grid, dim3(256), 0, s, a);
 }
 void launch_pairs(const PairArgs& a, int nbases, hipStream_t s) {

@@ -816,3 +816,44 @@ def test_library_exchange_single_rank(api, ctx, synth):
     for _ in range(3):      # repeated collectives on the communicator's stream
         assert np.array_equal(comm.topk_allgather(rows, 8)[0], rows)
     comm.close()
+
+
+@pytest.mark.gpu
+def test_ppf_matrix_symmetric_kernel_equals_direct_and_literal(api, synth, monkeypatch):
+    """k_ppf_matrix_sym derives key(j -> i) from the registers of key(i -> j) (half the pair evaluations): the whole
+    membership matrix must equal, bit for bit, the one of the direct threshold-bin kernel and the one of the literal
+    acosf kernel -- on a scene whose size is not a multiple of 64 (ragged last word and row tile)."""
+    import ctypes as C
+    sc = synth.make_scene(3001, seed=11)
+    mx, mn = synth.ellipsoid_model(2000)
+    keys = synth.ppf_key_table()
+    mats = {}
+    for name, env in (("sym", {}), ("direct", {"HOP_PPF_NO_SYM": "1"}), ("literal", {"HOP_PPF_LITERAL": "1"})):
+        for k in ("HOP_PPF_NO_SYM", "HOP_PPF_LITERAL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = api.Context(0)
+        try:
+            c.set_scene(sc.xyz, sc.nrm, sc.conf, 0.0)
+            c.set_model(api.HOP_MODEL_5MM, mx, mn)
+            c.set_ppf_keys(keys)
+            o = c.default_s4pcs_opts(sample_size=60, success_quadrilaterals=4, max_time_seconds=0, n_trials=4, random_seed=5489)
+            c.s4pcs_generate(o, cap=1 << 18)
+            fn = c.L.hop_debug_ppf_matrix
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+            n, w = C.c_int(0), C.c_int(0)
+            assert fn(c.h, None, 0, C.byref(n), C.byref(w)) == 0
+            m = np.zeros((n.value, w.value), np.uint64)
+            assert fn(c.h, m.ctypes.data_as(C.c_void_p), m.size, C.byref(n), C.byref(w)) == 0
+            mats[name] = m
+        finally:
+            c.close()
+    assert mats["sym"].shape[0] == 3001 and mats["sym"].any()
+    assert np.array_equal(mats["sym"], mats["direct"])
+    assert np.array_equal(mats["sym"], mats["literal"])
+    # no bit on the diagonal, none beyond the last point
+    n, w = mats["sym"].shape
+    bits = np.unpackbits(mats["sym"].view(np.uint8).reshape(n, -1), axis=1, bitorder="little")
+    assert not bits[:, n:].any() and not bits[np.arange(n), np.arange(n)].any()
