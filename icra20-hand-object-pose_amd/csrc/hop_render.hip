@@ -146,7 +146,9 @@ __global__ __launch_bounds__(64) void k_score_serial(const unsigned* __restrict_
   if (hyp >= n_hyp) return;
   float roi_diff = 0, bg_diff = 0;
   int roi_cnt = 0, bg_cnt = 0;
-  constexpr int U = 16;
+  // 64 loads in flight per lane (one wavefront serves 64 hypotheses and has the device to itself: memory latency is the
+  // whole cost); adding +0 to the sum a term does not belong to leaves that sum's bits unchanged (the terms are >= 0)
+  constexpr int U = 64;
   int px = 0;
   for (; px + U <= npx; px += U) {
     unsigned v[U];
@@ -155,16 +157,19 @@ __global__ __launch_bounds__(64) void k_score_serial(const unsigned* __restrict_
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float d = __uint_as_float(v[u] & 0x7fffffffu);
-      if (v[u] & 0x80000000u) roi_diff += d, roi_cnt++;
-      else bg_diff += d, bg_cnt++;
+      const bool roi = (v[u] & 0x80000000u) != 0u;
+      roi_diff += roi ? d : 0.f, bg_diff += roi ? 0.f : d;
+      roi_cnt += roi ? 1 : 0;
     }
   }
   for (; px < npx; ++px) {
     const unsigned v = terms[(size_t)px * n_hyp + hyp];
     const float d = __uint_as_float(v & 0x7fffffffu);
-    if (v & 0x80000000u) roi_diff += d, roi_cnt++;
-    else bg_diff += d, bg_cnt++;
+    const bool roi = (v & 0x80000000u) != 0u;
+    roi_diff += roi ? d : 0.f, bg_diff += roi ? 0.f : d;
+    roi_cnt += roi ? 1 : 0;
   }
+  bg_cnt = npx - roi_cnt;
   wrong[hyp] = roi_weight * roi_diff / roi_cnt + bg_diff / bg_cnt;
 }
 // sum_mode 1: one block per hypothesis, sums reduced in double
