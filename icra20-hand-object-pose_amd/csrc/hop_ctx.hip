@@ -366,6 +366,46 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
     const double R = (double)max_dist + 2.0 * (double)a.margin;
     const double step = ((double)cell + 2.0 * R) / 65535.0, qcs = (double)cell / step, qrs = R / step;
     bool in_range = true;
+    // The exact point and normal of a winner are fetched by index; neighbouring queries win neighbouring points, so the two
+    // arrays are stored in Morton order of the cloud and the entries carry the Morton rank (a wavefront's fetch then touches a
+    // handful of 128-byte lines instead of up to 64: tools/ubench/l1_rate.hip).  .w of a point = its original index (ties).
+    std::vector<uint32_t> rank(std::max(h.n, 1));
+    {
+      float lo3[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi3[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+      for (int i = 0; i < h.n; ++i) {
+        const float v[3] = {h.x[i], h.y[i], h.z[i]};
+        for (int ax = 0; ax < 3; ++ax) lo3[ax] = std::min(lo3[ax], v[ax]), hi3[ax] = std::max(hi3[ax], v[ax]);
+      }
+      const float ext = std::max({hi3[0] - lo3[0], hi3[1] - lo3[1], hi3[2] - lo3[2], 1.0e-9f});
+      auto spread = [](uint32_t v) {  // 10 bits -> every third bit
+        v = (v | (v << 16)) & 0x030000FFu, v = (v | (v << 8)) & 0x0300F00Fu, v = (v | (v << 4)) & 0x030C30C3u, v = (v | (v << 2)) & 0x09249249u;
+        return v;
+      };
+      std::vector<std::pair<uint32_t, int>> code(h.n);
+      for (int i = 0; i < h.n; ++i) {
+        const float v[3] = {h.x[i], h.y[i], h.z[i]};
+        uint32_t m = 0;
+        for (int ax = 0; ax < 3; ++ax) m |= spread((uint32_t)std::min(1023.f, std::max(0.f, (v[ax] - lo3[ax]) / ext * 1023.f))) << ax;
+        code[i] = {m, i};
+      }
+      std::sort(code.begin(), code.end());
+      // (the values come from the device cloud the other modes read: the host copy of the generator keeps normalised normals)
+      std::vector<float> dv(6 * (size_t)std::max(h.n, 1));
+      HIPCHK(c, hipMemcpyAsync(dv.data(), d.plane(0), sizeof(float) * 6 * (size_t)h.n, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      const size_t hn = (size_t)h.n;
+      std::vector<float4> pm(std::max(h.n, 1)), nm(std::max(h.n, 1));
+      for (int r = 0; r < h.n; ++r) {
+        const int i = code[r].second;
+        rank[i] = (uint32_t)r;
+        float wi;
+        memcpy(&wi, &i, 4);
+        pm[r] = make_float4(dv[i], dv[hn + i], dv[2 * hn + i], wi), nm[r] = make_float4(dv[3 * hn + i], dv[4 * hn + i], dv[5 * hn + i], 0.f);
+      }
+      HIPCHK(c, hipMemcpyAsync(cs.pts_idx_d.p, pm.data(), sizeof(float4) * (size_t)h.n, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(cs.nrm_idx_d.p, nm.data(), sizeof(float4) * (size_t)h.n, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     std::vector<uint32_t> rec(2 * ncell), ql;
     ql.reserve(2 * total + 4 * ncell);
     for (size_t k = 0; k < ncell; ++k) {
@@ -385,7 +425,7 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
             u[ax] = (uint32_t)std::min(65534.0, std::max(0.0, w));
           }
           memcpy(&idx, &t.w, 4);
-          lo = u[0] | (u[1] << 16), hi = u[2] | (idx << 16);
+          lo = u[0] | (u[1] << 16), hi = u[2] | (rank[idx] << 16);
         }
         ql.push_back(lo), ql.push_back(hi);
       }

@@ -1863,9 +1863,10 @@ __device__ __forceinline__ void q_chunk(Q3 l, const uint4& ch, unsigned& b1, uns
   const bool changed = b1 != prev;
   why = changed ? ch.y : why, whw = changed ? ch.w : whw;
 }
-// exact evaluation of the entries of a chunk that the ranking cannot separate from the winner (rare path)
+// exact evaluation of the entries of a chunk that the ranking cannot separate from the winner (rare path).  Entries carry
+// the Morton rank of their point (the index into pts_idx / nrm_idx); ties go to the lowest ORIGINAL index (pts_idx[].w).
 __device__ __forceinline__ void q_chunk_exact(const CellListDev& c, Q3 l, const uint4& ch, float lim, int widx, const float* T, V3 q, float& best,
-                                              int& bidx, V3& moved) {
+                                              int& bidx, int& borig, V3& moved) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const unsigned lo = e ? ch.z : ch.x, hi = e ? ch.w : ch.y;
@@ -1874,7 +1875,8 @@ __device__ __forceinline__ void q_chunk_exact(const CellListDev& c, Q3 l, const 
     const float4 t = c.pts_idx[j];
     const V3 tm = m4_point(T, v3(t.x, t.y, t.z));
     const float d2 = sqdist_flann(q, tm);
-    if (d2 < best || (d2 == best && j < bidx)) best = d2, bidx = j, moved = tm;
+    const int jo = __float_as_int(t.w);
+    if (d2 < best || (d2 == best && jo < borig)) best = d2, bidx = j, borig = jo, moved = tm;
   }
 }
 
@@ -1925,7 +1927,8 @@ __device__ __forceinline__ bool cells_nnq(const CellListDev& c, V3 qg, const flo
     ICP_COUNT(4, 1);
     ICP_COUNT_WAVE(5);
     const float lim = (f1 + tol) / c.q_step2;  // back to step units
-    for (int k = 0; k < nch; ++k) q_chunk_exact(c, l, lp[k], lim, widx, T, q, best, bidx, moved);
+    int borig = __float_as_int(w.w);
+    for (int k = 0; k < nch; ++k) q_chunk_exact(c, l, lp[k], lim, widx, T, q, best, bidx, borig, moved);
   }
   return false;
 }
