@@ -2703,11 +2703,14 @@ void launch_cell_list_local_work(const int* flag, const int* flag_scan, int ncel
 void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool write, int exist_mode, const int* work, int nwork, int* keep_buf,
                             int lanes, hipStream_t s) {
   if (nwork <= 0) return;
-  // lanes per voxel: 16 for the short lists (a few candidate rows of a few points: scene and Verify lists, 1.7x faster), a whole
-  // wavefront where the lists are long (the hand scene: the pairwise pass is O(L^2) per voxel and 16 lanes make few, long waves)
+  // lanes per voxel: 16 for the short lists (a few candidate rows of a few points: scene and Verify lists, 1.7x faster), 32 or a
+  // whole wavefront where the lists are long (the hand scene: 25 candidate rows per voxel, lists of up to a few hundred entries)
   if (lanes >= 64) {
     if (write) hipLaunchKernelGGL((k_cell_list_local<true, 64>), dim3((nwork + 3) / 4), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
     else hipLaunchKernelGGL((k_cell_list_local<false, 64>), dim3((nwork + 3) / 4), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
+  } else if (lanes == 32) {
+    if (write) hipLaunchKernelGGL((k_cell_list_local<true, 32>), dim3((nwork + 7) / 8), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
+    else hipLaunchKernelGGL((k_cell_list_local<false, 32>), dim3((nwork + 7) / 8), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
   } else {
     if (write) hipLaunchKernelGGL((k_cell_list_local<true, 16>), dim3((nwork + 15) / 16), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
     else hipLaunchKernelGGL((k_cell_list_local<false, 16>), dim3((nwork + 15) / 16), dim3(256), 0, s, a, g, exist_mode, work, nwork, keep_buf);
