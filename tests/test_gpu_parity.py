@@ -857,3 +857,34 @@ def test_ppf_matrix_symmetric_kernel_equals_direct_and_literal(api, synth, monke
     n, w = mats["sym"].shape
     bits = np.unpackbits(mats["sym"].view(np.uint8).reshape(n, -1), axis=1, bitorder="little")
     assert not bits[:, n:].any() and not bits[np.arange(n), np.arange(n)].any()
+
+
+@pytest.mark.gpu
+def test_icp_duplicate_model_points_tie_to_the_lowest_index(ctx, api, synth):
+    """Coincident model points with DIFFERENT normals: FLANN / the linear scan give a tie to the lowest original index, and
+    the normal of that point enters the residual.  The packed lists of nn_mode 3 quantise both copies to the same entry
+    coordinates and store them by Morton rank, so the tie must come out of the exact re-scan's original-index rule: the
+    same bits as the plain cell lists (nn_mode 2), the brute-force iteration counts."""
+    sc, mx, mn, _ = _scoring_case(synth, 6000, 1500, 9)
+    rng = np.random.default_rng(5)
+    tilt = mn + 0.2 * rng.normal(size=mn.shape).astype(np.float32)
+    tilt /= np.linalg.norm(tilt, axis=1, keepdims=True)
+    X = np.concatenate([mx, mx]).astype(np.float32)
+    Nn = np.concatenate([mn, tilt]).astype(np.float32)
+    perm = rng.permutation(len(X))                      # the copy with the lower index is sometimes the tilted one
+    X, Nn = X[perm], Nn[perm]
+    poses = synth.replay_poses(sc.gt_pose, 48, seed=3, max_rot_deg=15.0, max_trans=0.008)
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.0)
+    ctx.set_model(api.HOP_MODEL_5MM, X, Nn)
+    out = {}
+    for mode in (0, 2, 3):
+        ctx.hypos_upload(poses)
+        it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=mode, want_stats=True)
+        out[mode] = (it.copy(), cv.copy(), ctx.hypos_download()[0].copy())
+    assert np.array_equal(out[0][0], out[2][0]) and np.abs(out[0][2] - out[2][2]).max() < 2e-6
+    assert np.array_equal(out[2][0], out[3][0]) and np.array_equal(out[2][1], out[3][1]) and np.array_equal(out[2][2], out[3][2])
+    # the tilted normals matter: with the clean normals alone the poses come out differently
+    ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
+    ctx.hypos_upload(poses)
+    ctx.icp_refine(10, 45.0, 0.01, nn_mode=3)
+    assert np.abs(ctx.hypos_download()[0] - out[3][2]).max() > 1e-5
