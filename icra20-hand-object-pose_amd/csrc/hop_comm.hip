@@ -7,6 +7,7 @@
 // The unique id of the communicator is produced by rank 0 (hop_comm_unique_id) and handed to the other ranks by the
 // launcher (bench.py broadcasts it through torch.distributed; any out-of-band channel does).
 #include <dlfcn.h>
+#include <link.h>
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -37,9 +38,21 @@ Rccl& rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
+    // a copy the process already holds (PyTorch ships its own librccl.so) is taken first: one RCCL per process
+    std::string loaded;
+    dl_iterate_phdr(
+        [](struct dl_phdr_info* info, size_t, void* out) -> int {
+          if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl.so")) {
+            *static_cast<std::string*>(out) = info->dlpi_name;
+            return 1;
+          }
+          return 0;
+        },
+        &loaded);
+    if (!loaded.empty()) r.handle = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD);
     for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-      r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (r.handle) break;
+      r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!r.handle) {
       r.error = std::string("dlopen librccl.so: ") + (dlerror() ? dlerror() : "not found");
