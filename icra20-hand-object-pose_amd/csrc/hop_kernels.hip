@@ -2263,6 +2263,9 @@ __device__ __forceinline__ float wave_sum_f(float v) {
   return v;
 }
 
+// hypotheses per block of the reduced-sum kernel: 4 = one per wavefront (4 / 8 / 16 / 32: 3.29 / 3.62 / 3.75 / 3.91 ms at C2 --
+// the blocks of an XCD walk neighbouring point tiles of the same few hypotheses and share more of the model's lines)
+constexpr int LCP_FTH = 4;
 __global__ __launch_bounds__(256) void k_lcp_cells_fast(LcpArgs a, int hb, int hs, int npt) {
   // XCD-aware mapping: workgroups go to the 8 XCDs round-robin (blockIdx.x & 7) and each XCD has its own 4 MB L2; the
   // scene lists + model lists (~18 MB at C2) do not fit one L2, an eighth of the Morton-ordered scene with the model
@@ -2277,8 +2280,8 @@ __global__ __launch_bounds__(256) void k_lcp_cells_fast(LcpArgs a, int hb, int h
   const bool kin = k < a.ns;
   V3 s = v3(0, 0, 0), sn = v3(0, 0, 0);
   if (kin) s = v3(a.qx[k], a.qy[k], a.qz[k]), sn = v3(a.qnx[k], a.qny[k], a.qnz[k]);
-  for (int j = 0; j < LCP_TH / 4; ++j) {
-    const int hh = wave * (LCP_TH / 4) + j, hl = ht * LCP_TH + hh;
+  for (int j = 0; j < LCP_FTH / 4; ++j) {
+    const int hh = wave * (LCP_FTH / 4) + j, hl = ht * LCP_FTH + hh;
     if (hl >= hb) break;  // wave-uniform
     float v = 0.f;
     if (kin) {
@@ -2316,13 +2319,13 @@ __global__ __launch_bounds__(64) void k_lcp_sum_partial(LcpArgs a, int hb, int h
   a.score[a.h0 + hl] = (float)cp;
 }
 void launch_lcp_cells_fast(const LcpArgs& a, int hb, hipStream_t s) {
-  const int npt = (a.ns + 63) / 64, nht = (hb + LCP_TH - 1) / LCP_TH;
-  const int hs = ((hb + LCP_TH - 1) / LCP_TH) * LCP_TH;
+  const int npt = (a.ns + 63) / 64, nht = (hb + LCP_FTH - 1) / LCP_FTH;
+  const int hs = ((hb + LCP_FTH - 1) / LCP_FTH) * LCP_FTH;
   hipLaunchKernelGGL(k_lcp_cells_fast, dim3((unsigned)(8 * ((npt + 7) / 8) * nht)), dim3(256), 0, s, a, hb, hs, npt);
 }
 void launch_lcp_sum_partial(const LcpArgs& a, int hb, hipStream_t s) {
   const int npt = (a.ns + 63) / 64;
-  const int hs = ((hb + LCP_TH - 1) / LCP_TH) * LCP_TH;
+  const int hs = ((hb + LCP_FTH - 1) / LCP_FTH) * LCP_FTH;
   hipLaunchKernelGGL(k_lcp_sum_partial, dim3((hb + 63) / 64), dim3(64), 0, s, a, hb, hs, npt);
 }
 
