@@ -132,6 +132,7 @@ SIGNATURES = {
     "hop_lcp_select_best": (C.c_int, [_vp, C.POINTER(LcpOpts), fp, fp, ip]),
     "hop_cluster_poses": (C.c_int, [_vp, C.c_float, C.c_float, fp, C.c_int]),
     "hop_cluster_poses_host": (C.c_int, [fp, fp, ip, C.c_int, C.c_float, C.c_float, fp, ip, ip]),
+    "hop_cluster_pose_terms": (C.c_int, [fp, fp, fp]),
     "hop_topk_pack": (C.c_int, [_vp, C.c_int, C.c_int, fp, ip]),
     "hop_topk_merge": (C.c_int, [fp, C.c_int, C.c_int, fp, ip]),
     "hop_hand_set_scene": (C.c_int, [_vp, fp, C.c_int, fp, C.c_int, fp, C.c_int]),
@@ -731,6 +732,17 @@ def cluster_poses_host(poses, scores, ids, angle_deg, dist, sym_deg):
     if rc:
         raise HopError(rc, "hop_cluster_poses_host")
     return keep[:n.value].copy()
+
+
+def cluster_pose_terms(pose_a, pose_b):
+    """(eulerAngles(2,1,0) of pose_a [3], rotationGeodesicDistance(R_a, R_b), |t_a - t_b|) as clusterPoses evaluates them."""
+    a = np.ascontiguousarray(pose_a, dtype=np.float32).reshape(16)
+    b = np.ascontiguousarray(pose_b, dtype=np.float32).reshape(16)
+    out = np.zeros(5, np.float32)
+    rc = lib().hop_cluster_pose_terms(F(a), F(b), F(out))
+    if rc:
+        raise HopError(rc, "hop_cluster_pose_terms")
+    return out
 
 
 def rows_to_hypos(rows):

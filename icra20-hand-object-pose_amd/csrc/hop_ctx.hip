@@ -141,7 +141,7 @@ struct hop_ctx {
   int n_hyp = 0;
 
   // scoring workspaces
-  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv, icp_corr_idx, icp_hist, pose_inv;
+  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv, icp_corr_idx, icp_hist, icp_lm, pose_inv;
 
   // hand
   CloudDevice hand_scene_d, hand_lookup_d, hand_swivel_d, hand_model_d;
@@ -590,6 +590,15 @@ void euler_zyx(const float* T, float res[3]) {  // Eigen 3.3 eulerAngles(2,1,0),
   res[2] = std::atan2(s1 * R(0, 2) - c1 * R(1, 2), c1 * R(1, 1) - s1 * R(0, 1));
 }
 
+// rotationGeodesicDistance (Utils.cpp:29-32): std::acos(((R1 * R2).trace()-1) / 2.0) on the rotation blocks of two row-major 4x4 poses.
+// "(R1 * R2).trace()-1" is a float subtraction, "/ 2.0" promotes (pinned against the reference's vendored Eigen: tests/golden/icp_lm_kat.npz)
+float rotation_geodesic_distance(const float* cl, const float* cur) {
+  float tr[3];
+  for (int d = 0; d < 3; ++d) tr[d] = cl[4 * d + 0] * cur[0 + d] + (cl[4 * d + 1] * cur[4 + d] + cl[4 * d + 2] * cur[8 + d]);
+  const float trace = tr[0] + (tr[1] + tr[2]);
+  return (float)std::acos((double)(trace - 1.0f) / 2.0);
+}
+
 int cluster_core(const float* pose16, const float* lcp, const int* ids, int H, float angle_diff, float dist_diff,
                  const float* sym_deg3, std::vector<int>& keep) {
   keep.clear();
@@ -626,11 +635,7 @@ int cluster_core(const float* pose16, const float* lcp, const int* ids, int H, f
         isnew = false;
         break;
       }
-      // rotationGeodesicDistance (Utils.cpp:29-32): acos((trace(R0*R1)-1)/2.0)
-      float tr[3];
-      for (int d = 0; d < 3; ++d) tr[d] = cl[4 * d + 0] * cur[0 + d] + (cl[4 * d + 1] * cur[4 + d] + cl[4 * d + 2] * cur[8 + d]);
-      const float trace = tr[0] + (tr[1] + tr[2]);
-      const float rot_diff = (float)std::acos(((double)trace - 1) / 2.0);
+      const float rot_diff = rotation_geodesic_distance(cl, cur);
       if (rot_diff <= radian_thres) {
         isnew = false;
         break;
@@ -709,7 +714,7 @@ void hop_ctx_destroy(hop_ctx* c) {
                     &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
                     &c->hyp_score, &c->hyp_id, &c->hyp_key, &c->hyp_inv, &c->tmp_pose, &c->tmp_score, &c->tmp_id, &c->sort_keys_alt,
                     &c->sort_vals, &c->sort_vals_alt, &c->sort_tmp, &c->lcp_rev_idx, &c->lcp_rev_d2, &c->lcp_terms, &c->icp_moved,
-                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->icp_corr_idx, &c->icp_hist, &c->pose_inv, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
+                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->icp_corr_idx, &c->icp_hist, &c->icp_lm, &c->pose_inv, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
                     &c->hand_swivel_d.buf, &c->hand_model_d.buf, &c->finger_hist_d, &c->pso_particles_d, &c->pso_match_d,
                     &c->pso_terms_d, &c->pso_sum_d, &c->pso_cnt_d};
   for (DevBuf* b : bufs) b->release();
@@ -1297,6 +1302,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
   const int nb = icp_blocks_per_hyp(S.n, o->nn_mode >= 2);
   // batch so that the per-point workspace (moved source, 24 B/pt; cell-list path: correspondence, 4 B/pt) stays bounded
   const bool cells = o->nn_mode >= 2;
+  const bool lm_mode = o->nn_mode == 5;  // the reference's Levenberg-Marquardt minimiser (csrc/hop_icp_lm.hip)
   const size_t per_h = cells ? sizeof(int) * (size_t)S.n : sizeof(float) * 6 * (size_t)S.n;
   const size_t ws_cap = cells ? ((size_t)4 << 30) : ((size_t)1 << 30);
   const int HB = (int)std::max<size_t>(1, std::min<size_t>((size_t)H, ws_cap / per_h));
@@ -1327,16 +1333,30 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
   } else if (cells) {
     // cells of a sixth of the gating distance for the plain lists (nn_mode 2), a seventh for the packed ones (measured:
     // 6 / 7 / 8 / 10 / 12 -> 819 / 784 / 789 / 845 / 925 us per launch at C2)
-    float cell = o->max_corr_dist / (o->nn_mode >= 3 ? 7.f : 6.f);
+    float cell = o->max_corr_dist / ((o->nn_mode == 3 || o->nn_mode == 4) ? 7.f : 6.f);
     if (const char* e = getenv("HOP_ICP_CELL_DIV")) cell = o->max_corr_dist / (float)atof(e);
     CellListStore& cs = c->model_cells[HOP_MODEL_5MM];
-    const bool want_packed = o->nn_mode >= 3 && c->gen.model_h[HOP_MODEL_5MM].n < 0xFFFF;
+    const bool want_packed = (o->nn_mode == 3 || o->nn_mode == 4) && c->gen.model_h[HOP_MODEL_5MM].n < 0xFFFF;
     if (!cs.valid || cs.cell != cell || cs.max_dist != o->max_corr_dist || cs.coord_mag < c->coord_mag || (want_packed && !cs.pack_requested)) {
       const int rc = build_cell_lists(c, cs, c->gen.model_h[HOP_MODEL_5MM], c->model_d[HOP_MODEL_5MM], o->max_corr_dist, cell, want_packed);
       if (rc) return rc;
     }
     a.cells = cs.c;
-    if (o->nn_mode == 2) HIPCHK(c, c->icp_corr_idx.ensure(sizeof(int) * (size_t)S.n * HB));  // the fused kernels keep no correspondence array
+    if (o->nn_mode == 2 || lm_mode) HIPCHK(c, c->icp_corr_idx.ensure(sizeof(int) * (size_t)S.n * HB));  // the fused kernels keep no correspondence array
+    if (lm_mode) {
+      HIPCHK(c, c->icp_lm.ensure(sizeof(LmDev) * (size_t)HB + 64));
+      a.lm = c->icp_lm.as<LmDev>();
+      // PCL's gates (correspondence_estimation.hpp: double max_dist_sqr = max_distance * max_distance, skip if distance > it;
+      // correspondence_rejection_surface_normal: double(dot) > std::cos(angle / 180.0 * M_PI), Utils.cpp:205) against float values:
+      // d <= m and d > c for a float d and double m, c are d <= (largest float <= m) and d > (largest float <= c)
+      const double m_d = (double)o->max_corr_dist * (double)o->max_corr_dist;
+      float m_f = (float)m_d;
+      if ((double)m_f > m_d) m_f = std::nextafterf(m_f, -INFINITY);
+      const double c_d = std::cos((double)o->angle_deg / 180.0 * M_PI);
+      float c_f = (float)c_d;
+      if ((double)c_f > c_d) c_f = std::nextafterf(c_f, -INFINITY);
+      a.max_d2 = m_f, a.cos_thr = c_f;
+    }
     HIPCHK(c, c->icp_hist.ensure(sizeof(float) * 12 * (size_t)std::max(o->max_iter, 1) * HB));
     a.corr_idx = c->icp_corr_idx.as<int>(), a.hist = c->icp_hist.as<float>();
     HIPCHK(c, c->pose_inv.ensure(sizeof(float) * 12 * (size_t)H));
@@ -1352,6 +1372,32 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     const int hb = std::min(HB, H - h0);
     a.h0 = h0;
     launch_icp_init(a.state, hb, c->stream);
+    if (lm_mode) {
+      // per ICP iteration: correspondences, then one pass per function evaluation Eigen's minimiser asks for, until no hypothesis waits
+      unsigned* n_wait_d = reinterpret_cast<unsigned*>(c->icp_lm.as<char>() + sizeof(LmDev) * (size_t)HB);
+      for (int it = 0; it < o->max_iter; ++it) {
+        a.iter = it;
+        {
+          SpanGuard sg(c, T_ICP_NN);
+          launch_icp_corr_cells(a, hb, c->stream);
+        }
+        c->timing.n_icp_nn_launches += 1;
+        SpanGuard sg(c, T_ICP_SOLVE);
+        launch_icp_lm_begin(a, hb, c->stream);
+        for (int pass = 0;; ++pass) {
+          launch_icp_lm_pass(a, hb, pass == 0, c->stream);
+          HIPCHK(c, hipMemsetAsync(n_wait_d, 0, sizeof(unsigned), c->stream));
+          launch_icp_lm_solve(a, hb, nb, pass == 0, n_wait_d, c->stream);
+          unsigned n_wait = 0;
+          HIPCHK(c, hipMemcpyAsync(&n_wait, n_wait_d, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          if (n_wait == 0) break;
+          if (pass > 450) return HOP_E_STATE;  // maxfev = 400 evaluations bound every minimiser
+        }
+      }
+      launch_icp_finish(a, hb, c->icp_iters.as<int>(), c->icp_conv.as<int>(), c->stream);
+      continue;
+    }
     for (int it = 0; it < o->max_iter; ++it) {
       a.iter = it;
       {
@@ -1525,6 +1571,14 @@ int hop_cluster_poses_host(const float* poses16, const float* scores, const int*
   cluster_core(poses16, scores, ids, H, angle_deg, dist, sym_deg3, keep);
   for (size_t i = 0; i < keep.size(); ++i) keep_out[i] = keep[i];
   if (n_keep_out) *n_keep_out = (int)keep.size();
+  return HOP_OK;
+}
+
+int hop_cluster_pose_terms(const float* pose_a16, const float* pose_b16, float* out5) {
+  if (!pose_a16 || !pose_b16 || !out5) return HOP_E_INVALID;
+  euler_zyx(pose_a16, out5);
+  out5[3] = rotation_geodesic_distance(pose_a16, pose_b16);
+  out5[4] = vnorm(v3(pose_a16[3], pose_a16[7], pose_a16[11]) - v3(pose_b16[3], pose_b16[7], pose_b16[11]));
   return HOP_OK;
 }
 

@@ -208,6 +208,17 @@ struct IcpState {
   int iterations, active, converged, pad;
 };
 
+// nn_mode 5: state of Eigen::LevenbergMarquardt::minimize for one hypothesis (csrc/hop_icp_lm.hip)
+constexpr float LM_SQRT_EPS_F = 3.4526698300124393e-04f;  // sqrt(FLT_EPSILON) in float: ftol, xtol, NumericalDiff's eps
+struct LmDev {
+  float x[6], xc[6], p[6], h[6];  // accepted parameters, candidate to evaluate, last step, forward-difference steps at xc
+  float W[7][12];                 // warp matrices at xc and at xc + h_j e_j
+  double A[21], g[6], ff;         // J^T J (packed lower triangle), J^T f, |f|^2 at x
+  double diag[6], delta, par, xnorm, fnorm, gnorm, pnorm;
+  double mse_sum;                 // sum of squared correspondence distances of this ICP iteration
+  int iter, nfev, status, phase, cnt, waiting;
+};
+
 struct IcpArgs {
   const float *sx, *sy, *sz, *snx, *sny, *snz;
   int ns;
@@ -227,6 +238,7 @@ struct IcpArgs {
   float* hist;         // nn_mode 2: [hb][max_iter][12] increments solved so far
   const float* pose_inv;  // nn_mode 2: [H][12] inverse of the input poses
   const float4 *s_pts4, *s_nrm4;  // nn_mode 3/4: the Morton-ordered source as AoS float4 (two 16-byte loads per point)
+  LmDev* lm;                      // nn_mode 5: [hb]
 };
 
 struct PsoParticle {
@@ -323,6 +335,9 @@ void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_sum_t(const LcpArgs& a, int hb, hipStream_t s);
 int lcp_cells_row_stride(int hb);
 int icp_blocks_per_hyp(int ns, bool cells);
+void launch_icp_lm_begin(const IcpArgs& a, int hb, hipStream_t s);
+void launch_icp_lm_pass(const IcpArgs& a, int hb, bool first, hipStream_t s);
+void launch_icp_lm_solve(const IcpArgs& a, int hb, int nblocks, bool first, unsigned* n_waiting, hipStream_t s);
 void launch_icp_init(IcpState* st, int hb, hipStream_t s);
 void launch_icp_nn(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_nn_grid(const IcpArgs& a, int hb, hipStream_t s);

@@ -131,7 +131,15 @@ typedef struct {
   float max_corr_dist; /* icp_dist_thres  = 0.01   (:126) */
   int max_hypotheses;
   int nn_mode;         /* 0 brute force, 1 ring-expanding voxel grid, 2 NN cell lists, 3 NN cell lists with search and
-                      * accumulation in one kernel (same correspondences in all modes) */
+                      * accumulation in one kernel (same correspondences in all modes), 4 as 3 with the accumulated
+                      * transform applied once; modes 0-4 take ONE Gauss-Newton step of the linearised point-to-plane
+                      * problem per ICP iteration.
+                      * 5: the reference's own minimiser -- PCL's TransformationEstimationPointToPlane is
+                      * Eigen::LevenbergMarquardt<NumericalDiff<...>, float> on (t, quaternion xyz) run to ITS stopping rule per
+                      * ICP iteration (Utils.cpp:200-216; Eigen's NonLinearOptimization as vendored under
+                      * src/OpenGR_4pcs/3rdparty/Eigen/unsupported), with PCL's gates (strict normal test against the double
+                      * threshold, double distance gate) and stop rules (absolute MSE only, identity increment).  Several
+                      * passes over the correspondences per ICP iteration: ~3x the time of mode 4. */
 } hop_icp_opts;
 int hop_icp_refine(hop_ctx* ctx, const hop_icp_opts* opts, int* iterations_out /*H or NULL*/,
                    int* converged_out /*H or NULL*/);
@@ -154,6 +162,11 @@ int hop_cluster_poses(hop_ctx* ctx, float angle_deg, float dist, const float* sy
 int hop_cluster_poses_host(const float* poses16, const float* scores, const int* ids, int H,
                            float angle_deg, float dist, const float* sym_deg3, int* keep_out,
                            int* n_keep_out);
+
+/* the three quantities clusterPoses compares for a pair of poses, as pure host functions (known-answer tests against the
+ * reference's vendored Eigen): out5 = { eulerAngles(2,1,0) of pose_a's rotation [3] (PoseEstimator.cpp:156),
+ * rotationGeodesicDistance(R_a, R_b) (Utils.cpp:29-32), (t_a - t_b).norm() (PoseEstimator.cpp:148-153) } */
+int hop_cluster_pose_terms(const float* pose_a16, const float* pose_b16, float* out5);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU exchange: each rank packs its k best rows, ranks all-gather the tables (RCCL through

@@ -230,6 +230,148 @@ def gen_sdf():
     print("sdf ->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def _perturb(T, rot_deg, trans, rng):
+    ax = rng.standard_normal(3)
+    ax /= np.linalg.norm(ax)
+    a = np.deg2rad(rot_deg)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+    D = np.eye(4)
+    D[:3, :3] = R
+    D[:3, 3] = rng.standard_normal(3) * trans
+    return (T.astype(np.float64) @ D).astype(np.float32)
+
+
+def _random_rotations(rng, n):
+    q = rng.standard_normal((n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                  2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], axis=1).reshape(n, 3, 3)
+    return R.astype(np.float32)
+
+
+def gen_icp_lm():
+    """Row S2 (and S1's Eigen calls): what the reference's vendored Eigen returns -- oracle/_ref/libref_icp.so, ref_icp_driver.cpp.
+    icp_lm_kat.npz   : warp matrices, residuals, forward-difference Jacobians, Eigen::LevenbergMarquardt results on correspondence
+                       sets; eulerAngles(2,1,0), rotationGeodesicDistance, (t0-t1).norm(), inverse()*pose, 4x4 products
+    icp_lm_c1.npz    : refineByICP's <= 100 hypotheses of the C1 frame (example/depth7.png hand region, as-shipped chain) refined
+                       with the reference's minimiser inside the ICP loop
+    icp_lm_c2sub.npz : 96 replay poses on a 4000-point C2-style scene, the same"""
+    from scipy.spatial import cKDTree
+    assert orc.ref_icp_available(), "make -C oracle ref"
+    orc.ref_icp()
+    rng = np.random.default_rng(77)
+    d = {}
+    # ---- pure functions ------------------------------------------------------------------------------------------------------
+    X = (rng.standard_normal((3000, 6)) * np.array([0.01, 0.01, 0.01, 0.02, 0.02, 0.02])).astype(np.float32)
+    X[::3, 3:] *= 0.01
+    X[::7, 0] = 0
+    X[5::11, 4] = 0
+    X[0] = 0
+    d["warp_x"] = X
+    d["warp_T"] = np.stack([orc.lm_warp6(x, ref=True) for x in X])
+    R1, R2 = _random_rotations(rng, 3000), _random_rotations(rng, 3000)
+    # rotations at the branch points of eulerAngles: pitch near +-90 deg, yaw near 0 / 180 deg, and exact axis permutations
+    special = []
+    for yaw in (0.0, 1e-7, -1e-7, np.pi, np.pi - 1e-7, -np.pi + 1e-7, 0.5, -2.5):
+        for pitch in (0.0, np.pi / 2, -np.pi / 2, np.pi / 2 - 1e-4, -np.pi / 2 + 1e-4, 1.0):
+            for roll in (0.0, np.pi, -1.0, 3.0):
+                cz, sz, cy, sy, cx, sx = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+                Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+                Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+                Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+                special.append((Rz @ Ry @ Rx).astype(np.float32))
+    R1 = np.concatenate([np.asarray(special, np.float32), R1])
+    R2 = np.concatenate([R2[:len(special)], R2])
+    d["euler_R"] = R1
+    d["euler_zyx"] = np.stack([orc.euler_zyx(r, ref=True) for r in R1])
+    d["geo_R1"], d["geo_R2"] = R1, R2
+    d["geodesic"] = np.array([orc.geodesic(a, b, ref=True) for a, b in zip(R1, R2)], np.float32)
+    t0 = (rng.standard_normal((2000, 3)) * 0.2).astype(np.float32)
+    t1 = (t0 + rng.standard_normal((2000, 3)) * np.float32(0.01)).astype(np.float32)
+    d["tdiff_t0"], d["tdiff_t1"] = t0, t1
+    d["tdiff_norm"] = np.array([orc.tdiff_norm(a, b, ref=True) for a, b in zip(t0, t1)], np.float32)
+    A = np.tile(np.eye(4, dtype=np.float32), (500, 1, 1))
+    B = np.tile(np.eye(4, dtype=np.float32), (500, 1, 1))
+    A[:, :3, :3], B[:, :3, :3] = _random_rotations(rng, 500), _random_rotations(rng, 500)
+    A[:, :3, 3] = rng.standard_normal((500, 3)) * 0.3
+    B[:, :3, 3] = rng.standard_normal((500, 3)) * 0.3
+    d["mat_A"], d["mat_B"] = A, B
+    d["mat_inv_times"] = np.stack([orc.inverse_times(a, b, ref=True) for a, b in zip(A, B)])
+    d["mat_mul"] = np.stack([orc.mul4(a, b, ref=True) for a, b in zip(A, B)])
+    # ---- the minimiser on correspondence sets ------------------------------------------------------------------------------------
+    mx, mn = synth.ellipsoid_model(3000)
+    n_sets = 0
+    for k in range(16):
+        if k < 8:  # the ellipse: scene points against the model under a perturbed pose (the shape ICP sees; weakly constrained slides)
+            sc = synth.make_scene(700, seed=100 + k)
+            S, Sn = sc.xyz[sc.conf >= 0.8], sc.nrm[sc.conf >= 0.8]
+            T = _perturb(sc.gt_pose, rng.uniform(0.2, 8), rng.uniform(0.0005, 0.004), rng)
+            Mt = (mx @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+            Mnt = (mn @ T[:3, :3].T).astype(np.float32)
+            dist, i = cKDTree(Mt).query(S)
+            ok = (dist < 0.01) & ((Sn * Mnt[i]).sum(1) > np.cos(np.pi / 4))
+            P, Q, Nn = S[ok], Mt[i[ok]], Mnt[i[ok]]
+        else:  # a well-conditioned set: random points and normals, a known small motion, 0.5 mm noise
+            m = 600
+            P = (rng.uniform(-0.05, 0.05, (m, 3)) + np.array([0, 0, 0.4])).astype(np.float32)
+            Nn = rng.standard_normal((m, 3))
+            Nn = (Nn / np.linalg.norm(Nn, axis=1, keepdims=True)).astype(np.float32)
+            x = (rng.standard_normal(6) * np.array([.003, .003, .003, .01, .01, .01])).astype(np.float32)
+            Tw = orc.lm_warp6(x, ref=True).astype(np.float64)
+            Q = (P @ Tw[:3, :3].T + Tw[:3, 3] + rng.standard_normal((m, 3)) * 0.0005).astype(np.float32)
+        T, x6, st = orc.lm_point_to_plane(P, Q, Nn, ref=True)
+        xs = np.stack([np.zeros(6, np.float32), x6, (rng.standard_normal(6) * 1e-3).astype(np.float32)])
+        fj = [orc.lm_residuals_jacobian(P, Q, Nn, xx, ref=True) for xx in xs]
+        d[f"lm{k}_P"], d[f"lm{k}_Q"], d[f"lm{k}_N"] = P, Q, Nn
+        d[f"lm{k}_T"], d[f"lm{k}_x"], d[f"lm{k}_stats"] = T, x6, np.asarray(st, np.int32)
+        d[f"lm{k}_probe_x"] = xs
+        d[f"lm{k}_probe_f"] = np.stack([f for f, _ in fj])
+        d[f"lm{k}_probe_J"] = np.stack([J for _, J in fj])
+        n_sets += 1
+        print("lm set", k, "m", len(P), "status/nfev/iter", st, "|x|max %.4f" % np.abs(x6).max())
+    d["n_lm_sets"] = np.int32(n_sets)
+    path = os.path.join(OUT, "icp_lm_kat.npz")
+    np.savez_compressed(path, **d)
+    print("icp_lm_kat ->", path, os.path.getsize(path) // 1024, "KiB")
+    # ---- refineByICP with the reference's minimiser in the loop ---------------------------------------------------------------------
+    mx5, mn5 = synth.ellipsoid_model_spacing(0.005)
+    keys = synth.ppf_key_table()
+    g = np.load(os.path.join(OUT, "depth7_hand_region.npz"))
+    xyz, nrm = g["xyz"], g["nrm"]
+    conf = np.ones(len(xyz), np.float32)
+    oo = orc.OracleS4PCS()
+    oo.set_keys(keys)
+    oo.run(xyz, nrm, conf, mx5, mn5, 1)
+    op, ol = oo.hypos()
+    k1 = orc.cluster_poses(op, ol, np.arange(len(ol)), 30.0, 0.015, [180, 180, 180])
+    p1 = op[k1][:100]
+    orc.ref_icp_use(native=False)
+    p2, it, cv = orc.icp_refine_batch_lm(xyz, nrm, mx5, mn5, p1, 10, 45.0, 0.01, ref=True)
+    orc.ref_icp_use(native=True)  # the same source built with -march=native: the reference's own build-to-build spread
+    p2n, itn, cvn = orc.icp_refine_batch_lm(xyz, nrm, mx5, mn5, p1, 10, 45.0, 0.01, ref=True)
+    orc.ref_icp_use(native=False)
+    path = os.path.join(OUT, "icp_lm_c1.npz")
+    np.savez_compressed(path, poses_in=p1, lcp_in=ol[k1][:100], poses_out=p2, iterations=it, converged=cv,
+                        poses_out_native=p2n, iterations_native=itn, converged_native=cvn,
+                        note="scene: tests/golden/depth7_hand_region.npz; model: synth.ellipsoid_model_spacing(0.005); max_iter 10, 45 deg, 0.01 m")
+    print("icp_lm_c1 ->", path, len(p1), "hypotheses, mean iterations %.2f" % it.mean(), "converged", int(cv.sum()))
+    sc = synth.make_scene(4000, seed=7)
+    keep = sc.conf >= 0.8
+    poses = synth.replay_poses(sc.gt_pose, 96, seed=11, max_rot_deg=30.0, max_trans=0.015)
+    p2, it, cv = orc.icp_refine_batch_lm(sc.xyz[keep], sc.nrm[keep], mx5, mn5, poses, 10, 45.0, 0.01, ref=True)
+    orc.ref_icp_use(native=True)
+    p2n, itn, cvn = orc.icp_refine_batch_lm(sc.xyz[keep], sc.nrm[keep], mx5, mn5, poses, 10, 45.0, 0.01, ref=True)
+    orc.ref_icp_use(native=False)
+    path = os.path.join(OUT, "icp_lm_c2sub.npz")
+    np.savez_compressed(path, poses_in=poses, poses_out=p2, iterations=it, converged=cv, gt_pose=sc.gt_pose,
+                        poses_out_native=p2n, iterations_native=itn, converged_native=cvn,
+                        note="scene: synth.make_scene(4000, seed=7), points with conf >= 0.8; model: synth.ellipsoid_model_spacing(0.005); "
+                             "poses: synth.replay_poses(gt, 96, seed=11, 30 deg, 15 mm)")
+    print("icp_lm_c2sub ->", path, "mean iterations %.2f" % it.mean(), "converged", int(cv.sum()))
+
+
 if __name__ == "__main__":
     if not orc.ref_available():
         orc.build()
@@ -242,5 +384,7 @@ if __name__ == "__main__":
     for c in CASES:
         if not only or c[0] in only:
             gen_case(*c)
+    if not only or "icp_lm" in only:
+        gen_icp_lm()
     if not only or "plain" in only:
         gen_plain(*[c for c in CASES if c[0] == "case1"][0])

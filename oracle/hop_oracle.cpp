@@ -1106,6 +1106,366 @@ inline M4 inverse_affine(const M4& a) {
   return r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The reference's ICP minimiser, restated: PCL 1.9's TransformationEstimationPointToPlane is a
+// TransformationEstimationLM (registration/impl/transformation_estimation_lm.hpp:146-197): per ICP iteration
+//   Eigen::LevenbergMarquardt<Eigen::NumericalDiff<Functor>, float>::minimize(x), x = (t, quaternion xyz) = 0
+// on the float residuals (warp(x) p - q) . n.  The arithmetic is Eigen's unsupported NonLinearOptimization /
+// NumericalDiff modules, which ARE in the reference tree (src/OpenGR_4pcs/3rdparty/Eigen/unsupported/Eigen/src/
+// NonLinearOptimization/{LevenbergMarquardt.h:208-355, lmpar.h:163-293, qrsolv.h}, NumericalDiff/NumericalDiff.h:64-122);
+// oracle/ref_icp_driver.cpp compiles them in place (oracle/_ref/libref_icp.so) and tests/golden/icp_lm_*.npz holds what
+// they return.  This restatement (PINNED against those vectors, tests/test_oracle_golden.py) keeps
+//   * every residual and every forward-difference Jacobian entry bit-equal to what Eigen evaluates (float, the
+//     operation order of PCL's warp_point_rigid_6d.h:77-106 / warp_point_rigid.h:86-93 on Eigen's SSE2 reductions:
+//     a 4-element sum is (a0 + a2) + (a1 + a3)), including NumericalDiff's step h = sqrt(eps) |x_j| (or sqrt(eps));
+//   * the control flow of minimizeOneStep / lmpar2 with their float constants;
+// and replaces the m x 6 Householder QR by the 6 x 6 normal equations in double: R^T R = P^T J^T J P, so every
+// quantity the algorithm reads -- the Gauss-Newton direction, |D p|, |J p|, the scaled gradient, the lmpar
+// iteration -- is the same function of J^T J and J^T f.  Sums over the correspondences run in index order in double.
+// The result differs from Eigen's float run by the rounding of its float reductions (measured on the goldens:
+// see tests/test_oracle_golden.py), not bit for bit.  The GPU path (nn_mode 5) computes exactly this restatement.
+// ------------------------------------------------------------------------------------------------
+inline float sum4_sse2(float a0, float a1, float a2, float a3) { return (a0 + a2) + (a1 + a3); }  // Eigen predux<Packet4f>, SSE2
+
+// WarpPointRigid6D::setParam (warp_point_rigid_6d.h:77-95): Quaternionf(0, x3, x4, x5); w = sqrt(1 - q.dot(q)); normalize; toRotationMatrix.
+inline M4 lm_warp6(const float x[6]) {
+  M4 T;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) T.m[i][j] = 0.f;
+  T.m[0][3] = x[0], T.m[1][3] = x[1], T.m[2][3] = x[2], T.m[3][3] = 1.f;
+  float qx = x[3], qy = x[4], qz = x[5], qw = 0.f;
+  const float d = sum4_sse2(qx * qx, qy * qy, qz * qz, qw * qw);
+  qw = std::sqrt(1 - d);
+  const float nn = std::sqrt(sum4_sse2(qx * qx, qy * qy, qz * qz, qw * qw));
+  qx = qx / nn, qy = qy / nn, qz = qz / nn, qw = qw / nn;
+  const float tx = 2.f * qx, ty = 2.f * qy, tz = 2.f * qz;  // Geometry/Quaternion.h toRotationMatrix
+  const float twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  T.m[0][0] = 1.f - (tyy + tzz), T.m[0][1] = txy - twz, T.m[0][2] = txz + twy;
+  T.m[1][0] = txy + twz, T.m[1][1] = 1.f - (txx + tzz), T.m[1][2] = tyz - twx;
+  T.m[2][0] = txz - twy, T.m[2][1] = tyz + twx, T.m[2][2] = 1.f - (txx + tyy);
+  return T;
+}
+// warpPoint + TransformationEstimationPointToPlane::computeDistance: (Vector4f(p') - Vector4f(q,0)).dot(Vector4f(n,0))
+inline float lm_residual(const M4& T, V3 p, V3 q, V3 n) {
+  const V3 w = pcl_transform_point(T, p);
+  const float dx = w.x - q.x, dy = w.y - q.y, dz = w.z - q.z;
+  return sum4_sse2(dx * n.x, dy * n.y, dz * n.z, 0.f);
+}
+
+struct LmSums {  // what one pass over the correspondences returns for a parameter vector xc
+  double ff;     // sum f_i^2
+  double A[6][6];  // J^T J
+  double g[6];     // J^T f
+};
+constexpr float LM_SQRT_EPS = 3.4526698300124393e-04f;  // sqrt(FLT_EPSILON) in float: ftol, xtol and NumericalDiff's eps
+
+// f(xc) and the forward-difference Jacobian NumericalDiff::df returns at xc (NumericalDiff.h:64-122, mode Forward)
+void lm_pass(const std::vector<V3>& P, const std::vector<V3>& Q, const std::vector<V3>& Nn, const float xc[6], LmSums& s,
+             std::vector<float>* fvec_out = nullptr, std::vector<float>* jac_out = nullptr) {
+  const M4 T0 = lm_warp6(xc);
+  M4 Tj[6];
+  float h[6];
+  for (int j = 0; j < 6; ++j) {
+    float xx[6];
+    std::copy(xc, xc + 6, xx);
+    h[j] = LM_SQRT_EPS * std::fabs(xc[j]);
+    if (h[j] == 0.f) h[j] = LM_SQRT_EPS;
+    xx[j] += h[j];
+    Tj[j] = lm_warp6(xx);
+  }
+  s.ff = 0;
+  for (int a = 0; a < 6; ++a) {
+    s.g[a] = 0;
+    for (int b = 0; b < 6; ++b) s.A[a][b] = 0;
+  }
+  if (fvec_out) fvec_out->resize(P.size());
+  if (jac_out) jac_out->resize(P.size() * 6);
+  for (size_t i = 0; i < P.size(); ++i) {
+    const float f0 = lm_residual(T0, P[i], Q[i], Nn[i]);
+    double J[6];
+    for (int j = 0; j < 6; ++j) {
+      const float fj = lm_residual(Tj[j], P[i], Q[i], Nn[i]);
+      const float jf = (fj - f0) / h[j];
+      J[j] = (double)jf;
+      if (jac_out) (*jac_out)[6 * i + j] = jf;
+    }
+    if (fvec_out) (*fvec_out)[i] = f0;
+    s.ff += (double)f0 * (double)f0;
+    for (int a = 0; a < 6; ++a) {
+      s.g[a] += J[a] * (double)f0;
+      for (int b = 0; b <= a; ++b) s.A[a][b] += J[a] * J[b];
+    }
+  }
+  for (int a = 0; a < 6; ++a)
+    for (int b = a + 1; b < 6; ++b) s.A[a][b] = s.A[b][a];
+}
+
+// Cholesky with diagonal pivoting of a 6x6 SPD matrix: R upper, R^T R = P^T A P; the pivot order is the one a
+// column-pivoted QR of J takes (largest remaining column norm); rank by ColPivHouseholderQR::rank()'s rule
+// (|R_ii| > |R|_max * 6 * eps_float).
+struct PivChol {
+  double R[6][6];
+  int perm[6], rank;
+};
+void piv_chol(const double A[6][6], PivChol& c) {
+  double S[6][6];
+  for (int i = 0; i < 6; ++i) {
+    c.perm[i] = i;
+    for (int j = 0; j < 6; ++j) S[i][j] = A[i][j], c.R[i][j] = 0;
+  }
+  double maxpiv = 0;
+  int k = 0;
+  for (; k < 6; ++k) {
+    int best = k;
+    for (int j = k + 1; j < 6; ++j)
+      if (S[j][j] > S[best][best]) best = j;
+    if (!(S[best][best] > 0)) break;
+    if (best != k) {
+      for (int i = 0; i < 6; ++i) std::swap(S[i][k], S[i][best]);
+      for (int j = 0; j < 6; ++j) std::swap(S[k][j], S[best][j]);
+      for (int i = 0; i < k; ++i) std::swap(c.R[i][k], c.R[i][best]);
+      std::swap(c.perm[k], c.perm[best]);
+    }
+    const double d = std::sqrt(S[k][k]);
+    c.R[k][k] = d;
+    maxpiv = std::max(maxpiv, d);
+    for (int j = k + 1; j < 6; ++j) c.R[k][j] = S[k][j] / d;
+    for (int i = k + 1; i < 6; ++i)
+      for (int j = k + 1; j < 6; ++j) S[i][j] -= c.R[k][i] * c.R[k][j];
+  }
+  c.rank = 0;
+  const double thr = maxpiv * 6.0 * (double)FLT_EPSILON;
+  for (int i = 0; i < k; ++i)
+    if (c.R[i][i] > thr) c.rank++;
+    else break;
+}
+// x = least-squares ("basic") solution of J x ~ f from the factor: z1 = R11^-1 R11^-T (P^T g)_1, x = P [z1; 0]  (lmpar.h:196-203)
+void piv_chol_solve(const PivChol& c, const double g[6], double x[6]) {
+  double y[6] = {0, 0, 0, 0, 0, 0};
+  const int r = c.rank;
+  for (int i = 0; i < r; ++i) {
+    double s = g[c.perm[i]];
+    for (int k = 0; k < i; ++k) s -= c.R[k][i] * y[k];
+    y[i] = s / c.R[i][i];
+  }
+  double z[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = r - 1; i >= 0; --i) {
+    double s = y[i];
+    for (int k = i + 1; k < r; ++k) s -= c.R[i][k] * z[k];
+    z[i] = s / c.R[i][i];
+  }
+  for (int i = 0; i < 6; ++i) x[c.perm[i]] = z[i];
+}
+// w^T M^-1 w and M^-1 b for SPD M (plain Cholesky, double)
+bool spd_solve6(const double M[6][6], const double b[6], double x[6]) {
+  double A[6][6], bb[6];
+  for (int i = 0; i < 6; ++i) {
+    bb[i] = b[i];
+    for (int j = 0; j < 6; ++j) A[i][j] = M[i][j];
+  }
+  return solve6(A, bb, x);
+}
+inline double norm6(const double v[6]) {
+  double s = 0;
+  for (int i = 0; i < 6; ++i) s += v[i] * v[i];
+  return std::sqrt(s);
+}
+
+// internal::lmpar2 (lmpar.h:163-293) on the normal equations: the triangular solves against R become solves
+// against A = R^T R, qrsolv's least-squares problem [R; sqrt(par) D] becomes (A + par D^2) x = g.
+void lm_par(const double A[6][6], const double g[6], const double diag[6], double delta, double& par, double x[6]) {
+  const double dwarf = (double)FLT_MIN;
+  PivChol c;
+  piv_chol(A, c);
+  piv_chol_solve(c, g, x);
+  int iter = 0;
+  double wa2[6];
+  for (int j = 0; j < 6; ++j) wa2[j] = diag[j] * x[j];
+  double dxnorm = norm6(wa2);
+  double fp = dxnorm - delta;
+  if (fp <= (double)0.1f * delta) {
+    par = 0;
+    return;
+  }
+  double parl = 0;
+  if (c.rank == 6) {
+    double w[6], u[6];
+    for (int j = 0; j < 6; ++j) w[j] = diag[j] * wa2[j] / dxnorm;
+    if (spd_solve6(A, w, u)) {
+      double t2 = 0;
+      for (int j = 0; j < 6; ++j) t2 += w[j] * u[j];
+      const double temp = std::sqrt(t2);
+      parl = fp / delta / temp / temp;
+    }
+  }
+  double wa1[6];
+  for (int j = 0; j < 6; ++j) wa1[j] = g[j] / diag[j];
+  const double gnorm = norm6(wa1);
+  double paru = gnorm / delta;
+  if (paru == 0) paru = dwarf / std::min(delta, (double)0.1f);
+  par = std::max(par, parl);
+  par = std::min(par, paru);
+  if (par == 0) par = gnorm / dxnorm;
+  while (true) {
+    ++iter;
+    if (par == 0) par = std::max(dwarf, (double)0.001f * paru);
+    double M[6][6];
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) M[i][j] = A[i][j] + (i == j ? par * diag[i] * diag[i] : 0.0);
+    spd_solve6(M, g, x);
+    for (int j = 0; j < 6; ++j) wa2[j] = diag[j] * x[j];
+    dxnorm = norm6(wa2);
+    double temp = fp;
+    fp = dxnorm - delta;
+    if (std::fabs(fp) <= (double)0.1f * delta || (parl == 0 && fp <= temp && temp < 0) || iter == 10) break;
+    double w[6], u[6];
+    for (int j = 0; j < 6; ++j) w[j] = diag[j] * (wa2[j] / dxnorm);
+    spd_solve6(M, w, u);
+    double t2 = 0;
+    for (int j = 0; j < 6; ++j) t2 += w[j] * u[j];
+    temp = std::sqrt(t2);
+    const double parc = fp / delta / temp / temp;
+    if (fp > 0) parl = std::max(parl, par);
+    if (fp < 0) paru = std::min(paru, par);
+    par = std::max(parl, par + parc);
+  }
+  if (iter == 0) par = 0;
+}
+
+// LevenbergMarquardt::minimize (LevenbergMarquardt.h:157-355) as a state machine around passes over the correspondences:
+// begin -> [pass at xc] -> advance -> [pass at xc] -> advance ... until advance returns false.
+enum { LM_STATUS_RUNNING = -1, LM_REL_REDUCTION = 1, LM_REL_ERROR = 2, LM_REL_BOTH = 3, LM_COSINUS = 4, LM_MAXFEV = 5, LM_FTOL = 6, LM_XTOL = 7, LM_GTOL = 8 };
+struct LmState {
+  float x[6], xc[6];
+  LmSums cur;
+  double diag[6], delta, par, xnorm, fnorm, gnorm, pnorm;
+  float p[6];
+  int iter, nfev, status, phase;
+};
+void lm_begin(LmState& s) {
+  for (int j = 0; j < 6; ++j) s.x[j] = s.xc[j] = 0.f;
+  s.phase = 0, s.status = LM_STATUS_RUNNING, s.iter = 0, s.nfev = 0, s.par = 0, s.delta = 0, s.xnorm = 0, s.fnorm = 0, s.gnorm = 0, s.pnorm = 0;
+}
+inline double lm_scaled_norm(const double diag[6], const float v[6]) {
+  double q = 0;
+  for (int j = 0; j < 6; ++j) q += (diag[j] * (double)v[j]) * (diag[j] * (double)v[j]);
+  return std::sqrt(q);
+}
+// the do { lmpar; candidate } part of minimizeOneStep (LevenbergMarquardt.h:262-275): leaves the candidate in xc
+void lm_inner(LmState& s) {
+  double xs[6];
+  lm_par(s.cur.A, s.cur.g, s.diag, s.delta, s.par, xs);
+  for (int j = 0; j < 6; ++j) {
+    s.p[j] = -(float)xs[j];        // wa1 = -wa1
+    s.xc[j] = s.x[j] + s.p[j];     // wa2 = x + wa1 (float)
+  }
+  s.pnorm = lm_scaled_norm(s.diag, s.p);
+  if (s.iter == 1) s.delta = std::min(s.delta, s.pnorm);
+  s.phase = 1;
+}
+// the head of minimizeOneStep (LevenbergMarquardt.h:219-260); false = finished (status set)
+bool lm_outer(LmState& s) {
+  s.nfev += 7;  // NumericalDiff::df returns 1 + 6 evaluations
+  double wa2[6];
+  for (int j = 0; j < 6; ++j) wa2[j] = std::sqrt(s.cur.A[j][j]);
+  if (s.iter == 1) {
+    for (int j = 0; j < 6; ++j) s.diag[j] = wa2[j] == 0 ? 1.0 : wa2[j];
+    s.xnorm = lm_scaled_norm(s.diag, s.x);
+    s.delta = 100.0 * s.xnorm;
+    if (s.delta == 0) s.delta = 100.0;
+  }
+  s.gnorm = 0;
+  if (s.fnorm != 0)
+    for (int j = 0; j < 6; ++j)
+      if (wa2[j] != 0) s.gnorm = std::max(s.gnorm, std::fabs(s.cur.g[j] / s.fnorm / wa2[j]));
+  if (s.gnorm <= 0) {
+    s.status = LM_COSINUS;
+    return false;
+  }
+  for (int j = 0; j < 6; ++j) s.diag[j] = std::max(s.diag[j], wa2[j]);
+  lm_inner(s);
+  return true;
+}
+// consumes the sums of the pass at s.xc; true = another pass at (the new) s.xc is wanted
+bool lm_advance(LmState& s, const LmSums& cand) {
+  if (s.phase == 0) {  // minimizeInit
+    s.cur = cand;
+    s.nfev = 1;
+    s.fnorm = std::sqrt(cand.ff);
+    s.par = 0;
+    s.iter = 1;
+    return lm_outer(s);
+  }
+  const double ftol = (double)LM_SQRT_EPS, xtol = (double)LM_SQRT_EPS, eps = (double)FLT_EPSILON;
+  const double p1 = (double)0.1f, p25 = 0.25, p5 = 0.5, p75 = 0.75, p0001 = (double)1e-4f;
+  ++s.nfev;
+  const double fnorm1 = std::sqrt(cand.ff);
+  double actred = -1;
+  if (p1 * fnorm1 < s.fnorm) actred = 1.0 - (fnorm1 / s.fnorm) * (fnorm1 / s.fnorm);
+  double jp2 = 0;  // |J p|^2 = p^T A p  (wa3 = R P^T wa1)
+  for (int a = 0; a < 6; ++a)
+    for (int b = 0; b < 6; ++b) jp2 += (double)s.p[a] * s.cur.A[a][b] * (double)s.p[b];
+  const double t1r = std::sqrt(std::max(jp2, 0.0)) / s.fnorm, t2r = std::sqrt(s.par) * s.pnorm / s.fnorm;
+  const double temp1 = t1r * t1r, temp2 = t2r * t2r;
+  const double prered = temp1 + temp2 / p5, dirder = -(temp1 + temp2);
+  double ratio = 0;
+  if (prered != 0) ratio = actred / prered;
+  if (ratio <= p25) {
+    double temp = p5;
+    if (actred < 0) temp = p5 * dirder / (dirder + p5 * actred);
+    if (p1 * fnorm1 >= s.fnorm || temp < p1) temp = p1;
+    s.delta = temp * std::min(s.delta, s.pnorm / p1);
+    s.par /= temp;
+  } else if (!(s.par != 0 && ratio < p75)) {
+    s.delta = s.pnorm / p5;
+    s.par = p5 * s.par;
+  }
+  if (ratio >= p0001) {
+    for (int j = 0; j < 6; ++j) s.x[j] = s.xc[j];
+    s.cur = cand;
+    s.xnorm = lm_scaled_norm(s.diag, s.x);
+    s.fnorm = fnorm1;
+    ++s.iter;
+  }
+  const bool small_red = std::fabs(actred) <= ftol && prered <= ftol && p5 * ratio <= 1.0;
+  const bool small_err = s.delta <= xtol * s.xnorm;
+  if (small_red && small_err) s.status = LM_REL_BOTH;
+  else if (small_red) s.status = LM_REL_REDUCTION;
+  else if (small_err) s.status = LM_REL_ERROR;
+  else if (s.nfev >= 400) s.status = LM_MAXFEV;
+  else if (std::fabs(actred) <= eps && prered <= eps && p5 * ratio <= 1.0) s.status = LM_FTOL;
+  else if (s.delta <= eps * s.xnorm) s.status = LM_XTOL;
+  else if (s.gnorm <= eps) s.status = LM_GTOL;
+  if (s.status != LM_STATUS_RUNNING) return false;
+  if (ratio < p0001) {  // do { } while (ratio < 1e-4): same Jacobian, new lmpar
+    lm_inner(s);
+    return true;
+  }
+  return lm_outer(s);
+}
+
+// TransformationEstimationLM::estimateRigidTransformation on the correspondences (P moved source, Q target, N target
+// normals); fewer than 4: PCL prints an error and leaves the matrix as it was (returns false here).
+bool lm_point_to_plane(const std::vector<V3>& P, const std::vector<V3>& Q, const std::vector<V3>& Nn, M4& T, float x_out[6] = nullptr,
+                       int* stats = nullptr) {
+  if (P.size() < 4) return false;
+  LmState s;
+  lm_begin(s);
+  LmSums sums;
+  do lm_pass(P, Q, Nn, s.xc, sums);
+  while (lm_advance(s, sums));
+  T = lm_warp6(s.x);
+  if (x_out) std::copy(s.x, s.x + 6, x_out);
+  if (stats) stats[0] = s.status, stats[1] = s.nfev, stats[2] = s.iter;
+  return true;
+}
+
+// hook for the minimiser compiled from the reference's vendored Eigen (oracle/_ref/libref_icp.so, ref_lm_point_to_plane);
+// set from oracle/orc.py in the build container (and wherever the prebuilt file travelled)
+typedef int (*lm_estimator_fn)(int m, const float* src_xyz, const float* tgt_xyz, const float* tgt_nrm, float* T16_out, float* x6_out,
+                               int* stats, float* fnorm_out);
+lm_estimator_fn g_ref_lm_estimator = nullptr;
+
 // pcl::IterativeClosestPoint as configured by Utils::runICP (Utils.cpp:188-229) -- PARITY UNPINNED.
 // Restated behaviour (PCL 1.9 registration/impl/icp.hpp, correspondence_estimation.hpp,
 // correspondence_rejection_surface_normal.h, default_convergence_criteria.hpp):
@@ -1153,8 +1513,15 @@ IcpResult run_icp(const Cloud& src, const Cloud& tgt, bool use_tree, int max_ite
   if (use_tree) tree.build(tgt.pos);
   const float cos_thr = (float)std::cos((double)(rejection_angle_deg / 180.0f) * M_PI);
   const float max_d2 = max_corr_dist * max_corr_dist;
+  // minimiser >= 4 (the reference's Levenberg-Marquardt): the gates as PCL 1.9 writes them --
+  //   CorrespondenceEstimation::determineCorrespondences: double max_dist_sqr = max_distance * max_distance; skip if distance[0] > max_dist_sqr
+  //   CorrespondenceRejectorSurfaceNormal: double((s0*t0 + s1*t1) + s2*t2) > threshold_, threshold_ = std::cos(angle/180.0*M_PI) (Utils.cpp:205)
+  const bool pcl_gates = var.minimiser >= 4;
+  const double max_d2_d = (double)max_corr_dist * (double)max_corr_dist;
+  const double cos_thr_d = std::cos((double)rejection_angle_deg / 180.0 * M_PI);
   std::vector<V3> sp = src.pos, sn = src.nrm;  // moved source
   double mse_prev = std::numeric_limits<double>::max();
+  M4 T_lm = identity4();  // transformation_: survives an iteration whose estimator returns early (fewer than 4 correspondences)
   while (true) {
     // correspondences
     double A[6][6] = {}, b[6] = {};
@@ -1167,9 +1534,12 @@ IcpResult run_icp(const Cloud& src, const Cloud& tgt, bool use_tree, int max_ite
       int idx = -1;
       if (use_tree) tree.nearest(sp[i], d2, idx);
       else brute_nearest<true>(tgt.pos, sp[i], d2, idx);
-      if (idx < 0 || !(d2 <= max_d2)) continue;
+      if (idx < 0) continue;
+      if (pcl_gates ? (double)d2 > max_d2_d : !(d2 <= max_d2)) continue;
       const V3 nt = tgt.nrm[idx];
-      if (var.strict_normal ? !(dot(sn[i], nt) > cos_thr) : !(dot(sn[i], nt) >= cos_thr)) continue;
+      if (pcl_gates) {
+        if (!((double)((sn[i].x * nt.x + sn[i].y * nt.y) + sn[i].z * nt.z) > cos_thr_d)) continue;
+      } else if (var.strict_normal ? !(dot(sn[i], nt) > cos_thr) : !(dot(sn[i], nt) >= cos_thr)) continue;
       if (var.minimiser >= 2) corr_p.push_back(sp[i]), corr_q.push_back(tgt.pos[idx]), corr_n.push_back(nt);
       ++cnt;
       mse += (double)d2;
@@ -1224,7 +1594,26 @@ IcpResult run_icp(const Cloud& src, const Cloud& tgt, bool use_tree, int max_ite
     };
     M4 T;
     double wnorm = 0;
-    if (!gn_step(A, b, cs, cnt, T, wnorm)) {
+    if (var.minimiser >= 4) {
+      // 4: the restated Levenberg-Marquardt above; 5: the one compiled from the reference's vendored Eigen (hook)
+      if (var.minimiser == 5) {
+        if (!g_ref_lm_estimator) {
+          res.converged = false;
+          res.iterations = -1;
+          return res;
+        }
+        std::vector<float> a(3 * cnt), bq(3 * cnt), cn(3 * cnt);
+        for (int i = 0; i < cnt; ++i) {
+          a[3 * i] = corr_p[i].x, a[3 * i + 1] = corr_p[i].y, a[3 * i + 2] = corr_p[i].z;
+          bq[3 * i] = corr_q[i].x, bq[3 * i + 1] = corr_q[i].y, bq[3 * i + 2] = corr_q[i].z;
+          cn[3 * i] = corr_n[i].x, cn[3 * i + 1] = corr_n[i].y, cn[3 * i + 2] = corr_n[i].z;
+        }
+        float T16[16];
+        if (g_ref_lm_estimator(cnt, a.data(), bq.data(), cn.data(), T16, nullptr, nullptr, nullptr) == 0) T_lm = load4(T16);
+      } else
+        lm_point_to_plane(corr_p, corr_q, corr_n, T_lm);
+      T = T_lm;
+    } else if (!gn_step(A, b, cs, cnt, T, wnorm)) {
       res.converged = false;
       return res;
     }
@@ -1348,6 +1737,16 @@ IcpResult run_icp(const Cloud& src, const Cloud& tgt, bool use_tree, int max_ite
     if (res.iterations >= max_iter) {
       res.converged = true;
       return res;
+    }
+    if (pcl_gates) {
+      // DefaultConvergenceCriteria::hasConverged, criterion 2 with the thresholds ICP installs (rotation 1.0 - 0, translation 0):
+      // fires only for an increment that is exactly the identity
+      const double cos_angle = 0.5 * (double)(T.m[0][0] + T.m[1][1] + T.m[2][2] - 1);
+      const double translation_sqr = (double)(T.m[0][3] * T.m[0][3] + T.m[1][3] * T.m[1][3] + T.m[2][3] * T.m[2][3]);
+      if (cos_angle >= 1.0 && translation_sqr <= 0.0) {
+        res.converged = true;
+        return res;
+      }
     }
     if (std::fabs(mse - mse_prev) < 1e-6) {
       res.converged = true;
@@ -1693,6 +2092,61 @@ void orc_icp_refine_batch_variant(const float* Sxyz, const float* Snrm, int nS, 
   }
 }
 
+void orc_set_lm_estimator(void* fn) { g_ref_lm_estimator = (lm_estimator_fn)fn; }
+
+/* the restated minimiser alone (one estimateRigidTransformation call); AoS m x 3 inputs like ref_lm_point_to_plane */
+int orc_lm_point_to_plane(int m, const float* src_xyz, const float* tgt_xyz, const float* tgt_nrm, float* T16_out, float* x6_out, int* stats) {
+  std::vector<V3> P(m), Q(m), Nn(m);
+  for (int i = 0; i < m; ++i) {
+    P[i] = {src_xyz[3 * i], src_xyz[3 * i + 1], src_xyz[3 * i + 2]};
+    Q[i] = {tgt_xyz[3 * i], tgt_xyz[3 * i + 1], tgt_xyz[3 * i + 2]};
+    Nn[i] = {tgt_nrm[3 * i], tgt_nrm[3 * i + 1], tgt_nrm[3 * i + 2]};
+  }
+  M4 T;
+  if (!lm_point_to_plane(P, Q, Nn, T, x6_out, stats)) return -1;
+  store4(T, T16_out);
+  return 0;
+}
+void orc_lm_warp6(const float* x6, float* T16) { store4(lm_warp6(x6), T16); }
+/* f(x) and NumericalDiff's Jacobian at x (row-major m x 6) */
+void orc_lm_residuals_jacobian(int m, const float* src_xyz, const float* tgt_xyz, const float* tgt_nrm, const float* x6, float* fvec_out, float* jac_out) {
+  std::vector<V3> P(m), Q(m), Nn(m);
+  for (int i = 0; i < m; ++i) {
+    P[i] = {src_xyz[3 * i], src_xyz[3 * i + 1], src_xyz[3 * i + 2]};
+    Q[i] = {tgt_xyz[3 * i], tgt_xyz[3 * i + 1], tgt_xyz[3 * i + 2]};
+    Nn[i] = {tgt_nrm[3 * i], tgt_nrm[3 * i + 1], tgt_nrm[3 * i + 2]};
+  }
+  LmSums s;
+  std::vector<float> f, J;
+  lm_pass(P, Q, Nn, x6, s, &f, &J);
+  std::copy(f.begin(), f.end(), fvec_out);
+  std::copy(J.begin(), J.end(), jac_out);
+}
+// Utils::rotationGeodesicDistance, Utils.cpp:29-32: std::acos(((R1 * R2).trace()-1) / 2.0) returned as float
+float rotation_geodesic_distance(const float R0[3][3], const float R1[3][3]) {
+  M3 a, b;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) a.m[i][j] = R0[i][j], b.m[i][j] = R1[i][j];
+  const M3 p = mul(a, b);
+  const float tr = p.m[0][0] + (p.m[1][1] + p.m[2][2]);
+  return (float)std::acos((double)(tr - 1.0f) / 2.0);  // trace() - 1 in float, / 2.0 in double
+}
+float orc_geodesic(const float* R1_9, const float* R2_9) {
+  float a[3][3], b[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) a[i][j] = R1_9[3 * i + j], b[i][j] = R2_9[3 * i + j];
+  return rotation_geodesic_distance(a, b);
+}
+float orc_tdiff_norm(const float* t0, const float* t1) { return norm(V3{t0[0], t0[1], t0[2]} - V3{t1[0], t1[1], t1[2]}); }
+void orc_inverse_times(const float* Ticp16, const float* pose16, float* out16) { store4(mul4(inverse_affine(load4(Ticp16)), load4(pose16)), out16); }
+void orc_mul4(const float* A16, const float* B16, float* out16) { store4(mul4(load4(A16), load4(B16)), out16); }
+void orc_euler_zyx(const float* R9, float* out3) {
+  float R[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[i][j] = R9[3 * i + j];
+  euler_zyx(R, out3);
+}
+
 int orc_cluster_poses(const float* pose16, const float* lcp, const int* ids, int H, float angle_diff, float dist_diff,
                       const float* sym_deg3, int* keep_out) {
   if (H <= 0) return 0;
@@ -1734,12 +2188,7 @@ int orc_cluster_poses(const float* pose16, const float* lcp, const int* ids, int
         break;
       }
       // Utils::rotationGeodesicDistance, Utils.cpp:29-32: acos((trace(R1*R2)-1)/2.0), R1*R2 (not R1^T R2)
-      M3 a, b;
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) a.m[i][j] = R0[i][j], b.m[i][j] = R1[i][j];
-      const M3 p = mul(a, b);
-      const float tr = p.m[0][0] + (p.m[1][1] + p.m[2][2]);
-      const float rot_diff = (float)std::acos(((double)tr - 1) / 2.0);
+      const float rot_diff = rotation_geodesic_distance(R0, R1);
       if (rot_diff <= radian_thres) {
         isnew = false;
         break;

@@ -16,6 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "_build", "liboracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libref_s4pcs.so")
 REF_SDF_SO = os.path.join(HERE, "_ref", "libref_sdf.so")
+REF_ICP_SO = os.path.join(HERE, "_ref", "libref_icp.so")
+REF_ICP_NATIVE_SO = os.path.join(HERE, "_ref", "libref_icp_native.so")  # same source, -march=native: build-to-build spread of the reference
 
 fp = C.POINTER(C.c_float)
 dp = C.POINTER(C.c_double)
@@ -168,6 +170,18 @@ def lib():
         L.orc_probe_transform.argtypes = [fp, fp, fp]
         L.orc_probe_vec.argtypes = [fp, fp, fp]
         L.orc_probe_quat.argtypes = [fp, fp, fp]
+        L.orc_set_lm_estimator.argtypes = [C.c_void_p]
+        L.orc_lm_point_to_plane.restype = C.c_int
+        L.orc_lm_point_to_plane.argtypes = [C.c_int, fp, fp, fp, fp, fp, ip]
+        L.orc_lm_warp6.argtypes = [fp, fp]
+        L.orc_lm_residuals_jacobian.argtypes = [C.c_int, fp, fp, fp, fp, fp, fp]
+        L.orc_euler_zyx.argtypes = [fp, fp]
+        L.orc_geodesic.restype = C.c_float
+        L.orc_geodesic.argtypes = [fp, fp]
+        L.orc_tdiff_norm.restype = C.c_float
+        L.orc_tdiff_norm.argtypes = [fp, fp]
+        L.orc_inverse_times.argtypes = [fp, fp, fp]
+        L.orc_mul4.argtypes = [fp, fp, fp]
         _lib = L
     return _lib
 
@@ -363,6 +377,138 @@ def icp_refine_batch_variant(S, Sn, M, Mn, poses, max_iter=10, angle_deg=45.0, m
     lib().orc_icp_refine_batch_variant(F(Sp), F(Snp), Sp.shape[1], F(Mp), F(Mnp), Mp.shape[1], F(T), len(T), int(max_iter), C.c_float(angle_deg),
                                        C.c_float(max_corr_dist), int(minimiser), int(bool(strict_normal)), int(bool(relative_stop)), I(it), I(cv))
     return T.reshape(-1, 4, 4), it, cv
+
+
+# ---- the reference's ICP minimiser (Eigen::LevenbergMarquardt from the reference's vendored Eigen) --------------------------
+MIN_GN, MIN_LM_RESTATED, MIN_LM_REF = 0, 4, 5
+_ref_icp = None
+_ref_icp_native = None
+
+
+def ref_icp_available():
+    return os.path.exists(REF_ICP_SO)
+
+
+def ref_icp_use(native=False):
+    """Which build of the reference's minimiser liboracle's run_icp (minimiser 5) calls: the default g++ build (SSE2, no
+    contraction: the one the goldens come from) or the -march=native build of the same source."""
+    global _ref_icp_native
+    L = ref_icp()
+    if native:
+        if _ref_icp_native is None:
+            _ref_icp_native = C.CDLL(REF_ICP_NATIVE_SO)
+        L = _ref_icp_native
+    lib().orc_set_lm_estimator(C.cast(L.ref_lm_point_to_plane, C.c_void_p))
+
+
+def ref_icp():
+    """oracle/_ref/libref_icp.so (oracle/ref_icp_driver.cpp compiled against /root/reference/src/OpenGR_4pcs/3rdparty/Eigen).
+    Loading it also hands its minimiser to liboracle's run_icp (minimiser 5)."""
+    global _ref_icp
+    if _ref_icp is None:
+        L = C.CDLL(REF_ICP_SO)
+        L.ref_lm_point_to_plane.restype = C.c_int
+        L.ref_lm_point_to_plane.argtypes = [C.c_int, fp, fp, fp, fp, fp, ip, fp]
+        L.ref_probe_warp6.argtypes = [fp, fp]
+        L.ref_probe_residuals.argtypes = [C.c_int, fp, fp, fp, fp, fp]
+        L.ref_probe_jacobian.argtypes = [C.c_int, fp, fp, fp, fp, fp]
+        L.ref_probe_euler_zyx.argtypes = [fp, fp]
+        L.ref_probe_geodesic.restype = C.c_float
+        L.ref_probe_geodesic.argtypes = [fp, fp]
+        L.ref_probe_tdiff_norm.restype = C.c_float
+        L.ref_probe_tdiff_norm.argtypes = [fp, fp]
+        L.ref_probe_inverse_times.argtypes = [fp, fp, fp]
+        L.ref_probe_mul4.argtypes = [fp, fp, fp]
+        lib().orc_set_lm_estimator(C.cast(L.ref_lm_point_to_plane, C.c_void_p))
+        _ref_icp = L
+    return _ref_icp
+
+
+def _aos3(a):
+    return np.ascontiguousarray(np.asarray(a, np.float32).reshape(-1, 3))
+
+
+def lm_point_to_plane(src, tgt, nrm, ref=False):
+    """One TransformationEstimationLM::estimateRigidTransformation on given correspondences.
+    ref=True: Eigen's own LevenbergMarquardt (oracle/_ref); False: the restatement in liboracle.
+    Returns (T 4x4, x6, (status, nfev, iter))."""
+    a, b, c = _aos3(src), _aos3(tgt), _aos3(nrm)
+    T = np.zeros(16, np.float32)
+    x = np.zeros(6, np.float32)
+    st = np.zeros(3, np.int32)
+    if ref:
+        fn = np.zeros(1, np.float32)
+        rc = ref_icp().ref_lm_point_to_plane(len(a), F(a), F(b), F(c), F(T), F(x), I(st), F(fn))
+    else:
+        rc = lib().orc_lm_point_to_plane(len(a), F(a), F(b), F(c), F(T), F(x), I(st))
+    if rc != 0:
+        return None, None, None
+    return T.reshape(4, 4), x, tuple(int(v) for v in st)
+
+
+def lm_warp6(x6, ref=False):
+    x = np.ascontiguousarray(x6, np.float32)
+    T = np.zeros(16, np.float32)
+    (ref_icp().ref_probe_warp6 if ref else lib().orc_lm_warp6)(F(x), F(T))
+    return T.reshape(4, 4)
+
+
+def lm_residuals_jacobian(src, tgt, nrm, x6, ref=False):
+    a, b, c = _aos3(src), _aos3(tgt), _aos3(nrm)
+    x = np.ascontiguousarray(x6, np.float32)
+    f = np.zeros(len(a), np.float32)
+    J = np.zeros((len(a), 6), np.float32)
+    if ref:
+        ref_icp().ref_probe_residuals(len(a), F(a), F(b), F(c), F(x), F(f))
+        ref_icp().ref_probe_jacobian(len(a), F(a), F(b), F(c), F(x), F(J))
+    else:
+        lib().orc_lm_residuals_jacobian(len(a), F(a), F(b), F(c), F(x), F(f), F(J))
+    return f, J
+
+
+def icp_refine_batch_lm(S, Sn, M, Mn, poses, max_iter=10, angle_deg=45.0, max_corr_dist=0.01, ref=False):
+    """refineByICP with the reference's minimiser: PCL's gates and stopping rules (strict normal test, absolute MSE only)
+    around Levenberg-Marquardt -- ref=True: Eigen's own code from the reference tree (needs oracle/_ref/libref_icp.so),
+    False: the restatement (what the GPU's nn_mode 5 is compared with)."""
+    if ref:
+        ref_icp()
+    return icp_refine_batch_variant(S, Sn, M, Mn, poses, max_iter, angle_deg, max_corr_dist, minimiser=MIN_LM_REF if ref else MIN_LM_RESTATED,
+                                    strict_normal=True, relative_stop=False)
+
+
+def euler_zyx(R, ref=False):
+    r = np.ascontiguousarray(np.asarray(R, np.float32).reshape(9))
+    out = np.zeros(3, np.float32)
+    (ref_icp().ref_probe_euler_zyx if ref else lib().orc_euler_zyx)(F(r), F(out))
+    return out
+
+
+def geodesic(R1, R2, ref=False):
+    a = np.ascontiguousarray(np.asarray(R1, np.float32).reshape(9))
+    b = np.ascontiguousarray(np.asarray(R2, np.float32).reshape(9))
+    return float((ref_icp().ref_probe_geodesic if ref else lib().orc_geodesic)(F(a), F(b)))
+
+
+def tdiff_norm(t0, t1, ref=False):
+    a = np.ascontiguousarray(t0, np.float32)
+    b = np.ascontiguousarray(t1, np.float32)
+    return float((ref_icp().ref_probe_tdiff_norm if ref else lib().orc_tdiff_norm)(F(a), F(b)))
+
+
+def inverse_times(Ticp, pose, ref=False):
+    a = np.ascontiguousarray(np.asarray(Ticp, np.float32).reshape(16))
+    b = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
+    out = np.zeros(16, np.float32)
+    (ref_icp().ref_probe_inverse_times if ref else lib().orc_inverse_times)(F(a), F(b), F(out))
+    return out.reshape(4, 4)
+
+
+def mul4(A, B, ref=False):
+    a = np.ascontiguousarray(np.asarray(A, np.float32).reshape(16))
+    b = np.ascontiguousarray(np.asarray(B, np.float32).reshape(16))
+    out = np.zeros(16, np.float32)
+    (ref_icp().ref_probe_mul4 if ref else lib().orc_mul4)(F(a), F(b), F(out))
+    return out.reshape(4, 4)
 
 
 def cluster_poses(poses, lcp, ids, angle_deg, dist, sym_deg):
