@@ -50,6 +50,10 @@ class S4pcsStats(C.Structure):
                 ("ms_select", C.c_double), ("ms_device", C.c_double)]
 
 
+ICP_NN_MODE_REFERENCE = 6  # hop_icp_opts.nn_mode of the mirrors: Levenberg-Marquardt on (t, quaternion) to its stopping rule per ICP iteration
+ICP_NN_MODE_GN = 4         # one Gauss-Newton step per ICP iteration (faster; not what PCL computes)
+
+
 class IcpOpts(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("angle_deg", C.c_float), ("max_corr_dist", C.c_float),
                 ("max_hypotheses", C.c_int), ("nn_mode", C.c_int)]
@@ -892,7 +896,8 @@ class PoseEstimator:
         self.ctx.cluster_poses(angle_diff, dist_diff, [s["x"], s["y"], s["z"]], assign_id)
 
     def refineByICP(self):
-        self.ctx.icp_refine(10, float(self.cfg["icp_angle_thres"]), float(self.cfg["icp_dist_thres"]), max_hypotheses=100, nn_mode=3)
+        # nn_mode 6: the reference's minimiser (PCL's point-to-plane estimator = Eigen's Levenberg-Marquardt, Utils.cpp:200-216)
+        self.ctx.icp_refine(10, float(self.cfg["icp_angle_thres"]), float(self.cfg["icp_dist_thres"]), max_hypotheses=100, nn_mode=ICP_NN_MODE_REFERENCE)
 
     def selectBest(self):
         pose, score, idx = self.ctx.lcp_select_best(float(self.cfg["lcp"]["dist"]), float(self.cfg["lcp"]["normal_angle"]), -1)
@@ -998,7 +1003,7 @@ class HandT42:
             c.set_model(HOP_MODEL_5MM, bx, bn)                   # target (pclModel)
             c.model_owner = self                                 # a PoseEstimator on this context uploads its models again
             c.hypos_upload(np.eye(4, dtype=np.float32)[None])
-            c.icp_refine(50, 30.0, 0.03, nn_mode=0)
+            c.icp_refine(50, 30.0, 0.03, nn_mode=ICP_NN_MODE_REFERENCE)
             pose, _, _ = c.hypos_download()
             offset = np.linalg.inv(pose[0].astype(np.float64)).astype(np.float32)  # source -> target
         translation = float(np.linalg.norm(offset[:3, 3]))

@@ -15,7 +15,7 @@
 #include "hop_select.h"
 #include "hop_ctx_ext.h"
 
-#include <hipcub/hipcub.hpp>
+#include "hop_prim.h"
 #include <sys/mman.h>
 
 #include <algorithm>
@@ -300,6 +300,9 @@ int build_grid(hop_ctx* c, GridStore& gs, const float* x, const float* y, const 
 // packed: additionally the 16-byte cell records / 8-byte quantised entries of CellListDev::rec (ICP lookups, cells_nnq);
 // packing runs on the host (once per model and gating distance, like the lists themselves).
 int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const CloudDevice& d, float max_dist, float cell, bool packed = false) {
+  // nothing of a previous build may be taken for valid while this one overwrites its geometry and buffers (a failed build must not
+  // leave the old cell / max_dist next to new arrays)
+  cs.valid = false, cs.packed = false, cs.c.rec = nullptr, cs.c.qlist = nullptr;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (int i = 0; i < h.n; ++i) {
     mn[0] = std::min(mn[0], h.x[i]), mn[1] = std::min(mn[1], h.y[i]), mn[2] = std::min(mn[2], h.z[i]);
@@ -430,7 +433,12 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
         ql.push_back(lo), ql.push_back(hi);
       }
     }
-    if (!in_range) return HOP_E_STATE;
+    if (!in_range) {
+      // a list does not fit the 16-bit local frame: the plain lists built above are complete and exact on their own -- the callers
+      // fall back to them (launch_icp_fused) when rec is null; pts_idx / nrm_idx are read by the packed kernels only
+      cs.valid = true, cs.cell = cell, cs.max_dist = max_dist, cs.coord_mag = c->coord_mag;
+      return HOP_OK;
+    }
     if (ql.empty()) ql.assign(4, 0xFFFFFFFFu);
     HIPCHK(c, cs.rec_d.ensure(sizeof(uint32_t) * rec.size()));
     HIPCHK(c, cs.qlist_d.ensure(sizeof(uint32_t) * ql.size()));
@@ -479,9 +487,9 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   // stage 1: flag cells with candidates, compact them (in cell order) into a work list
   launch_cell_list_local_flag(a, g, flag, c->stream);
   size_t tmp_bytes = 0;
-  HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, flag, scan, (int)(ncell + 1), c->stream));
+  HIPCHK(c, prim_exclusive_sum(nullptr, tmp_bytes, flag, scan, (int)(ncell + 1), c->stream));
   HIPCHK(c, c->sort_tmp.ensure(tmp_bytes + 16));
-  HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->sort_tmp.p, tmp_bytes, flag, scan, (int)(ncell + 1), c->stream));
+  HIPCHK(c, prim_exclusive_sum(c->sort_tmp.p, tmp_bytes, flag, scan, (int)(ncell + 1), c->stream));
   int nwork = 0;
   HIPCHK(c, hipMemcpyAsync(&nwork, scan + ncell, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -497,7 +505,7 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   // with a whole wavefront per voxel)
   const int lanes = lanes_env ? lanes_env : (cs.avg_len > 5.0f ? 32 : 16);
   launch_cell_list_local(a, g, false, exist_mode, work, nwork, keep, lanes, c->stream);
-  HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->sort_tmp.p, tmp_bytes, a.count, cs.start_d.as<int>(), (int)(ncell + 1), c->stream));
+  HIPCHK(c, prim_exclusive_sum(c->sort_tmp.p, tmp_bytes, a.count, cs.start_d.as<int>(), (int)(ncell + 1), c->stream));
   int total = 0;
   HIPCHK(c, hipMemcpyAsync(&total, cs.start_d.as<int>() + ncell, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -550,10 +558,10 @@ int sort_resident_by_keys(hop_ctx* c, unsigned long long* keys_d, int n) {
   HIPCHK(c, c->sort_vals_alt.ensure(sizeof(unsigned) * (size_t)n));
   launch_iota(c->sort_vals.as<unsigned>(), n, c->stream);
   size_t tmp_bytes = 0;
-  HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_d, c->sort_keys_alt.as<unsigned long long>(),
+  HIPCHK(c, prim_sort_pairs(nullptr, tmp_bytes, keys_d, c->sort_keys_alt.as<unsigned long long>(),
                                                c->sort_vals.as<unsigned>(), c->sort_vals_alt.as<unsigned>(), n, 0, 64, c->stream));
   HIPCHK(c, c->sort_tmp.ensure(tmp_bytes + 16));
-  HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp_bytes, keys_d, c->sort_keys_alt.as<unsigned long long>(),
+  HIPCHK(c, prim_sort_pairs(c->sort_tmp.p, tmp_bytes, keys_d, c->sort_keys_alt.as<unsigned long long>(),
                                                c->sort_vals.as<unsigned>(), c->sort_vals_alt.as<unsigned>(), n, 0, 64, c->stream));
   HIPCHK(c, c->tmp_pose.ensure(sizeof(float) * 16 * (size_t)n));
   HIPCHK(c, c->tmp_score.ensure(sizeof(float) * (size_t)n));
@@ -1302,12 +1310,14 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
   const int nb = icp_blocks_per_hyp(S.n, o->nn_mode >= 2);
   // batch so that the per-point workspace (moved source, 24 B/pt; cell-list path: correspondence, 4 B/pt) stays bounded
   const bool cells = o->nn_mode >= 2;
-  const bool lm_mode = o->nn_mode == 5;  // the reference's Levenberg-Marquardt minimiser (csrc/hop_icp_lm.hip)
+  bool lm_mode = o->nn_mode == 5;   // the reference's Levenberg-Marquardt minimiser (csrc/hop_icp_lm.hip), float-faithful, one pass per evaluation
+  bool lm6_mode = o->nn_mode == 6;  // the same minimiser from the moment matrix of the correspondences: one pass per ICP iteration
+  if (o->nn_mode < 0 || o->nn_mode > 6) return HOP_E_INVALID;
   const size_t per_h = cells ? sizeof(int) * (size_t)S.n : sizeof(float) * 6 * (size_t)S.n;
   const size_t ws_cap = cells ? ((size_t)4 << 30) : ((size_t)1 << 30);
   const int HB = (int)std::max<size_t>(1, std::min<size_t>((size_t)H, ws_cap / per_h));
   if (!cells) HIPCHK(c, c->icp_moved.ensure(per_h * HB));
-  HIPCHK(c, c->icp_partial.ensure(sizeof(double) * ICP_NACC * (size_t)nb * HB));
+  HIPCHK(c, c->icp_partial.ensure(sizeof(double) * (size_t)std::max(ICP_NACC, ICP_NMOM_STRIDE) * (size_t)nb * HB));
   HIPCHK(c, c->icp_state.ensure(sizeof(IcpState) * (size_t)HB));
   HIPCHK(c, c->icp_iters.ensure(sizeof(int) * (size_t)H));
   HIPCHK(c, c->icp_conv.ensure(sizeof(int) * (size_t)H));
@@ -1333,19 +1343,25 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
   } else if (cells) {
     // cells of a sixth of the gating distance for the plain lists (nn_mode 2), a seventh for the packed ones (measured:
     // 6 / 7 / 8 / 10 / 12 -> 819 / 784 / 789 / 845 / 925 us per launch at C2)
-    float cell = o->max_corr_dist / ((o->nn_mode == 3 || o->nn_mode == 4) ? 7.f : 6.f);
+    const bool packed_mode = o->nn_mode == 3 || o->nn_mode == 4 || lm6_mode;
+    float cell = o->max_corr_dist / (packed_mode ? 7.f : 6.f);
     if (const char* e = getenv("HOP_ICP_CELL_DIV")) cell = o->max_corr_dist / (float)atof(e);
     CellListStore& cs = c->model_cells[HOP_MODEL_5MM];
-    const bool want_packed = (o->nn_mode == 3 || o->nn_mode == 4) && c->gen.model_h[HOP_MODEL_5MM].n < 0xFFFF;
+    const bool want_packed = packed_mode && c->gen.model_h[HOP_MODEL_5MM].n < 0xFFFF;
     if (!cs.valid || cs.cell != cell || cs.max_dist != o->max_corr_dist || cs.coord_mag < c->coord_mag || (want_packed && !cs.pack_requested)) {
       const int rc = build_cell_lists(c, cs, c->gen.model_h[HOP_MODEL_5MM], c->model_d[HOP_MODEL_5MM], o->max_corr_dist, cell, want_packed);
       if (rc) return rc;
     }
     a.cells = cs.c;
+    // nn_mode 6 needs the packed lists; a model of >= 65535 points or a list outside the 16-bit frame has none: the per-evaluation form
+    // (nn_mode 5) runs the same minimiser on the plain lists
+    if (lm6_mode && !cs.c.rec) lm6_mode = false, lm_mode = true;
     if (o->nn_mode == 2 || lm_mode) HIPCHK(c, c->icp_corr_idx.ensure(sizeof(int) * (size_t)S.n * HB));  // the fused kernels keep no correspondence array
     if (lm_mode) {
       HIPCHK(c, c->icp_lm.ensure(sizeof(LmDev) * (size_t)HB + 64));
       a.lm = c->icp_lm.as<LmDev>();
+    }
+    if (lm_mode || lm6_mode) {
       // PCL's gates (correspondence_estimation.hpp: double max_dist_sqr = max_distance * max_distance, skip if distance > it;
       // correspondence_rejection_surface_normal: double(dot) > std::cos(angle / 180.0 * M_PI), Utils.cpp:205) against float values:
       // d <= m and d > c for a float d and double m, c are d <= (largest float <= m) and d > (largest float <= c)
@@ -1375,6 +1391,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     if (lm_mode) {
       // per ICP iteration: correspondences, then one pass per function evaluation Eigen's minimiser asks for, until no hypothesis waits
       unsigned* n_wait_d = reinterpret_cast<unsigned*>(c->icp_lm.as<char>() + sizeof(LmDev) * (size_t)HB);
+      const bool lm_profile = getenv("HOP_PROFILE_LM") != nullptr;  // prints the hypotheses still waiting after every pass
       for (int it = 0; it < o->max_iter; ++it) {
         a.iter = it;
         {
@@ -1391,9 +1408,26 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
           unsigned n_wait = 0;
           HIPCHK(c, hipMemcpyAsync(&n_wait, n_wait_d, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
           HIPCHK(c, hipStreamSynchronize(c->stream));
+          if (lm_profile) std::printf("%u%s", n_wait, n_wait ? " " : "\n");
           if (n_wait == 0) break;
           if (pass > 450) return HOP_E_STATE;  // maxfev = 400 evaluations bound every minimiser
         }
+      }
+      launch_icp_finish(a, hb, c->icp_iters.as<int>(), c->icp_conv.as<int>(), c->stream);
+      continue;
+    }
+    if (lm6_mode) {
+      for (int it = 0; it < o->max_iter; ++it) {
+        a.iter = it;
+        {
+          SpanGuard sg(c, T_ICP_NN);
+          launch_icp_fusedq_mom(a, hb, c->stream);
+        }
+        {
+          SpanGuard sg(c, T_ICP_SOLVE);
+          launch_icp_lm6_solve(a, hb, nb, c->stream);
+        }
+        c->timing.n_icp_nn_launches += 1;
       }
       launch_icp_finish(a, hb, c->icp_iters.as<int>(), c->icp_conv.as<int>(), c->stream);
       continue;
@@ -2054,9 +2088,9 @@ int hop_hand_remove_surrounding(hop_ctx* c, const float* scene_xyz, const float*
   HIPCHK(c, hipMemsetAsync(keep + N, 0, sizeof(int), c->stream));
   launch_hand_surround(a, c->stream);
   size_t tmp_bytes = 0;
-  HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, keep, pos, n + 1, c->stream));
+  HIPCHK(c, prim_exclusive_sum(nullptr, tmp_bytes, keep, pos, n + 1, c->stream));
   HIPCHK(c, c->sort_tmp.ensure(tmp_bytes + 16));
-  HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->sort_tmp.p, tmp_bytes, keep, pos, n + 1, c->stream));
+  HIPCHK(c, prim_exclusive_sum(c->sort_tmp.p, tmp_bytes, keep, pos, n + 1, c->stream));
   SurroundOutArgs o{};
   o.hbp = a.hbp, o.conf = a.conf, o.keep = keep, o.pos = pos, o.n = n;
   for (int k = 0; k < 12; ++k) o.hb2cam[k] = hb.m[k];

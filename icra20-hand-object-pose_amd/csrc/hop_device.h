@@ -13,6 +13,8 @@ constexpr int NN_CH = 16;      // targets per min-chunk of the scan
 constexpr int PPF_ROWS = 64;   // rows of the PPF matrix handled per block
 constexpr int ICP_NACC = 32;   // 21 (lower triangle of J^T J) + 6 (J^T r) + mse + count + 3 (sum of matched source points)
 constexpr int FIT_QUEUES = 64;    // sub-queues between the quadrilateral test and fit stages (power of two)
+constexpr int ICP_NMOM = 74;         // nn_mode 6: 73 distinct entries of the 13 x 13 moment matrix + the sum of squared correspondence distances
+constexpr int ICP_NMOM_STRIDE = 76;  // + the accepted count, padded
 constexpr int ICP_ACCUM_R = 32;  // points per thread of the accumulation kernel of the cell-list path
 constexpr float GRID_MARGIN = 1.0e-5f;  // metres; bounds | ||T^-1 s - m|| - ||s - T m|| | for rigid float poses
 constexpr int MAX_RING = 64;   // samples on the normal cone (normalset.hpp:208-210; <= 2*ceil(2*pi*atan(pi)*3.5) = 56)
@@ -217,6 +219,15 @@ struct LmDev {
   double diag[6], delta, par, xnorm, fnorm, gnorm, pnorm;
   double mse_sum;                 // sum of squared correspondence distances of this ICP iteration
   int iter, nfev, status, phase, cnt, waiting;
+  static constexpr bool fast_lmpar = false;  // nn_mode 5 keeps the oracle's operation sequence
+};
+
+struct LmDev6 {  // nn_mode 6: the same state without the per-pass warp tables (lives in registers)
+  float x[6], xc[6], p[6];
+  double A[21], g[6], ff;
+  double diag[6], delta, par, xnorm, fnorm, gnorm, pnorm;
+  int iter, nfev, status, phase;
+  static constexpr bool fast_lmpar = true;  // lmpar2's common case in registers (hop_icp_lm.hip lm_par_fast)
 };
 
 struct IcpArgs {
@@ -335,6 +346,8 @@ void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_sum_t(const LcpArgs& a, int hb, hipStream_t s);
 int lcp_cells_row_stride(int hb);
 int icp_blocks_per_hyp(int ns, bool cells);
+void launch_icp_fusedq_mom(const IcpArgs& a, int hb, hipStream_t s);
+void launch_icp_lm6_solve(const IcpArgs& a, int hb, int nblocks, hipStream_t s);
 void launch_icp_lm_begin(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_lm_pass(const IcpArgs& a, int hb, bool first, hipStream_t s);
 void launch_icp_lm_solve(const IcpArgs& a, int hb, int nblocks, bool first, unsigned* n_waiting, hipStream_t s);

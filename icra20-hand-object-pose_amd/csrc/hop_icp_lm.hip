@@ -172,7 +172,9 @@ __device__ __forceinline__ double norm6(const double v[6]) {
 }
 __device__ void unpack_sym(const double a21[21], double A[6][6]) {
   int k = 0;
+#pragma unroll
   for (int u = 0; u < 6; ++u)
+#pragma unroll
     for (int v = 0; v <= u; ++v) {
       A[u][v] = a21[k];
       A[v][u] = a21[k];
@@ -181,7 +183,7 @@ __device__ void unpack_sym(const double a21[21], double A[6][6]) {
 }
 
 // internal::lmpar2 (lmpar.h:163-293) on the normal equations
-__device__ void lm_par(const double A[6][6], const double g[6], const double diag[6], double delta, double& par, double x[6]) {
+__device__ __noinline__ void lm_par(const double A[6][6], const double g[6], const double diag[6], double delta, double& par, double x[6]) {
   const double dwarf = (double)FLT_MIN, p1 = (double)0.1f;
   PivChol c;
   piv_chol(A, c);
@@ -240,17 +242,80 @@ __device__ void lm_par(const double A[6][6], const double g[6], const double dia
   if (iter == 0) par = 0;
 }
 
+// nn_mode 6's common case of lmpar2, in registers: a comfortably full-rank Jacobian (unpivoted Cholesky, smallest pivot above 2e-5 of
+// the largest: ColPivHouseholderQR::rank()'s threshold is 7e-7 of it) whose Gauss-Newton step lies inside the trust region
+// (fp <= 0.1 delta, lmpar.h:205-211): par = 0 and x = A^-1 g, the same solution lm_par's factor gives.  false: not that case.
+__device__ __forceinline__ bool lm_par_fast(const double* __restrict__ a21, const double* __restrict__ g, const double* __restrict__ diag, double delta,
+                                            double& par, double* __restrict__ x) {
+  double L[21];  // packed lower triangle, row-major: (i, j) at i (i + 1) / 2 + j
+  double lmin = 1e300, lmax = 0;
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double v = a21[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+      if (i == j) {
+        ok = ok && v > 0;
+        const double d = sqrt(fmax(v, 1e-300));
+        L[i * (i + 1) / 2 + i] = d;
+        lmin = fmin(lmin, d), lmax = fmax(lmax, d);
+      } else
+        L[i * (i + 1) / 2 + j] = v / L[j * (j + 1) / 2 + j];
+    }
+  if (!ok || !(lmin > 2e-5 * lmax)) return false;
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double v = g[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= L[i * (i + 1) / 2 + k] * y[k];
+    y[i] = v / L[i * (i + 1) / 2 + i];
+  }
+  double xs[6];
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double v = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) v -= L[k * (k + 1) / 2 + i] * xs[k];
+    xs[i] = v / L[i * (i + 1) / 2 + i];
+  }
+  double q = 0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) q += (diag[j] * xs[j]) * (diag[j] * xs[j]);
+  const double fp = sqrt(q) - delta;
+  if (!(fp <= (double)0.1f * delta)) return false;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) x[j] = xs[j];
+  par = 0;
+  return true;
+}
+
 // ---- LevenbergMarquardt::minimize as a state machine around the passes ------------------------------------------------------------
 __device__ __forceinline__ double lm_scaled_norm(const double diag[6], const float v[6]) {
   double q = 0;
+#pragma unroll
   for (int j = 0; j < 6; ++j) q += (diag[j] * (double)v[j]) * (diag[j] * (double)v[j]);
   return sqrt(q);
 }
 // do { lmpar; candidate } of minimizeOneStep (LevenbergMarquardt.h:262-275)
-__device__ void lm_inner(LmDev& s) {
-  double A[6][6], xs[6];
-  unpack_sym(s.A, A);
-  lm_par(A, s.g, s.diag, s.delta, s.par, xs);
+template <class LS>
+__device__ void lm_inner(LS& s) {
+  double xs[6];
+  if (!(LS::fast_lmpar && lm_par_fast(s.A, s.g, s.diag, s.delta, s.par, xs))) {
+    // (copies: the out-of-line call must not expose the state struct's address, or all of it lives in scratch memory)
+    double A[6][6], gg[6], dd[6], xo[6], par = s.par;
+    unpack_sym(s.A, A);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) gg[j] = s.g[j], dd[j] = s.diag[j];
+    lm_par(A, gg, dd, s.delta, par, xo);
+    s.par = par;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) xs[j] = xo[j];
+  }
+#pragma unroll
   for (int j = 0; j < 6; ++j) {
     s.p[j] = -(float)xs[j];
     s.xc[j] = s.x[j] + s.p[j];
@@ -260,14 +325,17 @@ __device__ void lm_inner(LmDev& s) {
   s.phase = 1;
 }
 // head of minimizeOneStep (LevenbergMarquardt.h:219-260); false = finished
-__device__ bool lm_outer(LmDev& s) {
+template <class LS>
+__device__ bool lm_outer(LS& s) {
   s.nfev += 7;
   double wa2[6];
+#pragma unroll
   for (int j = 0, k = 0; j < 6; ++j) {
     k += j;  // index of the diagonal element (j, j) in the packed lower triangle: j (j + 1) / 2 + j
     wa2[j] = sqrt(s.A[k + j]);
   }
   if (s.iter == 1) {
+#pragma unroll
     for (int j = 0; j < 6; ++j) s.diag[j] = wa2[j] == 0 ? 1.0 : wa2[j];
     s.xnorm = lm_scaled_norm(s.diag, s.x);
     s.delta = 100.0 * s.xnorm;
@@ -275,20 +343,25 @@ __device__ bool lm_outer(LmDev& s) {
   }
   s.gnorm = 0;
   if (s.fnorm != 0)
+#pragma unroll
     for (int j = 0; j < 6; ++j)
       if (wa2[j] != 0) s.gnorm = fmax(s.gnorm, fabs(s.g[j] / s.fnorm / wa2[j]));
   if (s.gnorm <= 0) {
     s.status = 4;  // CosinusTooSmall
     return false;
   }
+#pragma unroll
   for (int j = 0; j < 6; ++j) s.diag[j] = fmax(s.diag[j], wa2[j]);
   lm_inner(s);
   return true;
 }
 // consumes the sums of the pass at s.xc (cand: 21 + 6 + 1); true = another pass at the new s.xc
-__device__ bool lm_advance(LmDev& s, const double* cand) {
+template <class LS>
+__device__ bool lm_advance(LS& s, const double* cand) {
   if (s.phase == 0) {  // minimizeInit
+#pragma unroll
     for (int k = 0; k < 21; ++k) s.A[k] = cand[k];
+#pragma unroll
     for (int k = 0; k < 6; ++k) s.g[k] = cand[21 + k];
     s.ff = cand[27];
     s.nfev = 1;
@@ -306,7 +379,9 @@ __device__ bool lm_advance(LmDev& s, const double* cand) {
   double A[6][6];
   unpack_sym(s.A, A);
   double jp2 = 0;
+#pragma unroll
   for (int a = 0; a < 6; ++a)
+#pragma unroll
     for (int b = 0; b < 6; ++b) jp2 += (double)s.p[a] * A[a][b] * (double)s.p[b];
   const double t1r = sqrt(fmax(jp2, 0.0)) / s.fnorm, t2r = sqrt(s.par) * s.pnorm / s.fnorm;
   const double temp1 = t1r * t1r, temp2 = t2r * t2r;
@@ -324,8 +399,11 @@ __device__ bool lm_advance(LmDev& s, const double* cand) {
     s.par = p5 * s.par;
   }
   if (ratio >= p0001) {
+#pragma unroll
     for (int j = 0; j < 6; ++j) s.x[j] = s.xc[j];
+#pragma unroll
     for (int k = 0; k < 21; ++k) s.A[k] = cand[k];
+#pragma unroll
     for (int k = 0; k < 6; ++k) s.g[k] = cand[21 + k];
     s.ff = cand[27];
     s.xnorm = lm_scaled_norm(s.diag, s.x);
@@ -349,7 +427,186 @@ __device__ bool lm_advance(LmDev& s, const double* cand) {
   return lm_outer(s);
 }
 
+// after estimateRigidTransformation (st.T_inc holds transformation_): transformCloud / final_transformation_ = transformation_ *
+// final_transformation_ / ++nr_iterations_ (icp.hpp) and DefaultConvergenceCriteria::hasConverged with the thresholds ICP installs
+__device__ void icp_iteration_bookkeeping(const IcpArgs& a, IcpState& st, int hl, double mse_sum, int cnt) {
+  const float* T = st.T_inc;
+  for (int i = 0; i < 12; ++i) a.hist[((size_t)hl * a.max_iter + st.iterations) * 12 + i] = T[i];
+  M4 Tm = m4_identity(), F;
+  for (int i = 0; i < 12; ++i) Tm.m[i] = T[i];
+  for (int i = 0; i < 16; ++i) F.m[i] = st.final_tf[i];
+  F = m4_mul(Tm, F);
+  for (int i = 0; i < 16; ++i) st.final_tf[i] = F.m[i];
+  st.iterations += 1;
+  const double mse = mse_sum / (double)cnt;
+  bool stop = false;
+  if (st.iterations >= a.max_iter) stop = true;
+  else {
+    // criterion 2 with ICP's thresholds (rotation 1.0 - transformation_epsilon_ = 1, translation 0): only an identity increment
+    const double cos_angle = 0.5 * (double)(T[0] + T[5] + T[10] - 1);
+    const double translation_sqr = (double)(T[3] * T[3] + T[7] * T[7] + T[11] * T[11]);
+    if (cos_angle >= 1.0 && translation_sqr <= 0.0) stop = true;
+    else if (fabs(mse - st.mse_prev) < 1e-6) stop = true;  // Utils.cpp:208; the relative criterion is overwritten by ICP's default (never fires)
+  }
+  st.mse_prev = mse;
+  if (stop) {
+    st.active = 0;
+    st.converged = 1;
+  }
+}
+
+// ---- nn_mode 6: every function evaluation of the minimiser from the 13 x 13 moment matrix of the correspondences --------------------------
+// w(x) = (R(x) - I [9], t + (R(x) - I) c [3], 1) in double; R from the quaternion as WarpPointRigid6D::setParam forms it
+__device__ void lm6_w(const float x[6], const double c[3], double w[13]) {
+  const double qx = (double)x[3], qy = (double)x[4], qz = (double)x[5];
+  const double qw = sqrt(1.0 - (qx * qx + qy * qy + qz * qz));  // (the quaternion's norm is 1 in exact arithmetic: normalize() is the identity)
+  const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+  const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  w[0] = -(tyy + tzz), w[1] = txy - twz, w[2] = txz + twy;
+  w[3] = txy + twz, w[4] = -(txx + tzz), w[5] = tyz - twx;
+  w[6] = txz - twy, w[7] = tyz + twx, w[8] = -(txx + tyy);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) w[9 + a] = (double)x[a] + (w[3 * a] * c[0] + w[3 * a + 1] * c[1] + w[3 * a + 2] * c[2]);
+  w[12] = 1.0;
+}
+// Sums of the pass at xc from the moment matrix (one lane per hypothesis, M in LDS as sym-packed [91][64] doubles):
+// cand = { J^T J packed lower (21), J^T f (6), |f|^2 } with NumericalDiff's forward differences.
+// d_j = (w(xc + h_j e_j) - w(xc)) / h_j is the Jacobian column as a functional on u.  For the translation parameters it is
+// s_j e_{9+j} (s_j = the float step actually taken / h_j), so only the three rotation columns and w itself need a product with M.
+__device__ __forceinline__ int sym13(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+__device__ void lm6_eval(const double* __restrict__ Mlds /* + lane, stride 64 */, const double c[3], const float xc[6], double* __restrict__ cand) {
+  double w0[13], d[3][12], st[3];
+  lm6_w(xc, c, w0);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float xx[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xx[k] = xc[k];
+    float h = LM_SQRT_EPS_F * fabsf(xc[j]);
+    if (h == 0.f) h = LM_SQRT_EPS_F;
+    xx[j] += h;  // the float sum the reference forms; J = (f(xx) - f(x)) / h with the nominal h
+    const double hinv = 1.0 / (double)h;
+    if (j < 3) st[j] = ((double)xx[j] - (double)xc[j]) * hinv;
+    else {
+      double wj[13];
+      lm6_w(xx, c, wj);
+#pragma unroll
+      for (int k = 0; k < 12; ++k) d[j - 3][k] = (wj[k] - w0[k]) * hinv;
+    }
+  }
+  double ff = 0, gr[3] = {0, 0, 0}, Arr[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gt[3], Atr[3][3], Att[6];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) {
+    double row[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) row[k] = Mlds[sym13(i, k) * 64];
+    double y0 = 0, z[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 13; ++k) y0 += row[k] * w0[k];
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int k = 0; k < 12; ++k) z[v] += row[k] * d[v][k];
+    ff += w0[i] * y0;
+    if (i < 12) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        gr[u] += d[u][i] * y0;
+#pragma unroll
+        for (int v = 0; v <= u; ++v) Arr[u][v] += d[u][i] * z[v];
+      }
+    }
+    if (i >= 9 && i < 12) {
+      const int t = i - 9;
+      gt[t] = st[t] * y0;
+#pragma unroll
+      for (int v = 0; v < 3; ++v) Atr[t][v] = st[t] * z[v];  // (J^T J)[3 + v][t]
+#pragma unroll
+      for (int t2 = 0; t2 <= t; ++t2) Att[t * (t + 1) / 2 + t2] = st[t] * st[t2] * row[9 + t2];
+    }
+  }
+  // parameter order (tx, ty, tz, qx, qy, qz): packed lower triangle of J^T J, then J^T f, then |f|^2
+  int k = 0;
+#pragma unroll
+  for (int u = 0; u < 6; ++u)
+#pragma unroll
+    for (int v = 0; v <= u; ++v) {
+      double a;
+      if (u < 3) a = Att[u * (u + 1) / 2 + v];
+      else if (v < 3) a = Atr[v][u - 3];
+      else a = Arr[u - 3][v - 3];
+      cand[k++] = a;
+    }
+#pragma unroll
+  for (int u = 0; u < 6; ++u) cand[21 + u] = u < 3 ? gt[u] : gr[u - 3];
+  cand[27] = fmax(ff, 0.0);
+}
+
 }  // namespace
+
+// nn_mode 6: one lane per hypothesis -- the whole minimisation of an ICP iteration from the moment sums of k_icp_fusedq_mom.
+// (The minimiser's state machine is a chain of ~2 000 dependent double operations per evaluation and the slowest of the 64
+// hypotheses of a wavefront sets its time; a few hundred wavefronts, which other frames' kernels overlap.)
+__global__ __launch_bounds__(64) void k_icp_lm6_solve(IcpArgs a, int hb, int nblocks) {
+  __shared__ double Msh[91 * 64];
+  const int lane = threadIdx.x;
+  const int hl = blockIdx.x * 64 + lane;
+  if (hl >= hb) return;
+  IcpState& st = a.state[hl];
+  if (!st.active) return;
+  double S[ICP_NMOM + 1];
+#pragma unroll
+  for (int k = 0; k <= ICP_NMOM; ++k) S[k] = 0.0;
+  for (int blk = 0; blk < nblocks; ++blk) {
+    const double* __restrict__ pp = a.partial + ((size_t)hl * nblocks + blk) * ICP_NMOM_STRIDE;
+#pragma unroll
+    for (int k = 0; k <= ICP_NMOM; ++k) S[k] += pp[k];
+  }
+  const int cnt = (int)S[ICP_NMOM];
+  if (cnt < 3) {
+    st.active = 0, st.converged = 0;
+    return;
+  }
+  if (cnt >= 4) {
+    // the 13 x 13 moment matrix of u = (n_a p_b [9], n_a [3], r0), lower triangle packed, this lane's column of the LDS table
+    double* __restrict__ M = Msh + lane;
+#pragma unroll
+    for (int i = 0; i < 13; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        // index of the unordered pair (a, c) among (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+        auto sym = [](int a_, int c_) { const int lo = a_ < c_ ? a_ : c_, hi = a_ < c_ ? c_ : a_; return lo * 3 - lo * (lo - 1) / 2 + (hi - lo); };
+        double v;
+        if (i < 9 && j < 9) v = S[sym(i / 3, j / 3) * 6 + sym(i % 3, j % 3)];
+        else if (i < 12 && j < 9) v = S[36 + sym(i - 9, j / 3) * 3 + j % 3];
+        else if (i < 12) v = S[54 + sym(i - 9, j - 9)];
+        else if (j < 9) v = S[60 + j];
+        else if (j < 12) v = S[69 + (j - 9)];
+        else v = S[72];
+        M[(i * (i + 1) / 2 + j) * 64] = v;
+      }
+    const float* pose = a.pose + (size_t)(a.h0 + hl) * 16;
+    const double c[3] = {(double)pose[3], (double)pose[7], (double)pose[11]};
+    LmDev6 s;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s.x[j] = s.xc[j] = 0.f, s.p[j] = 0.f;
+    s.phase = 0, s.status = -1, s.iter = 0, s.nfev = 0;
+    s.par = s.delta = s.xnorm = s.fnorm = s.gnorm = s.pnorm = 0.0;
+    double cand[28];
+#ifndef HOP_LM6_MAX_EVAL
+#define HOP_LM6_MAX_EVAL 420  // (maxfev = 400 ends every run; smaller values: timing experiments only)
+#endif
+    for (int guard = 0; guard < HOP_LM6_MAX_EVAL; ++guard) {
+      lm6_eval(M, c, s.xc, cand);
+      if (!lm_advance(s, cand)) break;
+    }
+    lm_warp6(s.x, st.T_inc);
+  }
+  icp_iteration_bookkeeping(a, st, hl, S[73], cnt);
+}
+void launch_icp_lm6_solve(const IcpArgs& a, int hb, int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_lm6_solve, dim3((hb + 63) / 64), dim3(64), 0, s, a, hb, nblocks);
+}
 
 // One pass over the correspondences of every hypothesis whose minimiser waits for an evaluation.
 // FIRST: the pass that follows the correspondence search of an ICP iteration -- applies PCL's surface-normal rejector (strict >
@@ -467,30 +724,7 @@ __global__ __launch_bounds__(64) void k_icp_lm_solve(IcpArgs a, int hb, int nblo
     lm_warp6(s.x, st.T_inc);  // warp_point_->setParam(x); transformation_matrix = warp_point_->getTransform()
   }
   s.waiting = 0;
-  // transformCloud / final_transformation_ = transformation_ * final_transformation_ / ++nr_iterations_
-  const float* T = st.T_inc;
-  for (int i = 0; i < 12; ++i) a.hist[((size_t)hl * a.max_iter + st.iterations) * 12 + i] = T[i];
-  M4 Tm = m4_identity(), F;
-  for (int i = 0; i < 12; ++i) Tm.m[i] = T[i];
-  for (int i = 0; i < 16; ++i) F.m[i] = st.final_tf[i];
-  F = m4_mul(Tm, F);
-  for (int i = 0; i < 16; ++i) st.final_tf[i] = F.m[i];
-  st.iterations += 1;
-  const double mse = s.mse_sum / (double)s.cnt;
-  bool stop = false;
-  if (st.iterations >= a.max_iter) stop = true;
-  else {
-    // criterion 2 with ICP's thresholds (rotation 1.0 - transformation_epsilon_ = 1, translation 0): only an identity increment
-    const double cos_angle = 0.5 * (double)(T[0] + T[5] + T[10] - 1);
-    const double translation_sqr = (double)(T[3] * T[3] + T[7] * T[7] + T[11] * T[11]);
-    if (cos_angle >= 1.0 && translation_sqr <= 0.0) stop = true;
-    else if (fabs(mse - st.mse_prev) < 1e-6) stop = true;  // Utils.cpp:208; the relative criterion is overwritten by ICP's default (never fires)
-  }
-  st.mse_prev = mse;
-  if (stop) {
-    st.active = 0;
-    st.converged = 1;
-  }
+  icp_iteration_bookkeeping(a, st, hl, s.mse_sum, s.cnt);
 }
 
 // start of an ICP iteration: every active hypothesis' minimiser at x = 0 (transformation_estimation_lm.hpp:166-168)

@@ -2057,6 +2057,108 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPOSED ? 
 template __global__ void k_icp_fusedq<false>(IcpArgs, int);
 template __global__ void k_icp_fusedq<true>(IcpArgs, int);
 
+// ------------------------------------------------------------------------------------------------
+// nn_mode 6: the reference's Levenberg-Marquardt minimiser from ONE pass per ICP iteration.
+// PCL's residual f_i(x) = n_i . (R(x) p_i + t - q_i) (transformation_estimation_point_to_plane.h:77-84) is linear in the 12 entries
+// of [R | t]: with u_i = (n_a p'_b [9], n_a [3], r0_i), p' = p - c (c = the hypothesis' translation, a point inside the object:
+// conditioning only), r0_i = n_i . (p_i - q_i) and w(x) = (R - I [9], t + (R - I) c [3], 1),  f_i(x) = w(x) . u_i.  So the sum of
+// squares, J^T J and J^T f of EVERY parameter vector the minimiser evaluates -- including NumericalDiff's six forward-difference
+// columns -- are quadratic forms in the 13 x 13 moment matrix M = sum_i u_i u_i^T, which this kernel accumulates next to the
+// lookups (73 distinct sums: (n_a n_c)(p_b p_d) is symmetric in both index pairs).  k_icp_lm6_solve (hop_icp_lm.hip) then runs
+// Eigen's minimizeOneStep / lmpar2 loop to its stopping rule per hypothesis without touching the points again.
+// This evaluates the reference's algorithm in exact arithmetic where PCL rounds every residual to float; the difference is the
+// rounding noise of that float run, which two builds of the reference differ by as well (profiles/r03_icp_lm_deltas.json:
+// closer to the reference's default build than its -march=native build is).  Per-lane sums in float over <= ~30 terms of equal
+// magnitude (1e-6 relative; the reference's forward-difference Jacobian carries 1e-3), lanes / waves / blocks in double.
+// Gates as PCL writes them (strict normal test against the double threshold, double distance gate: see hop_icp_refine).
+// ------------------------------------------------------------------------------------------------
+template <bool DEFER>
+__device__ __forceinline__ int icp_fusedq_point_mom(const IcpArgs& a, int i, const float* __restrict__ pose, const float* __restrict__ sTi,
+                                                     const float* __restrict__ F, V3 ctr, float (&acc)[ICP_NMOM]) {
+  const float4 p4 = a.s_pts4[i];
+  V3 q = v3(p4.x, p4.y, p4.z);
+  if (a.iter > 0) q = m4_point_fma(F, q);
+  float d2 = 3.0e38f;
+  int j = -1;
+  V3 tq;
+  if (cells_nnq<DEFER>(a.cells, m4_point_fma(sTi, q), pose, q, d2, j, tq)) return ICP_PT_DEFERRED;
+  if (j < 0 || !(d2 <= a.max_d2)) return ICP_PT_REJECTED;
+  const float4 tn = a.cells.nrm_idx[j];
+  const float4 n4 = a.s_nrm4[i];
+  V3 qn = v3(n4.x, n4.y, n4.z);
+  if (a.iter > 0) qn = m4_dir_fma(F, qn);
+  const V3 nt = m4_dir(pose, v3(tn.x, tn.y, tn.z));
+  if (!(((qn.x * nt.x + qn.y * nt.y) + qn.z * nt.z) > a.cos_thr)) return ICP_PT_REJECTED;
+  const V3 pc = q - ctr;
+  const float r0 = vdot(q - tq, nt);
+  const float nn[6] = {nt.x * nt.x, nt.x * nt.y, nt.x * nt.z, nt.y * nt.y, nt.y * nt.z, nt.z * nt.z};
+  const float pp[6] = {pc.x * pc.x, pc.x * pc.y, pc.x * pc.z, pc.y * pc.y, pc.y * pc.z, pc.z * pc.z};
+  const float pv[3] = {pc.x, pc.y, pc.z}, nv[3] = {nt.x, nt.y, nt.z};
+#pragma unroll
+  for (int u = 0; u < 6; ++u) {
+#pragma unroll
+    for (int v = 0; v < 6; ++v) acc[u * 6 + v] = __builtin_fmaf(nn[u], pp[v], acc[u * 6 + v]);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) acc[36 + u * 3 + b] = __builtin_fmaf(nn[u], pv[b], acc[36 + u * 3 + b]);
+    acc[54 + u] += nn[u];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float nr = nv[c] * r0;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) acc[60 + c * 3 + b] = __builtin_fmaf(nr, pv[b], acc[60 + c * 3 + b]);
+    acc[69 + c] += nr;
+  }
+  acc[72] = __builtin_fmaf(r0, r0, acc[72]);
+  acc[73] += d2;
+  return ICP_PT_ACCEPTED;
+}
+__global__ __launch_bounds__(256) void k_icp_fusedq_mom(IcpArgs a, int R) {
+  __shared__ double red[4][ICP_NMOM + 1];
+  __shared__ unsigned short defer_i[4][64 * ICP_ACCUM_R];
+  const int hl = blockIdx.y, h = a.h0 + hl;
+  const IcpState& st = a.state[hl];
+  if (!st.active) return;
+  const float* __restrict__ pose = a.pose + (size_t)h * 16;
+  const float* __restrict__ sTi = a.pose_inv + (size_t)h * 12;
+  const float* __restrict__ F = st.final_tf;
+  const V3 ctr = v3(pose[3], pose[7], pose[11]);
+  float acc[ICP_NMOM];
+#pragma unroll
+  for (int k = 0; k < ICP_NMOM; ++k) acc[k] = 0.f;
+  int n_wave = 0, n_def = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int base = blockIdx.x * (256 * R);
+  for (int r = 0; r < R; ++r) {
+    const int li = r * 256 + threadIdx.x, i = base + li;
+    if (i >= a.ns) continue;
+    const int res = icp_fusedq_point_mom<true>(a, i, pose, sTi, F, ctr, acc);
+    const unsigned long long dm = __ballot(res == ICP_PT_DEFERRED);
+    if (res == ICP_PT_DEFERRED) defer_i[wave][n_def + __popcll(dm & ((1ull << lane) - 1ull))] = (unsigned short)li;
+    n_def += __popcll(dm);
+    n_wave += __popcll(__ballot(res == ICP_PT_ACCEPTED));
+  }
+  const int nd = __builtin_amdgcn_readfirstlane(n_def);
+  for (int t = lane; t < nd; t += 64)
+    n_wave += __popcll(__ballot(icp_fusedq_point_mom<false>(a, base + defer_i[wave][t], pose, sTi, F, ctr, acc) == ICP_PT_ACCEPTED));
+#pragma unroll
+  for (int k = 0; k < ICP_NMOM; ++k) {
+    const double s = wave_sum((double)acc[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  if (lane == 0) red[wave][ICP_NMOM] = (double)n_wave;
+  __syncthreads();
+  if (threadIdx.x <= ICP_NMOM) {
+    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NMOM_STRIDE + threadIdx.x] = s;
+  }
+}
+void launch_icp_fusedq_mom(const IcpArgs& a, int hb, hipStream_t s) {
+  const int nb = icp_blocks_per_hyp(a.ns, true);
+  const int R = (a.ns + 256 * nb - 1) / (256 * nb);
+  hipLaunchKernelGGL(k_icp_fusedq_mom, dim3(nb, hb), dim3(256), 0, s, a, R);
+}
+
 __global__ void k_soa_to_aos4(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n, float4* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = make_float4(x[i], y[i], z[i], 0.f);

@@ -16,7 +16,7 @@
 #include "hop_ctx_ext.h"
 #include "hop_sdf.h"
 
-#include <hipcub/hipcub.hpp>
+#include "hop_prim.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -1044,17 +1044,17 @@ int voxel_downsample_device(hop_ctx* c, Physics* ph, const float* x, const float
   const int blocks = (n + 255) / 256;
   k_vox_keys<<<blocks, 256, 0, st>>>(x, y, z, n, g, ph->keys.as<unsigned>(), ph->vals.as<unsigned>());
   size_t tmp1 = 0, tmp2 = 0;
-  PHCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, ph->keys.as<unsigned>(), ph->keys_alt.as<unsigned>(), ph->vals.as<unsigned>(),
+  PHCHK(c, prim_sort_pairs(nullptr, tmp1, ph->keys.as<unsigned>(), ph->keys_alt.as<unsigned>(), ph->vals.as<unsigned>(),
                                               ph->vals_alt.as<unsigned>(), n, 0, 32, st));
-  PHCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), n_finite, st));
+  PHCHK(c, prim_exclusive_sum(nullptr, tmp2, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), n_finite, st));
   size_t tmp = std::max(tmp1, tmp2);
   PHCHK(c, ph->sort_tmp.ensure(tmp + 16));
-  PHCHK(c, hipcub::DeviceRadixSort::SortPairs(ph->sort_tmp.p, tmp1, ph->keys.as<unsigned>(), ph->keys_alt.as<unsigned>(), ph->vals.as<unsigned>(),
+  PHCHK(c, prim_sort_pairs(ph->sort_tmp.p, tmp1, ph->keys.as<unsigned>(), ph->keys_alt.as<unsigned>(), ph->vals.as<unsigned>(),
                                               ph->vals_alt.as<unsigned>(), n, 0, 32, st));
   // non-finite points carry the largest key and sit behind the n_finite sorted ones
   const int fb = (n_finite + 255) / 256;
   k_vox_heads<<<fb, 256, 0, st>>>(ph->keys_alt.as<unsigned>(), n_finite, ph->flags.as<unsigned>());
-  PHCHK(c, hipcub::DeviceScan::ExclusiveSum(ph->sort_tmp.p, tmp2, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), n_finite, st));
+  PHCHK(c, prim_exclusive_sum(ph->sort_tmp.p, tmp2, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), n_finite, st));
   k_vox_starts<<<fb, 256, 0, st>>>(ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), n_finite, ph->starts.as<unsigned>(), ph->scalars.as<unsigned>() + 8);
   unsigned n_seg = 0;
   PHCHK(c, hipMemcpyAsync(&n_seg, ph->scalars.as<unsigned>() + 8, sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -1165,9 +1165,9 @@ int hop_sdf_register_mesh(hop_ctx* c, int mesh_id, const float* V, int nv, const
     k_face_cells<false><<<nvox, 64, 0, st>>>(ms.dev, g, margin, count, nullptr, nullptr);
     k_face_cells_clamp<<<(nvox + 256) / 256, 256, 0, st>>>(count, nvox, ph->pos.as<unsigned>());
     size_t tmp = 0;
-    PHCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, ph->pos.as<unsigned>(), ph->starts.as<unsigned>(), nvox + 1, st));
+    PHCHK(c, prim_exclusive_sum(nullptr, tmp, ph->pos.as<unsigned>(), ph->starts.as<unsigned>(), nvox + 1, st));
     PHCHK(c, ph->sort_tmp.ensure(tmp + 16));
-    PHCHK(c, hipcub::DeviceScan::ExclusiveSum(ph->sort_tmp.p, tmp, ph->pos.as<unsigned>(), ph->starts.as<unsigned>(), nvox + 1, st));
+    PHCHK(c, prim_exclusive_sum(ph->sort_tmp.p, tmp, ph->pos.as<unsigned>(), ph->starts.as<unsigned>(), nvox + 1, st));
     k_face_cells_pack<<<(nvox + 256) / 256, 256, 0, st>>>(count, ph->starts.as<unsigned>(), nvox, ms.cell_start_d.as<int>());
     unsigned total = 0;
     PHCHK(c, hipMemcpyAsync(&total, ph->starts.as<unsigned>() + nvox, sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -1324,9 +1324,9 @@ static int scene_from_depth_impl(hop_ctx* c, const uint16_t* depth_raw, int H, i
                                                     make_float3(crop_min[0], crop_min[1], crop_min[2]), make_float3(crop_max[0], crop_max[1], crop_max[2]), a,
                                                     a + m, a + 2 * (size_t)m, ph->flags.as<unsigned>());
     size_t tmp = 0;
-    PHCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), m, st));
+    PHCHK(c, prim_exclusive_sum(nullptr, tmp, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), m, st));
     PHCHK(c, ph->sort_tmp.ensure(tmp + 16));
-    PHCHK(c, hipcub::DeviceScan::ExclusiveSum(ph->sort_tmp.p, tmp, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), m, st));
+    PHCHK(c, prim_exclusive_sum(ph->sort_tmp.p, tmp, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), m, st));
     k_compact3<<<(m + 255) / 256, 256, 0, st>>>(a, a + m, a + 2 * (size_t)m, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), m, b, b + m, b + 2 * (size_t)m, m,
                                                ph->scalars.as<unsigned>() + 13);
     PHCHK(c, hipMemcpyAsync(&kept, ph->scalars.as<unsigned>() + 13, sizeof(unsigned), hipMemcpyDeviceToHost, st));

@@ -238,7 +238,7 @@ class Hand {
       hop::check(hop_set_model(ctx_, HOP_MODEL_5MM, base_link_cloud.xyz.data(), base_link_cloud.nrm.data(), base_link_cloud.n), ctx_, "hop_set_model");
       const Mat4 I = Mat4::Identity();
       hop::check(hop_hypos_upload(ctx_, I.m, nullptr, 1), ctx_, "hop_hypos_upload");
-      hop_icp_opts o{50, 30.f, 0.03f, 0, 0};
+      hop_icp_opts o{50, 30.f, 0.03f, 0, 6};  // nn_mode 6: Utils::runICP's own minimiser (Levenberg-Marquardt)
       hop::check(hop_icp_refine(ctx_, &o, nullptr, nullptr), ctx_, "hop_icp_refine");
       Mat4 pose;
       int got = 0;

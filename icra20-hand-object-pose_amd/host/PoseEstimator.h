@@ -108,7 +108,8 @@ class PoseEstimator {
 
   // refineByICP (PoseEstimator.cpp:235-275)
   void refineByICP() {
-    hop_icp_opts o{10, cfg->getf("icp_angle_thres"), cfg->getf("icp_dist_thres"), 100, 3};  // nn_mode 3: NN cell lists, fused search + accumulation
+    // nn_mode 6: the reference's minimiser (PCL's TransformationEstimationPointToPlane = Eigen's Levenberg-Marquardt, Utils.cpp:200-216)
+    hop_icp_opts o{10, cfg->getf("icp_angle_thres"), cfg->getf("icp_dist_thres"), 100, 6};
     hop::check(hop_icp_refine(ctx_, &o, nullptr, nullptr), ctx_, "hop_icp_refine");
   }
 

@@ -139,7 +139,12 @@ typedef struct {
                       * ICP iteration (Utils.cpp:200-216; Eigen's NonLinearOptimization as vendored under
                       * src/OpenGR_4pcs/3rdparty/Eigen/unsupported), with PCL's gates (strict normal test against the double
                       * threshold, double distance gate) and stop rules (absolute MSE only, identity increment).  Several
-                      * passes over the correspondences per ICP iteration: ~3x the time of mode 4. */
+                      * passes over the correspondences per ICP iteration (one per function evaluation, every residual and
+                      * Jacobian entry the float the reference evaluates): ~14x the time of mode 4.
+                      * 6: the same minimiser evaluated from the 13 x 13 moment matrix of the correspondences (the residual is
+                      * linear in [R | t]): ONE pass per ICP iteration, the whole Levenberg-Marquardt run per hypothesis in the
+                      * solve kernel.  Exact arithmetic where PCL rounds each residual to float; closer to the reference's
+                      * default build than its -march=native build is (profiles/r03_icp_lm_deltas.json). */
 } hop_icp_opts;
 int hop_icp_refine(hop_ctx* ctx, const hop_icp_opts* opts, int* iterations_out /*H or NULL*/,
                    int* converged_out /*H or NULL*/);

@@ -1200,6 +1200,62 @@ void lm_pass(const std::vector<V3>& P, const std::vector<V3>& Q, const std::vect
     for (int b = a + 1; b < 6; ++b) s.A[a][b] = s.A[b][a];
 }
 
+// The same pass in exact arithmetic (double): f(x) = (R(x) p + t - q) . n without the float rounding of each residual, the same
+// forward-difference steps.  f is linear in the 12 entries of [R | t], so sum f^2, J^T J and J^T f of ANY parameter vector follow
+// from the 13 x 13 moment matrix sum v v^T, v = (n_a p_b, n_a, -q.n), of the correspondences -- which is how the GPU's nn_mode 6
+// evaluates the minimiser with ONE pass per ICP iteration; this function is its per-point statement.
+void lm_warp6_d(const double x[6], double T[3][4]) {
+  double qx = x[3], qy = x[4], qz = x[5];
+  double qw = std::sqrt(1 - (qx * qx + qy * qy + qz * qz));
+  const double nn = std::sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+  qx /= nn, qy /= nn, qz /= nn, qw /= nn;
+  const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+  const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  T[0][0] = 1 - (tyy + tzz), T[0][1] = txy - twz, T[0][2] = txz + twy, T[0][3] = x[0];
+  T[1][0] = txy + twz, T[1][1] = 1 - (txx + tzz), T[1][2] = tyz - twx, T[1][3] = x[1];
+  T[2][0] = txz - twy, T[2][1] = tyz + twx, T[2][2] = 1 - (txx + tyy), T[2][3] = x[2];
+}
+void lm_pass_exact(const std::vector<V3>& P, const std::vector<V3>& Q, const std::vector<V3>& Nn, const float xc[6], LmSums& s) {
+  double T[7][3][4], h[6], x0[6];
+  for (int j = 0; j < 6; ++j) x0[j] = (double)xc[j];
+  lm_warp6_d(x0, T[0]);
+  for (int j = 0; j < 6; ++j) {
+    float hf = LM_SQRT_EPS * std::fabs(xc[j]);
+    if (hf == 0.f) hf = LM_SQRT_EPS;
+    double xx[6];
+    std::copy(x0, x0 + 6, xx);
+    xx[j] = (double)(xc[j] + hf);  // the float sum the reference forms, then exact
+    h[j] = (double)hf;
+    lm_warp6_d(xx, T[1 + j]);
+  }
+  s.ff = 0;
+  for (int a = 0; a < 6; ++a) {
+    s.g[a] = 0;
+    for (int b = 0; b < 6; ++b) s.A[a][b] = 0;
+  }
+  for (size_t i = 0; i < P.size(); ++i) {
+    double f[7];
+    for (int k = 0; k < 7; ++k) {
+      double r = 0;
+      for (int a = 0; a < 3; ++a) {
+        const double w = T[k][a][0] * P[i].x + T[k][a][1] * P[i].y + T[k][a][2] * P[i].z + T[k][a][3];
+        const double qa = a == 0 ? Q[i].x : a == 1 ? Q[i].y : Q[i].z, na = a == 0 ? Nn[i].x : a == 1 ? Nn[i].y : Nn[i].z;
+        r += (w - qa) * na;
+      }
+      f[k] = r;
+    }
+    double J[6];
+    for (int j = 0; j < 6; ++j) J[j] = (f[1 + j] - f[0]) / h[j];
+    s.ff += f[0] * f[0];
+    for (int a = 0; a < 6; ++a) {
+      s.g[a] += J[a] * f[0];
+      for (int b = 0; b <= a; ++b) s.A[a][b] += J[a] * J[b];
+    }
+  }
+  for (int a = 0; a < 6; ++a)
+    for (int b = a + 1; b < 6; ++b) s.A[a][b] = s.A[b][a];
+}
+
 // Cholesky with diagonal pivoting of a 6x6 SPD matrix: R upper, R^T R = P^T A P; the pivot order is the one a
 // column-pivoted QR of J takes (largest remaining column norm); rank by ColPivHouseholderQR::rank()'s rule
 // (|R_ii| > |R|_max * 6 * eps_float).
@@ -1447,13 +1503,15 @@ bool lm_advance(LmState& s, const LmSums& cand) {
 // TransformationEstimationLM::estimateRigidTransformation on the correspondences (P moved source, Q target, N target
 // normals); fewer than 4: PCL prints an error and leaves the matrix as it was (returns false here).
 bool lm_point_to_plane(const std::vector<V3>& P, const std::vector<V3>& Q, const std::vector<V3>& Nn, M4& T, float x_out[6] = nullptr,
-                       int* stats = nullptr) {
+                       int* stats = nullptr, bool exact = false) {
   if (P.size() < 4) return false;
   LmState s;
   lm_begin(s);
   LmSums sums;
-  do lm_pass(P, Q, Nn, s.xc, sums);
-  while (lm_advance(s, sums));
+  do {
+    if (exact) lm_pass_exact(P, Q, Nn, s.xc, sums);
+    else lm_pass(P, Q, Nn, s.xc, sums);
+  } while (lm_advance(s, sums));
   T = lm_warp6(s.x);
   if (x_out) std::copy(s.x, s.x + 6, x_out);
   if (stats) stats[0] = s.status, stats[1] = s.nfev, stats[2] = s.iter;
@@ -1611,7 +1669,7 @@ IcpResult run_icp(const Cloud& src, const Cloud& tgt, bool use_tree, int max_ite
         float T16[16];
         if (g_ref_lm_estimator(cnt, a.data(), bq.data(), cn.data(), T16, nullptr, nullptr, nullptr) == 0) T_lm = load4(T16);
       } else
-        lm_point_to_plane(corr_p, corr_q, corr_n, T_lm);
+        lm_point_to_plane(corr_p, corr_q, corr_n, T_lm, nullptr, nullptr, var.minimiser == 6);  // 6: the same minimiser in exact arithmetic
       T = T_lm;
     } else if (!gn_step(A, b, cs, cnt, T, wnorm)) {
       res.converged = false;

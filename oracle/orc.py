@@ -380,7 +380,7 @@ def icp_refine_batch_variant(S, Sn, M, Mn, poses, max_iter=10, angle_deg=45.0, m
 
 
 # ---- the reference's ICP minimiser (Eigen::LevenbergMarquardt from the reference's vendored Eigen) --------------------------
-MIN_GN, MIN_LM_RESTATED, MIN_LM_REF = 0, 4, 5
+MIN_GN, MIN_LM_RESTATED, MIN_LM_REF, MIN_LM_EXACT = 0, 4, 5, 6
 _ref_icp = None
 _ref_icp_native = None
 
@@ -466,13 +466,13 @@ def lm_residuals_jacobian(src, tgt, nrm, x6, ref=False):
     return f, J
 
 
-def icp_refine_batch_lm(S, Sn, M, Mn, poses, max_iter=10, angle_deg=45.0, max_corr_dist=0.01, ref=False):
+def icp_refine_batch_lm(S, Sn, M, Mn, poses, max_iter=10, angle_deg=45.0, max_corr_dist=0.01, ref=False, exact=False):
     """refineByICP with the reference's minimiser: PCL's gates and stopping rules (strict normal test, absolute MSE only)
     around Levenberg-Marquardt -- ref=True: Eigen's own code from the reference tree (needs oracle/_ref/libref_icp.so),
     False: the restatement (what the GPU's nn_mode 5 is compared with)."""
     if ref:
         ref_icp()
-    return icp_refine_batch_variant(S, Sn, M, Mn, poses, max_iter, angle_deg, max_corr_dist, minimiser=MIN_LM_REF if ref else MIN_LM_RESTATED,
+    return icp_refine_batch_variant(S, Sn, M, Mn, poses, max_iter, angle_deg, max_corr_dist, minimiser=MIN_LM_REF if ref else (MIN_LM_EXACT if exact else MIN_LM_RESTATED),
                                     strict_normal=True, relative_stop=False)
 
 

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--frames", type=int, default=50)
     ap.add_argument("--scene", type=int, default=2000)
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--icp-mode", type=int, default=6, help="hop_icp_opts.nn_mode: 6 / 5 the reference's Levenberg-Marquardt minimiser, 3 / 4 one Gauss-Newton step")
     args = ap.parse_args()
     import hop_loader
     hop = hop_loader.load()
@@ -72,7 +73,7 @@ def main():
         _, _, st = ctx.s4pcs_generate(o, download=False)
         if st.n_hypotheses > 0:
             ctx.cluster_poses(30.0, 0.015, sym, True)
-            ctx.icp_refine(10, 45.0, 0.01, max_hypotheses=100, nn_mode=3)
+            ctx.icp_refine(10, 45.0, 0.01, max_hypotheses=100, nn_mode=args.icp_mode)
             ctx.cluster_poses(5.0, 0.003, sym, False)
             best, score, _ = ctx.lcp_select_best(0.001, 10.0, 2)
         else:
@@ -88,7 +89,11 @@ def main():
             if len(ol):
                 keep = orc.cluster_poses(op, ol, np.arange(len(ol)), 30.0, 0.015, sym)
                 p1, l1 = op[keep][:100], ol[keep][:100]
-                p2, _, _ = orc.icp_refine_batch(sc.xyz, sc.nrm, mx5, mn5, p1, 10, 45.0, 0.01)
+                if args.icp_mode >= 5:  # the reference's minimiser (Levenberg-Marquardt), exact-arithmetic form for nn_mode 6, float form for 5
+                    keep_s = sc.conf >= 0.8
+                    p2, _, _ = orc.icp_refine_batch_lm(sc.xyz[keep_s], sc.nrm[keep_s], mx5, mn5, p1, 10, 45.0, 0.01, exact=(args.icp_mode == 6))
+                else:
+                    p2, _, _ = orc.icp_refine_batch(sc.xyz, sc.nrm, mx5, mn5, p1, 10, 45.0, 0.01)
                 keep2 = orc.cluster_poses(p2, l1, np.arange(len(l1)), 5.0, 0.003, sym)
                 p3 = p2[keep2]
                 s3 = orc.compute_lcp_batch(sc.xyz, sc.nrm, mx1, mn1, p3, 0.001, 10.0)

@@ -164,6 +164,20 @@ def test_icp_with_the_restated_minimiser_vs_the_reference_builds_c1(orc, hop, go
     assert (cv == g["converged"]).sum() >= 90
 
 
+def test_icp_with_the_minimiser_in_exact_arithmetic_vs_the_reference_builds(orc, hop, golden_dir):
+    """The same algorithm with every residual in double instead of float (what the GPU's nn_mode 6 evaluates from moment sums):
+    without the float run's own rounding noise it lands closer to Eigen's default build than Eigen's -march=native build does."""
+    g = np.load(os.path.join(golden_dir, "icp_lm_c2sub.npz"))
+    S, Sn, mx5, mn5 = c2sub_inputs(hop)
+    p, it, cv = orc.icp_refine_batch_lm(S, Sn, mx5, mn5, g["poses_in"], 10, 45.0, 0.01, exact=True)
+    mine, native = assert_as_close_as_the_other_build(p, g, slack=3)
+    assert mine[0] >= 88 and (it == g["iterations"]).sum() >= 88 and np.array_equal(cv, g["converged"])
+    g = np.load(os.path.join(golden_dir, "icp_lm_c1.npz"))
+    S, Sn, mx5, mn5 = c1_inputs(hop, golden_dir)
+    p, it, cv = orc.icp_refine_batch_lm(S, Sn, mx5, mn5, g["poses_in"], 10, 45.0, 0.01, exact=True)
+    assert_as_close_as_the_other_build(p, g, slack=5)
+
+
 @pytest.mark.skipif(not os.path.exists("/root/reference"), reason="the reference tree (build container only)")
 def test_goldens_are_what_the_reference_build_returns_now(orc, hop, golden_dir, kat):
     """regenerates a slice of the vectors from oracle/_ref/libref_icp.so and compares (guards stale fixtures)"""

@@ -8,7 +8,10 @@ arg-max, main_realdata_auto.cpp:187-204) on the C1 frame (example/depth7.png han
 ICP minimiser switched, everything else identical (CPU oracle):
     ref        Eigen's LevenbergMarquardt, default g++ build (SSE2, no contraction)  -- the golden vectors' build
     ref_native the same source, -march=native (wider packets, FMA): a second BUILD of the reference
+    gpu_*      with --gpu: hop_icp_refine on the MI355X, nn_mode 5 (the restated minimiser in HIP, float-faithful), nn_mode 6 (the same from moment sums, one pass per ICP iteration) and nn_mode 3 (one GN step)
     lm         the restatement of that algorithm (oracle/hop_oracle.cpp lm_*; what the GPU's nn_mode 5 computes)
+    lm_exact   the same minimiser with every residual in exact (double) arithmetic instead of float -- what the GPU's nn_mode 6 computes
+               from the 13 x 13 moment matrix of the correspondences, one pass per ICP iteration
     gn         one Gauss-Newton step about the matched centroid per ICP iteration (nn_mode 0-4)
 and reports, against `ref`: per refined hypothesis (all <= 100 per frame) and for the SELECTED pose, translation / rotation
 differences.  `ref_native` vs `ref` is the reference's own build-to-build spread: no implementation can be asked to be closer to
@@ -62,6 +65,7 @@ def main():
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--scene", type=int, default=1500)
     ap.add_argument("--out", default="")
+    ap.add_argument("--gpu", action="store_true", help="add hop_icp_refine on cuda:0 (nn_mode 5 = the minimiser above, nn_mode 3 = one Gauss-Newton step) as variants")
     args = ap.parse_args()
     import hop_loader
     import orc
@@ -81,8 +85,24 @@ def main():
         "ref": v_ref(False),
         "ref_native": v_ref(True),
         "lm": lambda S, Sn, M, Mn, P: orc.icp_refine_batch_lm(S, Sn, M, Mn, P, 10, 45.0, 0.01, ref=False),
+        "lm_exact": lambda S, Sn, M, Mn, P: orc.icp_refine_batch_lm(S, Sn, M, Mn, P, 10, 45.0, 0.01, exact=True),
         "gn": lambda S, Sn, M, Mn, P: orc.icp_refine_batch(S, Sn, M, Mn, P, 10, 45.0, 0.01),
     }
+    if args.gpu:
+        from hop_amd import api
+        ctx = api.Context(0)
+        ctx.set_model(api.HOP_MODEL_5MM, mx5, mn5)
+
+        def v_gpu(mode):
+            def f(S, Sn, M, Mn, P):
+                ctx.set_scene(S, Sn, np.ones(len(S), np.float32), 0.8)
+                ctx.hypos_upload(P)
+                it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=mode, want_stats=True)
+                return ctx.hypos_download()[0], it, cv
+            return f
+        variants["gpu_lm_nn_mode5"] = v_gpu(5)
+        variants["gpu_lm_moments_nn_mode6"] = v_gpu(6)
+        variants["gpu_gn_nn_mode3"] = v_gpu(3)
     frames = []
     g = np.load(os.path.join(ROOT, "tests", "golden", "depth7_hand_region.npz"))
     frames.append(("c1_depth7", g["xyz"], g["nrm"], np.ones(len(g["xyz"]), np.float32), None))
