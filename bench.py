@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--particles", type=int, default=200)
     ap.add_argument("--hand-scene", type=int, default=20000)
     ap.add_argument("--verify-mode", type=int, default=2, help="0 brute-force LDS scan, 1 voxel grid, 2 EXIST-mode cell lists (identical counts)")
-    ap.add_argument("--nn-mode", type=int, default=4, help="ICP nearest neighbour: 0 brute force, 1 voxel grids, 2 NN cell lists, 3 packed NN cell lists "
+    ap.add_argument("--nn-mode", type=int, default=6, help="ICP nearest neighbour: 0 brute force, 1 voxel grids, 2 NN cell lists, 3 packed NN cell lists "
                     "with search and accumulation in one kernel (identical correspondences in modes 0-3), 4 = 3 with the increments "
                     "composed into one transform per iteration (poses equal to ~1e-6, tests/test_gpu_fullsize.py)")
     ap.add_argument("--lcp-mode", type=int, default=3, help="computeLCP: 0 brute force, 1 voxel grids, 2 NN cell lists with the reference's ordered "
@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--strong-scene", type=int, default=50000)
     ap.add_argument("--no-serial-frame", action="store_true", help="skip the extra undisturbed frame used for per-kernel timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-modes", action="store_true", help="skip the short runs of the other ICP / sum configurations after the timed region")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the separate measurement of the physics rejection (SURVEY 8f N1)")
     ap.add_argument("--physics-hyps", type=int, default=2048)
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
@@ -289,36 +290,95 @@ def host_cpp_leg(w):
                 "frame_ms_median": float(np.median(ms[1:])), "frame_ms_all": ms}
 
 
+def _cpu_identity():
+    """CPU model string and physical core count as lscpu reports them (from /proc/cpuinfo)."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                phys = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":", 1)[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return model, (len(cores) or (os.cpu_count() or 1))
+
+
 def cpu_baseline(w, budget_s):
-    """The oracle ("port", kd-tree NN, OpenMP on all host cores) on a bounded sample of the same workload."""
+    """the oracle ("port": kd-tree NN, the reference's algorithms incl. its Levenberg-Marquardt ICP minimiser) on a
+    BOUNDED sample of the same workload, one warm-up then the median of 5, at 1 thread and at all physical cores; R_gen (hypotheses the
+    generator emits incl. Verify per second), R_icp (hypothesis-iterations per second), R_lcp (hypotheses scored per second) separately
+    and the end-to-end rate H / (t_gen + t_icp + t_lcp) with the same H through all three stages (the GPU line's accounting)."""
+    import ctypes
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
     orc.build()
-    cores = os.cpu_count() or 1
+    model_name, phys = _cpu_identity()
+    logical = os.cpu_count() or 1
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+    except OSError:
+        gomp = None
+
+    def threads(n):
+        if gomp is not None:
+            gomp.omp_set_num_threads(int(n))
+
     sc, (mx, mn) = w.sc, w.model
-    n_bases_s = 24
-    t0 = time.perf_counter()
-    oo = orc.OracleS4PCS(sample_size=100, success_quadrilaterals=n_bases_s, n_trials=n_bases_s)
-    oo.set_keys(w.keys)
-    n_gen = oo.run(sc.xyz, sc.nrm, sc.conf, mx, mn, 1)
-    t_gen = time.perf_counter() - t0
-    pose, lcp = oo.hypos()
-    n_h = min(len(pose), 4 * cores)
-    order = np.argsort(-lcp, kind="stable")[:n_h]
-    p = pose[order]
-    t0 = time.perf_counter()
-    p2, it, cv = orc.icp_refine_batch(sc.xyz, sc.nrm, mx, mn, p, 10, 45.0, 0.01, use_tree=True)
-    t_icp = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    orc.compute_lcp_batch(sc.xyz, sc.nrm, mx, mn, p2, 0.001, 10.0, use_tree=True)
-    t_lcp = time.perf_counter() - t0
-    # same accounting as the GPU line: H hypotheses through gen (all bases) + ICP + LCP
+    keep = sc.conf >= 0.8
+    S, Sn = sc.xyz[keep], sc.nrm[keep]
     H, B = w.args.hyps, w.args.bases
-    t_frame = t_gen * (B / n_bases_s) + H * (t_icp + t_lcp) / max(n_h, 1)
-    return {"value": H / t_frame, "unit": "hypotheses/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (kd-tree NN; generator single-thread as the reference's base loop, ICP/LCP OpenMP x{cores}): "
-                      f"{n_bases_s} of {B} base trials ({n_gen} hyps, {t_gen:.2f}s), {n_h} of {H} hypotheses ICP {t_icp:.2f}s "
-                      f"+ computeLCP {t_lcp:.2f}s; extrapolated to the full frame"}
+    t_start = time.perf_counter()
+
+    def med5(fn):
+        fn()  # warm-up
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), r
+
+    # generator: the reference's base loop is sequential (one thread), so is the oracle's
+    threads(1)
+    n_bases_s = 6
+    def gen():
+        oo = orc.OracleS4PCS(sample_size=100, success_quadrilaterals=n_bases_s, n_trials=n_bases_s)
+        oo.set_keys(w.keys)
+        n = oo.run(sc.xyz, sc.nrm, sc.conf, mx, mn, 1)
+        return n, oo.hypos()
+    t_gen, (n_gen, (pose, lcp)) = med5(gen)
+    order = np.argsort(-lcp, kind="stable")
+    out = {"unit": "hypotheses/s", "kind": "port", "cpu_model": model_name, "physical_cores": phys, "logical_cpus": logical,
+           "protocol": "one warm-up, median of 5 (BASELINE.md section 3); ICP = Utils::runICP with PCL's Levenberg-Marquardt minimiser (oracle restatement, float)",
+           "R_gen_hyp_per_s_1thread": n_gen / t_gen, "runs": {}}
+    for label, nt in (("1_thread", 1), ("all_physical_cores", phys)):
+        threads(nt)
+        n_h = int(min(len(pose), max(4, 2 * nt)))
+        p = np.ascontiguousarray(pose[order[:n_h]])
+        t_icp, (p2, it, cv) = med5(lambda: orc.icp_refine_batch_lm(S, Sn, mx, mn, p, 10, 45.0, 0.01))
+        t_lcp, _ = med5(lambda: orc.compute_lcp_batch(sc.xyz, sc.nrm, mx, mn, p2, 0.001, 10.0, use_tree=True))
+        t_frame = t_gen * (B / n_bases_s) + H * (t_icp + t_lcp) / n_h
+        out["runs"][label] = {"threads": nt, "hypotheses_in_sample": n_h, "R_icp_hyp_iters_per_s": float(np.sum(it)) / t_icp, "R_lcp_hyp_per_s": n_h / t_lcp,
+                              "t_gen_s": t_gen, "t_icp_s": t_icp, "t_lcp_s": t_lcp, "end_to_end_hyp_per_s": H / t_frame}
+        if time.perf_counter() - t_start > 3 * budget_s:
+            break
+    threads(logical)
+    best = out["runs"].get("all_physical_cores") or out["runs"]["1_thread"]
+    out["value"] = best["end_to_end_hyp_per_s"]
+    out["cores"] = best["threads"]
+    out["sample"] = (f"{n_bases_s} of {B} base trials ({n_gen} hypotheses) single-thread as the reference's base loop; ICP + computeLCP on the "
+                     f"{best['hypotheses_in_sample']} best of them with {best['threads']} OpenMP threads; each stage the median of 5 after a warm-up; "
+                     f"end-to-end = H / (t_gen B/{n_bases_s} + H (t_icp + t_lcp) / {best['hypotheses_in_sample']}) with H = {H}")
+    out["what_cannot_be_timed"] = "the reference's own PCL / Armadillo path (libraries absent); its OpenGR generator was timed in the build container: profiles/r03_ref_generator_c2.json"
+    return out
 
 
 def main():
@@ -478,6 +538,39 @@ def main():
         if use_dist:
             exchange(info_serial["rows"])   # keep the collective sequence identical on every rank
 
+    # The same workload in the other configurations, measured after the timed region (they do not enter `value`): ICP with one
+    # Gauss-Newton step per iteration instead of the reference's Levenberg-Marquardt minimiser, and the configuration in which
+    # every stage is bit-equal to the oracle's operation order (chained ICP increments, ordered computeLCP / objFuncPSO sums).
+    alt = {}
+    if not strong and not args.no_alt_modes:
+        base_cfg = (args.nn_mode, args.lcp_mode, args.pso_sum_mode)
+        for label, cfg in (("icp_one_gauss_newton_step_nn_mode4", (4, args.lcp_mode, args.pso_sum_mode)),
+                           ("bit_exact_order_nn_mode3_lcp_mode2_pso_sum_mode0", (3, 2, 0))):
+            if cfg == base_cfg:
+                continue
+            args.nn_mode, args.lcp_mode, args.pso_sum_mode = cfg
+            for S in w.slots:
+                S["ctx"].hand_set_sum_mode(args.pso_sum_mode)
+            run_frames(F)
+            barrier()
+            ta = time.perf_counter()
+            ai, _ = run_frames(2 * F)
+            barrier()
+            dt = time.perf_counter() - ta
+            hl = float(sum(i["h"] for i in ai))
+            if use_dist:
+                tt = torch.tensor([hl], dtype=torch.float64, device=xdev)
+                dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+                td = torch.tensor([dt], dtype=torch.float64, device=xdev)
+                dist.all_reduce(td, op=dist.ReduceOp.MAX)
+                hl, dt = float(tt.item()), float(td.item())
+            alt[label] = {"value": hl / dt, "unit": "hypotheses/s", "ms_per_step": 1e3 * dt / (2 * F), "steps": 2 * F,
+                          "nn_mode": cfg[0], "lcp_mode": cfg[1], "pso_sum_mode": cfg[2],
+                          "best_pose_max_abs_diff_vs_default": float(np.abs(ai[-1]["best"] - infos[-1]["best"]).max())}
+        args.nn_mode, args.lcp_mode, args.pso_sum_mode = base_cfg
+        for S in w.slots:
+            S["ctx"].hand_set_sum_mode(args.pso_sum_mode)
+
     h_local = sum(i["h"] for i in infos)
     if use_dist:
         t = torch.tensor([elapsed, float(h_local)], dtype=torch.float64, device=xdev)
@@ -517,8 +610,11 @@ def main():
                 kern["k_icp_nn"] = kern.pop("k_icp_corr_cells")
                 kern.pop("k_icp_accum")
             elif args.nn_mode >= 3:
-                kern["k_icp_fusedq"] = kern.pop("k_icp_corr_cells")
+                # nn_mode 6: lookups + the 13 x 13 moment sums in one kernel, then the whole Levenberg-Marquardt run per hypothesis
+                kern["k_icp_fusedq_mom" if args.nn_mode == 6 else "k_icp_fusedq"] = kern.pop("k_icp_corr_cells")
                 kern.pop("k_icp_accum")
+                if args.nn_mode >= 5:
+                    kern["k_icp_lm6_solve" if args.nn_mode == 6 else "k_icp_lm_pass+solve"] = (tmx["ms_icp_solve"], tmx["n_icp_nn_launches"], 0.0, 0.0)
             return kern
 
         def roofline_of(kern, dom, frames):
@@ -594,7 +690,14 @@ def main():
             "icp_hypothesis_iterations_per_step": hyp_iters / steps,
             "hypotheses_generated_per_step": infos[-1]["h_gen"], "candidates_verified_per_step": infos[-1]["n_cand"],
             "best_lcp_score": infos[-1]["score"],
+            "alt_modes": alt,
         }
+        out["config"]["icp_minimiser"] = ("Levenberg-Marquardt on (t, quaternion) to Eigen's stopping rule per ICP iteration = the reference's "
+                                          "(PCL TransformationEstimationPointToPlane, Utils.cpp:200-216)" if args.nn_mode >= 5 else
+                                          "one Gauss-Newton step per ICP iteration (NOT the reference's minimiser; see alt_modes / --nn-mode 6)")
+        out["config"]["parity_note"] = ("ICP nn_mode 6: the reference's minimiser evaluated from moment sums (exact arithmetic where PCL rounds residuals to float); "
+                                        "computeLCP lcp_mode 3 and objFuncPSO sum mode 1 re-associate float sums (<= 1e-4 / 1e-5 relative). "
+                                        "alt_modes.bit_exact_order_* is the configuration whose stages follow the oracle's operation order bit for bit.")
         if not args.no_cpu_baseline and world == 1 and not strong:
             try:
                 out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget_s)

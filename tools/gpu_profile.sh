@@ -7,7 +7,7 @@ TAG=${1:-prof}
 OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python /root/repo/bench.py --no-cpu-baseline --no-next-rows"
+B="python /root/repo/bench.py --no-cpu-baseline --no-next-rows --no-alt-modes"
 rocprofv3 --kernel-trace --stats -d $OUT/stats_default -o b -- $B --steps 32 --warmup 8 > $OUT/bench_default.json 2> $OUT/bench_default.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats_serial -o b -- $B --inflight 1 --steps 8 --warmup 2 > $OUT/bench_serial.json 2> $OUT/bench_serial.err
 S="$B --inflight 1 --steps 2 --warmup 1"
