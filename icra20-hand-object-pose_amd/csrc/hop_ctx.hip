@@ -2131,6 +2131,15 @@ int hop_debug_icp_counters(hop_ctx* c, unsigned long long* out8, int reset) {
   return HOP_OK;
 }
 
+// development aid, not part of the ABI: statistics of the Levenberg-Marquardt minimiser of nn_mode 6 (zero unless built with -DHOP_LM_COUNT)
+int hop_debug_lm_counters(hop_ctx* c, unsigned long long* out8, int reset) {
+  if (!c || !out8) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hop::lm_counters_read(out8, reset != 0);
+  return HOP_OK;
+}
+
 // development aid, not part of the ABI: the PPF key membership matrix of the last hop_generate (n rows of `words` 64-bit words)
 int hop_debug_ppf_matrix(hop_ctx* c, unsigned long long* out, size_t cap_words, int* n_out, int* words_out) {
   if (!c || !n_out || !words_out) return HOP_E_INVALID;

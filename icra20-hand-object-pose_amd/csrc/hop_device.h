@@ -313,6 +313,7 @@ void launch_hand_surround(const SurroundArgs& a, hipStream_t s);
 void launch_hand_surround_out(const SurroundOutArgs& a, hipStream_t s);
 
 void icp_counters_read(unsigned long long* out8, bool reset);
+void lm_counters_read(unsigned long long* out8, bool reset);
 // launchers (hop_kernels.hip)
 void launch_ppf_matrix(const PpfMatrixArgs& a, hipStream_t s);
 void launch_pairs(const PairArgs& a, int nbases, hipStream_t s);

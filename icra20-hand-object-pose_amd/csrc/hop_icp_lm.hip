@@ -31,6 +31,21 @@
 #include "hop_math.h"
 
 namespace hop {
+// -DHOP_LM_COUNT (tools/build_variant.sh): statistics of the minimiser -- [0] hypotheses solved, [1] evaluations, [2] general lmpar
+// calls (out of line), [3] runs ended by maxfev, [4] fast lmpar calls
+__device__ unsigned long long g_lm_count[8];
+#ifdef HOP_LM_COUNT
+#define LM_COUNT(slot, v) atomicAdd(&g_lm_count[slot], (unsigned long long)(v))
+#else
+#define LM_COUNT(slot, v) do { } while (0)
+#endif
+void lm_counters_read(unsigned long long* out8, bool reset) {
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lm_count), sizeof(unsigned long long) * 8);
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lm_count), z, sizeof(z));
+  }
+}
 namespace {
 
 __device__ __forceinline__ double lm_wave_sum(double v) {
@@ -242,12 +257,29 @@ __device__ __noinline__ void lm_par(const double A[6][6], const double g[6], con
   if (iter == 0) par = 0;
 }
 
-// nn_mode 6's common case of lmpar2, in registers: a comfortably full-rank Jacobian (unpivoted Cholesky, smallest pivot above 2e-5 of
-// the largest: ColPivHouseholderQR::rank()'s threshold is 7e-7 of it) whose Gauss-Newton step lies inside the trust region
-// (fp <= 0.1 delta, lmpar.h:205-211): par = 0 and x = A^-1 g, the same solution lm_par's factor gives.  false: not that case.
-__device__ __forceinline__ bool lm_par_fast(const double* __restrict__ a21, const double* __restrict__ g, const double* __restrict__ diag, double delta,
-                                            double& par, double* __restrict__ x) {
-  double L[21];  // packed lower triangle, row-major: (i, j) at i (i + 1) / 2 + j
+// 1 / sqrt(x) to double precision from the hardware estimate and two Newton steps (nn_mode 6 only: its arithmetic is "exact" up to
+// 1e-15, no operation order to preserve): the state machine spends most of its instructions in IEEE divisions and square roots
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
+}
+__device__ __forceinline__ double rcp_nr(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  return r;
+}
+
+// nn_mode 6: lmpar2 (lmpar.h:163-293) in registers for a comfortably full-rank Jacobian (unpivoted Cholesky, smallest pivot above 2e-5
+// of the largest: ColPivHouseholderQR::rank()'s threshold is 7e-7 of it) -- every index static, no scratch memory, reciprocal
+// square roots instead of divisions.  The triangular solves against R become solves against the Cholesky factor of A = J^T J,
+// qrsolv's problem [R; sqrt(par) D] the factor of A + par D^2: the same numbers lm_par computes.  false: rank-deficient or
+// ill-conditioned -- the caller takes the general, pivoted routine.
+__device__ __forceinline__ bool chol6_regs(const double* __restrict__ a21, const double* __restrict__ diag, double par, double* __restrict__ L,
+                                           double* __restrict__ Linv) {
   double lmin = 1e300, lmax = 0;
   bool ok = true;
 #pragma unroll
@@ -255,41 +287,111 @@ __device__ __forceinline__ bool lm_par_fast(const double* __restrict__ a21, cons
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
       double v = a21[i * (i + 1) / 2 + j];
+      if (i == j) v = fma(par * diag[i], diag[i], v);
 #pragma unroll
       for (int k = 0; k < j; ++k) v -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
       if (i == j) {
-        ok = ok && v > 0;
-        const double d = sqrt(fmax(v, 1e-300));
+        ok = ok && v > 1e-290;
+        const double r = rsqrt_nr(fmax(v, 1e-290)), d = v * r;
         L[i * (i + 1) / 2 + i] = d;
+        Linv[i] = r;
         lmin = fmin(lmin, d), lmax = fmax(lmax, d);
       } else
-        L[i * (i + 1) / 2 + j] = v / L[j * (j + 1) / 2 + j];
+        L[i * (i + 1) / 2 + j] = v * Linv[j];
     }
-  if (!ok || !(lmin > 2e-5 * lmax)) return false;
-  double y[6];
+  return ok && lmin > 2e-5 * lmax;
+}
+__device__ __forceinline__ void chol6_fwd(const double* __restrict__ L, const double* __restrict__ Linv, const double* __restrict__ b, double* __restrict__ y) {
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    double v = g[i];
+    double v = b[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) v -= L[i * (i + 1) / 2 + k] * y[k];
-    y[i] = v / L[i * (i + 1) / 2 + i];
+    y[i] = v * Linv[i];
   }
-  double xs[6];
+}
+__device__ __forceinline__ void chol6_bwd(const double* __restrict__ L, const double* __restrict__ Linv, const double* __restrict__ y, double* __restrict__ x) {
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
     double v = y[i];
 #pragma unroll
-    for (int k = i + 1; k < 6; ++k) v -= L[k * (k + 1) / 2 + i] * xs[k];
-    xs[i] = v / L[i * (i + 1) / 2 + i];
+    for (int k = i + 1; k < 6; ++k) v -= L[k * (k + 1) / 2 + i] * x[k];
+    x[i] = v * Linv[i];
   }
+}
+__device__ __forceinline__ double dnorm6(const double* __restrict__ diag, const double* __restrict__ x, double* __restrict__ wa2) {
   double q = 0;
 #pragma unroll
-  for (int j = 0; j < 6; ++j) q += (diag[j] * xs[j]) * (diag[j] * xs[j]);
-  const double fp = sqrt(q) - delta;
-  if (!(fp <= (double)0.1f * delta)) return false;
+  for (int j = 0; j < 6; ++j) {
+    wa2[j] = diag[j] * x[j];
+    q = fma(wa2[j], wa2[j], q);
+  }
+  return q > 1e-290 ? q * rsqrt_nr(q) : 0.0;
+}
+__device__ __forceinline__ bool lm_par_fast(const double* __restrict__ a21, const double* __restrict__ g, const double* __restrict__ diag, double delta,
+                                            double& par_io, double* __restrict__ x) {
+  const double dwarf = (double)FLT_MIN, p1 = (double)0.1f;
+  double L[21], Linv[6], y[6], xs[6], wa2[6], w[6];
+  if (!chol6_regs(a21, diag, 0.0, L, Linv)) return false;
+  chol6_fwd(L, Linv, g, y);
+  chol6_bwd(L, Linv, y, xs);
+  double dxnorm = dnorm6(diag, xs, wa2);
+  double fp = dxnorm - delta;
+  if (fp <= p1 * delta) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) x[j] = xs[j];
+    par_io = 0;
+    LM_COUNT(4, 1);
+    return true;
+  }
+  LM_COUNT(5, 1);
+  const double dinv = rcp_nr(delta);
+  // parl = fp / delta / |R^-T D (D x) / |D x||^2 (the Jacobian has full rank here)
+  {
+    const double ninv = rcp_nr(dxnorm);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) w[j] = diag[j] * wa2[j] * ninv;
+    chol6_fwd(L, Linv, w, y);
+  }
+  double t2 = 0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) t2 = fma(y[j], y[j], t2);
+  double parl = fp * dinv * rcp_nr(t2);
+  double gq = 0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const double v = g[j] * rcp_nr(diag[j]);
+    gq = fma(v, v, gq);
+  }
+  const double gnorm = gq > 1e-290 ? gq * rsqrt_nr(gq) : 0.0;
+  double paru = gnorm * dinv;
+  if (paru == 0) paru = dwarf / fmin(delta, p1);
+  double par = fmin(fmax(par_io, parl), paru);
+  if (par == 0) par = gnorm * rcp_nr(dxnorm);
+  for (int iter = 1;; ++iter) {
+    if (par == 0) par = fmax(dwarf, (double)0.001f * paru);
+    if (!chol6_regs(a21, diag, par, L, Linv)) return false;  // (A + par D^2 is better conditioned than A: does not happen)
+    chol6_fwd(L, Linv, g, y);
+    chol6_bwd(L, Linv, y, xs);
+    dxnorm = dnorm6(diag, xs, wa2);
+    const double temp = fp;
+    fp = dxnorm - delta;
+    if (fabs(fp) <= p1 * delta || (parl == 0 && fp <= temp && temp < 0) || iter == 10) break;
+    const double ninv = rcp_nr(dxnorm);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) w[j] = diag[j] * (wa2[j] * ninv);
+    chol6_fwd(L, Linv, w, y);
+    double t3 = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) t3 = fma(y[j], y[j], t3);
+    const double parc = fp * dinv * rcp_nr(t3);
+    if (fp > 0) parl = fmax(parl, par);
+    if (fp < 0) paru = fmin(paru, par);
+    par = fmax(parl, par + parc);
+  }
 #pragma unroll
   for (int j = 0; j < 6; ++j) x[j] = xs[j];
-  par = 0;
+  par_io = par;
   return true;
 }
 
@@ -307,6 +409,7 @@ __device__ void lm_inner(LS& s) {
   if (!(LS::fast_lmpar && lm_par_fast(s.A, s.g, s.diag, s.delta, s.par, xs))) {
     // (copies: the out-of-line call must not expose the state struct's address, or all of it lives in scratch memory)
     double A[6][6], gg[6], dd[6], xo[6], par = s.par;
+    LM_COUNT(2, 1);
     unpack_sym(s.A, A);
 #pragma unroll
     for (int j = 0; j < 6; ++j) gg[j] = s.g[j], dd[j] = s.diag[j];
@@ -328,11 +431,15 @@ __device__ void lm_inner(LS& s) {
 template <class LS>
 __device__ bool lm_outer(LS& s) {
   s.nfev += 7;
-  double wa2[6];
+  double wa2[6], wa2inv[6];
 #pragma unroll
   for (int j = 0, k = 0; j < 6; ++j) {
     k += j;  // index of the diagonal element (j, j) in the packed lower triangle: j (j + 1) / 2 + j
-    wa2[j] = sqrt(s.A[k + j]);
+    if (LS::fast_lmpar) {
+      const double a = s.A[k + j], r = a > 1e-290 ? rsqrt_nr(a) : 0.0;
+      wa2[j] = a * r, wa2inv[j] = r;
+    } else
+      wa2[j] = sqrt(s.A[k + j]);
   }
   if (s.iter == 1) {
 #pragma unroll
@@ -342,10 +449,18 @@ __device__ bool lm_outer(LS& s) {
     if (s.delta == 0) s.delta = 100.0;
   }
   s.gnorm = 0;
-  if (s.fnorm != 0)
+  if (s.fnorm != 0) {
+    if (LS::fast_lmpar) {
+      const double finv = rcp_nr(s.fnorm);
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
-      if (wa2[j] != 0) s.gnorm = fmax(s.gnorm, fabs(s.g[j] / s.fnorm / wa2[j]));
+      for (int j = 0; j < 6; ++j)
+        if (wa2[j] != 0) s.gnorm = fmax(s.gnorm, fabs(s.g[j] * finv * wa2inv[j]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        if (wa2[j] != 0) s.gnorm = fmax(s.gnorm, fabs(s.g[j] / s.fnorm / wa2[j]));
+    }
+  }
   if (s.gnorm <= 0) {
     s.status = 4;  // CosinusTooSmall
     return false;
@@ -373,9 +488,7 @@ __device__ bool lm_advance(LS& s, const double* cand) {
   const double ftol = (double)LM_SQRT_EPS_F, xtol = (double)LM_SQRT_EPS_F, eps = (double)FLT_EPSILON;
   const double p1 = (double)0.1f, p25 = 0.25, p5 = 0.5, p75 = 0.75, p0001 = (double)1e-4f;
   ++s.nfev;
-  const double fnorm1 = sqrt(cand[27]);
-  double actred = -1;
-  if (p1 * fnorm1 < s.fnorm) actred = 1.0 - (fnorm1 / s.fnorm) * (fnorm1 / s.fnorm);
+  double fnorm1, actred = -1, temp1, temp2;
   double A[6][6];
   unpack_sym(s.A, A);
   double jp2 = 0;
@@ -383,11 +496,23 @@ __device__ bool lm_advance(LS& s, const double* cand) {
   for (int a = 0; a < 6; ++a)
 #pragma unroll
     for (int b = 0; b < 6; ++b) jp2 += (double)s.p[a] * A[a][b] * (double)s.p[b];
-  const double t1r = sqrt(fmax(jp2, 0.0)) / s.fnorm, t2r = sqrt(s.par) * s.pnorm / s.fnorm;
-  const double temp1 = t1r * t1r, temp2 = t2r * t2r;
+  if (LS::fast_lmpar) {
+    // the same quantities without the square roots that are squared again: (|J p| / |f|)^2 = p^T A p / |f|^2
+    const double c27 = cand[27];
+    fnorm1 = c27 > 1e-290 ? c27 * rsqrt_nr(c27) : 0.0;
+    const double finv = rcp_nr(s.fnorm), r1 = fnorm1 * finv;
+    if (p1 * fnorm1 < s.fnorm) actred = 1.0 - r1 * r1;
+    temp1 = fmax(jp2, 0.0) * finv * finv;
+    temp2 = s.par * (s.pnorm * finv) * (s.pnorm * finv);
+  } else {
+    fnorm1 = sqrt(cand[27]);
+    if (p1 * fnorm1 < s.fnorm) actred = 1.0 - (fnorm1 / s.fnorm) * (fnorm1 / s.fnorm);
+    const double t1r = sqrt(fmax(jp2, 0.0)) / s.fnorm, t2r = sqrt(s.par) * s.pnorm / s.fnorm;
+    temp1 = t1r * t1r, temp2 = t2r * t2r;
+  }
   const double prered = temp1 + temp2 / p5, dirder = -(temp1 + temp2);
   double ratio = 0;
-  if (prered != 0) ratio = actred / prered;
+  if (prered != 0) ratio = LS::fast_lmpar ? actred * rcp_nr(prered) : actred / prered;
   if (ratio <= p25) {
     double temp = p5;
     if (actred < 0) temp = p5 * dirder / (dirder + p5 * actred);
@@ -459,7 +584,8 @@ __device__ void icp_iteration_bookkeeping(const IcpArgs& a, IcpState& st, int hl
 // w(x) = (R(x) - I [9], t + (R(x) - I) c [3], 1) in double; R from the quaternion as WarpPointRigid6D::setParam forms it
 __device__ void lm6_w(const float x[6], const double c[3], double w[13]) {
   const double qx = (double)x[3], qy = (double)x[4], qz = (double)x[5];
-  const double qw = sqrt(1.0 - (qx * qx + qy * qy + qz * qz));  // (the quaternion's norm is 1 in exact arithmetic: normalize() is the identity)
+  const double qw2 = 1.0 - (qx * qx + qy * qy + qz * qz);  // (the quaternion's norm is 1 in exact arithmetic: normalize() is the identity)
+  const double qw = qw2 > 1e-290 ? qw2 * rsqrt_nr(qw2) : sqrt(qw2);
   const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
   const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
   w[0] = -(tyy + tzz), w[1] = txy - twz, w[2] = txz + twy;
@@ -596,10 +722,13 @@ __global__ __launch_bounds__(64) void k_icp_lm6_solve(IcpArgs a, int hb, int nbl
 #ifndef HOP_LM6_MAX_EVAL
 #define HOP_LM6_MAX_EVAL 420  // (maxfev = 400 ends every run; smaller values: timing experiments only)
 #endif
+    LM_COUNT(0, 1);
     for (int guard = 0; guard < HOP_LM6_MAX_EVAL; ++guard) {
       lm6_eval(M, c, s.xc, cand);
+      LM_COUNT(1, 1);
       if (!lm_advance(s, cand)) break;
     }
+    if (s.status == 5) LM_COUNT(3, 1);
     lm_warp6(s.x, st.T_inc);
   }
   icp_iteration_bookkeeping(a, st, hl, S[73], cnt);
