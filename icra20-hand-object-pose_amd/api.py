@@ -738,6 +738,27 @@ def cluster_poses_host(poses, scores, ids, angle_deg, dist, sym_deg):
     return keep[:n.value].copy()
 
 
+def compute_ppf(ctx, cloud_xyz, downsample_size=0.001, normal_radius=0.003, ppf_density=0.005):
+    """The offline tool src/perception/src/app/computePPF.cpp:56-107 chained from the library's calls: 1 mm voxel grid, centring on the
+    bounding-box mid point, Utils::calNormalMLS (radius 3 mm, points replaced by their projections), normals flipped outward
+    (flipNormalTowardsViewpoint towards the origin, then negated), the cloud the tool saves as model.ply, the 5 mm voxel grid of it and
+    the PPF keys of all its ordered pairs.  Returns dict(model001=(xyz, nrm) [centred, as model.ply], model=(xyz, nrm) [5 mm, moved back
+    as the tool does before it writes the table], keys (n, 4) int32, mid (3,))."""
+    x1 = ctx.voxel_downsample(np.ascontiguousarray(cloud_xyz, np.float32), downsample_size)
+    mn, mx = x1.min(axis=0), x1.max(axis=0)
+    mid = ((mn + mx).astype(np.float32).astype(np.float64) / 2.0).astype(np.float32)     # (minPt.x + maxPt.x) / 2.0 assigned to a float
+    xc = (x1 - mid).astype(np.float32)
+    px, pn, _, _ = ctx.normals_mls(xc, normal_radius, 2)
+    # pcl::flipNormalTowardsViewpoint(pt, 0, 0, 0, n): flip if the normal points away from the viewpoint; then the tool negates it
+    vp = -px.astype(np.float32)
+    flip = np.einsum("ij,ij->i", vp, pn) < 0
+    pn = np.where(flip[:, None], -pn, pn)
+    pn = (-pn).astype(np.float32)
+    m5x, m5n = ctx.voxel_downsample_normals(px, pn, ppf_density)
+    keys = ctx.model_ppf_keys(m5x, m5n)
+    return dict(model001=(px, pn), model=((m5x + mid).astype(np.float32), m5n), keys=keys, mid=mid)
+
+
 def cluster_pose_terms(pose_a, pose_b):
     """(eulerAngles(2,1,0) of pose_a [3], rotationGeodesicDistance(R_a, R_b), |t_a - t_b|) as clusterPoses evaluates them."""
     a = np.ascontiguousarray(pose_a, dtype=np.float32).reshape(16)

@@ -169,6 +169,175 @@ def make_scene(n_points: int, seed: int = 7, semi=SEMI_AXES, noise=0.0005, clutt
                  np.ascontiguousarray(conf[order]), T, n_obj)
 
 
+# --------------------------------------------------------------------------- the other objects of config_autodataset.yaml:35-59
+# Stand-ins for BASELINE configs[2] ("cuboid + cylinder + tless"): the reference's meshes are download links (README.md:49-54).  Each
+# has the symmetry class its `object_symmetry` entry declares, so that clusterPoses' per-axis folding (PoseEstimator.cpp:135-196)
+# is exercised with 90 (cuboid z), 0 (cylinder z, tless3 y) and 360 (no symmetry) next to the ellipse's 180.
+OBJECT_SYMMETRY = {"ellipse": (180.0, 180.0, 180.0), "cuboid": (180.0, 180.0, 90.0), "cylinder": (180.0, 180.0, 0.0),
+                   "tless3": (360.0, 0.0, 360.0), "mustard": (360.0, 360.0, 360.0)}
+
+
+def _plane_patch(origin, eu, ev, nu, nv, normal):
+    u = (np.arange(nu) + 0.5) / nu
+    v = (np.arange(nv) + 0.5) / nv
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    P = np.asarray(origin)[None] + uu.reshape(-1, 1) * np.asarray(eu)[None] + vv.reshape(-1, 1) * np.asarray(ev)[None]
+    return P, np.tile(np.asarray(normal, np.float64), (len(P), 1))
+
+
+def _box_surface(lo, hi, spacing):
+    lo, hi = np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+    P, N = [], []
+    for ax in range(3):
+        o = [a for a in range(3) if a != ax]
+        ext = hi - lo
+        nu, nv = max(1, int(round(ext[o[0]] / spacing))), max(1, int(round(ext[o[1]] / spacing)))
+        for val, sgn in ((lo[ax], -1.0), (hi[ax], 1.0)):
+            org = lo.copy()
+            org[ax] = val
+            eu, ev, nn = np.zeros(3), np.zeros(3), np.zeros(3)
+            eu[o[0]], ev[o[1]], nn[ax] = ext[o[0]], ext[o[1]], sgn
+            a, b = _plane_patch(org, eu, ev, nu, nv, nn)
+            P.append(a), N.append(b)
+    return np.concatenate(P), np.concatenate(N)
+
+
+def _cylinder_surface(radius, z0, z1, spacing, axis=2, caps=(True, True), inner_cap_radius=(0.0, 0.0)):
+    """side + caps of a cylinder about `axis`; a cap can be an annulus (inner radius > 0)"""
+    P, N = [], []
+    nz = max(1, int(round((z1 - z0) / spacing)))
+    nt = max(8, int(round(2 * math.pi * radius / spacing)))
+    zz = z0 + (np.arange(nz) + 0.5) / nz * (z1 - z0)
+    tt = (np.arange(nt) + 0.5) / nt * 2 * math.pi
+    T, Z = np.meshgrid(tt, zz, indexing="ij")
+    side = np.stack([radius * np.cos(T).ravel(), radius * np.sin(T).ravel(), Z.ravel()], axis=1)
+    sn = np.stack([np.cos(T).ravel(), np.sin(T).ravel(), np.zeros(T.size)], axis=1)
+    P.append(side), N.append(sn)
+    for k, (z, sgn) in enumerate(((z0, -1.0), (z1, 1.0))):
+        if not caps[k]:
+            continue
+        r_in = inner_cap_radius[k]
+        nr = max(1, int(round((radius - r_in) / spacing)))
+        for i in range(nr):
+            r = r_in + (i + 0.5) / nr * (radius - r_in)
+            m = max(6, int(round(2 * math.pi * r / spacing)))
+            t = (np.arange(m) + 0.5 * (i % 2)) / m * 2 * math.pi
+            P.append(np.stack([r * np.cos(t), r * np.sin(t), np.full(m, z)], axis=1))
+            N.append(np.tile(np.array([0.0, 0.0, sgn]), (m, 1)))
+    P, N = np.concatenate(P), np.concatenate(N)
+    if axis != 2:  # z -> the requested axis (a cyclic permutation keeps the orientation)
+        perm = {0: [2, 0, 1], 1: [1, 2, 0]}[axis]
+        P, N = P[:, perm], N[:, perm]
+    return P, N
+
+
+def object_surface(name: str, spacing: float):
+    """(xyz, outward unit normals) float32 of the stand-in object `name` in its model frame, ~`spacing` between neighbours."""
+    if name == "ellipse":
+        return ellipsoid_model_spacing(spacing)
+    if name == "cuboid":       # square cross-section in x / y (90 degrees about z), 180 about x and y
+        P, N = _box_surface((-0.025, -0.025, -0.04), (0.025, 0.025, 0.04), spacing)
+    elif name == "cylinder":   # any angle about z, 180 about x and y
+        P, N = _cylinder_surface(0.022, -0.045, 0.045, spacing)
+    elif name == "tless3":     # two coaxial cylinders about y: any angle about y, nothing else
+        a, an = _cylinder_surface(0.030, -0.030, 0.000, spacing, axis=1, caps=(True, True), inner_cap_radius=(0.0, 0.016))
+        b, bn = _cylinder_surface(0.016, 0.000, 0.035, spacing, axis=1, caps=(False, True))
+        P, N = np.concatenate([a, b]), np.concatenate([an, bn])
+    elif name == "mustard":    # no symmetry: a box with an off-centre box on top and a side handle
+        parts = [_box_surface((-0.03, -0.02, -0.045), (0.03, 0.02, 0.03), spacing), _box_surface((-0.03, -0.012, 0.03), (-0.005, 0.012, 0.06), spacing),
+                 _box_surface((0.03, -0.008, -0.02), (0.042, 0.008, 0.005), spacing)]
+        P, N = np.concatenate([q[0] for q in parts]), np.concatenate([q[1] for q in parts])
+        # drop the faces of a part that lie inside another part (they are not on the surface of the union)
+        def inside(pts, lo, hi, eps=1e-6):
+            return np.all((pts > np.asarray(lo) + eps) & (pts < np.asarray(hi) - eps), axis=1)
+        boxes = [((-0.03, -0.02, -0.045), (0.03, 0.02, 0.03)), ((-0.03, -0.012, 0.03), (-0.005, 0.012, 0.06)), ((0.03, -0.008, -0.02), (0.042, 0.008, 0.005))]
+        keep = np.ones(len(P), bool)
+        for lo, hi in boxes:
+            keep &= ~inside(P, lo, hi)
+        # faces glued to a neighbour: the contact patches z = 0.03 (top box on the body) and x = 0.03 (handle on the body)
+        glue = (np.isclose(P[:, 2], 0.03) & (P[:, 0] > -0.03) & (P[:, 0] < -0.005) & (np.abs(P[:, 1]) < 0.012)) | \
+               (np.isclose(P[:, 0], 0.03) & (np.abs(P[:, 1]) < 0.008) & (P[:, 2] > -0.02) & (P[:, 2] < 0.005))
+        P, N = P[keep & ~glue], N[keep & ~glue]
+    else:
+        raise ValueError(name)
+    return np.ascontiguousarray(P, np.float32), np.ascontiguousarray(N, np.float32)
+
+
+def object_model(name: str, spacing: float):
+    """Model cloud of the stand-in at a voxel level (5 mm / 1 mm): surface samples thinned to one per voxel."""
+    xyz, nrm = object_surface(name, spacing * 0.5)
+    xyz, nrm = voxel_thin(xyz, spacing, nrm)
+    return np.ascontiguousarray(xyz), np.ascontiguousarray(nrm)
+
+
+def make_object_scene(name: str, n_points: int, seed: int = 7, noise=0.0004, clutter_frac=0.1, normal_jitter_deg=3.0) -> Scene:
+    """make_scene for any stand-in object: the camera-facing part of its surface (normal test; self-occlusion of the two non-convex
+    stand-ins is ignored) under a random SE(3), noise, finger-like clutter slabs next to it."""
+    if name == "ellipse":
+        return make_scene(n_points, seed=seed)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    R = random_rotation(rng)
+    t = np.array([rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), rng.uniform(0.3, 0.5)])
+    T = se3(R, t)
+    n_clutter = int(round(n_points * clutter_frac))
+    n_obj = n_points - n_clutter
+    sp = 0.0012
+    while True:
+        dx, dn = object_surface(name, sp)
+        perm = rng.permutation(len(dx))
+        xyz = apply(T, dx[perm]).astype(np.float64)
+        nrm = rotate(T, dn[perm]).astype(np.float64)
+        view = xyz / np.linalg.norm(xyz, axis=1, keepdims=True)
+        vis = np.einsum("ij,ij->i", nrm, view) < -0.05
+        if vis.sum() >= n_obj:
+            break
+        sp *= 0.8
+    xyz, nrm = xyz[vis][:n_obj], nrm[vis][:n_obj]
+    xyz = xyz + rng.normal(scale=noise, size=xyz.shape)
+    jit = rng.normal(scale=math.radians(normal_jitter_deg), size=nrm.shape)
+    nrm = nrm + np.cross(jit, nrm)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    ext = np.abs(dx).max(axis=0)
+    cl, cn = [], []
+    for s_ in (-1.0, 1.0):
+        k = n_clutter // 2 if s_ < 0 else n_clutter - n_clutter // 2
+        local = np.stack([np.full(k, s_ * (ext[0] + 0.004)) + rng.normal(scale=0.0004, size=k), rng.uniform(-0.012, 0.012, size=k),
+                          rng.uniform(-0.03, 0.03, size=k)], axis=1)
+        cl.append(local)
+        cn.append(np.tile(np.array([0.0, 0.0, 1.0]), (k, 1)))
+    cl = apply(T, np.concatenate(cl)).astype(np.float64)
+    cn = rotate(T, np.concatenate(cn)).astype(np.float64)
+    flip = np.einsum("ij,ij->i", cn, cl) > 0
+    cn[flip] *= -1
+    all_xyz = np.concatenate([xyz, cl]).astype(np.float32)
+    all_nrm = np.concatenate([nrm, cn]).astype(np.float32)
+    conf = np.concatenate([np.ones(len(xyz)), np.full(len(cl), 0.85)]).astype(np.float32)
+    order = rng.permutation(len(all_xyz))
+    return Scene(np.ascontiguousarray(all_xyz[order]), np.ascontiguousarray(all_nrm[order]), np.ascontiguousarray(conf[order]), T, n_obj)
+
+
+def symmetry_rotations(name: str, steps_for_continuous: int = 72):
+    """Rotations of the model frame that map the stand-in onto itself (for pose comparison modulo symmetry): products of the per-axis
+    groups of OBJECT_SYMMETRY (0 = continuous, sampled)."""
+    groups = []
+    for ax, deg in enumerate(OBJECT_SYMMETRY[name]):
+        if deg >= 360.0:
+            angles = [0.0]
+        elif deg == 0.0:
+            angles = [2 * math.pi * k / steps_for_continuous for k in range(steps_for_continuous)]
+        else:
+            angles = [math.radians(deg) * k for k in range(int(round(360.0 / deg)))]
+        e = np.zeros(3)
+        e[ax] = 1.0
+        groups.append([rot_from_axis_angle(e, a) for a in angles])
+    out = []
+    for a in groups[0]:
+        for b in groups[1]:
+            for c in groups[2]:
+                out.append(a @ b @ c)
+    return out
+
+
 # --------------------------------------------------------------------------- PPF key table
 _DIST_DISCRET = 5
 _ANGLE_DISCRET = 10
