@@ -129,7 +129,7 @@ class Workload:
         self.slots.append(dict(ctx=c, hand=None, opts=None))
         self.ctx = c
 
-    def step_strong(self, slot=0, topk=0, id_offset=0):
+    def step_strong(self, slot=0, topk=0, id_offset=0, rows_dev=None):
         """One pass over this rank's block of the fixed hypothesis set: refineByICP + selectBest on all of it, top-k table."""
         c = self.slots[slot]["ctx"]
         tf = time.perf_counter()
@@ -139,7 +139,11 @@ class Workload:
         t3 = time.perf_counter()
         best, score, idx = c.lcp_select_best(0.001, 10.0, self.args.lcp_mode)
         t4 = time.perf_counter()
-        rows = c.topk_pack(topk, id_offset=self.h0)[0] if topk > 0 else None
+        if rows_dev is not None:
+            c.topk_pack_device(topk, self.h0, rows_dev)
+            rows = None
+        else:
+            rows = c.topk_pack(topk, id_offset=self.h0)[0] if topk > 0 else None
         return dict(h=len(self.shard), h_gen=0, n_cand=0, n_bases=0, best=best, score=score, icp_hyp_iters=int(np.sum(it)), n_pairs=0, n_quads=0,
                     rows=rows, t_frame=t2 - tf, t_pso=0.0, t_gen=0.0, t_icp=t3 - t2, t_lcp=t4 - t3, ms_select=0.0)
 
@@ -155,7 +159,7 @@ class Workload:
             h.matchOneComponentPSO("finger_1_2", 0, 90, True, 0.005, 60, 5)
         return m1, m2
 
-    def step(self, slot=0, topk=0, id_offset=0):
+    def step(self, slot=0, topk=0, id_offset=0, rows_dev=None):
         """One frame on one context.  Returns the stage times and, if topk > 0, the packed top-k table."""
         S = self.slots[slot]
         c, h = S["ctx"], S["hand"]
@@ -175,7 +179,11 @@ class Workload:
         t3 = time.perf_counter()
         best, score, idx = c.lcp_select_best(0.001, 10.0, self.args.lcp_mode)
         t4 = time.perf_counter()
-        rows = c.topk_pack(topk, id_offset=id_offset)[0] if topk > 0 else None
+        if rows_dev is not None:     # multi-GPU with the library's communicator: the table stays on the device (hop_topk_pack_device)
+            c.topk_pack_device(topk, id_offset, rows_dev)
+            rows = None
+        else:
+            rows = c.topk_pack(topk, id_offset=id_offset)[0] if topk > 0 else None
         return dict(h=hh, h_gen=st.n_hypotheses, n_cand=st.n_candidates, n_bases=st.n_bases, best=best, score=score,
                     icp_hyp_iters=int(np.sum(it)), n_pairs=st.n_pairs, n_quads=st.n_quads, rows=rows,
                     t_frame=t0 - tf, t_pso=t1 - t0, t_gen=t2 - t1, t_icp=t3 - t2, t_lcp=t4 - t3, ms_select=st.ms_select)
@@ -444,15 +452,17 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
-            exchange_kind = "hop_topk_allgather (RCCL inside libhop.so)"
+            exchange_kind = "hop_topk_pack_device + hop_topk_allgather_device (RCCL inside libhop.so; table on the device end to end)"
         elif comm is not None:
             comm.close()
             comm = None
 
-    def exchange(rows):
+    def exchange(rows, rows_dev=None):
         if not use_dist:
             return rows
         if comm is not None:
+            if rows_dev is not None:
+                return comm.topk_allgather_device(rows_dev, K)[0]   # device table -> ncclAllGather -> merge kernel -> 9 KB to the host
             return comm.topk_allgather(rows, K)[0]
         t = torch.from_numpy(rows).to(xdev)
         out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=xdev)
@@ -474,11 +484,14 @@ def main():
         infos = [None] * n
         ready = [threading.Event() for _ in range(n)]
         errors = []
+        # one device table per frame of this call (9 KB each): the worker packs into it, the main thread all-gathers from it in frame order
+        tables = torch.empty((n, K, api.TOPK_ROW_FLOATS), dtype=torch.float32, device=dev) if comm is not None else None
+        ptr = (lambda f: tables[f].data_ptr()) if tables is not None else (lambda f: None)
 
         def worker(slot):
             try:
                 for f in range(slot, n, F):
-                    infos[f] = w.step(slot, K, rank * (1 << 24))
+                    infos[f] = w.step(slot, K, rank * (1 << 24), rows_dev=ptr(f))
                     ready[f].set()
             except BaseException as e:  # surface the failure in the main thread
                 errors.append(e)
@@ -500,7 +513,7 @@ def main():
             ready[f].wait()
             if errors:
                 break
-            table = exchange(infos[f]["rows"])
+            table = exchange(infos[f]["rows"], ptr(f))
         for t in threads:
             t.join()
         if errors:
@@ -531,12 +544,13 @@ def main():
         c0 = w.slots[0]["ctx"]
         c0.timing_enable(True)
         c0.timing_reset()
-        info_serial = w.step(0, K, rank * (1 << 24))
+        serial_table = torch.empty((K, api.TOPK_ROW_FLOATS), dtype=torch.float32, device=dev) if comm is not None else None
+        info_serial = w.step(0, K, rank * (1 << 24), rows_dev=serial_table.data_ptr() if serial_table is not None else None)
         c0.synchronize()
         tm_serial = c0.timing_get()
         c0.timing_enable(False)
         if use_dist:
-            exchange(info_serial["rows"])   # keep the collective sequence identical on every rank
+            exchange(info_serial["rows"], serial_table.data_ptr() if serial_table is not None else None)   # keep the collective sequence identical on every rank
 
     # The same workload in the other configurations, measured after the timed region (they do not enter `value`): ICP with one
     # Gauss-Newton step per iteration instead of the reference's Levenberg-Marquardt minimiser, and the configuration in which
@@ -692,6 +706,11 @@ def main():
             "best_lcp_score": infos[-1]["score"],
             "alt_modes": alt,
         }
+        if comm is not None:
+            nr, us, cnt = comm.info()
+            out["config"]["rccl_ranks"] = nr
+            out["exchange"] = {"mean_us": us, "count": cnt, "what": "ncclAllGather of the 128 x 72-byte table from device memory + merge kernel + 9 KB to the host, "
+                                                                        "wall time per call on the main thread (the pack runs on the frame's own thread)"}
         out["config"]["icp_minimiser"] = ("Levenberg-Marquardt on (t, quaternion) to Eigen's stopping rule per ICP iteration = the reference's "
                                           "(PCL TransformationEstimationPointToPlane, Utils.cpp:200-216)" if args.nn_mode >= 5 else
                                           "one Gauss-Newton step per ICP iteration (NOT the reference's minimiser; see alt_modes / --nn-mode 6)")

@@ -28,6 +28,7 @@ ip = C.POINTER(C.c_int)
 HOP_MODEL_5MM = 0
 HOP_MODEL_1MM = 1
 TOPK_ROW_FLOATS = 18
+FRAME_ROW_FLOATS = 17  # hop_frames_allgather: frame index, pose[16]
 
 
 class HopError(RuntimeError):
@@ -148,6 +149,10 @@ SIGNATURES = {
     "hop_comm_destroy": (None, [_vp]),
     "hop_comm_last_error": (C.c_char_p, [_vp]),
     "hop_topk_allgather": (C.c_int, [_vp, fp, C.c_int, fp, ip]),
+    "hop_topk_pack_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_void_p, ip]),
+    "hop_topk_allgather_device": (C.c_int, [_vp, C.c_void_p, C.c_int, fp, ip]),
+    "hop_comm_info": (C.c_int, [_vp, ip, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "hop_frames_allgather": (C.c_int, [_vp, fp, C.c_int, C.c_int, fp]),
     "hop_hand_set_sum_mode": (C.c_int, [_vp, C.c_int]),
     "hop_hand_pso_eval_batch": (C.c_int, [_vp, dp, C.c_int, dp]),
     "hop_pso_default_settings": (None, [C.POINTER(PsoSettings)]),
@@ -600,6 +605,12 @@ class Context:
         self._chk(self.L.hop_topk_pack(self.h, k, id_offset, F(rows), C.byref(n)), "hop_topk_pack")
         return rows, n.value
 
+    def topk_pack_device(self, k, id_offset, rows_dev_ptr):
+        """the same table written into DEVICE memory (k * 18 floats at rows_dev_ptr): no download of the set, no host sort"""
+        n = C.c_int(0)
+        self._chk(self.L.hop_topk_pack_device(self.h, int(k), int(id_offset), C.c_void_p(int(rows_dev_ptr)), C.byref(n)), "hop_topk_pack_device")
+        return n.value
+
     # ---- hand
     def hand_set_scene(self, scene_xyz, lookup_nrm, swivel_xyz):
         S, Ln, W = soa(scene_xyz), soa(lookup_nrm), soa(swivel_xyz)
@@ -708,6 +719,30 @@ class Comm:
         if rc:
             raise HopError(rc, "hop_topk_allgather", (self.L.hop_comm_last_error(self.h) or b"").decode())
         return out, n.value
+
+    def topk_allgather_device(self, rows_dev_ptr, k):
+        """rows on the device (Context.topk_pack_device) -> ncclAllGather -> merge kernel: only the k merged rows come back to the host"""
+        out = np.zeros((k, TOPK_ROW_FLOATS), np.float32)
+        n = C.c_int(0)
+        rc = self.L.hop_topk_allgather_device(self.h, C.c_void_p(int(rows_dev_ptr)), int(k), F(out), C.byref(n))
+        if rc:
+            raise HopError(rc, "hop_topk_allgather_device", (self.L.hop_comm_last_error(self.h) or b"").decode())
+        return out, n.value
+
+    def info(self):
+        """(ncclCommCount, mean exchange time in microseconds, number of exchanges)"""
+        n, us, cnt = C.c_int(0), C.c_double(0), C.c_long(0)
+        self.L.hop_comm_info(self.h, C.byref(n), C.byref(us), C.byref(cnt))
+        return n.value, us.value, cnt.value
+
+    def frames_allgather(self, rows, rows_per_rank, world):
+        """C4: rows (n_local, 17) = frame index + 4 x 4 pose; returns (world * rows_per_rank, 17), padding rows have index -1"""
+        r = np.ascontiguousarray(rows, np.float32).reshape(-1, FRAME_ROW_FLOATS)
+        out = np.zeros((world * rows_per_rank, FRAME_ROW_FLOATS), np.float32)
+        rc = self.L.hop_frames_allgather(self.h, F(r) if len(r) else None, len(r), int(rows_per_rank), F(out))
+        if rc:
+            raise HopError(rc, "hop_frames_allgather", (self.L.hop_comm_last_error(self.h) or b"").decode())
+        return out
 
     def close(self):
         if self.h:
@@ -1070,7 +1105,9 @@ class HandT42:
                 max_match, best_height = int(cnt), float(h)
         offset = np.eye(4, dtype=np.float32)
         offset[2, 3] = best_height
-        return (handbase_in_cam @ offset).astype(np.float32), best_height, counts
+        new = handbase_in_cam.copy()      # handbase_in_cam * offset (:1050) in float, term by term (no fused multiply-add of a BLAS kernel)
+        new[:3, 3] = handbase_in_cam[:3, 2] * np.float32(best_height) + handbase_in_cam[:3, 3]
+        return new, best_height, counts
 
     def setCurSceneFromRegion(self, region_xyz_cam, region_nrm_cam, handbase_in_cam):
         """Hand::setCurScene from the 3 mm hand-region cloud in the camera frame (Hand.cpp:289-332, after handbaseICP):

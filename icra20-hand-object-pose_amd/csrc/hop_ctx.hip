@@ -141,7 +141,7 @@ struct hop_ctx {
   int n_hyp = 0;
 
   // scoring workspaces
-  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv, icp_corr_idx, icp_hist, icp_lm, pose_inv;
+  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv, icp_corr_idx, icp_hist, icp_lm, pose_inv, topk_rows;
 
   // hand
   CloudDevice hand_scene_d, hand_lookup_d, hand_swivel_d, hand_model_d;
@@ -722,7 +722,7 @@ void hop_ctx_destroy(hop_ctx* c) {
                     &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
                     &c->hyp_score, &c->hyp_id, &c->hyp_key, &c->hyp_inv, &c->tmp_pose, &c->tmp_score, &c->tmp_id, &c->sort_keys_alt,
                     &c->sort_vals, &c->sort_vals_alt, &c->sort_tmp, &c->lcp_rev_idx, &c->lcp_rev_d2, &c->lcp_terms, &c->icp_moved,
-                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->icp_corr_idx, &c->icp_hist, &c->icp_lm, &c->pose_inv, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
+                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->icp_corr_idx, &c->icp_hist, &c->icp_lm, &c->pose_inv, &c->topk_rows, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
                     &c->hand_swivel_d.buf, &c->hand_model_d.buf, &c->finger_hist_d, &c->pso_particles_d, &c->pso_match_d,
                     &c->pso_terms_d, &c->pso_sum_d, &c->pso_cnt_d};
   for (DevBuf* b : bufs) b->release();
@@ -1645,41 +1645,45 @@ int hop_cluster_poses(hop_ctx* c, float angle_deg, float dist, const float* sym_
 }
 
 // ---------------------------------------------------------------------------------------------- top-k exchange
+int hop_topk_pack_device(hop_ctx* c, int k, int id_offset, float* rows_dev, int* n_rows_out);
 int hop_topk_pack(hop_ctx* c, int k, int id_offset, float* rows_out, int* n_rows_out) {
   if (!c || k <= 0 || !rows_out) return HOP_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
+  // sorted and packed on the device (hop_topk_pack_device); only the k rows cross PCIe
+  HIPCHK(c, c->topk_rows.ensure(sizeof(float) * (size_t)k * HOP_TOPK_ROW_FLOATS));
+  const int rc = hop_topk_pack_device(c, k, id_offset, c->topk_rows.as<float>(), n_rows_out);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(rows_out, c->topk_rows.p, sizeof(float) * (size_t)k * HOP_TOPK_ROW_FLOATS, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+// the same table written on the DEVICE (rows_dev: k rows of HOP_TOPK_ROW_FLOATS floats in device memory): 64-bit HypoCompare keys, one
+// radix sort of (key, index) pairs, one pack kernel -- the resident set is neither reordered nor copied to the host.  Returns after
+// the work has completed on the context's stream (the caller may use rows_dev from any stream).
+int hop_topk_pack_device(hop_ctx* c, int k, int id_offset, float* rows_dev, int* n_rows_out) {
+  if (!c || k <= 0 || !rows_dev) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
   const int H = c->n_hyp;
-  std::vector<float> pose((size_t)std::max(H, 1) * 16), sc(std::max(H, 1));
-  std::vector<int> ids(std::max(H, 1));
+  const unsigned* order = nullptr;
   if (H > 0) {
-    int n = 0;
-    const int rc = hop_hypos_download(c, pose.data(), sc.data(), ids.data(), H, &n);
-    if (rc) return rc;
+    HIPCHK(c, c->hyp_key.ensure(sizeof(unsigned long long) * (size_t)H));
+    HIPCHK(c, c->sort_keys_alt.ensure(sizeof(unsigned long long) * (size_t)H));
+    HIPCHK(c, c->sort_vals.ensure(sizeof(unsigned) * (size_t)H));
+    HIPCHK(c, c->sort_vals_alt.ensure(sizeof(unsigned) * (size_t)H));
+    launch_score_keys(c->hyp_score.as<float>(), c->hyp_id.as<int>(), H, c->hyp_key.as<unsigned long long>(), c->stream);
+    launch_iota(c->sort_vals.as<unsigned>(), H, c->stream);
+    size_t tmp_bytes = 0;
+    HIPCHK(c, prim_sort_pairs(nullptr, tmp_bytes, c->hyp_key.as<unsigned long long>(), c->sort_keys_alt.as<unsigned long long>(), c->sort_vals.as<unsigned>(),
+                              c->sort_vals_alt.as<unsigned>(), (size_t)H, 0, 64, c->stream));
+    HIPCHK(c, c->sort_tmp.ensure(tmp_bytes + 16));
+    HIPCHK(c, prim_sort_pairs(c->sort_tmp.p, tmp_bytes, c->hyp_key.as<unsigned long long>(), c->sort_keys_alt.as<unsigned long long>(), c->sort_vals.as<unsigned>(),
+                              c->sort_vals_alt.as<unsigned>(), (size_t)H, 0, 64, c->stream));
+    order = c->sort_vals_alt.as<unsigned>();
   }
-  std::vector<int> order(H);
-  std::iota(order.begin(), order.end(), 0);
-  std::sort(order.begin(), order.end(), [&](int a, int b) {
-    if (sc[a] > sc[b]) return true;
-    if (sc[a] < sc[b]) return false;
-    return ids[a] < ids[b];
-  });
-  const int m = std::min(k, H);
-  for (int r = 0; r < k; ++r) {
-    float* row = rows_out + (size_t)r * HOP_TOPK_ROW_FLOATS;
-    if (r < m) {
-      const int h = order[r];
-      row[0] = sc[h];
-      const int id = ids[h] + id_offset;
-      std::memcpy(&row[1], &id, 4);
-      std::memcpy(&row[2], &pose[16 * (size_t)h], sizeof(float) * 16);
-    } else {
-      row[0] = -FLT_MAX;
-      const int id = -1;
-      std::memcpy(&row[1], &id, 4);
-      for (int q = 0; q < 16; ++q) row[2 + q] = 0.f;
-    }
-  }
-  if (n_rows_out) *n_rows_out = m;
+  launch_topk_pack(order, H, k, id_offset, c->hyp_pose.as<float>(), c->hyp_score.as<float>(), c->hyp_id.as<int>(), rows_dev, c->stream);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n_rows_out) *n_rows_out = std::min(k, H);
   return HOP_OK;
 }
 

@@ -324,6 +324,7 @@ void launch_emit(const EmitArgs& a, int blocks, hipStream_t s);
 void launch_gather_hypos(const unsigned* perm, int n, const float* pose_in, const float* score_in, float* pose_out,
                          float* score_out, int* id_out, hipStream_t s);
 void launch_iota(unsigned* p, int n, hipStream_t s);
+void launch_topk_pack(const unsigned* order, int H, int k, int id_offset, const float* pose, const float* score, const int* ids, float* rows, hipStream_t s);
 void launch_score_keys(const float* score, const int* ids, int n, unsigned long long* key, hipStream_t s);
 void launch_lcp_reverse(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_forward(const LcpArgs& a, int hb, hipStream_t s);

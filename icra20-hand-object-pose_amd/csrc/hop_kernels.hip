@@ -10,6 +10,7 @@
 //     dx^2+(dy^2+dz^2) for the generator's Verify, FLANN's (dx^2+dy^2)+dz^2 for PCL searches), compiled
 //     with -ffp-contract=off, so inlier counts and nearest indices are bit-reproducible.
 //   * per-hypothesis integer results are reduced with wave ballots + one atomic per (wave, hypothesis).
+#include "../../include/hop.h"
 #include "hop_device.h"
 
 namespace hop {
@@ -640,6 +641,24 @@ __global__ void k_gather_hypos(const unsigned* __restrict__ perm, int n, const f
     score_out[h] = score_in[src];
     id_out[h] = h;
   }
+}
+// row r of the top-k table (hop.h: score, id, pose[16]) from the r-th entry of the sorted order; rows beyond the set: score -FLT_MAX, id -1
+__global__ void k_topk_pack(const unsigned* __restrict__ order, int H, int k, int id_offset, const float* __restrict__ pose, const float* __restrict__ score,
+                            const int* __restrict__ ids, float* __restrict__ rows) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = t / HOP_TOPK_ROW_FLOATS, q = t % HOP_TOPK_ROW_FLOATS;
+  if (r >= k) return;
+  float v;
+  if (r < H) {
+    const unsigned h = order[r];
+    v = q == 0 ? score[h] : q == 1 ? __int_as_float(ids[h] + id_offset) : pose[(size_t)h * 16 + (q - 2)];
+  } else
+    v = q == 0 ? -3.402823466e+38f : q == 1 ? __int_as_float(-1) : 0.f;
+  rows[t] = v;
+}
+void launch_topk_pack(const unsigned* order, int H, int k, int id_offset, const float* pose, const float* score, const int* ids, float* rows, hipStream_t s) {
+  const int n = k * HOP_TOPK_ROW_FLOATS;
+  hipLaunchKernelGGL(k_topk_pack, dim3((n + 255) / 256), dim3(256), 0, s, order, H, k, id_offset, pose, score, ids, rows);
 }
 __global__ void k_iota(unsigned* p, int n) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;

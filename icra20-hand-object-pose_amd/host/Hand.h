@@ -125,7 +125,10 @@ class Hand {
                                   scene_hand_region.nrm.data(), scene_hand_region.n, scene_remove_swivel.xyz.data(),
                                   scene_remove_swivel.n),
                ctx_, "hop_hand_set_scene");
+    _n_removed_noise = scene_hand_region_removed_noise.n, _n_remove_swivel = scene_remove_swivel.n;
   }
+  // (points of scene_hand_region_removed_noise, of scene_remove_swivel) of the last setCurScene
+  std::pair<int, int> sceneSizes() const { return {_n_removed_noise, _n_remove_swivel}; }
 
   // Hand::getTFHandBase (Hand.cpp:505-523)
   void getTFHandBase(std::string cur_name, Mat4& tf_in_handbase) {
@@ -182,6 +185,11 @@ class Hand {
   // hand->_handbase_in_cam.inverse() (PoseEstimator.cpp:554,566): inverse of an affine matrix, adjugate in double
   void camToHandbase(float out[16]) const { affineInverse(_handbase_in_cam.m, out); }
   static void affineInverse(const float* a, float out[16]) {
+    double d[16];
+    affineInverseD(a, d);
+    for (int i = 0; i < 16; ++i) out[i] = (float)d[i];
+  }
+  static void affineInverseD(const float* a, double out[16]) {
     double m[3][3], inv[3][3];
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) m[i][j] = a[4 * i + j];
@@ -192,11 +200,11 @@ class Hand {
     inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det, inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
     inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det, inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det;
     inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
-    for (int i = 0; i < 16; ++i) out[i] = (i == 15) ? 1.f : 0.f;
+    for (int i = 0; i < 16; ++i) out[i] = (i == 15) ? 1.0 : 0.0;
     for (int i = 0; i < 3; ++i) {
       double t = 0;
-      for (int j = 0; j < 3; ++j) out[4 * i + j] = (float)inv[i][j], t -= inv[i][j] * (double)a[4 * j + 3];
-      out[4 * i + 3] = (float)t;
+      for (int j = 0; j < 3; ++j) out[4 * i + j] = inv[i][j], t -= inv[i][j] * (double)a[4 * j + 3];
+      out[4 * i + 3] = t;
     }
   }
 
@@ -234,15 +242,21 @@ class Hand {
     const hop::Cloud src = selectRows(hx, hn, m, keep);
     Mat4 offset = Mat4::Identity();
     if (src.n > 0) {  // Utils::runICP(scene_handbase, handbase, offset, 50, 30, 0.03, 1e-4), :734
-      hop::check(hop_set_scene(ctx_, src.xyz.data(), src.nrm.data(), nullptr, src.n, 0.f), ctx_, "hop_set_scene");
-      hop::check(hop_set_model(ctx_, HOP_MODEL_5MM, base_link_cloud.xyz.data(), base_link_cloud.nrm.data(), base_link_cloud.n), ctx_, "hop_set_model");
+      // a context of its own if the application gave one (setHandbaseIcpContext): the object's models and their NN lists on the
+      // PoseEstimator's context then survive the frame; the hand-base cloud is uploaded there once
+      hop_ctx* ic = icp_ctx_ ? icp_ctx_ : ctx_;
+      hop::check(hop_set_scene(ic, src.xyz.data(), src.nrm.data(), nullptr, src.n, 0.f), ic, "hop_set_scene");
+      if (!icp_ctx_ || !icp_model_set_) {
+        hop::check(hop_set_model(ic, HOP_MODEL_5MM, base_link_cloud.xyz.data(), base_link_cloud.nrm.data(), base_link_cloud.n), ic, "hop_set_model");
+        icp_model_set_ = icp_ctx_ != nullptr;
+      }
       const Mat4 I = Mat4::Identity();
-      hop::check(hop_hypos_upload(ctx_, I.m, nullptr, 1), ctx_, "hop_hypos_upload");
+      hop::check(hop_hypos_upload(ic, I.m, nullptr, 1), ic, "hop_hypos_upload");
       hop_icp_opts o{50, 30.f, 0.03f, 0, 6};  // nn_mode 6: Utils::runICP's own minimiser (Levenberg-Marquardt)
-      hop::check(hop_icp_refine(ctx_, &o, nullptr, nullptr), ctx_, "hop_icp_refine");
+      hop::check(hop_icp_refine(ic, &o, nullptr, nullptr), ic, "hop_icp_refine");
       Mat4 pose;
       int got = 0;
-      hop::check(hop_hypos_download(ctx_, pose.m, nullptr, nullptr, 1, &got), ctx_, "hop_hypos_download");
+      hop::check(hop_hypos_download(ic, pose.m, nullptr, nullptr, 1, &got), ic, "hop_hypos_download");
       affineInverse(pose.m, offset.m);  // offset = refined_pose.inverse(): source -> target
     }
     const float translation = std::sqrt(offset.m[3] * offset.m[3] + offset.m[7] * offset.m[7] + offset.m[11] * offset.m[11]);
@@ -259,9 +273,16 @@ class Hand {
     bool is_identity = true;
     for (int i = 0; i < 16; ++i) is_identity = is_identity && offset.m[i] == ((i % 5 == 0) ? 1.f : 0.f);
     if (!is_identity) _component_status["handbase"] = true;
-    Mat4 offset_inv;
-    affineInverse(offset.m, offset_inv.m);
-    _handbase_in_cam = _handbase_in_cam * offset_inv;  // :771
+    // handbase_in_cam * offset.inverse() (:771) with the inverse and the product in double, rounded once (the Python mirror does the same)
+    double oi[16], prod[16];
+    affineInverseD(offset.m, oi);
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        double acc = 0;
+        for (int k = 0; k < 4; ++k) acc += (double)_handbase_in_cam.m[4 * i + k] * oi[4 * k + j];
+        prod[4 * i + j] = acc;
+      }
+    for (int i = 0; i < 16; ++i) _handbase_in_cam.m[i] = (float)prod[i];
   }
   // HandT42::adjustHandHeight (Hand.cpp:999-1051); scene_hand_region: the 3 mm hand-region cloud, camera frame, with normals
   void adjustHandHeight(const hop::Cloud& scene_hand_region) {
@@ -444,8 +465,14 @@ class Hand {
   ConfigParser* cfg;
   hop_pso_settings _pso_settings;
 
+  // optional second context for handbaseICP's Utils::runICP call (see there)
+  void setHandbaseIcpContext(hop_ctx* c) { icp_ctx_ = c, icp_model_set_ = false; }
+
  protected:
   hop_ctx* ctx_;
+  hop_ctx* icp_ctx_ = nullptr;
+  bool icp_model_set_ = false;
+  int _n_removed_noise = 0, _n_remove_swivel = 0;
 };
 
 class HandT42 : public Hand {

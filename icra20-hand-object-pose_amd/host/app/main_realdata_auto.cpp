@@ -27,7 +27,7 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
-#include "../Hand.h"
+#include "../Frame.h"
 
 static hop::Cloud read_cloud(const std::string& path) {
   // int32 n, int32 has_conf, then 3n float xyz planes, 3n float normal planes, [n float conf]
@@ -76,8 +76,52 @@ int main(int argc, char** argv) {
       return 3;
     }
   }
+  if (argc >= 6 && std::string(argv[2]) == "--depth") {
+    // main_realdata_auto <config.yaml> --depth <assets_dir> <depth.png> <handbase_in_cam.txt> [out_dir]: the whole driver from the 16-bit
+    // depth image (main_realdata_auto.cpp:54-205; the reference reads rgb / depth / palm_in_base / arm poses from the config's paths)
+    try {
+      ConfigParser cfg(argv[1]);
+      const hop::Assets assets(argv[3]);
+      const hop::Calibration cal(cfg);
+      std::vector<uint16_t> depth;
+      int H = 0, W = 0;
+      hop::read_png16(argv[4], depth, H, W);
+      const Mat4 handbase_in_cam = hop::parse_pose_txt(argv[5]);
+      const std::string out_dir = argc > 6 ? argv[6] : ".";
+      PoseEstimator est(&cfg, assets.model, assets.model001);
+      HandT42 hand(&cfg, est.ctx());
+      assets.addTo(hand);
+      hop_ctx* icp_ctx = nullptr;  // handbaseICP's own context: the object's models stay on the estimator's
+      hop::check(hop_ctx_create(0, &icp_ctx), nullptr, "hop_ctx_create");
+      hand.setHandbaseIcpContext(icp_ctx);
+      hop::FrameInfo info;
+      const auto t0 = std::chrono::steady_clock::now();
+      const Mat4 pose = hop::process_frame(cfg, assets, est, hand, depth, H, W, cal.K9, handbase_in_cam, 0.001, true, true, &info);
+      std::printf("frame_ms %.3f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      std::printf("valid pixels %d, hand region %d, without hand %d, object segment %d, generated %d, clusters %d, after ICP %d, after physics %d, after render %d\n",
+                  info.n_valid, info.n_hand_region, info.n_without_hand, info.n_object_segment, info.n_generated, info.n_clusters, info.n_after_icp,
+                  info.n_after_physics, info.n_after_render);
+      std::ofstream ff(out_dir + "/model2scene.txt");
+      ff.precision(9);
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) ff << pose.m[4 * r + c] << (c == 3 ? "\n" : " ");
+      std::ofstream fa(out_dir + "/finger_angles.txt");
+      fa.precision(9);
+      for (auto& kv : info.angles) fa << kv.first << " " << kv.second << "\n";
+      hop_ctx_destroy(icp_ctx);
+      std::ofstream fhb(out_dir + "/handbase_in_cam.txt");
+      fhb.precision(9);
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) fhb << info.handbase_in_cam.m[4 * r + c] << (c == 3 ? "\n" : " ");
+      return 0;
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "error: %s\n", e.what());
+      return 3;
+    }
+  }
   if (argc < 3) {
-    std::cout << "usage: main_realdata_auto <config.yaml> <frame_dir> [out_dir]\n       main_realdata_auto --dump-config <config.yaml>\n";
+    std::cout << "usage: main_realdata_auto <config.yaml> <frame_dir> [out_dir]\n       main_realdata_auto <config.yaml> --depth <assets_dir> <depth.png> "
+                 "<handbase_in_cam.txt> [out_dir]\n       main_realdata_auto --dump-config <config.yaml>\n";
     return 2;
   }
   try {

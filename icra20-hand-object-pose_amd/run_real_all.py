@@ -77,7 +77,7 @@ def estimate_frame(ctx, xyz, nrm, conf, sym):
     return best
 
 
-def run(record_dir, model_name="ellipse", rank=0, world=1, device=0, ctx=None):
+def run(record_dir, model_name="ellipse", rank=0, world=1, device=0, ctx=None, poses_out=None):
     """Processes this rank's frames; returns the indices it wrote."""
     own = ctx is None
     ctx = ctx or api.Context(device)
@@ -94,9 +94,50 @@ def run(record_dir, model_name="ellipse", rank=0, world=1, device=0, ctx=None):
         os.makedirs(d, exist_ok=True)
         np.savetxt(os.path.join(d, "model2scene.txt"), pose.astype(np.float64))
         done.append(idx)
+        if poses_out is not None:
+            poses_out[idx] = pose
     if own:
         ctx.close()
     return done
+
+
+def gather_frame_poses(local, all_keys, rank, world, comm=None, dist=None):
+    """BASELINE configs[3] "RCCL gather of per-frame best pose" / SURVEY 8(e) "C4 frames": every rank holds the poses of the frames it
+    processed (`local`: key -> 4 x 4); `all_keys` is the globally agreed, sorted list of frame keys (every rank enumerates the same
+    directory).  ONE collective at the end of the shard: rows {frame number, pose} padded to the largest shard --
+    hop_frames_allgather (ncclAllGather inside libhop.so) when an RCCL communicator is given, torch.distributed.all_gather (gloo: the
+    CPU tests) otherwise.  Returns {key: pose} of ALL frames on every rank."""
+    number = {k: i for i, k in enumerate(all_keys)}
+    # the largest shard, which every rank derives from the same list and the same rule (frame index mod world, per record)
+    owner = lambda k: (k[1] if isinstance(k, tuple) else k) % world
+    counts = [0] * world
+    for k in all_keys:
+        counts[owner(k)] += 1
+    rows_per_rank = max(1, max(counts))
+    rows = np.zeros((len(local), api.FRAME_ROW_FLOATS), np.float32)
+    for r, (k, pose) in enumerate(sorted(local.items(), key=lambda kv: number[kv[0]])):
+        rows[r, 0] = number[k]
+        rows[r, 1:] = np.asarray(pose, np.float32).reshape(16)
+    if len(rows) > rows_per_rank:
+        raise ValueError("a rank holds more frames than its share: the shard is not frame index mod world")
+    if world == 1 and comm is None:
+        table = rows
+    elif comm is not None:
+        table = comm.frames_allgather(rows, rows_per_rank, world)
+    else:
+        import torch
+        pad = np.zeros((rows_per_rank, api.FRAME_ROW_FLOATS), np.float32)
+        pad[:, 0] = -1
+        pad[:len(rows)] = rows
+        t = torch.from_numpy(pad)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        table = torch.cat(parts).numpy()
+    out = {}
+    for row in table:
+        if row[0] >= 0:
+            out[all_keys[int(round(float(row[0])))]] = row[1:].reshape(4, 4).copy()
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ the reference's layout
@@ -162,6 +203,47 @@ class Assets:
         self.keys = keys if keys is not None else synth.ppf_key_table()
 
 
+def write_assets_dir(assets, path):
+    """The Assets in the binary layout the C++ drivers read (host/Frame.h hop::Assets; host/app/run_real_all.cpp, main_realdata_auto.cpp --depth):
+    model.bin, model001.bin, ppf_keys.bin, hand.txt + one cloud file per link, base_link.bin, meshes.txt + one mesh file per mesh."""
+    os.makedirs(path, exist_ok=True)
+
+    def wc(name, xyz, nrm=None):
+        xyz = np.asarray(xyz, np.float32)
+        nrm = np.zeros_like(xyz) if nrm is None else np.asarray(nrm, np.float32)
+        with open(os.path.join(path, name), "wb") as f:
+            np.array([len(xyz), 0], np.int32).tofile(f)
+            np.ascontiguousarray(xyz.T).tofile(f)
+            np.ascontiguousarray(nrm.T).tofile(f)
+
+    def wm(name, V, Fi):
+        with open(os.path.join(path, name), "wb") as f:
+            np.array([len(V), len(Fi)], np.int32).tofile(f)
+            np.ascontiguousarray(V, np.float32).tofile(f)
+            np.ascontiguousarray(Fi, np.int32).tofile(f)
+
+    wc("model.bin", *assets.model)
+    wc("model001.bin", *assets.model001)
+    with open(os.path.join(path, "ppf_keys.bin"), "wb") as f:
+        np.array([len(assets.keys)], np.int32).tofile(f)
+        np.ascontiguousarray(assets.keys, np.int32).tofile(f)
+    hand = assets.hand
+    with open(os.path.join(path, "hand.txt"), "w") as f:
+        for name in hand.clouds:
+            if name == "base_link":
+                continue
+            wc(f"{name}.bin", *hand.clouds[name])
+            f.write(f"{name} {hand.parents[name]} {name}.bin " + " ".join(repr(float(v)) for v in hand.tf_in_parent[name].reshape(16)) + "\n")
+    wc("base_link.bin", *hand.clouds["base_link"])
+    with open(os.path.join(path, "meshes.txt"), "w") as f:
+        wm("object.mesh", *assets.mesh)
+        f.write("object object.mesh\n")
+        for name, (V, Fi) in hand.meshes.items():
+            wm(f"{name}.mesh", V, Fi)
+            f.write(f"{name} {name}.mesh\n")
+    return path
+
+
 def process_frame(ctx, cfg, assets, depth_raw, K, handbase_in_cam, depth_unit=0.001, use_physics=True, use_render=True, info=None):
     """run_real_all.cpp:116-241 for one frame; returns model2scene (identity when no pose is found, main :189-196).  ``info``
     (a dict) receives the intermediate results the tests look at."""
@@ -217,6 +299,13 @@ def process_frame(ctx, cfg, assets, depth_raw, K, handbase_in_cam, depth_unit=0.
     info["n_object_segment"] = len(sx)
     if len(sx) < 4:
         return ident
+    if os.environ.get("HOP_APP_DEBUG"):
+        sm = lambda a: float(np.where(np.isfinite(a), a, 1e3).astype(np.float64).sum())
+        print("debug sums: scene_organized %d %.9g %.9g | scene_rgb %d %.9g %.9g | region %d %.9g | without_hand %d %.9g %.9g %.9g | mls %d %.9g %.9g | segment %d %.9g %.9g %.9g"
+              % (int(fin.sum()), sm(scene_organized[fin]), sm(scene_organized_n[fin]), len(scene_rgb), sm(scene_rgb), sm(scene_rgb_n), len(rx), sm(rx), len(ox), sm(ox), sm(on), sm(oc),
+                 len(mp), sm(mp), sm(mnrm), len(sx), sm(sx), sm(sn), sm(scf)))
+    if os.environ.get("HOP_APP_DEBUG_DIR"):
+        np.savez(os.path.join(os.environ["HOP_APP_DEBUG_DIR"], "py.npz"), ox=ox, on=on, oc=oc, mp=mp, mn=mnrm, mk=mk, sx=sx, sn=sn, scf=scf, rgb=scene_rgb[keep_n], rgbn=scene_rgb_n[keep_n])
     # :230-241
     est = api.PoseEstimator(cfg, assets.model, assets.model001, ctx=ctx)
     est.setCurScene(sx, sn, scf, cloud_withouthand_raw=cloud_withouthand_raw, depth_raw=depth_raw, depth_unit=depth_unit, K=K)
@@ -224,7 +313,9 @@ def process_frame(ctx, cfg, assets, depth_raw, K, handbase_in_cam, depth_unit=0.
     est.registerMesh(assets.mesh[0], assets.mesh[1], "object")
     if not est.runSuper4pcs(assets.keys):
         return ident
+    info["n_generated"] = ctx.hypos_count()
     est.clusterPoses(30, 0.015, True)
+    info["n_clusters"] = ctx.hypos_count()
     est.refineByICP()
     est.clusterPoses(5, 0.003, False)
     info["n_after_icp"] = ctx.hypos_count()
@@ -256,7 +347,10 @@ def write_synthetic_record(base_dir, model_name="ellipse", record="synthetic_000
     cfg["cam1_in_leftarm"] = [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]
     cfg["handbase_in_palm"] = [float(v) for v in np.eye(4).reshape(16)]
     with open(os.path.join(base_dir, "config_autodataset.yaml"), "w") as f:
-        yaml.safe_dump(cfg, f)
+        class _Dumper(yaml.SafeDumper):     # lists in flow style ("cam_K: [..]"), mappings in block style: the form of the reference's file
+            pass
+        _Dumper.add_representer(list, lambda d, data: d.represent_sequence("tag:yaml.org,2002:seq", data, flow_style=True))
+        yaml.dump(cfg, f, Dumper=_Dumper, default_flow_style=False)
     fmt = lambda T: "\n".join(" ".join(repr(float(v)) for v in row) for row in np.asarray(T, np.float64)) + "\n"
     for k in range(n_frames):
         g = synth.grasp_depth_frame(seed=seed0 + k)
@@ -268,7 +362,8 @@ def write_synthetic_record(base_dir, model_name="ellipse", record="synthetic_000
     return rec
 
 
-def run_raw(base_dir, cfg, model_name=None, records=None, rank=0, world=1, device=0, ctx=None, assets=None, force=False, use_physics=True, use_render=True):
+def run_raw(base_dir, cfg, model_name=None, records=None, rank=0, world=1, device=0, ctx=None, assets=None, force=False, use_physics=True, use_render=True,
+            poses_out=None):
     """run_real_all.cpp:70-273: every frame of every record directory of <base_dir>/<model_name>/; this rank's share
     (frame index mod world); returns {record: [indices written]}."""
     own = ctx is None
@@ -284,6 +379,8 @@ def run_raw(base_dir, cfg, model_name=None, records=None, rank=0, world=1, devic
         for idx in shard(raw_frame_indices(rec), rank, world):
             out = os.path.join(rec, "predict", str(idx), "model2scene.txt")
             if os.path.exists(out) and not force:
+                if poses_out is not None:
+                    poses_out[(record, idx)] = np.loadtxt(out).astype(np.float32)
                 continue                                            # resume: the frame was finished by an earlier run
             leftarm_in_base = parse_pose_txt(os.path.join(rec, f"arm_left_link_7_t_{idx}.txt"))
             palm_in_baselink = parse_pose_txt(os.path.join(rec, f"palm_in_base{idx}.txt"))
@@ -293,13 +390,16 @@ def run_raw(base_dir, cfg, model_name=None, records=None, rank=0, world=1, devic
             np.savetxt(out + ".tmp", pose.astype(np.float64))
             os.replace(out + ".tmp", out)                           # a killed run never leaves a half-written result
             done[record].append(idx)
+            if poses_out is not None:
+                poses_out[(record, idx)] = pose
     if own:
         ctx.close()
     return done
 
 
-def eval_raw(base_dir, model_name, model_pts):
-    """scripts/eval_all.py:36-79 over every record directory of one object."""
+def eval_raw(base_dir, model_name, model_pts, pred=None):
+    """scripts/eval_all.py:36-79 over every record directory of one object; `pred` ({(record, idx): pose}, the gathered table) replaces
+    reading predict/<idx>/model2scene.txt back."""
     errs = {}
     mdir = os.path.join(base_dir, model_name)
     for record in sorted(d for d in os.listdir(mdir) if os.path.isdir(os.path.join(mdir, d))):
@@ -307,9 +407,12 @@ def eval_raw(base_dir, model_name, model_pts):
         for idx in raw_frame_indices(rec):
             gt_file = os.path.join(rec, "refined_gt", f"ob_in_cam{idx}.txt")
             pred_file = os.path.join(rec, "predict", str(idx), "model2scene.txt")
-            pred = np.loadtxt(pred_file) if os.path.exists(pred_file) else np.eye(4)
+            if pred is not None:
+                pr = np.asarray(pred.get((record, idx), np.eye(4)), np.float64)
+            else:
+                pr = np.loadtxt(pred_file) if os.path.exists(pred_file) else np.eye(4)
             gt = parse_pose_txt(gt_file).astype(np.float64) if os.path.exists(gt_file) else np.eye(4)
-            errs[(record, idx)] = adi(pred[:3, :3], pred[:3, 3], gt[:3, :3], gt[:3, 3], np.asarray(model_pts, np.float64))
+            errs[(record, idx)] = adi(pr[:3, :3], pr[:3, 3], gt[:3, :3], gt[:3, 3], np.asarray(model_pts, np.float64))
     e = np.array(list(errs.values()))
     n = max(len(e), 1)
     return {"total": int(len(e)), "recall_5mm": float(np.sum(e < 0.005) / n), "recall_10mm": float(np.sum(e < 0.010) / n), "errs": errs}
@@ -323,16 +426,19 @@ def adi(R_est, t_est, R_gt, t_gt, pts):
     return float(nn_dists.mean())
 
 
-def eval_all(record_dir, model_pts):
+def eval_all(record_dir, model_pts, pred=None):
     """scripts/eval_all.py:36-79 for one object: ADI of every frame that has a ground truth (a missing prediction counts
     as the identity, as there), recall at 5 mm (the authors' threshold) and at 10 mm."""
     errs = {}
     for idx in frame_indices(record_dir):
         gt_file = os.path.join(record_dir, "refined_gt", f"ob_in_cam{idx}.txt")
         pred_file = os.path.join(record_dir, "predict", str(idx), "model2scene.txt")
-        pred = np.loadtxt(pred_file) if os.path.exists(pred_file) else np.eye(4)
+        if pred is not None:
+            pr = np.asarray(pred.get(idx, np.eye(4)), np.float64)
+        else:
+            pr = np.loadtxt(pred_file) if os.path.exists(pred_file) else np.eye(4)
         gt = np.loadtxt(gt_file) if os.path.exists(gt_file) else np.eye(4)
-        errs[idx] = adi(pred[:3, :3], pred[:3, 3], gt[:3, :3], gt[:3, 3], np.asarray(model_pts, np.float64))
+        errs[idx] = adi(pr[:3, :3], pr[:3, 3], gt[:3, :3], gt[:3, 3], np.asarray(model_pts, np.float64))
     e = np.array(list(errs.values()))
     n = max(len(e), 1)
     return {"total": int(len(e)), "recall_5mm": float(np.sum(e < 0.005) / n), "recall_10mm": float(np.sum(e < 0.010) / n), "errs": errs}
@@ -351,13 +457,21 @@ def main():
         ap.error("--base (the reference's layout) or --root (prepared clouds) is required")
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    dist = None
+    dist, comm = None, None
     if world > 1:
         import torch
         import torch.distributed as dist
         local = local % max(torch.cuda.device_count(), 1)  # self-test: several ranks on one GPU (HOP_BENCH_BACKEND=gloo)
         torch.cuda.set_device(local)
-        dist.init_process_group(backend=os.environ.get("HOP_BENCH_BACKEND", "nccl"))
+        backend = os.environ.get("HOP_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend=backend)
+        if backend == "nccl":
+            # the library's own RCCL communicator for the final gather: rank 0's unique id travels through torch.distributed
+            idt = torch.zeros(128, dtype=torch.uint8, device=torch.device("cuda", local))
+            if rank == 0:
+                idt = torch.tensor(list(api.Comm.unique_id()), dtype=torch.uint8, device=torch.device("cuda", local))
+            dist.broadcast(idt, 0)
+            comm = api.Comm(local, bytes(idt.cpu().numpy().tolist()), rank, world)
     if args.base:
         from . import config as hop_config
         if args.synthetic and rank == 0:
@@ -366,25 +480,35 @@ def main():
             dist.barrier()
         cfg_path = args.config or (os.path.join(args.base, "config_autodataset.yaml") if os.path.exists(os.path.join(args.base, "config_autodataset.yaml")) else None)
         cfg = hop_config.load_config(cfg_path)
-        done = run_raw(args.base, cfg, args.model, rank=rank, world=world, device=local, force=args.force)
-        if dist is not None:
-            dist.barrier()
+        model_name = args.model or cfg["model_name"]
+        if model_name != "ellipse":
+            #  only the synthetic ellipse has assets here: the paper's meshes / PPF tables are download links
+            raise SystemExit(f"no assets for model '{model_name}': this runner ships the synthetic ellipse only (pass --model ellipse or supply Assets through run_raw)")
+        local_poses = {}
+        done = run_raw(args.base, cfg, model_name, rank=rank, world=world, device=local, force=args.force, poses_out=local_poses)
+        mdir = os.path.join(args.base, model_name)
+        all_keys = [(rec, i) for rec in sorted(d for d in os.listdir(mdir) if os.path.isdir(os.path.join(mdir, d))) for i in raw_frame_indices(os.path.join(mdir, rec))]
+        gathered = gather_frame_poses(local_poses, all_keys, rank, world, comm=comm, dist=dist)   # the one collective of the run
         if rank == 0:
-            r = eval_raw(args.base, args.model or cfg["model_name"], synth.ellipsoid_model(4000)[0])
+            r = eval_raw(args.base, model_name, Assets().model001[0], pred=gathered)
             r.pop("errs")
-            print(json.dumps({"frames_this_rank": sum(len(v) for v in done.values()), "world": world, **r}))
+            print(json.dumps({"frames_this_rank": sum(len(v) for v in done.values()), "frames_gathered": len(gathered), "world": world,
+                              "gather": "hop_frames_allgather (RCCL)" if comm is not None else ("torch.distributed all_gather" if dist is not None else "none"), **r}))
     else:
         if args.synthetic and rank == 0:
             write_synthetic_dataset(args.root, args.synthetic)
         if dist is not None:
             dist.barrier()
-        done = run(args.root, rank=rank, world=world, device=local)
-        if dist is not None:
-            dist.barrier()
+        local_poses = {}
+        done = run(args.root, rank=rank, world=world, device=local, poses_out=local_poses)
+        gathered = gather_frame_poses(local_poses, frame_indices(args.root), rank, world, comm=comm, dist=dist)
         if rank == 0:
-            r = eval_all(args.root, synth.ellipsoid_model(4000)[0])
+            r = eval_all(args.root, synth.ellipsoid_model(4000)[0], pred=gathered)
             r.pop("errs")
-            print(json.dumps({"frames_this_rank": len(done), "world": world, **r}))
+            print(json.dumps({"frames_this_rank": len(done), "frames_gathered": len(gathered), "world": world,
+                              "gather": "hop_frames_allgather (RCCL)" if comm is not None else ("torch.distributed all_gather" if dist is not None else "none"), **r}))
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

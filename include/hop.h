@@ -195,6 +195,18 @@ int hop_comm_create(int device, const unsigned char id[HOP_COMM_ID_BYTES], int r
 void hop_comm_destroy(hop_comm* comm);
 const char* hop_comm_last_error(const hop_comm* comm /* may be NULL: why RCCL could not be loaded */);
 int hop_topk_allgather(hop_comm* comm, const float* rows_in, int k, float* merged_out, int* n_rows_out);
+/* the resident set's top-k table written on the device (rows_dev: device memory, k rows) -- no download, no host sort */
+int hop_topk_pack_device(hop_ctx* ctx, int k, int id_offset, float* rows_dev, int* n_rows_out);
+/* the exchange with the table on the device: rows_dev (device memory, written by hop_topk_pack_device) -> ncclAllGather -> merge
+ * kernel; only the k merged rows return to the host.  Same result as hop_topk_pack + hop_topk_allgather. */
+int hop_topk_allgather_device(hop_comm* comm, const float* rows_dev, int k, float* merged_out, int* n_rows_out);
+/* ncclCommCount of the communicator, mean wall time [us] and number of the top-k exchanges so far */
+int hop_comm_info(hop_comm* comm, int* rccl_ranks_out, double* mean_exchange_us_out, long* exchanges_out);
+/* BASELINE configs[3] (frames sharded over the GPUs, "RCCL gather of per-frame best pose"; the reference writes one 4 x 4 matrix per
+ * frame, run_real_all.cpp:256-262): rows of HOP_FRAME_ROW_FLOATS floats = { frame index, pose[16] row-major }, n_local <= rows_per_rank
+ * rows from this rank, ONE ncclAllGather; all_out: world * rows_per_rank rows in rank order, padding rows have frame index -1. */
+#define HOP_FRAME_ROW_FLOATS 17
+int hop_frames_allgather(hop_comm* comm, const float* rows_local, int n_local, int rows_per_rank, float* all_out);
 
 /* ------------------------------------------------------------------------------------------------
  * Hand-state search: Hand::matchOneComponentPSO (src/perception/src/Hand.cpp:603-672) ->

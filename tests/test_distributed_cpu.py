@@ -122,3 +122,42 @@ def test_strong_scaling_shards_reproduce_the_global_topk(tmp_path, H):
     best = np.lexsort((np.arange(H), -scores))[:k]      # what one GPU holding all H hypotheses would report
     pose, score, ids = api.rows_to_hypos(m0)
     assert np.array_equal(ids, best) and np.array_equal(score, scores[best]) and np.array_equal(pose.reshape(-1, 16), poses[best])
+
+
+def _frames_worker(rank, world, port, n_frames, out_dir):
+    """BASELINE configs[3] without the kernels: frame f belongs to rank f mod world (run_real_all.shard); every rank holds the poses of
+    its frames and takes part in the ONE gather at the end of the run (run_real_all.gather_frame_poses)."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import hop_loader
+    hop = hop_loader.load()
+    from hop_amd import run_real_all as rra
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    keys = [("rec_a", i) for i in range(0, n_frames, 2)] + [("rec_b", i) for i in range(1, n_frames, 2)]
+    keys.sort()
+    rng = np.random.default_rng(5)
+    truth = {k: rng.normal(size=(4, 4)).astype(np.float32) for k in keys}      # the same on every rank: what each frame "computes"
+    mine = {k: truth[k] for k in keys if k[1] % world == rank}                # run_raw: frame index mod world inside every record
+    got = rra.gather_frame_poses(mine, keys, rank, world, comm=None, dist=dist)
+    assert sorted(got) == keys
+    np.save(os.path.join(out_dir, f"frames_{rank}.npy"), np.stack([got[k] for k in keys]))
+    np.save(os.path.join(out_dir, "frames_truth.npy"), np.stack([truth[k] for k in keys]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [7, 2, 1])
+def test_c4_frame_poses_gathered_from_two_ranks(tmp_path, n_frames):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import hop_loader
+    hop_loader.load()
+    from hop_amd import api
+    api.build_library()
+    port = _free_port()
+    mp.spawn(_frames_worker, args=(2, port, n_frames, str(tmp_path)), nprocs=2, join=True)
+    t = np.load(tmp_path / "frames_truth.npy")
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"frames_{r}.npy"), t), "every rank ends with every frame's pose"

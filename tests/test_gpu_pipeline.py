@@ -130,3 +130,54 @@ def test_dataset_runner_on_the_reference_layout(hop, tmp_path):
     assert rr.run_raw(base, cfg) == {"synthetic_000": []}                       # resume: nothing left to do
     os.remove(os.path.join(rec, "predict", "1", "model2scene.txt"))
     assert rr.run_raw(base, cfg, rank=1, world=2) == {"synthetic_000": [1]}     # frame 1 belongs to rank 1 of 2
+
+
+def test_cpp_drivers_from_the_depth_image_equal_the_python_mirror(hop, tmp_path):
+    """The C++ host above the C-ABI from what the robot records (north_star: "host C++ calling hand-written HIP kernels ... drops in behind
+    main_realdata_auto"): host/app/run_real_all (run_real_all.cpp:70-273, the reference's directory layout, 16-bit PNG depth frames and
+    pose text files read in C++) and host/app/main_realdata_auto --depth (main_realdata_auto.cpp:54-205) against the Python mirror
+    run_real_all.process_frame on the same frames: the same pose, hand-base correction and finger angles."""
+    import subprocess
+    from hop_amd import config as hop_config
+    from hop_amd import run_real_all as rr
+    lib = os.path.join(ROOT, "icra20-hand-object-pose_amd", "lib")
+    base = str(tmp_path / "auto_collect")
+    rec = rr.write_synthetic_record(base, "ellipse", n_frames=2)
+    cfg_path = os.path.join(base, "config_autodataset.yaml")
+    cfg = hop_config.load_config(cfg_path)
+    assets = rr.Assets()
+    adir = rr.write_assets_dir(assets, str(tmp_path / "assets"))
+    # Python mirror, frame by frame
+    from hop_amd import api
+    ctx = api.Context(0)
+    K, _, _ = rr.calibration(cfg)
+    py = {}
+    for idx in (0, 1):
+        hb = rr.handbase_in_cam_of(cfg, rr.parse_pose_txt(os.path.join(rec, f"arm_left_link_7_t_{idx}.txt")), rr.parse_pose_txt(os.path.join(rec, f"palm_in_base{idx}.txt")))
+        info = {}
+        py[idx] = (rr.process_frame(ctx, cfg, assets, rr.read_depth_png(os.path.join(rec, f"depth{idx}.png")), K, hb, info=info), info, hb)
+    ctx.close()
+    # C++ dataset driver
+    r = subprocess.run([os.path.join(lib, "run_real_all"), cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for idx in (0, 1):
+        cpp = np.loadtxt(os.path.join(rec, "predict", str(idx), "model2scene.txt")).astype(np.float32)
+        assert np.abs(cpp - py[idx][0]).max() < 2e-6, (idx, cpp, py[idx][0])
+    r2 = subprocess.run([os.path.join(lib, "run_real_all"), cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0 and "0 frames written" in r2.stdout and "2 resumed" in r2.stdout            # resume
+    ev = rr.eval_raw(base, "ellipse", assets.model001[0])
+    assert ev["total"] == 2 and ev["recall_10mm"] >= 0.5
+    # C++ single-frame driver from the depth image
+    out = tmp_path / "out"
+    out.mkdir()
+    hbf = tmp_path / "hb.txt"
+    hbf.write_text("\n".join(" ".join(repr(float(v)) for v in row) for row in py[0][2]) + "\n")
+    r3 = subprocess.run([os.path.join(lib, "main_realdata_auto"), cfg_path, "--depth", adir, os.path.join(rec, "depth0.png"), str(hbf), str(out)],
+                        capture_output=True, text=True, timeout=600)
+    assert r3.returncode == 0, r3.stdout + r3.stderr
+    assert np.abs(np.loadtxt(out / "model2scene.txt").astype(np.float32) - py[0][0]).max() < 2e-6
+    assert np.abs(np.loadtxt(out / "handbase_in_cam.txt").astype(np.float32) - py[0][1]["handbase_in_cam"]).max() < 2e-6
+    ang = {ln.split()[0]: float(ln.split()[1]) for ln in (out / "finger_angles.txt").read_text().splitlines()}
+    assert set(ang) == set(py[0][1]["angles"])
+    for k, v in ang.items():
+        assert abs(v - py[0][1]["angles"][k]) < 1e-6
