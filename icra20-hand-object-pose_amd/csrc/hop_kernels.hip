@@ -2132,7 +2132,10 @@ __device__ __forceinline__ int icp_fusedq_point_mom(const IcpArgs& a, int i, con
   acc[73] += d2;
   return ICP_PT_ACCEPTED;
 }
-__global__ __launch_bounds__(256) void k_icp_fusedq_mom(IcpArgs a, int R) {
+#ifndef HOP_ICP_MOM_W
+#define HOP_ICP_MOM_W 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM_W))) void k_icp_fusedq_mom(IcpArgs a, int R) {
   __shared__ double red[4][ICP_NMOM + 1];
   __shared__ unsigned short defer_i[4][64 * ICP_ACCUM_R];
   const int hl = blockIdx.y, h = a.h0 + hl;
@@ -2399,6 +2402,7 @@ __global__ __launch_bounds__(256) void k_lcp_cells_fast(LcpArgs a, int hb, int h
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int k = pt * 64 + lane;
   const bool kin = k < a.ns;
+  const float inv_dist = 1.f / a.dist;
   V3 s = v3(0, 0, 0), sn = v3(0, 0, 0);
   if (kin) s = v3(a.qx[k], a.qy[k], a.qz[k]), sn = v3(a.qnx[k], a.qny[k], a.qnz[k]);
   for (int j = 0; j < LCP_FTH / 4; ++j) {
@@ -2413,17 +2417,25 @@ __global__ __launch_bounds__(256) void k_lcp_cells_fast(LcpArgs a, int hb, int h
       V3 pm;
       cells_nn1f(a.model_cells, m4_point_fma(Ti, s), T, s, best, pos, pm);
       if (pos >= 0 && best < a.dist * a.dist) {
+        // this mode's contract is 1e-4 relative on the score: the normalisation and the (1 - d / dist) factor use the hardware's
+        // reciprocal square root / square root (1 ulp) instead of the IEEE division and square-root sequences (~100 of the ~590 vector
+        // instructions of a lookup, profiles/r03_pmc_sq.txt); nn_mode 2 keeps the reference's operations
         const float4 mnr = a.model_cells.nrm[pos];
-        const V3 nmod = vnormalized(m4_dir(T, v3(mnr.x, mnr.y, mnr.z)));
-        const float f = lcp_term_unit(sn, nmod, best, a.dist, a.cos_thres);
-        if (f >= 0.f) v = f;
+        const V3 nraw = m4_dir(T, v3(mnr.x, mnr.y, mnr.z));
+        V3 nmod = nraw * __builtin_amdgcn_rsqf(vsqn(nraw));
+        float d1 = vdot(sn, nmod);
+        // a dot product within 2e-6 of the threshold is decided by the reference's own operations (the fast value is within 3e-7 of it):
+        // which terms enter the sum is exactly the reference's choice
+        if (fabsf(d1 - a.cos_thres) < 2.0e-6f) nmod = vnormalized(nraw), d1 = vdot(sn, nmod);
+        if (d1 > a.cos_thres) v = d1 * (1.f - __builtin_amdgcn_sqrtf(best) * inv_dist);
         float rbest = 3.0e38f;
         int rk = -1;
         cells_nn_plain(a.scene_cells, pm, rbest, rk);
         if (rk >= 0) {
           const float4 rn = a.scene_cells.nrm[rk];
-          const float g = lcp_term_unit(nmod, v3(rn.x, rn.y, rn.z), rbest, a.dist, a.cos_thres);
-          if (g >= 0.f) v += g;
+          float d2r = vdot(nmod, v3(rn.x, rn.y, rn.z));
+          if (fabsf(d2r - a.cos_thres) < 2.0e-6f) d2r = vdot(vnormalized(nraw), v3(rn.x, rn.y, rn.z));
+          if (d2r > a.cos_thres) v += d2r * (1.f - __builtin_amdgcn_sqrtf(rbest) * inv_dist);
         }
       }
     }
