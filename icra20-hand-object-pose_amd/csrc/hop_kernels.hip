@@ -228,6 +228,120 @@ __global__ __launch_bounds__(256) void k_ppf_matrix_sym(PpfMatrixArgs a) {
   if (both && jvalid) a.out[(size_t)j * a.words + ib] = rev;
 }
 
+// k_ppf_matrix_sym wrote its words where they fell: a row's forward word as one 8-byte store per wavefront, the reverse words as 64
+// scattered 8-byte stores -- 172 MB of HBM writes for the 50 MB matrix (profiles/r02_pmc_hbm.txt).  The tiled form computes an
+// PPF_TW x PPF_TW-word tile per block, stages the forward words and the transposed reverse words in LDS and writes both as
+// row segments of PPF_TW words.  Same evaluations, same bits (tests/test_gpu_parity.py compares the kernels).
+#ifndef HOP_PPF_TW
+#define HOP_PPF_TW 4
+#endif
+constexpr int PPF_TW = HOP_PPF_TW;  // words per tile edge (4: 32-byte segments, 16 KB of LDS; 8: 64-byte segments, 64 KB -- too few waves per SIMD)
+constexpr int PPF_WQ = PPF_TW / 4;  // column words per wavefront
+__global__ __launch_bounds__(256) void k_ppf_matrix_tile(PpfMatrixArgs a) {
+  __shared__ float rows[PPF_ROWS][8];
+  __shared__ float sthr[32];
+  __shared__ unsigned long long tfw[PPF_TW * 64][PPF_TW];  // forward: [row in tile][column word]
+  __shared__ unsigned long long trv[PPF_TW * 64][PPF_TW];  // reverse: [column in tile = output row][row word]
+  const int TI = blockIdx.y, TJ = blockIdx.x;
+  if (TJ < TI) return;
+  const bool diag = TI == TJ;
+  if (threadIdx.x < 32) sthr[threadIdx.x] = a.angle_thr[threadIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = threadIdx.x; t < PPF_TW * 64 * PPF_TW; t += 256) (&tfw[0][0])[t] = 0ull, (&trv[0][0])[t] = 0ull;
+  auto member = [&](int d, int a1, int a2, int a3) -> bool {
+    const unsigned bit = ((unsigned)(d * 19 + a1) * 19u + (unsigned)a2) * 19u + (unsigned)a3;
+    return (a.bitmap[bit >> 5] >> (bit & 31)) & 1u;
+  };
+  // the two column words of this wavefront
+  V3 pj[PPF_WQ], nj[PPF_WQ];
+  bool jvalid[PPF_WQ];
+  int jcol[PPF_WQ];
+#pragma unroll
+  for (int q = 0; q < PPF_WQ; ++q) {
+    const int jb = TJ * PPF_TW + wave + 4 * q, j = jb * 64 + lane;
+    jcol[q] = j;
+    jvalid[q] = jb < a.words && j < a.n;
+    pj[q] = v3(0, 0, 0), nj[q] = v3(0, 0, 1);
+    if (jvalid[q]) pj[q] = v3(a.x[j], a.y[j], a.z[j]), nj[q] = v3(a.nx[j], a.ny[j], a.nz[j]);
+  }
+  for (int ibl = 0; ibl < PPF_TW; ++ibl) {
+    const int ib = TI * PPF_TW + ibl, i0 = ib * 64;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int i = i0 + threadIdx.x;
+      if (i < a.n) {
+        rows[threadIdx.x][0] = a.x[i], rows[threadIdx.x][1] = a.y[i], rows[threadIdx.x][2] = a.z[i];
+        rows[threadIdx.x][3] = a.nx[i], rows[threadIdx.x][4] = a.ny[i], rows[threadIdx.x][5] = a.nz[i];
+      }
+    }
+    __syncthreads();
+    const int rmax = min(64, a.n - i0);
+    if (rmax <= 0) continue;
+#pragma unroll
+    for (int q = 0; q < PPF_WQ; ++q) {
+      const int jbl = wave + 4 * q, jb = TJ * PPF_TW + jbl;
+      if (jb >= a.words || jb < ib) continue;  // (below the diagonal: produced as the reverse words of the mirrored pair)
+      const bool both = jb != ib;
+      unsigned long long rev = 0ull;
+      for (int r = 0; r < rmax; ++r) {
+        const V3 pi = v3(rows[r][0], rows[r][1], rows[r][2]);
+        const V3 ni = v3(rows[r][3], rows[r][4], rows[r][5]);
+        bool fwd = false, bwd = false;
+        if (jvalid[q] && (i0 + r) != jcol[q]) {
+          const float nrm = vnorm(pi - pj[q]) * 1000.f;
+          if (nrm < 2147483648.0f) {
+            const int k0 = ppf_closest_bin((int)nrm, 5);
+            const V3 dir = vnormalized(pj[q] - pi);
+            const float s1 = vdot(ni, dir), s2 = vdot(nj[q], dir), s3 = vdot(ni, nj[q]);
+            int b1, b2, b3;
+            if (ppf_angle_bin_thr(s1, sthr, &b1) && ppf_angle_bin_thr(s2, sthr, &b2) && ppf_angle_bin_thr(s3, sthr, &b3)) {
+              const int d = k0 / 5, a3 = b3 / 10;
+              if (k0 >= 0 && d < a.dist_bins) {
+                fwd = member(d, b1 / 10, b2 / 10, a3);
+                if (both) {
+                  int c1, c2;
+                  (void)ppf_angle_bin_thr(-s2, sthr, &c1), (void)ppf_angle_bin_thr(-s1, sthr, &c2);
+                  bwd = member(d, c1 / 10, c2 / 10, a3);
+                }
+              }
+            }
+          }
+        }
+        const unsigned long long word = __ballot(fwd);
+        if (lane == 0) tfw[ibl * 64 + r][jbl] = word;
+        rev |= (unsigned long long)bwd << r;
+      }
+      if (both) trv[jbl * 64 + lane][ibl] = rev;
+    }
+  }
+  __syncthreads();
+  // write-out: 64-byte row segments (16 bytes per thread and step)
+  const int row0_f = TI * PPF_TW * 64, col0_f = TJ * PPF_TW;  // forward tile: rows of TI, column words of TJ
+  const int row0_r = TJ * PPF_TW * 64, col0_r = TI * PPF_TW;  // reverse tile: rows of TJ, column words of TI
+  for (int t = threadIdx.x; t < PPF_TW * 64 * (PPF_TW / 2); t += 256) {
+    const int rl = t / (PPF_TW / 2), c2 = (t % (PPF_TW / 2)) * 2;
+    if (diag) {
+      // one output tile: column words at or right of the row's own word come from the forward pass, the others are reverse words
+      const int row = row0_f + rl, rw = rl >> 6;
+      if (row < a.n) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int c = c2 + u;
+          if (col0_f + c < a.words) a.out[(size_t)row * a.words + col0_f + c] = c >= rw ? tfw[rl][c] : trv[rl][c];
+        }
+      }
+    } else {
+      const int rowf = row0_f + rl, rowr = row0_r + rl;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = c2 + u;
+        if (rowf < a.n && col0_f + c < a.words) a.out[(size_t)rowf * a.words + col0_f + c] = tfw[rl][c];
+        if (rowr < a.n && col0_r + c < a.words) a.out[(size_t)rowr * a.words + col0_r + c] = trv[rl][c];
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3a: pair extraction for a batch of bases (FunctorSuper4PCS::ExtractPairs + PairCreationFunctor::process
 // + AdaptivePointFilter, FunctorSuper4pcs.h:79-116, pairCreationFunctor.h:189-214, PointPairFilter.h:88-172)
@@ -2741,8 +2855,13 @@ __global__ void k_grid_cell_ids(const float* __restrict__ x, const float* __rest
 // ------------------------------------------------------------------------------------------------
 void launch_ppf_matrix(const PpfMatrixArgs& a, hipStream_t s) {
   dim3 grid((a.words + 3) / 4, (a.n + PPF_ROWS - 1) / PPF_ROWS);
-  const bool sym = !getenv("HOP_PPF_NO_SYM");  // (tests compare the two kernels)
-  if (a.angle_thr && sym) hipLaunchKernelGGL(k_ppf_matrix_sym, grid, dim3(256), 0, s, a);
+  const bool sym = !getenv("HOP_PPF_NO_SYM");  // (tests compare the kernels)
+  // measured (C2, N = 20 000): the tiled form halves the HBM writes (172 -> 88 MB) and is SLOWER, 1.48 vs 1.18 ms (8 x 8 words: 2.9 ms) --
+  // the kernel is bound by its vector instructions and the bitmap probes, not by its stores; it stays an experiment switch
+  if (a.angle_thr && sym && getenv("HOP_PPF_TILE")) {
+    const int tiles = (a.words + PPF_TW - 1) / PPF_TW;
+    hipLaunchKernelGGL(k_ppf_matrix_tile, dim3(tiles, tiles), dim3(256), 0, s, a);
+  } else if (a.angle_thr && sym) hipLaunchKernelGGL(k_ppf_matrix_sym, grid, dim3(256), 0, s, a);
   else if (a.angle_thr) hipLaunchKernelGGL(k_ppf_matrix<true>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(k_ppf_matrix<false>, grid, dim3(256), 0, s, a);
 }
