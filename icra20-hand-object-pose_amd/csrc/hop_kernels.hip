@@ -2224,6 +2224,10 @@ __device__ __forceinline__ int icp_fusedq_point_mom(const IcpArgs& a, int i, con
   if (!(((qn.x * nt.x + qn.y * nt.y) + qn.z * nt.z) > a.cos_thr)) return ICP_PT_REJECTED;
   const V3 pc = q - ctr;
   const float r0 = vdot(q - tq, nt);
+#ifdef HOP_ICP_MOM_NOACC  // experiment: the lookups and gates alone
+  acc[0] += (r0 + d2) + (nt.x + pc.x);
+  return ICP_PT_ACCEPTED;
+#endif
   const float nn[6] = {nt.x * nt.x, nt.x * nt.y, nt.x * nt.z, nt.y * nt.y, nt.y * nt.z, nt.z * nt.z};
   const float pp[6] = {pc.x * pc.x, pc.x * pc.y, pc.x * pc.z, pc.y * pc.y, pc.y * pc.z, pc.z * pc.z};
   const float pv[3] = {pc.x, pc.y, pc.z}, nv[3] = {nt.x, nt.y, nt.z};
@@ -2246,6 +2250,7 @@ __device__ __forceinline__ int icp_fusedq_point_mom(const IcpArgs& a, int i, con
   acc[73] += d2;
   return ICP_PT_ACCEPTED;
 }
+#ifndef HOP_ICP_MOM_MFMA
 #ifndef HOP_ICP_MOM_W
 #define HOP_ICP_MOM_W 4
 #endif
@@ -2289,6 +2294,159 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM
     a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NMOM_STRIDE + threadIdx.x] = s;
   }
 }
+#else
+// EXPERIMENT (tools/build_variant.sh mfma -DHOP_ICP_MOM_MFMA; measured SLOWER): the moment matrix on the
+// matrix cores.  M = sum_i u_i u_i^T is a rank-1-update GEMM: v_mfma_f32_16x16x4_f32 (exact f32,
+// bitwise an fmaf chain: MI355X_MICROARCH.md) takes four points per instruction, A[c][k] = B[k][c] = component c of point k.
+// u (15 of 16 rows used) = (n_a p'_b [9], n_a [3], r0, d2, 1): M[13][14] = sum of squared correspondence distances,
+// M[14][14] = the number of accepted correspondences.  Per batch of 64 lookups a wavefront
+//   * writes the accepted lanes' u (zeros for the others) to its 4 KB of LDS, point-major: 4 x ds_write_b128 per lane, the 16-byte
+//     groups XOR-swizzled by (point >> 2) & 3 so that the 16 lanes of a write phase cover the 64 banks;
+//   * reads them back component-major for instruction t = points 4t .. 4t+3: lane l needs component l & 15 of point 4t + (l >> 4),
+//     which is word 64 t + l up to the swizzle inside its 16-word group: one conflict-free ds_read_b32 per instruction;
+//   * issues 16 MFMAs into two accumulators (even / odd t: no back-to-back dependency), then adds them to 4 doubles per lane.
+// The wavefront's 256 entries of M therefore cost 4 + 8 accumulator registers instead of 74 (and no cross-lane reduction at the
+// end), the kernel fits 8 waves per SIMD instead of 4, and the matrix pipe works while other wavefronts scan their lists.
+// Sums: 64 terms per batch in float inside the MFMAs (the same 1e-6 relative as 30 terms per lane before), batches / waves / blocks
+// in double.  The deferred lookups (see k_icp_fusedq) are queued per wavefront and run as dense batches of 64.
+typedef float mom_f32x4 __attribute__((ext_vector_type(4)));
+struct MomTab {
+  unsigned char at[ICP_NMOM + 1];  // entry (row * 16 + col) of the 16 x 16 tile that holds sum k of the solver's layout
+  constexpr MomTab() : at{} {
+    const int pa[6] = {0, 0, 0, 1, 1, 2}, pc[6] = {0, 1, 2, 1, 2, 2};
+    for (int u = 0; u < 6; ++u) {
+      for (int v = 0; v < 6; ++v) at[u * 6 + v] = (unsigned char)((pa[u] * 3 + pa[v]) * 16 + pc[u] * 3 + pc[v]);  // sum n_a n_c p_b p_d
+      for (int b = 0; b < 3; ++b) at[36 + u * 3 + b] = (unsigned char)((pa[u] * 3 + b) * 16 + 9 + pc[u]);          // sum n_a n_c p_b
+      at[54 + u] = (unsigned char)((9 + pa[u]) * 16 + 9 + pc[u]);                                                 // sum n_a n_c
+    }
+    for (int c = 0; c < 3; ++c) {
+      for (int b = 0; b < 3; ++b) at[60 + c * 3 + b] = (unsigned char)((c * 3 + b) * 16 + 12);  // sum n_c r0 p_b
+      at[69 + c] = (unsigned char)((9 + c) * 16 + 12);                                          // sum n_c r0
+    }
+    at[72] = 12 * 16 + 12;        // sum r0^2
+    at[73] = 13 * 16 + 14;        // sum d2
+    at[ICP_NMOM] = 14 * 16 + 14;  // count
+  }
+};
+__constant__ MomTab c_mom_tab = MomTab();
+#ifndef HOP_ICP_MOM_W
+#define HOP_ICP_MOM_W 7  // (72 VGPRs; 8 spills)
+#endif
+#ifndef HOP_ICP_MOM_FLUSH
+#define HOP_ICP_MOM_FLUSH 1  // batches of 64 lookups between two additions of the float tile to the double sums
+#endif
+// lookup + gates of one source point; on acceptance the ingredients of u
+template <bool DEFER>
+__device__ __forceinline__ int icp_mom_point(const IcpArgs& a, int i, const float* __restrict__ pose, const float* __restrict__ sTi,
+                                              const float* __restrict__ F, V3 ctr, V3& nt, V3& pc, float& r0, float& d2) {
+  const float4 p4 = a.s_pts4[i];
+  V3 q = v3(p4.x, p4.y, p4.z);
+  if (a.iter > 0) q = m4_point_fma(F, q);
+  float best = 3.0e38f;
+  int j = -1;
+  V3 tq;
+  if (cells_nnq<DEFER>(a.cells, m4_point_fma(sTi, q), pose, q, best, j, tq)) return ICP_PT_DEFERRED;
+  if (j < 0 || !(best <= a.max_d2)) return ICP_PT_REJECTED;
+  const float4 tn = a.cells.nrm_idx[j];
+  const float4 n4 = a.s_nrm4[i];
+  V3 qn = v3(n4.x, n4.y, n4.z);
+  if (a.iter > 0) qn = m4_dir_fma(F, qn);
+  const V3 n = m4_dir(pose, v3(tn.x, tn.y, tn.z));
+  if (!(((qn.x * n.x + qn.y * n.y) + qn.z * n.z) > a.cos_thr)) return ICP_PT_REJECTED;
+  nt = n, pc = q - ctr, r0 = vdot(q - tq, n), d2 = best;
+  return ICP_PT_ACCEPTED;
+}
+// one batch: the wavefront's accepted lanes (mask ok != 0) -> LDS -> 16 MFMAs
+__device__ __forceinline__ void icp_mom_batch(float* __restrict__ stage, int lane, bool ok, V3 nt, V3 pc, float r0, float d2, mom_f32x4& C0,
+                                              mom_f32x4& C1) {
+  const float one = ok ? 1.f : 0.f;  // (nt, pc, r0, d2 are zero on the lanes that were not accepted)
+  char* __restrict__ wp = (char*)stage + lane * 64;
+  const unsigned sx = ((unsigned)(lane >> 2) & 3u) << 4;
+  *(float4*)(wp + (0x00u ^ sx)) = make_float4(nt.x * pc.x, nt.x * pc.y, nt.x * pc.z, nt.y * pc.x);
+  *(float4*)(wp + (0x10u ^ sx)) = make_float4(nt.y * pc.y, nt.y * pc.z, nt.z * pc.x, nt.z * pc.y);
+  *(float4*)(wp + (0x20u ^ sx)) = make_float4(nt.z * pc.z, nt.x, nt.y, nt.z);
+  *(float4*)(wp + (0x30u ^ sx)) = make_float4(r0, d2, one, 0.f);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const unsigned c = (unsigned)lane & 15u, grp = (unsigned)lane & 48u;  // word offset of the lane's 16-word group inside an instruction's 64
+  float v[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) v[t] = stage[64 * t + grp + ((((c >> 2) ^ (unsigned)(t & 3)) << 2) | (c & 3u))];
+#pragma unroll
+  for (int t = 0; t < 16; t += 2) {
+    C0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t], v[t], C0, 0, 0, 0);
+    C1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t + 1], v[t + 1], C1, 0, 0, 0);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next batch's writes stay behind these reads)
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void icp_mom_flush(double (&cd)[4], mom_f32x4& C0, mom_f32x4& C1) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cd[k] += (double)C0[k] + (double)C1[k];
+  C0 = C1 = mom_f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM_W))) void k_icp_fusedq_mom(IcpArgs a, int R) {
+  __shared__ __attribute__((aligned(16))) float stage[4][64 * 16];  // (the cross-wave sum reuses it: 4 x 256 doubles)
+  __shared__ unsigned short defer_i[4][128];
+  const int hl = blockIdx.y, h = a.h0 + hl;
+  const IcpState& st = a.state[hl];
+  if (!st.active) return;
+  const float* __restrict__ pose = a.pose + (size_t)h * 16;
+  const float* __restrict__ sTi = a.pose_inv + (size_t)h * 12;
+  const float* __restrict__ F = st.final_tf;
+  const V3 ctr = v3(pose[3], pose[7], pose[11]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  mom_f32x4 C0 = {0.f, 0.f, 0.f, 0.f}, C1 = {0.f, 0.f, 0.f, 0.f};
+  double cd[4] = {0.0, 0.0, 0.0, 0.0};
+  int n_def = 0, pending = 0;
+  const int base = blockIdx.x * (256 * R);
+  for (int r = 0; r < R; ++r) {
+    const int li = r * 256 + threadIdx.x, i = base + li;
+    V3 nt = v3(0.f, 0.f, 0.f), pc = v3(0.f, 0.f, 0.f);
+    float r0 = 0.f, d2 = 0.f;
+    const int res = i < a.ns ? icp_mom_point<true>(a, i, pose, sTi, F, ctr, nt, pc, r0, d2) : ICP_PT_REJECTED;
+    const unsigned long long dm = __ballot(res == ICP_PT_DEFERRED);
+    if (res == ICP_PT_DEFERRED) defer_i[wave][n_def + __popcll(dm & ((1ull << lane) - 1ull))] = (unsigned short)li;
+    n_def += __popcll(dm);
+    if (__ballot(res == ICP_PT_ACCEPTED) != 0ull) {
+      icp_mom_batch(stage[wave], lane, res == ICP_PT_ACCEPTED, nt, pc, r0, d2, C0, C1);
+      if (++pending == HOP_ICP_MOM_FLUSH) icp_mom_flush(cd, C0, C1), pending = 0;
+    }
+    while (n_def >= 64 || (r == R - 1 && n_def > 0)) {  // a dense batch of the queued lookups (wave-uniform condition)
+      const int take = n_def < 64 ? n_def : 64;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int mine = lane < take ? (int)defer_i[wave][lane] : -1;
+      const int rest = lane + 64 < n_def ? (int)defer_i[wave][lane + 64] : -1;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (rest >= 0) defer_i[wave][lane] = (unsigned short)rest;
+      n_def -= take;
+      V3 nt2 = v3(0.f, 0.f, 0.f), pc2 = v3(0.f, 0.f, 0.f);
+      float r02 = 0.f, d22 = 0.f;
+      const int res2 = mine >= 0 ? icp_mom_point<false>(a, base + mine, pose, sTi, F, ctr, nt2, pc2, r02, d22) : ICP_PT_REJECTED;
+      if (__ballot(res2 == ICP_PT_ACCEPTED) != 0ull) {
+        icp_mom_batch(stage[wave], lane, res2 == ICP_PT_ACCEPTED, nt2, pc2, r02, d22, C0, C1);
+        if (++pending == HOP_ICP_MOM_FLUSH) icp_mom_flush(cd, C0, C1), pending = 0;
+      }
+    }
+  }
+  if (pending) icp_mom_flush(cd, C0, C1);
+  // tile entry (row, col): lane (row / 4) * 16 + col, register row % 4
+  __syncthreads();
+  double* __restrict__ red = (double*)&stage[0][0];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[wave * 256 + ((lane >> 4) * 4 + k) * 16 + (lane & 15)] = cd[k];
+  __syncthreads();
+  if (threadIdx.x <= ICP_NMOM) {
+    const int e = c_mom_tab.at[threadIdx.x];
+    const double s = (red[e] + red[256 + e]) + (red[512 + e] + red[768 + e]);
+    a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NMOM_STRIDE + threadIdx.x] = s;
+  }
+}
+#endif
 void launch_icp_fusedq_mom(const IcpArgs& a, int hb, hipStream_t s) {
   const int nb = icp_blocks_per_hyp(a.ns, true);
   const int R = (a.ns + 256 * nb - 1) / (256 * nb);
