@@ -245,6 +245,7 @@ class Context:
         if rc:
             raise HopError(rc, "hop_ctx_create")
         self.h = h
+        self.device = device
         self._keep = []
 
     def close(self):
@@ -1026,6 +1027,7 @@ class HandT42:
         self._component_status = {n: False for n in hand.parents}
         self._finger_properties = {n: finger_property(hand.clouds[n][0], 10) for n in hand.parents if "finger" in n}
         self.gripper_min_dist = 0.0
+        self._icp_ctx = None
         hm = cfg["hand_match"]
         self._pso = dict(n_pop=int(hm["pso"]["n_pop"]), n_gen=int(hm["pso"]["n_gen"]), check_freq=int(hm["pso"]["check_freq"]),
                          c_cog=float(hm["pso"]["pso_par_c_cog"]), c_soc=float(hm["pso"]["pso_par_c_soc"]),
@@ -1037,6 +1039,11 @@ class HandT42:
             self._ctx = Context(self._device)
         return self._ctx
 
+    def setHandbaseIcpContext(self, ctx):
+        """handbaseICP runs Utils::runICP on its own scene / model: give it a context of its own (host/Hand.h
+        setHandbaseIcpContext does the same) and the PoseEstimator's models, with the lists built for them, stay on the main one."""
+        self._icp_ctx = ctx
+
     def setCurScene(self, scene_removed_noise_xyz, scene_hand_region_nrm, scene_remove_swivel_xyz):
         """Products of Hand::setCurScene (Hand.cpp:327-332), all in the hand-base frame."""
         self.ctx.hand_set_scene(scene_removed_noise_xyz, scene_hand_region_nrm, scene_remove_swivel_xyz)
@@ -1045,8 +1052,10 @@ class HandT42:
         """Hand::handbaseICP (Hand.cpp:677-777): corrects handbase_in_cam by a point-to-plane ICP of the scene around the
         palm against the base_link cloud.  Returns (new handbase_in_cam, cam2handbase_offset).  Uses the context's scene,
         5 mm model and hypothesis slots for the ICP (Utils::runICP is the function refineByICP calls): run it before the
-        PoseEstimator of the frame is set up, as main_realdata_auto.cpp does (:99 vs :183)."""
+        PoseEstimator of the frame is set up, as main_realdata_auto.cpp does (:99 vs :183) -- or, with setHandbaseIcpContext, a
+        context of its own for the ICP (the voxel grid and the crop before it use no slot)."""
         c = self.ctx
+        ci = self._icp_ctx or c
         handbase_in_cam = np.asarray(handbase_in_cam, np.float32)
         cam_in_handbase = np.linalg.inv(handbase_in_cam.astype(np.float64)).astype(np.float32)
         sx, sn = c.voxel_downsample_normals(scene_xyz_cam, scene_nrm_cam, 0.005)
@@ -1055,12 +1064,13 @@ class HandT42:
         offset = np.eye(4, dtype=np.float32)
         if keep.sum() > 0:
             bx, bn = self.hand.clouds["base_link"]
-            c.set_scene(hx[keep], hn[keep], None, 0.0)          # Utils::runICP source (pclSegment)
-            c.set_model(HOP_MODEL_5MM, bx, bn)                   # target (pclModel)
-            c.model_owner = self                                 # a PoseEstimator on this context uploads its models again
-            c.hypos_upload(np.eye(4, dtype=np.float32)[None])
-            c.icp_refine(50, 30.0, 0.03, nn_mode=ICP_NN_MODE_REFERENCE)
-            pose, _, _ = c.hypos_download()
+            ci.set_scene(hx[keep], hn[keep], None, 0.0)         # Utils::runICP source (pclSegment)
+            if getattr(ci, "model_owner", None) is not self.hand:  # target (pclModel): base_link, uploaded once per context
+                ci.set_model(HOP_MODEL_5MM, bx, bn)
+                ci.model_owner = self.hand                       # (a PoseEstimator on this context uploads its models again)
+            ci.hypos_upload(np.eye(4, dtype=np.float32)[None])
+            ci.icp_refine(50, 30.0, 0.03, nn_mode=ICP_NN_MODE_REFERENCE)
+            pose, _, _ = ci.hypos_download()
             offset = np.linalg.inv(pose[0].astype(np.float64)).astype(np.float32)  # source -> target
         translation = float(np.linalg.norm(offset[:3, 3]))
         if translation >= 0.05:                                   # :740-745

@@ -11,7 +11,9 @@
 //   * the camera model those files define: window x = fx X/Z + cx, window y (top-down, after the read-back flip)
 //     = fy Y/Z + (H - cy) -- the principal point ends up mirrored vertically --, one sample per pixel centre;
 //   * a z-buffer rasteriser: the hand once per frame, the object once per hypothesis (one thread per (hypothesis, face),
-//     ordered-float atomicMin per covered pixel), composed with GL_LESS in the reference's draw order (hand, then object);
+//     ordered-float atomicMin per covered pixel; triangles crossing the near plane are clipped as OpenGL clips them, triangles
+//     whose window box exceeds 256 pixels are queued and drawn by a workgroup each), composed with GL_LESS in the reference's
+//     draw order (hand, then object);
 //   * depth through the read-back's float expression, rounded to whole millimetres, clamped to [0.1, 2.0] m;
 //   * the score loop of :398-440 with its always-true sub-conditions.  sum_mode 0 adds the 307 200 per-pixel terms into
 //     one float in row order like the reference (after ~1e5 background pixels worth 2.0 each, millimetre-sized terms
@@ -49,12 +51,12 @@ struct RCam {
 };
 
 struct Render : HopExt {
-  DevBuf raw, real, hand_V, hand_F, hand_z, obj_V, obj_F, zbuf, terms, sums, poses, out_depth, out_owner;
+  DevBuf raw, real, hand_V, hand_F, hand_z, obj_V, obj_F, zbuf, terms, sums, poses, out_depth, out_owner, big_q;
   RCam cam{};
   int hand_nf = 0, obj_nv = 0, obj_nf = 0;
   bool have_frame = false, have_object = false;
   ~Render() override {
-    for (DevBuf* b : {&raw, &real, &hand_V, &hand_F, &hand_z, &obj_V, &obj_F, &zbuf, &terms, &sums, &poses, &out_depth, &out_owner}) b->release();
+    for (DevBuf* b : {&raw, &real, &hand_V, &hand_F, &hand_z, &obj_V, &obj_F, &zbuf, &terms, &sums, &poses, &out_depth, &out_owner, &big_q}) b->release();
   }
 };
 Render* render_ext(hop_ctx* c) {
@@ -84,40 +86,134 @@ __device__ __forceinline__ float readback_m(float d) {  // simulation_io.cpp:427
   return m;
 }
 
-// one thread per (hypothesis, face); poses == nullptr: the vertices are used as they are (hand meshes, camera frame)
+// A triangle in window coordinates (x, y, 1/Z per vertex).
+struct WinTri {
+  double x[3], y[3], iz[3];
+};
+// OpenGL clips a primitive against the frustum before it rasterises it.  Every fragment is tested against [0.1, 2.0] below, so
+// clipping at ANY plane 0 < Zc <= 0.1 draws the same pixels: the triangle is cut at Zc = 0.05 (Sutherland-Hodgman, one plane) to
+// keep the perspective division away from Z <= 0, and the quadrilateral a cut can leave is a fan of two triangles.  A triangle
+// wholly at Z >= Zc is projected from its float vertices as before (oracle/render_oracle.cpp clip_project: the same operations).
+constexpr float Z_CLIP = 0.05f;
+__device__ __forceinline__ int clip_project(const V3 q[3], const RCam& c, WinTri out[2]) {
+  const bool in[3] = {q[0].z >= Z_CLIP, q[1].z >= Z_CLIP, q[2].z >= Z_CLIP};
+  const double oy = (double)c.H - c.cy;
+  if (in[0] && in[1] && in[2]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      out[0].x[k] = (double)c.fx * q[k].x / q[k].z + c.cx;
+      out[0].y[k] = (double)c.fy * q[k].y / q[k].z + oy;
+      out[0].iz[k] = 1.0 / q[k].z;
+    }
+    return 1;
+  }
+  if (!in[0] && !in[1] && !in[2]) return 0;
+  double px[4], py[4], piz[4];
+  int n = 0;
+  for (int k = 0; k < 3; ++k) {
+    const int m = (k + 1) % 3;
+    const double ax = q[k].x, ay = q[k].y, az = q[k].z, bx = q[m].x, by = q[m].y, bz = q[m].z;
+    if (in[k]) px[n] = (double)c.fx * ax / az + c.cx, py[n] = (double)c.fy * ay / az + oy, piz[n] = 1.0 / az, ++n;
+    if (in[k] != in[m]) {  // the crossing point, always computed from the inside vertex
+      const double ix = in[k] ? ax : bx, iy = in[k] ? ay : by, izz = in[k] ? az : bz;
+      const double ox = in[k] ? bx : ax, oyy = in[k] ? by : ay, oz = in[k] ? bz : az;
+      const double t = ((double)Z_CLIP - izz) / (oz - izz);
+      const double X = ix + t * (ox - ix), Y = iy + t * (oyy - iy), Z = (double)Z_CLIP;
+      px[n] = (double)c.fx * X / Z + c.cx, py[n] = (double)c.fy * Y / Z + oy, piz[n] = 1.0 / Z, ++n;
+    }
+  }
+  int nt = 0;
+  for (int k = 1; k + 1 < n; ++k, ++nt) {
+    const int id[3] = {0, k, k + 1};
+    for (int v = 0; v < 3; ++v) out[nt].x[v] = px[id[v]], out[nt].y[v] = py[id[v]], out[nt].iz[v] = piz[id[v]];
+  }
+  return nt;
+}
+__device__ __forceinline__ int face_triangles(const float* __restrict__ V, const int* __restrict__ F, int f, const float* __restrict__ pose, const RCam& c,
+                                               WinTri out[2]) {
+  V3 q[3];
+  for (int k = 0; k < 3; ++k) {
+    const float* p = V + 3 * (size_t)F[3 * f + k];
+    q[k] = v3(p[0], p[1], p[2]);
+    if (pose) q[k] = m4_point(pose, q[k]);  // Utils::transformPolygonMesh
+  }
+  return clip_project(q, c, out);
+}
+struct TriBox {
+  double area;
+  int w0, w1, h0, h1;
+};
+__device__ __forceinline__ bool tri_box(const WinTri& t, const RCam& c, TriBox& b) {
+  const double* x = t.x;
+  const double* y = t.y;
+  b.area = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
+  if (b.area == 0.0) return false;
+  b.w0 = max(0, (int)floor(fmin(fmin(x[0], x[1]), x[2]) - 0.5)), b.w1 = min(c.W - 1, (int)ceil(fmax(fmax(x[0], x[1]), x[2]) - 0.5));
+  b.h0 = max(0, (int)floor(fmin(fmin(y[0], y[1]), y[2]) - 0.5)), b.h1 = min(c.H - 1, (int)ceil(fmax(fmax(y[0], y[1]), y[2]) - 0.5));
+  return b.w0 <= b.w1 && b.h0 <= b.h1;
+}
+__device__ __forceinline__ void tri_pixel(const WinTri& t, double area, int w, int h, int W, unsigned* __restrict__ zb) {
+  const double* x = t.x;
+  const double* y = t.y;
+  const double px = w + 0.5, py = h + 0.5;
+  const double e0 = (x[2] - x[1]) * (py - y[1]) - (y[2] - y[1]) * (px - x[1]);
+  const double e1 = (x[0] - x[2]) * (py - y[2]) - (y[0] - y[2]) * (px - x[2]);
+  const double e2 = (x[1] - x[0]) * (py - y[0]) - (y[1] - y[0]) * (px - x[0]);
+  if (!((e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0))) return;
+  const double Z = area / (e0 * t.iz[0] + e1 * t.iz[1] + e2 * t.iz[2]);
+  if (!(Z >= 0.1 && Z <= 2.0)) return;
+  atomicMin(&zb[(size_t)h * W + w], __float_as_uint(window_depth(Z)));  // positive floats order like their bits
+}
+
+// one thread per (hypothesis, face); poses == nullptr: the vertices are used as they are (hand meshes, camera frame).  A triangle
+// whose window box holds more than RASTER_BIG pixels (a mesh close to the camera, a coarse mesh: up to the whole image) is not walked
+// by its thread -- that one lane would set the duration of the launch -- but queued for k_raster_big, where a workgroup shares its box.
+// (queue full: walked here after all.)  The z-buffer's atomicMin makes the result independent of who draws what.
+constexpr int RASTER_BIG = 256;
+struct BigQueue {
+  unsigned* count;
+  unsigned long long* item;  // (hypothesis * nf + face) * 2 + sub-triangle
+  unsigned cap;
+};
 __global__ void k_raster(const float* __restrict__ V, const int* __restrict__ F, int nf, const float* __restrict__ poses, int n_hyp, RCam c,
-                         unsigned* __restrict__ zbuf) {
+                         unsigned* __restrict__ zbuf, BigQueue bq) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)nf * n_hyp) return;
   const int hyp = (int)(t / nf), f = (int)(t - (long long)hyp * nf);
   unsigned* zb = zbuf + (size_t)hyp * c.H * c.W;
-  double x[3], y[3], iz[3];
-  bool ok = true;
-  for (int k = 0; k < 3; ++k) {
-    const float* p = V + 3 * (size_t)F[3 * f + k];
-    V3 q = v3(p[0], p[1], p[2]);
-    if (poses) q = m4_point(poses + 16 * (size_t)hyp, q);  // Utils::transformPolygonMesh
-    if (!(q.z > 1e-6f)) ok = false;
-    x[k] = (double)c.fx * q.x / q.z + c.cx;
-    y[k] = (double)c.fy * q.y / q.z + ((double)c.H - c.cy);
-    iz[k] = 1.0 / q.z;
-  }
-  if (!ok) return;
-  const double area = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
-  if (area == 0.0) return;
-  const int w0 = max(0, (int)floor(fmin(fmin(x[0], x[1]), x[2]) - 0.5)), w1 = min(c.W - 1, (int)ceil(fmax(fmax(x[0], x[1]), x[2]) - 0.5));
-  const int h0 = max(0, (int)floor(fmin(fmin(y[0], y[1]), y[2]) - 0.5)), h1 = min(c.H - 1, (int)ceil(fmax(fmax(y[0], y[1]), y[2]) - 0.5));
-  for (int h = h0; h <= h1; ++h)
-    for (int w = w0; w <= w1; ++w) {
-      const double px = w + 0.5, py = h + 0.5;
-      const double e0 = (x[2] - x[1]) * (py - y[1]) - (y[2] - y[1]) * (px - x[1]);
-      const double e1 = (x[0] - x[2]) * (py - y[2]) - (y[0] - y[2]) * (px - x[2]);
-      const double e2 = (x[1] - x[0]) * (py - y[0]) - (y[1] - y[0]) * (px - x[0]);
-      if (!((e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0))) continue;
-      const double Z = area / (e0 * iz[0] + e1 * iz[1] + e2 * iz[2]);
-      if (!(Z >= 0.1 && Z <= 2.0)) continue;
-      atomicMin(&zb[(size_t)h * c.W + w], __float_as_uint(window_depth(Z)));  // positive floats order like their bits
+  WinTri tri[2];
+  const int nt = face_triangles(V, F, f, poses ? poses + 16 * (size_t)hyp : nullptr, c, tri);
+  for (int s = 0; s < nt; ++s) {
+    TriBox b;
+    if (!tri_box(tri[s], c, b)) continue;
+    if ((long long)(b.w1 - b.w0 + 1) * (b.h1 - b.h0 + 1) > RASTER_BIG && bq.cap) {
+      const unsigned at = atomicAdd(bq.count, 1u);
+      if (at < bq.cap) {
+        bq.item[at] = (unsigned long long)t * 2ull + (unsigned)s;
+        continue;
+      }
     }
+    for (int h = b.h0; h <= b.h1; ++h)
+      for (int w = b.w0; w <= b.w1; ++w) tri_pixel(tri[s], b.area, w, h, c.W, zb);
+  }
+}
+// the queued triangles, one workgroup each (grid-stride over the queue: its length stays on the device)
+__global__ __launch_bounds__(256) void k_raster_big(const float* __restrict__ V, const int* __restrict__ F, int nf, const float* __restrict__ poses, RCam c,
+                                                    unsigned* __restrict__ zbuf, BigQueue bq) {
+  const unsigned n = min(*bq.count, bq.cap);
+  for (unsigned qi = blockIdx.x; qi < n; qi += gridDim.x) {
+    const unsigned long long it = bq.item[qi];
+    const long long t = (long long)(it >> 1);
+    const int s = (int)(it & 1ull);
+    const int hyp = (int)(t / nf), f = (int)(t - (long long)hyp * nf);
+    unsigned* zb = zbuf + (size_t)hyp * c.H * c.W;
+    WinTri tri[2];
+    (void)face_triangles(V, F, f, poses ? poses + 16 * (size_t)hyp : nullptr, c, tri);
+    TriBox b;
+    if (!tri_box(tri[s], c, b)) continue;
+    const int bw = b.w1 - b.w0 + 1, np = bw * (b.h1 - b.h0 + 1);
+    for (int k = threadIdx.x; k < np; k += 256) tri_pixel(tri[s], b.area, b.w0 + k % bw, b.h0 + k / bw, c.W, zb);
+  }
 }
 
 __device__ __forceinline__ void pixel_term(float real, unsigned zh, unsigned zo, float& diff, bool& roi) {
@@ -213,6 +309,19 @@ __global__ void k_compose_image(const unsigned* __restrict__ hand_z, const unsig
   owner[px] = roi ? 2 : (zh < Z_CLEAR ? 1 : 0);
 }
 
+// both passes of the rasteriser over `work` = nf * n_hyp (hypothesis, face) pairs
+constexpr unsigned BIG_CAP = 1u << 20;
+int run_raster(hop_ctx* c, Render* r, const float* V, const int* F, int nf, const float* poses, int n_hyp, unsigned* zbuf) {
+  hipStream_t st = hop_ctx_stream(c);
+  RDCHK(c, r->big_q.ensure(16 + sizeof(unsigned long long) * (size_t)BIG_CAP));
+  BigQueue bq{r->big_q.as<unsigned>(), reinterpret_cast<unsigned long long*>(static_cast<char*>(r->big_q.p) + 16), BIG_CAP};
+  RDCHK(c, hipMemsetAsync(r->big_q.p, 0, 16, st));
+  const long long work = (long long)nf * n_hyp;
+  k_raster<<<(unsigned)((work + 63) / 64), 64, 0, st>>>(V, F, nf, poses, n_hyp, r->cam, zbuf, bq);
+  k_raster_big<<<(unsigned)std::min<long long>(2 * work, 4096), 256, 0, st>>>(V, F, nf, poses, r->cam, zbuf, bq);
+  return HOP_OK;
+}
+
 int fill_clear(hop_ctx* c, void* p, size_t words) {
   RDCHK(c, hipMemsetD32Async((hipDeviceptr_t)p, (int)Z_CLEAR, words, hop_ctx_stream(c)));
   return HOP_OK;
@@ -245,7 +354,8 @@ int hop_render_set_frame(hop_ctx* c, const uint16_t* depth_raw, int H, int W, do
     RDCHK(c, r->hand_F.ensure(sizeof(int) * 3 * (size_t)hand_nf));
     RDCHK(c, hipMemcpyAsync(r->hand_V.p, hand_V, sizeof(float) * 3 * (size_t)hand_nv, hipMemcpyHostToDevice, st));
     RDCHK(c, hipMemcpyAsync(r->hand_F.p, hand_F, sizeof(int) * 3 * (size_t)hand_nf, hipMemcpyHostToDevice, st));
-    k_raster<<<(hand_nf + 63) / 64, 64, 0, st>>>(r->hand_V.as<float>(), r->hand_F.as<int>(), hand_nf, nullptr, 1, r->cam, r->hand_z.as<unsigned>());
+    rc = run_raster(c, r, r->hand_V.as<float>(), r->hand_F.as<int>(), hand_nf, nullptr, 1, r->hand_z.as<unsigned>());
+    if (rc) return rc;
   }
   RDCHK(c, hipGetLastError());
   RDCHK(c, hipStreamSynchronize(st));
@@ -285,7 +395,8 @@ int hop_render_depth(hop_ctx* c, const float* pose16, float* depth_m_out, unsign
     RDCHK(c, hipMemcpyAsync(r->poses.p, pose16, sizeof(float) * 16, hipMemcpyHostToDevice, st));
     int rc = fill_clear(c, r->zbuf.p, npx);
     if (rc) return rc;
-    k_raster<<<(r->obj_nf + 63) / 64, 64, 0, st>>>(r->obj_V.as<float>(), r->obj_F.as<int>(), r->obj_nf, r->poses.as<float>(), 1, r->cam, r->zbuf.as<unsigned>());
+    rc = run_raster(c, r, r->obj_V.as<float>(), r->obj_F.as<int>(), r->obj_nf, r->poses.as<float>(), 1, r->zbuf.as<unsigned>());
+    if (rc) return rc;
     oz = r->zbuf.as<unsigned>();
   }
   k_compose_image<<<(unsigned)((npx + 255) / 256), 256, 0, st>>>(r->hand_z.as<unsigned>(), oz, (int)npx, r->out_depth.as<float>(), r->out_owner.as<unsigned char>());
@@ -317,9 +428,8 @@ int hop_reject_by_render(hop_ctx* c, float roi_weight, float keep_ratio, int sum
     const int hb = std::min(HB, n - h0);
     int rc = fill_clear(c, r->zbuf.p, npx * (size_t)hb);
     if (rc) return rc;
-    const long long work = (long long)r->obj_nf * hb;
-    k_raster<<<(unsigned)((work + 63) / 64), 64, 0, st>>>(r->obj_V.as<float>(), r->obj_F.as<int>(), r->obj_nf, hv.pose + 16 * (size_t)h0, hb, r->cam,
-                                                         r->zbuf.as<unsigned>());
+    rc = run_raster(c, r, r->obj_V.as<float>(), r->obj_F.as<int>(), r->obj_nf, hv.pose + 16 * (size_t)h0, hb, r->zbuf.as<unsigned>());
+    if (rc) return rc;
     if (sum_mode == 0) {
       const long long t = (long long)npx * hb;
       k_score_terms<<<(unsigned)((t + 255) / 256), 256, 0, st>>>(r->real.as<float>(), r->hand_z.as<unsigned>(), r->zbuf.as<unsigned>(), (int)npx, hb,

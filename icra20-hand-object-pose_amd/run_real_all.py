@@ -244,6 +244,18 @@ def write_assets_dir(assets, path):
     return path
 
 
+def _frame_state(ctx, cfg, assets):
+    """What run_real_all.cpp builds once before its frame loop (:56-60), kept per context: the PoseEstimator (its two models and
+    the lists built on them stay resident) and a second context for handbaseICP's own scene / model."""
+    st = getattr(ctx, "_frame_state", None)
+    if st is None or st["cfg"] is not cfg or st["assets"] is not assets:
+        old_icp = st["icp_ctx"] if st else None
+        st = {"cfg": cfg, "assets": assets, "est": api.PoseEstimator(cfg, assets.model, assets.model001, ctx=ctx),
+              "icp_ctx": old_icp or api.Context(ctx.device)}
+        ctx._frame_state = st
+    return st
+
+
 def process_frame(ctx, cfg, assets, depth_raw, K, handbase_in_cam, depth_unit=0.001, use_physics=True, use_render=True, info=None):
     """run_real_all.cpp:116-241 for one frame; returns model2scene (identity when no pose is found, main :189-196).  ``info``
     (a dict) receives the intermediate results the tests look at."""
@@ -263,6 +275,7 @@ def process_frame(ctx, cfg, assets, depth_raw, K, handbase_in_cam, depth_unit=0.
         return ident
     # :155 Hand::setCurScene (Hand.cpp:279-334): handbaseICP on the organised cloud, 3 mm hand region, outlier filters
     h = api.HandT42(cfg, assets.hand, ctx=ctx)
+    h.setHandbaseIcpContext(_frame_state(ctx, cfg, assets)["icp_ctx"])
     ext = np.abs(assets.model001[0].min(axis=0) - assets.model001[0].max(axis=0))
     h.gripper_min_dist = 0.8 * float(ext.min())                       # run_real_all.cpp:41-45
     fin = np.isfinite(scene_organized_n).all(axis=1)                  # (runICP drops NaN normals first, Utils.cpp:198-199)
@@ -307,7 +320,7 @@ def process_frame(ctx, cfg, assets, depth_raw, K, handbase_in_cam, depth_unit=0.
     if os.environ.get("HOP_APP_DEBUG_DIR"):
         np.savez(os.path.join(os.environ["HOP_APP_DEBUG_DIR"], "py.npz"), ox=ox, on=on, oc=oc, mp=mp, mn=mnrm, mk=mk, sx=sx, sn=sn, scf=scf, rgb=scene_rgb[keep_n], rgbn=scene_rgb_n[keep_n])
     # :230-241
-    est = api.PoseEstimator(cfg, assets.model, assets.model001, ctx=ctx)
+    est = _frame_state(ctx, cfg, assets)["est"]   # (run_real_all.cpp:56-60: built once, outside the frame loop)
     est.setCurScene(sx, sn, scf, cloud_withouthand_raw=cloud_withouthand_raw, depth_raw=depth_raw, depth_unit=depth_unit, K=K)
     est.registerHandMesh(h)
     est.registerMesh(assets.mesh[0], assets.mesh[1], "object")

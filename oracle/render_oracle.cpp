@@ -36,39 +36,82 @@ inline unsigned short readback_mm(float d) {
   return (unsigned short)std::round(1000 * (-zf * zn / ((zf - zn) * (d - zf / (zf - zn)))));
 }
 
+// A triangle in window coordinates (x, y, 1/Z per vertex).
+struct WinTri {
+  double x[3], y[3], iz[3];
+};
+// OpenGL clips a primitive against the frustum before it rasterises it; the planes that matter here are near (Z >= 0.1) and far.
+// Every fragment is tested against [0.1, 2.0] below, so clipping at ANY plane 0 < Zc <= 0.1 draws the same pixels: the triangle is
+// cut at Zc = 0.05 (Sutherland-Hodgman, one plane) only to keep the perspective division away from Z <= 0, and the quadrilateral a
+// cut can leave is drawn as a fan of two triangles.  A triangle wholly at Z >= Zc is projected from its float vertices as before.
+constexpr float Z_CLIP = 0.05f;
+inline int clip_project(const float p[3][3], const Cam& c, WinTri out[2]) {
+  const bool in[3] = {p[0][2] >= Z_CLIP, p[1][2] >= Z_CLIP, p[2][2] >= Z_CLIP};
+  const double oy = (double)c.H - c.cy;
+  if (in[0] && in[1] && in[2]) {
+    for (int k = 0; k < 3; ++k) {
+      out[0].x[k] = (double)c.fx * p[k][0] / p[k][2] + c.cx;
+      out[0].y[k] = (double)c.fy * p[k][1] / p[k][2] + oy;
+      out[0].iz[k] = 1.0 / p[k][2];
+    }
+    return 1;
+  }
+  if (!in[0] && !in[1] && !in[2]) return 0;
+  double px[4], py[4], piz[4];
+  int n = 0;
+  for (int k = 0; k < 3; ++k) {
+    const int m = (k + 1) % 3;
+    const double ax = p[k][0], ay = p[k][1], az = p[k][2], bx = p[m][0], by = p[m][1], bz = p[m][2];
+    if (in[k]) px[n] = (double)c.fx * ax / az + c.cx, py[n] = (double)c.fy * ay / az + oy, piz[n] = 1.0 / az, ++n;
+    if (in[k] != in[m]) {  // the edge crosses the plane: the crossing point, always computed from the inside vertex
+      const double ix = in[k] ? ax : bx, iy = in[k] ? ay : by, izz = in[k] ? az : bz;
+      const double ox = in[k] ? bx : ax, oyy = in[k] ? by : ay, oz = in[k] ? bz : az;
+      const double t = ((double)Z_CLIP - izz) / (oz - izz);
+      const double X = ix + t * (ox - ix), Y = iy + t * (oyy - iy), Z = (double)Z_CLIP;
+      px[n] = (double)c.fx * X / Z + c.cx, py[n] = (double)c.fy * Y / Z + oy, piz[n] = 1.0 / Z, ++n;
+    }
+  }
+  int nt = 0;
+  for (int k = 1; k + 1 < n; ++k, ++nt) {
+    const int id[3] = {0, k, k + 1};
+    for (int v = 0; v < 3; ++v) out[nt].x[v] = px[id[v]], out[nt].y[v] = py[id[v]], out[nt].iz[v] = piz[id[v]];
+  }
+  return nt;
+}
+
 // nearest fragment per pixel (window depth, float; 1.0 = cleared) of a triangle soup given in the camera frame
 void rasterise(const float* V, const int* F, int nf, const Cam& c, std::vector<float>& depth, std::vector<unsigned char>* owner, unsigned char id) {
   for (int f = 0; f < nf; ++f) {
-    double x[3], y[3], iz[3];
-    bool ok = true;
-    for (int k = 0; k < 3; ++k) {
-      const float* p = V + 3 * (size_t)F[3 * f + k];
-      if (!(p[2] > 1e-6f)) ok = false;
-      x[k] = (double)c.fx * p[0] / p[2] + c.cx;
-      y[k] = (double)c.fy * p[1] / p[2] + ((double)c.H - c.cy);
-      iz[k] = 1.0 / p[2];
-    }
-    if (!ok) continue;  // behind the camera: outside what the frustum keeps of such a triangle is not restated
-    const double area = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
-    if (area == 0.0) continue;
-    const int w0 = std::max(0, (int)std::floor(std::min({x[0], x[1], x[2]}) - 0.5)), w1 = std::min(c.W - 1, (int)std::ceil(std::max({x[0], x[1], x[2]}) - 0.5));
-    const int h0 = std::max(0, (int)std::floor(std::min({y[0], y[1], y[2]}) - 0.5)), h1 = std::min(c.H - 1, (int)std::ceil(std::max({y[0], y[1], y[2]}) - 0.5));
-    for (int h = h0; h <= h1; ++h)
-      for (int w = w0; w <= w1; ++w) {
-        const double px = w + 0.5, py = h + 0.5;
-        const double e0 = (x[2] - x[1]) * (py - y[1]) - (y[2] - y[1]) * (px - x[1]);
-        const double e1 = (x[0] - x[2]) * (py - y[2]) - (y[0] - y[2]) * (px - x[2]);
-        const double e2 = (x[1] - x[0]) * (py - y[0]) - (y[1] - y[0]) * (px - x[0]);
-        if (!((e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0))) continue;
-        const double Z = area / (e0 * iz[0] + e1 * iz[1] + e2 * iz[2]);  // 1/Z is affine in window coordinates
-        if (!(Z >= 0.1 && Z <= 2.0)) continue;                            // near / far planes
-        const float d = window_depth(Z);
-        const size_t i = (size_t)h * c.W + w;
-        if (d < depth[i]) {  // GL_LESS
-          depth[i] = d;
-          if (owner) (*owner)[i] = id;
+    float p[3][3];
+    for (int k = 0; k < 3; ++k)
+      for (int a = 0; a < 3; ++a) p[k][a] = V[3 * (size_t)F[3 * f + k] + a];
+    WinTri tri[2];
+    const int nt = clip_project(p, c, tri);
+    for (int s = 0; s < nt; ++s) {
+      const double* x = tri[s].x;
+      const double* y = tri[s].y;
+      const double* iz = tri[s].iz;
+      const double area = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
+      if (area == 0.0) continue;
+      const int w0 = std::max(0, (int)std::floor(std::min({x[0], x[1], x[2]}) - 0.5)), w1 = std::min(c.W - 1, (int)std::ceil(std::max({x[0], x[1], x[2]}) - 0.5));
+      const int h0 = std::max(0, (int)std::floor(std::min({y[0], y[1], y[2]}) - 0.5)), h1 = std::min(c.H - 1, (int)std::ceil(std::max({y[0], y[1], y[2]}) - 0.5));
+      for (int h = h0; h <= h1; ++h)
+        for (int w = w0; w <= w1; ++w) {
+          const double px = w + 0.5, py = h + 0.5;
+          const double e0 = (x[2] - x[1]) * (py - y[1]) - (y[2] - y[1]) * (px - x[1]);
+          const double e1 = (x[0] - x[2]) * (py - y[2]) - (y[0] - y[2]) * (px - x[2]);
+          const double e2 = (x[1] - x[0]) * (py - y[0]) - (y[1] - y[0]) * (px - x[0]);
+          if (!((e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0))) continue;
+          const double Z = area / (e0 * iz[0] + e1 * iz[1] + e2 * iz[2]);  // 1/Z is affine in window coordinates
+          if (!(Z >= 0.1 && Z <= 2.0)) continue;                            // near / far planes
+          const float d = window_depth(Z);
+          const size_t i = (size_t)h * c.W + w;
+          if (d < depth[i]) {  // GL_LESS
+            depth[i] = d;
+            if (owner) (*owner)[i] = id;
+          }
         }
-      }
+    }
   }
 }
 

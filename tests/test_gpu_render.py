@@ -91,3 +91,35 @@ def test_reject_by_render_edge_cases(ctx, api, hop, frame):
         c2.hypos_upload(np.eye(4, dtype=np.float32)[None])
         c2.reject_by_render(2.0, 0.3)      # no frame: HOP_E_STATE
     c2.close()
+
+
+def test_near_plane_crossing_and_image_sized_triangles_equal_oracle(ctx, orc, hop, frame):
+    """a ground-like quad from behind the camera to 1.5 m (clipped at the near plane like OpenGL does, not dropped) as the hand layer, and
+    an object whose two triangles cover the whole image (the workgroup-per-triangle pass): same images as the oracle, bit for bit; then
+    the object close enough to cross the near plane under one of two hypotheses: same wrong ratios"""
+    g = frame
+    K = g["K"]
+    ground_V = np.array([[-0.4, 0.05, -1.0], [0.4, 0.05, -1.0], [0.4, 0.05, 1.5], [-0.4, 0.05, 1.5]], np.float32)
+    quad_F = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    wall_V = np.array([[-2.0, -2.0, 1.2], [2.0, -2.0, 1.0], [2.0, 2.0, 1.1], [-2.0, 2.0, 1.3]], np.float32)
+    ctx.render_set_frame(g["depth"], 0.001, K, ground_V, quad_F)
+    ctx.render_set_object(wall_V, quad_F)
+    I4 = np.eye(4, dtype=np.float32)
+    d, o = ctx.render_depth(I4)
+    rd, ro = orc.render(ground_V, quad_F, wall_V, quad_F, K, 480, 640)
+    assert np.array_equal(o, ro) and np.array_equal(d, rd)
+    assert (o == 1).sum() > 50000 and (o == 2).sum() > 100000 and (o == 0).sum() == 0
+    # hypotheses: the true pose, and one that pulls the object mesh through the near plane (part of it behind the camera)
+    hV, hF = g["hand_mesh_cam"]
+    near = g["object_in_cam"].copy()
+    near[2, 3] = 0.08                     # (the mesh then spans Z from about 0.03 to 0.13)
+    poses = np.stack([g["object_in_cam"], near])
+    ctx.render_set_frame(g["depth"], 0.001, K, hV, hF)
+    ctx.render_set_object(g["object_V"], g["object_F"])
+    ctx.hypos_upload(poses)
+    wr, keep = ctx.reject_by_render(2.0, 0.3, sum_mode=0)
+    rwr, rkeep = orc.reject_by_render(g["depth"], 0.001, K, hV, hF, g["object_V"], g["object_F"], poses, 2.0, 0.3)
+    assert np.array_equal(wr.view(np.int32), rwr.view(np.int32)) and np.array_equal(keep, rkeep)
+    assert np.isfinite(wr).all() and wr[0] < wr[1]
+    dn, on = ctx.render_depth(near)
+    assert (on == 2).sum() > 5000           # what lies beyond the near plane is drawn instead of vanishing with the rest

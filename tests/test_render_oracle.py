@@ -70,3 +70,23 @@ def test_wrong_ratio_by_hand(orc):
     # shifted pose: 12 of ~120 columns leave the roi (real invalid there -> 2.0 each) -> roi_diff / roi_cnt = 2.0 * 12 / 120
     assert abs(wr[1] - (2.0 + 2.0 * 2.0 * 12 / 120)) < 0.02
     assert keep.tolist() == [0, 2, 1]                       # n < 10: everything is kept, ascending wrong ratio
+
+
+def test_triangles_crossing_the_near_plane_are_clipped_not_dropped(orc):
+    """a ground-like quad in the plane Y = 0.05 m from Z = -1 (behind the camera) to Z = 1.5: OpenGL clips it at the near plane and
+    draws the rest; row h shows Z = fy * 0.05 / (h + 0.5 - (H - cy))"""
+    V = np.array([[-0.4, 0.05, -1.0], [0.4, 0.05, -1.0], [0.4, 0.05, 1.5], [-0.4, 0.05, 1.5]], np.float32)
+    F = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    none = (np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32))
+    d, o = orc.render(none[0], none[1], V, F, K, H, W)
+    rows = np.arange(H) + 0.5 - (H - 230.0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        Z = np.where(rows > 0, 600 * np.float64(np.float32(0.05)) / rows, np.inf)
+    seen = (Z >= 0.1) & (Z <= 1.5)
+    assert seen.sum() > 150
+    mid = W // 2
+    assert np.array_equal(o[:, mid] == 2, seen)
+    exp = np.round(Z[seen] * 1000) / 1000
+    assert np.abs(d[seen, mid] - exp).max() < 1.01e-3      # (the read-back's float expression rounds to the millimetre)
+    # the part of the image the quad covers widens towards the camera: at the bottom row it spans the whole width
+    assert (o[H - 1] == 2).all() and not (o[0] == 2).any()
