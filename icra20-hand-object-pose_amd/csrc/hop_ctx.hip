@@ -151,6 +151,8 @@ struct hop_ctx {
   int pso_sum_mode = 0;  // hop_hand_set_sum_mode
   DevBuf finger_hist_d, pso_particles_d, pso_match_d, pso_terms_d, pso_sum_d, pso_cnt_d;
   PinnedBuf pso_particles_h, pso_out_h;
+  PinnedBuf stage_up, stage_down;  // hop_ctx_h2d / hop_ctx_d2h
+  size_t stage_cur = 0;
   bool have_finger = false, have_hand_scene = false;
 
   // row modules (hop_physics.hip)
@@ -659,6 +661,31 @@ int cluster_core(const float* pose16, const float* lcp, const int* ids, int H, f
 // ==================================================================================================
 // ---------------------------------------------------------------------------------------------- hop_ctx_ext.h
 hipStream_t hop_ctx_stream(hop_ctx* c) { return c->stream; }
+constexpr size_t STAGE_MIN = 256u << 10;
+hipError_t hop_ctx_h2d(hop_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes < STAGE_MIN) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (c->stage_cur + need > c->stage_up.cap) {  // the area is full: wait for the copies that read it, then start over (or grow)
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return e;
+    c->stage_cur = 0;
+    if (need > c->stage_up.cap && (e = c->stage_up.ensure(std::max(need, (size_t)16 << 20))) != hipSuccess) return e;
+  }
+  char* at = static_cast<char*>(c->stage_up.p) + c->stage_cur;
+  std::memcpy(at, src, bytes);
+  c->stage_cur += need;
+  return hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, c->stream);
+}
+hipError_t hop_ctx_d2h(hop_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes < STAGE_MIN) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+  hipError_t e = c->stage_down.ensure(bytes);
+  if (e != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(c->stage_down.p, src, bytes, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+  c->stage_cur = 0;  // everything queued before has completed: the upload area is free again
+  std::memcpy(dst, c->stage_down.p, bytes);
+  return hipSuccess;
+}
 int hop_ctx_device(const hop_ctx* c) { return c->device; }
 void hop_ctx_set_error(hop_ctx* c, const std::string& msg) { c->last_error = msg; }
 HopExt*& hop_ctx_ext(hop_ctx* c, int slot) { return c->ext[slot]; }
@@ -728,7 +755,7 @@ void hop_ctx_destroy(hop_ctx* c) {
   for (DevBuf* b : bufs) b->release();
   c->verify_grid.release(), c->model_grid[0].release(), c->model_grid[1].release(), c->scene_grid.release(), c->hand_grid.release();
   c->model_cells[0].release(), c->model_cells[1].release(), c->scene_cells.release(), c->verify_cells.release(), c->hand_cells.release();
-  c->ppf_matrix_h.release(), c->bases_h.release(), c->cnt_h.release(), c->pso_particles_h.release(), c->pso_out_h.release();
+  c->ppf_matrix_h.release(), c->bases_h.release(), c->cnt_h.release(), c->pso_particles_h.release(), c->pso_out_h.release(), c->stage_up.release(), c->stage_down.release();
   for (HopExt*& e : c->ext) {
     delete e;
     e = nullptr;

@@ -79,6 +79,13 @@ int hop_ctx_device(const hop_ctx* c);
 void hop_ctx_set_error(hop_ctx* c, const std::string& msg);
 HopExt*& hop_ctx_ext(hop_ctx* c, int slot);
 HopHypView hop_ctx_hyp(hop_ctx* c);
+// Large transfers between the caller's (pageable) arrays and the device go through pinned staging buffers of the context: the runtime's
+// own path for pageable copies of a megabyte and more pins and unpins the caller's pages per call -- 15 ms for the 2 x 3.7 MB of an
+// organised 640 x 480 cloud, against 0.6 ms staged (measured from host/app/run_real_all: HOP_APP_TIMING).  Below 256 KB both are plain
+// hipMemcpyAsync calls.  hop_ctx_h2d is asynchronous on the context's stream (the staging area is recycled at the context's
+// synchronisation points); hop_ctx_d2h returns with the data in `dst` (it synchronises the stream when it stages).
+hipError_t hop_ctx_h2d(hop_ctx* c, void* dst_device, const void* src_host, size_t bytes);
+hipError_t hop_ctx_d2h(hop_ctx* c, void* dst_host, const void* src_device, size_t bytes);
 void hop_ctx_hyp_set_count(hop_ctx* c, int n);
 
 // hop_normals.hip: integral-image normals of an organised device cloud (planes of H*W floats each)

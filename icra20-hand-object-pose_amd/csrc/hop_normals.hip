@@ -433,12 +433,12 @@ int hop_normals_integral_image(hop_ctx* c, const float* xyz, int H, int W, float
   const size_t n = (size_t)H * W;
   NRCHK(c, nr->xyz.ensure(sizeof(float) * 3 * n));
   NRCHK(c, nr->nrm.ensure(sizeof(float) * 3 * n));
-  NRCHK(c, hipMemcpyAsync(nr->xyz.p, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, st));
+  NRCHK(c, hop_ctx_h2d(c, nr->xyz.p, xyz, sizeof(float) * 3 * n));
   float* p = nr->xyz.as<float>();
   float* q = nr->nrm.as<float>();
   const int rc = hop_normals_ii_device(c, p, p + n, p + 2 * n, H, W, max_depth_change_factor, normal_smoothing_size, depth_dependent_smoothing, q, q + n, q + 2 * n);
   if (rc) return rc;
-  NRCHK(c, hipMemcpyAsync(nrm_out, q, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
+  NRCHK(c, hop_ctx_d2h(c, nrm_out, q, sizeof(float) * 3 * n));
   NRCHK(c, hipStreamSynchronize(st));
   return HOP_OK;
 }

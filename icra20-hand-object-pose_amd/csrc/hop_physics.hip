@@ -320,7 +320,17 @@ struct MeshStore {
   DevBuf tri_d, nrm_d, nodes_d, order_d, leaf_d, leaf_first_d, leaf_obb_d, cell_start_d, cell_faces_d;
   SdfMeshDev dev{};
   bool valid = false;
-  void release() { tri_d.release(), nrm_d.release(), nodes_d.release(), order_d.release(), leaf_d.release(), leaf_first_d.release(), leaf_obb_d.release(), cell_start_d.release(), cell_faces_d.release(), valid = false; }
+  // what the structures were built from: registering the same triangles again (the object mesh, once per frame in the reference's
+  // loop, PoseEstimator.cpp:505-508) finds them standing
+  std::vector<float> key_V, key_pose;
+  std::vector<int32_t> key_F;
+  bool same_as(const float* V, int nv, const int32_t* F, int nf, const float* pose16) const {
+    return valid && key_V.size() == 3 * (size_t)nv && key_F.size() == 3 * (size_t)nf && key_pose.size() == (pose16 ? 16u : 0u) &&
+           (nv == 0 || std::memcmp(key_V.data(), V, sizeof(float) * 3 * (size_t)nv) == 0) &&
+           (nf == 0 || std::memcmp(key_F.data(), F, sizeof(int32_t) * 3 * (size_t)nf) == 0) &&
+           (!pose16 || std::memcmp(key_pose.data(), pose16, sizeof(float) * 16) == 0);
+  }
+  void release() { key_V.clear(), key_F.clear(), key_pose.clear(), tri_d.release(), nrm_d.release(), nodes_d.release(), order_d.release(), leaf_d.release(), leaf_first_d.release(), leaf_obb_d.release(), cell_start_d.release(), cell_faces_d.release(), valid = false; }
 };
 
 struct Cloud3 {
@@ -1088,6 +1098,15 @@ int hop_sdf_register_mesh(hop_ctx* c, int mesh_id, const float* V, int nv, const
   PHCHK(c, hipSetDevice(hop_ctx_device(c)));
   Physics* ph = physics(c);
   hipStream_t st = hop_ctx_stream(c);
+  {
+    MeshStore& standing = ph->mesh[mesh_id];
+    static const bool no_reuse = getenv("HOP_SDF_NO_REUSE") != nullptr;
+    if (!no_reuse && standing.same_as(V, nv, F, nf, pose16)) {
+      standing.dev.has_pose = 0;  // (a fresh registration clears what hop_sdf_set_mesh_pose set)
+      return HOP_OK;
+    }
+    standing.valid = false, standing.key_V.clear(), standing.key_F.clear(), standing.key_pose.clear();  // until the rebuild below completes
+  }
   HostMesh hm;
   prepare_mesh(hm, V, nv, F, nf, pose16);
   TreeBuilder tb(hm);
@@ -1181,6 +1200,9 @@ int hop_sdf_register_mesh(hop_ctx* c, int mesh_id, const float* V, int nv, const
     ms.dev.cell_nx = g.nx, ms.dev.cell_ny = g.ny, ms.dev.cell_nz = g.nz;
     ph->last_cells_total = (long long)total, ph->last_cells_voxels = nvox;
   }
+  ms.key_V.assign(V, V + 3 * (size_t)nv), ms.key_F.assign(F, F + 3 * (size_t)nf);
+  if (pose16) ms.key_pose.assign(pose16, pose16 + 16);
+  else ms.key_pose.clear();
   return HOP_OK;
 }
 
@@ -1286,7 +1308,7 @@ static int scene_from_depth_impl(hop_ctx* c, const uint16_t* depth_raw, int H, i
   hipStream_t st = hop_ctx_stream(c);
   const int n = H * W;
   PHCHK(c, ph->keys_alt.ensure(sizeof(uint16_t) * (size_t)n));  // staging of the raw image
-  PHCHK(c, hipMemcpyAsync(ph->keys_alt.p, depth_raw, sizeof(uint16_t) * (size_t)n, hipMemcpyHostToDevice, st));
+  PHCHK(c, hop_ctx_h2d(c, ph->keys_alt.p, depth_raw, sizeof(uint16_t) * (size_t)n));
   PHCHK(c, ph->tmp_cloud.buf.ensure(sizeof(float) * 3 * (size_t)n));
   ph->tmp_cloud.n = n;
   PHCHK(c, ph->scalars.ensure(sizeof(unsigned) * 16));

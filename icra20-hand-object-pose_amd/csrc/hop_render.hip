@@ -17,7 +17,8 @@
 //   * depth through the read-back's float expression, rounded to whole millimetres, clamped to [0.1, 2.0] m;
 //   * the score loop of :398-440 with its always-true sub-conditions.  sum_mode 0 adds the 307 200 per-pixel terms into
 //     one float in row order like the reference (after ~1e5 background pixels worth 2.0 each, millimetre-sized terms
-//     round away: the result depends on that order); sum_mode 1 reduces them in double (block reduction);
+//     round away: the result depends on that order) -- one lane per hypothesis fed through LDS by the rest of its workgroup;
+//     sum_mode 1 reduces them in double (block reduction);
 //   * the survivors: max(int(keep_ratio n), 10) smallest wrong ratios, ascending (the reference's priority queue).
 // Parity unpinned: no OpenGL exists here to pin pixel coverage or depth quantisation against; the CPU restatement
 // (oracle/render_oracle.cpp) is checked on hand-computed triangles.
@@ -225,7 +226,7 @@ __device__ __forceinline__ void pixel_term(float real, unsigned zh, unsigned zo,
   else diff = fabsf(sim - real);
 }
 
-// sum_mode 0, pass 1: the per-pixel term of every hypothesis, [pixel][hypothesis]; bit 31 = object pixel (diff >= 0)
+// sum_mode 0, pass 1: the per-pixel term of every hypothesis, [hypothesis][pixel]; bit 31 = object pixel (diff >= 0)
 __global__ void k_score_terms(const float* __restrict__ real, const unsigned* __restrict__ hand_z, const unsigned* __restrict__ zbuf, int npx, int n_hyp,
                               unsigned* __restrict__ terms) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,39 +235,64 @@ __global__ void k_score_terms(const float* __restrict__ real, const unsigned* __
   float diff;
   bool roi;
   pixel_term(real[px], hand_z[px], zbuf[(size_t)hyp * npx + px], diff, roi);
-  terms[(size_t)px * n_hyp + hyp] = __float_as_uint(diff) | (roi ? 0x80000000u : 0u);
+  terms[t] = __float_as_uint(diff) | (roi ? 0x80000000u : 0u);
 }
-// sum_mode 0, pass 2: one lane per hypothesis adds its terms in row order (the reference's loop, :402-437)
-__global__ __launch_bounds__(64) void k_score_serial(const unsigned* __restrict__ terms, int npx, int n_hyp, float roi_weight, float* __restrict__ wrong) {
-  const int hyp = blockIdx.x * blockDim.x + threadIdx.x;
-  if (hyp >= n_hyp) return;
+// sum_mode 0, pass 2: the reference's loop (:402-437) adds the 307 200 terms of a hypothesis into two floats in row order -- a serial
+// chain of float additions whose result depends on that order.  One workgroup per hypothesis: three wavefronts stream its terms into a
+// double-buffered LDS tile, already split into the two sums' operands (adding +0 to the sum a term does not belong to leaves that sum's
+// bits unchanged: the terms are >= 0) and count the object pixels (integers: any order); ONE lane of the fourth wavefront does nothing
+// but the additions, 2.5 instructions per term.  (Before: one lane per hypothesis reading [pixel][hypothesis] with 64 loads in flight,
+// 6.3 ms for the ~20 hypotheses of a frame -- bound by the latency of its own loads.)
+constexpr int SCORE_CH = 2048;
+__global__ __launch_bounds__(256) void k_score_serial(const unsigned* __restrict__ terms, int npx, int n_hyp, float roi_weight, float* __restrict__ wrong) {
+  __shared__ __attribute__((aligned(16))) float sa[2][SCORE_CH], sb[2][SCORE_CH];
+  __shared__ int s_cnt[3];
+  const int hyp = blockIdx.x;
+  const unsigned* __restrict__ tp = terms + (size_t)hyp * npx;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nch = (npx + SCORE_CH - 1) / SCORE_CH;
+  int my_roi = 0;
   float roi_diff = 0, bg_diff = 0;
-  int roi_cnt = 0, bg_cnt = 0;
-  // 64 loads in flight per lane (one wavefront serves 64 hypotheses and has the device to itself: memory latency is the
-  // whole cost); adding +0 to the sum a term does not belong to leaves that sum's bits unchanged (the terms are >= 0)
-  constexpr int U = 64;
-  int px = 0;
-  for (; px + U <= npx; px += U) {
-    unsigned v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = terms[(size_t)(px + u) * n_hyp + hyp];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float d = __uint_as_float(v[u] & 0x7fffffffu);
-      const bool roi = (v[u] & 0x80000000u) != 0u;
-      roi_diff += roi ? d : 0.f, bg_diff += roi ? 0.f : d;
-      roi_cnt += roi ? 1 : 0;
+  auto fill = [&](int c) {  // wavefronts 1..3
+    const int b = c & 1, base = c * SCORE_CH;
+    for (int i = (wave - 1) * 64 + lane; i < SCORE_CH; i += 192) {
+      const int px = base + i;
+      const unsigned v = px < npx ? tp[px] : 0u;
+      const float d = __uint_as_float(v & 0x7fffffffu);
+      const bool roi = (v & 0x80000000u) != 0u;
+      sa[b][i] = roi ? d : 0.f, sb[b][i] = roi ? 0.f : d;
+      my_roi += roi ? 1 : 0;
     }
+  };
+  if (wave > 0) fill(0);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    if (wave > 0) {
+      if (c + 1 < nch) fill(c + 1);
+    } else if (lane == 0) {
+      const float4* __restrict__ a4 = reinterpret_cast<const float4*>(sa[c & 1]);
+      const float4* __restrict__ b4 = reinterpret_cast<const float4*>(sb[c & 1]);
+#pragma unroll 4
+      for (int i = 0; i < SCORE_CH / 4; ++i) {
+        const float4 a = a4[i], b = b4[i];
+        roi_diff += a.x, bg_diff += b.x;
+        roi_diff += a.y, bg_diff += b.y;
+        roi_diff += a.z, bg_diff += b.z;
+        roi_diff += a.w, bg_diff += b.w;
+      }
+    }
+    __syncthreads();
   }
-  for (; px < npx; ++px) {
-    const unsigned v = terms[(size_t)px * n_hyp + hyp];
-    const float d = __uint_as_float(v & 0x7fffffffu);
-    const bool roi = (v & 0x80000000u) != 0u;
-    roi_diff += roi ? d : 0.f, bg_diff += roi ? 0.f : d;
-    roi_cnt += roi ? 1 : 0;
+  if (wave > 0) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) my_roi += __shfl_down(my_roi, off);
+    if (lane == 0) s_cnt[wave - 1] = my_roi;
   }
-  bg_cnt = npx - roi_cnt;
-  wrong[hyp] = roi_weight * roi_diff / roi_cnt + bg_diff / bg_cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int roi_cnt = s_cnt[0] + s_cnt[1] + s_cnt[2], bg_cnt = npx - roi_cnt;
+    wrong[hyp] = roi_weight * roi_diff / roi_cnt + bg_diff / bg_cnt;
+  }
 }
 // sum_mode 1: one block per hypothesis, sums reduced in double
 __global__ __launch_bounds__(256) void k_score_reduce(const float* __restrict__ real, const unsigned* __restrict__ hand_z, const unsigned* __restrict__ zbuf, int npx,
@@ -344,7 +370,7 @@ int hop_render_set_frame(hop_ctx* c, const uint16_t* depth_raw, int H, int W, do
   RDCHK(c, r->raw.ensure(sizeof(uint16_t) * npx));
   RDCHK(c, r->real.ensure(sizeof(float) * npx));
   RDCHK(c, r->hand_z.ensure(sizeof(unsigned) * npx));
-  RDCHK(c, hipMemcpyAsync(r->raw.p, depth_raw, sizeof(uint16_t) * npx, hipMemcpyHostToDevice, st));
+  RDCHK(c, hop_ctx_h2d(c, r->raw.p, depth_raw, sizeof(uint16_t) * npx));
   k_real_depth<<<(unsigned)((npx + 255) / 256), 256, 0, st>>>(r->raw.as<unsigned short>(), (int)npx, depth_unit, r->real.as<float>());
   int rc = fill_clear(c, r->hand_z.p, npx);
   if (rc) return rc;
@@ -434,7 +460,7 @@ int hop_reject_by_render(hop_ctx* c, float roi_weight, float keep_ratio, int sum
       const long long t = (long long)npx * hb;
       k_score_terms<<<(unsigned)((t + 255) / 256), 256, 0, st>>>(r->real.as<float>(), r->hand_z.as<unsigned>(), r->zbuf.as<unsigned>(), (int)npx, hb,
                                                                 r->terms.as<unsigned>());
-      k_score_serial<<<(hb + 63) / 64, 64, 0, st>>>(r->terms.as<unsigned>(), (int)npx, hb, roi_weight, r->sums.as<float>() + h0);
+      k_score_serial<<<hb, 256, 0, st>>>(r->terms.as<unsigned>(), (int)npx, hb, roi_weight, r->sums.as<float>() + h0);
     } else {
       k_score_reduce<<<hb, 256, 0, st>>>(r->real.as<float>(), r->hand_z.as<unsigned>(), r->zbuf.as<unsigned>(), (int)npx, roi_weight, r->sums.as<float>() + h0);
     }

@@ -11,6 +11,7 @@
 #define HOP_HOST_FRAME_H_
 #include <zlib.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <fstream>
@@ -251,6 +252,7 @@ struct FrameInfo {
   std::map<std::string, float> angles;
   Mat4 handbase_in_cam = Mat4::Identity();
   float score = 0;
+  std::vector<std::pair<const char*, double>> stage_ms;  // host wall time per stage of process_frame, in order
 };
 
 inline Cloud compact(const std::vector<float>& x, const std::vector<float>& n, int stride, int m, const std::vector<float>* conf = nullptr) {
@@ -275,6 +277,12 @@ inline Mat4 process_frame(ConfigParser& cfg, const Assets& assets, PoseEstimator
     if (info_out) *info_out = info;
     return r;
   };
+  auto lap_t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* name) {
+    const auto t = std::chrono::steady_clock::now();
+    info.stage_ms.emplace_back(name, std::chrono::duration<double, std::milli>(t - lap_t0).count());
+    lap_t0 = t;
+  };
   hand.reset();
   est.reset();
   hand._handbase_in_cam = handbase_in_cam_reported;
@@ -293,6 +301,7 @@ inline Mat4 process_frame(ConfigParser& cfg, const Assets& assets, PoseEstimator
       }
     }
   check(hop_normals_integral_image(ctx, org.data(), H, W, 0.02f, 10.0f, 1, org_n.data()), ctx, "hop_normals_integral_image");
+  lap("organised cloud + integral-image normals");
   Cloud scene_organized;  // valid z and finite normals (runICP drops NaN normals first, Utils.cpp:198-199)
   {
     std::vector<size_t> idx;
@@ -317,6 +326,7 @@ inline Mat4 process_frame(ConfigParser& cfg, const Assets& assets, PoseEstimator
   check(hop_scene_from_depth_normals(ctx, depth_raw.data(), H, W, depth_unit, K9, cam_in_handbase, hand._handbase_in_cam.m, 0.001f, crop_min, crop_max, 0.02f, 10.0f,
                                      sx.data(), sn.data(), (int)npx, &n_rgb, counts),
         ctx, "hop_scene_from_depth_normals");
+  lap("scene_from_depth_normals");
   info.n_valid = counts[0], info.n_hand_region = n_rgb;
   if (n_rgb == 0) return done(ident);
   const Cloud scene_rgb = compact(sx, sn, (int)npx, n_rgb);
@@ -331,6 +341,7 @@ inline Mat4 process_frame(ConfigParser& cfg, const Assets& assets, PoseEstimator
     cfg.gripper_min_dist = 0.8f * std::min(std::min(std::abs(mn[0] - mx[0]), std::abs(mn[1] - mx[1])), std::abs(mn[2] - mx[2]));  // run_real_all.cpp:41-45
   }
   hand.handbaseICP(scene_organized, assets.base_link);
+  lap("compaction + handbaseICP");
   info.handbase_in_cam = hand._handbase_in_cam;
   std::vector<float> rx(3 * (size_t)n_rgb), rn(3 * (size_t)n_rgb);
   int n_region = 0;
@@ -338,6 +349,7 @@ inline Mat4 process_frame(ConfigParser& cfg, const Assets& assets, PoseEstimator
         "hop_voxel_downsample_normals");
   const Cloud region = compact(rx, rn, n_rgb, n_region);
   hand.setCurSceneFromRegion(region);
+  lap("3 mm region + setCurScene");
   // :158-185 finger states
   const float f1_min = cfg.getf("hand_match.finger1_min_match"), f2_min = cfg.getf("hand_match.finger2_min_match");
   const float f1_d = cfg.getf("hand_match.finger1_dist_thres"), f2_d = cfg.getf("hand_match.finger2_dist_thres");
@@ -354,6 +366,7 @@ inline Mat4 process_frame(ConfigParser& cfg, const Assets& assets, PoseEstimator
       }
     }
   // :187-188
+  lap("finger PSO");
   hand.adjustHandHeight(region);
   hand.makeHandCloud();
   // :193-199 hand points removed, confidences; :201 MLS normals; :203-225 generator cloud
@@ -371,6 +384,7 @@ inline Mat4 process_frame(ConfigParser& cfg, const Assets& assets, PoseEstimator
   }
   const Cloud without_hand = hand.removeSurroundingPointsAndAssignProbability(finite_rgb, hand._handbase_in_cam, near * near);
   info.n_without_hand = without_hand.n;
+  lap("height + hand cloud + hand-point removal");
   if (without_hand.n < 3) return done(ident);
   const int nw = without_hand.n;
   std::vector<float> mp(3 * (size_t)nw), mnrm(3 * (size_t)nw), mcurv(nw);
@@ -385,6 +399,7 @@ inline Mat4 process_frame(ConfigParser& cfg, const Assets& assets, PoseEstimator
   check(hop_object_segment(ctx, mls.xyz.data(), mls.nrm.data(), mls.conf.data(), n_mls, 0.003f, ox.data(), on.data(), oc.data(), std::max(n_mls, 1), &n_seg), ctx,
         "hop_object_segment");
   info.n_object_segment = n_seg;
+  lap("MLS + object segment");
   if (n_seg < 4) return done(ident);
   const Cloud object_segment = compact(ox, on, std::max(n_mls, 1), n_seg, &oc);
   if (std::getenv("HOP_APP_DEBUG")) {
@@ -414,25 +429,33 @@ inline Mat4 process_frame(ConfigParser& cfg, const Assets& assets, PoseEstimator
   est.setDepth(depth_raw, H, W, depth_unit, K9);
   est.registerHandMesh(&hand);
   est.registerMesh(assets.object_mesh, "object", ident.m);
+  lap("estimator scene + mesh registration");
   if (!est.runSuper4pcs(assets.ppf_keys)) return done(ident);
   info.n_generated = est.numHypos();
+  lap("runSuper4pcs");
   est.clusterPoses(30, 0.015, true);
   info.n_clusters = est.numHypos();
+  lap("clusterPoses 1");
   est.refineByICP();
+  lap("refineByICP");
   est.clusterPoses(5, 0.003, false);
   info.n_after_icp = est.numHypos();
   if (use_physics) {
+    lap("clusterPoses 2");
     est.rejectByCollisionOrNonTouching(&hand);
     info.n_after_physics = est.numHypos();
+    lap("rejectByCollisionOrNonTouching");
   }
   if (use_render && est.numHypos() > 0) {
     est.rejectByRender(cfg.getf("pose_estimator_wrong_ratio", 0.f), &hand);
     info.n_after_render = est.numHypos();
+    lap("rejectByRender");
   }
   if (est.numHypos() == 0) return done(ident);
   PoseHypo best(-1);
   est.selectBest(best);
   info.score = best._lcp_score;
+  lap("selectBest");
   Mat4 r;
   for (int i = 0; i < 16; ++i) r.m[i] = best._pose[i];
   return done(r);

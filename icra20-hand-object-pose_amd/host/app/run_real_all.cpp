@@ -4,15 +4,19 @@
 //
 //   run_real_all <config_autodataset.yaml> <assets_dir> <base_dir> [model_name]
 //   RANK / WORLD_SIZE in the environment shard the frames (frame index mod world, as the Python runner does; the reference is one process);
-//   HOP_FORCE=1 recomputes frames whose result exists (default: resume).
+//   HOP_FORCE=1 recomputes frames whose result exists (default: resume); HOP_INFLIGHT=N keeps N frames in flight on the device (N host
+//   threads, each with its own estimator / hand / contexts; default 1 = the reference's sequential loop); LOCAL_RANK picks the device.
 // assets_dir holds what the reference loads from PLY / OBJ / Boost archive / URDF files (download links): see hop::Assets (host/Frame.h).
 #include <dirent.h>
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <iostream>
+#include <mutex>
 #include <regex>
+#include <thread>
 
 #include "../Frame.h"
 
@@ -43,28 +47,28 @@ static void mkdirs(const std::string& p) {
   }
 }
 
+struct FrameJob {
+  std::string record, rec;
+  int idx;
+};
+
 int main(int argc, char** argv) {
   if (argc < 4) {
     std::cout << "usage: run_real_all <config.yaml> <assets_dir> <base_dir> [model_name]\n";
     return 2;
   }
   try {
-    ConfigParser cfg(argv[1]);
+    ConfigParser cfg0(argv[1]);
     const hop::Assets assets(argv[2]);
-    const std::string base = argv[3], model_name = argc > 4 ? argv[4] : cfg.model_name;
+    const std::string base = argv[3], model_name = argc > 4 ? argv[4] : cfg0.model_name;
     const int rank = std::getenv("RANK") ? std::atoi(std::getenv("RANK")) : 0, world = std::getenv("WORLD_SIZE") ? std::max(1, std::atoi(std::getenv("WORLD_SIZE"))) : 1;
     const bool force = std::getenv("HOP_FORCE") != nullptr;
-    const hop::Calibration cal(cfg);
-    // run_real_all.cpp:56-68: estimator and hand are built ONCE, reset between frames (:265-266)
-    PoseEstimator est(&cfg, assets.model, assets.model001);
-    HandT42 hand(&cfg, est.ctx());
-    assets.addTo(hand);
-    hop_ctx* icp_ctx = nullptr;
-    hop::check(hop_ctx_create(0, &icp_ctx), nullptr, "hop_ctx_create");
-    hand.setHandbaseIcpContext(icp_ctx);
+    const int inflight = std::getenv("HOP_INFLIGHT") ? std::max(1, std::atoi(std::getenv("HOP_INFLIGHT"))) : 1;
+    const int device = std::getenv("LOCAL_RANK") ? std::atoi(std::getenv("LOCAL_RANK")) : 0;
     const std::string mdir = base + "/" + model_name;
-    int n_done = 0, n_skipped = 0;
-    double ms_total = 0;
+    // this rank's frames that have no result yet (the reference walks the same directories in the same order, :70-115)
+    std::vector<FrameJob> jobs;
+    int n_skipped = 0;
     const std::regex rgb_re("rgb([0-9]+)\\..*");
     for (const std::string& record : list_dir(mdir, true)) {
       const std::string rec = mdir + "/" + record;
@@ -76,39 +80,80 @@ int main(int argc, char** argv) {
       std::sort(frames.begin(), frames.end());
       for (int idx : frames) {
         if (idx % world != rank) continue;
-        const std::string out_dir = rec + "/predict/" + std::to_string(idx), out = out_dir + "/model2scene.txt";
-        {
-          std::ifstream ex(out);
-          if (ex && !force) {
-            ++n_skipped;
-            continue;
-          }
-        }
-        const auto t0 = std::chrono::steady_clock::now();
-        const Mat4 leftarm_in_base = hop::parse_pose_txt(rec + "/arm_left_link_7_t_" + std::to_string(idx) + ".txt");
-        const Mat4 palm_in_baselink = hop::parse_pose_txt(rec + "/palm_in_base" + std::to_string(idx) + ".txt");
-        std::vector<uint16_t> depth;
-        int H = 0, W = 0;
-        hop::read_png16(rec + "/depth" + std::to_string(idx) + ".png", depth, H, W);
-        hop::FrameInfo info;
-        const Mat4 pose = hop::process_frame(cfg, assets, est, hand, depth, H, W, cal.K9, cal.handbaseInCam(leftarm_in_base, palm_in_baselink), 0.001, true, true, &info);
-        mkdirs(out_dir);
-        {
-          std::ofstream ff(out + ".tmp");  // a killed run never leaves a half-written result
-          ff.precision(9);
-          for (int r = 0; r < 4; ++r)
-            for (int c = 0; c < 4; ++c) ff << pose.m[4 * r + c] << (c == 3 ? "\n" : " ");
-        }
-        std::rename((out + ".tmp").c_str(), out.c_str());
-        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        ms_total += ms;
-        ++n_done;
-        std::printf("%s/%d: %.1f ms, %d hand-region points, %d object points, %d hypotheses after ICP, score %.2f\n", record.c_str(), idx, ms, info.n_hand_region,
-                    info.n_object_segment, info.n_after_icp, info.score);
+        std::ifstream ex(rec + "/predict/" + std::to_string(idx) + "/model2scene.txt");
+        if (ex && !force) ++n_skipped;
+        else jobs.push_back({record, rec, idx});
       }
     }
-    std::printf("rank %d of %d: %d frames written (%.1f ms per frame), %d resumed\n", rank, world, n_done, n_done ? ms_total / n_done : 0.0, n_skipped);
-    hop_ctx_destroy(icp_ctx);
+    // Frames are independent (the reference resets its estimator and hand between them, :265-266), so HOP_INFLIGHT workers -- each with
+    // its own estimator, hand and pair of contexts (= HIP streams) on this rank's device, all built ONCE as the reference builds its
+    // pair (:56-68) -- take them from one counter: the host work of a frame (PNG decoding, base selection, the PSO bookkeeping) then
+    // runs beside the kernels of the other frames.  Same results as one worker: nothing is shared but the read-only assets.
+    std::atomic<size_t> next{0};
+    std::atomic<int> n_done{0};
+    std::mutex io;
+    std::string first_error;
+    double ms_total = 0;
+    std::vector<std::pair<std::string, double>> stage_total;  // HOP_APP_TIMING=1: host wall time per stage, summed over the frames
+    const auto wall0 = std::chrono::steady_clock::now();
+    auto worker = [&]() {
+      try {
+        ConfigParser cfg(argv[1]);
+        const hop::Calibration cal(cfg);
+        PoseEstimator est(&cfg, assets.model, assets.model001, device);
+        HandT42 hand(&cfg, est.ctx());
+        assets.addTo(hand);
+        hop_ctx* icp_ctx = nullptr;
+        hop::check(hop_ctx_create(device, &icp_ctx), nullptr, "hop_ctx_create");
+        hand.setHandbaseIcpContext(icp_ctx);
+        for (size_t k = next.fetch_add(1); k < jobs.size(); k = next.fetch_add(1)) {
+          const FrameJob& j = jobs[k];
+          const std::string out_dir = j.rec + "/predict/" + std::to_string(j.idx), out = out_dir + "/model2scene.txt";
+          const auto t0 = std::chrono::steady_clock::now();
+          const Mat4 leftarm_in_base = hop::parse_pose_txt(j.rec + "/arm_left_link_7_t_" + std::to_string(j.idx) + ".txt");
+          const Mat4 palm_in_baselink = hop::parse_pose_txt(j.rec + "/palm_in_base" + std::to_string(j.idx) + ".txt");
+          std::vector<uint16_t> depth;
+          int H = 0, W = 0;
+          hop::read_png16(j.rec + "/depth" + std::to_string(j.idx) + ".png", depth, H, W);
+          hop::FrameInfo info;
+          const Mat4 pose = hop::process_frame(cfg, assets, est, hand, depth, H, W, cal.K9, cal.handbaseInCam(leftarm_in_base, palm_in_baselink), 0.001, true, true, &info);
+          mkdirs(out_dir);
+          {
+            std::ofstream ff(out + ".tmp");  // a killed run never leaves a half-written result
+            ff.precision(9);
+            for (int r = 0; r < 4; ++r)
+              for (int c = 0; c < 4; ++c) ff << pose.m[4 * r + c] << (c == 3 ? "\n" : " ");
+          }
+          std::rename((out + ".tmp").c_str(), out.c_str());
+          const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+          std::lock_guard<std::mutex> lk(io);
+          ms_total += ms;
+          ++n_done;
+          for (size_t q = 0; q < info.stage_ms.size(); ++q) {
+            if (q >= stage_total.size() || stage_total[q].first != info.stage_ms[q].first) stage_total.insert(stage_total.begin() + q, {info.stage_ms[q].first, 0.0});
+            stage_total[q].second += info.stage_ms[q].second;
+          }
+          std::printf("%s/%d: %.1f ms, %d hand-region points, %d object points, %d hypotheses after ICP, score %.2f\n", j.record.c_str(), j.idx, ms,
+                      info.n_hand_region, info.n_object_segment, info.n_after_icp, info.score);
+        }
+        hop_ctx_destroy(icp_ctx);
+      } catch (const std::exception& e) {
+        std::lock_guard<std::mutex> lk(io);
+        if (first_error.empty()) first_error = e.what();
+        next.store(jobs.size());  // the other workers finish their frame and stop
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int w = 1; w < std::min<int>(inflight, (int)std::max<size_t>(jobs.size(), 1)); ++w) pool.emplace_back(worker);
+    worker();
+    for (std::thread& t : pool) t.join();
+    if (!first_error.empty()) throw std::runtime_error(first_error);
+    const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    const int nd = n_done.load();
+    std::printf("rank %d of %d: %d frames written (%.1f ms per frame alone, %d in flight: %.1f ms of wall per frame), %d resumed\n", rank, world, nd,
+                nd ? ms_total / nd : 0.0, inflight, nd ? wall / nd : 0.0, n_skipped);
+    if (std::getenv("HOP_APP_TIMING") && nd)
+      for (const auto& st : stage_total) std::printf("  %-45s %8.2f ms per frame\n", st.first.c_str(), st.second / nd);
     return 0;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());

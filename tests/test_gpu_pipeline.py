@@ -167,6 +167,13 @@ def test_cpp_drivers_from_the_depth_image_equal_the_python_mirror(hop, tmp_path)
     assert r2.returncode == 0 and "0 frames written" in r2.stdout and "2 resumed" in r2.stdout            # resume
     ev = rr.eval_raw(base, "ellipse", assets.model001[0])
     assert ev["total"] == 2 and ev["recall_10mm"] >= 0.5
+    # frames in flight from the C++ host (HOP_INFLIGHT workers, each with its own estimator / hand / contexts): the same files
+    seq = {idx: open(os.path.join(rec, "predict", str(idx), "model2scene.txt")).read() for idx in (0, 1)}
+    r4 = subprocess.run([os.path.join(lib, "run_real_all"), cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=600,
+                        env=dict(os.environ, HOP_INFLIGHT="2", HOP_FORCE="1"))
+    assert r4.returncode == 0 and "2 frames written" in r4.stdout and "2 in flight" in r4.stdout, r4.stdout + r4.stderr
+    for idx in (0, 1):
+        assert open(os.path.join(rec, "predict", str(idx), "model2scene.txt")).read() == seq[idx]
     # C++ single-frame driver from the depth image
     out = tmp_path / "out"
     out.mkdir()
