@@ -207,6 +207,8 @@ int hop_comm_create(int device, const unsigned char id[HOP_COMM_ID_BYTES], int r
 void hop_comm_destroy(hop_comm* c) {
   if (!c) return;
   DeviceGuard dg(c->device);
+  // everything this communicator queued has completed before it, its stream and its buffers go
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) rccl().CommDestroy(c->comm);
   if (c->send) (void)hipFree(c->send);
   if (c->recv) (void)hipFree(c->recv);

@@ -238,7 +238,7 @@ int upload_cloud(hop_ctx* c, CloudDevice& d, const CloudHost& h) {
   if (h.n == 0) return HOP_OK;
   const std::vector<float>* pl[6] = {&h.x, &h.y, &h.z, &h.nx, &h.ny, &h.nz};
   for (int k = 0; k < 6; ++k)
-    HIPCHK(c, hipMemcpyAsync(d.buf.as<float>() + (size_t)k * h.n, pl[k]->data(), sizeof(float) * h.n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hop_ctx_h2d(c, d.buf.as<float>() + (size_t)k * h.n, pl[k]->data(), sizeof(float) * h.n));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return HOP_OK;
 }
@@ -287,8 +287,8 @@ int build_grid(hop_ctx* c, GridStore& gs, const float* x, const float* y, const 
   }
   HIPCHK(c, gs.cell_start_d.ensure(sizeof(int) * (ncell + 1)));
   HIPCHK(c, gs.pts_d.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
-  HIPCHK(c, hipMemcpyAsync(gs.cell_start_d.p, start.data(), sizeof(int) * (ncell + 1), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(gs.pts_d.p, pts.data(), sizeof(float4) * (size_t)std::max(n, 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hop_ctx_h2d(c, gs.cell_start_d.p, start.data(), sizeof(int) * (ncell + 1)));
+  HIPCHK(c, hop_ctx_h2d(c, gs.pts_d.p, pts.data(), sizeof(float4) * (size_t)std::max(n, 1)));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   g.cell_start = gs.cell_start_d.as<int>();
   g.pts = gs.pts_d.as<float4>();
@@ -332,14 +332,14 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
   launch_cell_list_bounds(a, c->stream);
   launch_cell_list_count(a, c->stream);
   std::vector<int> cnt(ncell), start(ncell + 1, 0);
-  HIPCHK(c, hipMemcpyAsync(cnt.data(), cs.count_d.p, sizeof(int) * ncell, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hop_ctx_d2h(c, cnt.data(), cs.count_d.p, sizeof(int) * ncell));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (size_t k = 0; k < ncell; ++k) start[k + 1] = start[k] + cnt[k];
   const size_t total = (size_t)start[ncell];
   HIPCHK(c, cs.pts_d.ensure(sizeof(float4) * std::max<size_t>(total, 1)));
   HIPCHK(c, cs.nrm_d.ensure(sizeof(float4) * std::max<size_t>(total, 1)));
   a.nrm = cs.nrm_d.as<float4>();
-  HIPCHK(c, hipMemcpyAsync(cs.start_d.p, start.data(), sizeof(int) * (ncell + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hop_ctx_h2d(c, cs.start_d.p, start.data(), sizeof(int) * (ncell + 1)));
   a.start = cs.start_d.as<int>(), a.pts = cs.pts_d.as<float4>();
   launch_cell_list_fill(a, c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -364,7 +364,7 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
   // its 32-bit integer squared distances need every coordinate difference below 37 800 steps: cell < 0.3 max_dist)
   if (packed && h.n < 0xFFFF && cell < 0.3f * max_dist) {
     std::vector<float4> hp(std::max<size_t>(total, 1));
-    HIPCHK(c, hipMemcpyAsync(hp.data(), cs.pts_d.p, sizeof(float4) * total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hop_ctx_d2h(c, hp.data(), cs.pts_d.p, sizeof(float4) * total));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // per-cell quantisation frame: every list member lies within max_dist + margin of the cell's box on every axis
     // (cell_list_thr2), so [corner - R, corner + cell + R] holds it
@@ -396,7 +396,7 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
       std::sort(code.begin(), code.end());
       // (the values come from the device cloud the other modes read: the host copy of the generator keeps normalised normals)
       std::vector<float> dv(6 * (size_t)std::max(h.n, 1));
-      HIPCHK(c, hipMemcpyAsync(dv.data(), d.plane(0), sizeof(float) * 6 * (size_t)h.n, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hop_ctx_d2h(c, dv.data(), d.plane(0), sizeof(float) * 6 * (size_t)h.n));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       const size_t hn = (size_t)h.n;
       std::vector<float4> pm(std::max(h.n, 1)), nm(std::max(h.n, 1));
@@ -407,8 +407,8 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
         memcpy(&wi, &i, 4);
         pm[r] = make_float4(dv[i], dv[hn + i], dv[2 * hn + i], wi), nm[r] = make_float4(dv[3 * hn + i], dv[4 * hn + i], dv[5 * hn + i], 0.f);
       }
-      HIPCHK(c, hipMemcpyAsync(cs.pts_idx_d.p, pm.data(), sizeof(float4) * (size_t)h.n, hipMemcpyHostToDevice, c->stream));
-      HIPCHK(c, hipMemcpyAsync(cs.nrm_idx_d.p, nm.data(), sizeof(float4) * (size_t)h.n, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hop_ctx_h2d(c, cs.pts_idx_d.p, pm.data(), sizeof(float4) * (size_t)h.n));
+      HIPCHK(c, hop_ctx_h2d(c, cs.nrm_idx_d.p, nm.data(), sizeof(float4) * (size_t)h.n));
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     std::vector<uint32_t> rec(2 * ncell), ql;
@@ -444,8 +444,8 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
     if (ql.empty()) ql.assign(4, 0xFFFFFFFFu);
     HIPCHK(c, cs.rec_d.ensure(sizeof(uint32_t) * rec.size()));
     HIPCHK(c, cs.qlist_d.ensure(sizeof(uint32_t) * ql.size()));
-    HIPCHK(c, hipMemcpyAsync(cs.rec_d.p, rec.data(), sizeof(uint32_t) * rec.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(cs.qlist_d.p, ql.data(), sizeof(uint32_t) * ql.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hop_ctx_h2d(c, cs.rec_d.p, rec.data(), sizeof(uint32_t) * rec.size()));
+    HIPCHK(c, hop_ctx_h2d(c, cs.qlist_d.p, ql.data(), sizeof(uint32_t) * ql.size()));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     cs.c.rec = cs.rec_d.as<uint2>(), cs.c.qlist = cs.qlist_d.as<uint4>();
     cs.c.q_cs = (float)qcs, cs.c.q_rs = (float)(qrs + 0.5), cs.c.q_step2 = (float)(step * step);  // + 0.5: the lookup truncates
@@ -493,7 +493,7 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   HIPCHK(c, c->sort_tmp.ensure(tmp_bytes + 16));
   HIPCHK(c, prim_exclusive_sum(c->sort_tmp.p, tmp_bytes, flag, scan, (int)(ncell + 1), c->stream));
   int nwork = 0;
-  HIPCHK(c, hipMemcpyAsync(&nwork, scan + ncell, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hop_ctx_d2h(c, &nwork, scan + ncell, sizeof(int)));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, cs.work_d.ensure(sizeof(int) * (size_t)std::max(nwork, 1)));
   HIPCHK(c, cs.keep_d.ensure(sizeof(int) * (size_t)std::max(nwork, 1) * cell_list_local_keep()));
@@ -509,7 +509,7 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   launch_cell_list_local(a, g, false, exist_mode, work, nwork, keep, lanes, c->stream);
   HIPCHK(c, prim_exclusive_sum(c->sort_tmp.p, tmp_bytes, a.count, cs.start_d.as<int>(), (int)(ncell + 1), c->stream));
   int total = 0;
-  HIPCHK(c, hipMemcpyAsync(&total, cs.start_d.as<int>() + ncell, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hop_ctx_d2h(c, &total, cs.start_d.as<int>() + ncell, sizeof(int)));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, cs.pts_d.ensure(sizeof(float4) * (size_t)std::max(total, 1)));
   if (normals) HIPCHK(c, cs.nrm_d.ensure(sizeof(float4) * (size_t)std::max(total, 1)));
@@ -661,9 +661,10 @@ int cluster_core(const float* pose16, const float* lcp, const int* ids, int H, f
 // ==================================================================================================
 // ---------------------------------------------------------------------------------------------- hop_ctx_ext.h
 hipStream_t hop_ctx_stream(hop_ctx* c) { return c->stream; }
-constexpr size_t STAGE_MIN = 256u << 10;
+// (HOP_STAGE_MIN=<bytes> moves the threshold; a huge value turns staging off)
+static const size_t STAGE_MIN = getenv("HOP_STAGE_MIN") ? (size_t)std::atoll(getenv("HOP_STAGE_MIN")) : (size_t)64 << 10;
 hipError_t hop_ctx_h2d(hop_ctx* c, void* dst, const void* src, size_t bytes) {
-  if (bytes < STAGE_MIN) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+  if (bytes < STAGE_MIN) return hop_ctx_h2d(c, dst, src, bytes);
   const size_t need = (bytes + 255) & ~(size_t)255;
   if (c->stage_cur + need > c->stage_up.cap) {  // the area is full: wait for the copies that read it, then start over (or grow)
     hipError_t e = hipStreamSynchronize(c->stream);
@@ -672,12 +673,23 @@ hipError_t hop_ctx_h2d(hop_ctx* c, void* dst, const void* src, size_t bytes) {
     if (need > c->stage_up.cap && (e = c->stage_up.ensure(std::max(need, (size_t)16 << 20))) != hipSuccess) return e;
   }
   char* at = static_cast<char*>(c->stage_up.p) + c->stage_cur;
+  static const bool prof = getenv("HOP_PROFILE_STAGE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   std::memcpy(at, src, bytes);
+  const auto t1 = std::chrono::steady_clock::now();
   c->stage_cur += need;
-  return hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, c->stream);
+  const hipError_t e = hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, c->stream);
+  if (prof) {
+    const auto t2 = std::chrono::steady_clock::now();
+    (void)hipStreamSynchronize(c->stream);
+    const auto t3 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::printf("stage h2d %zu bytes: memcpy %.3f ms, enqueue %.3f ms, wait %.3f ms\n", bytes, ms(t0, t1), ms(t1, t2), ms(t2, t3));
+  }
+  return e;
 }
 hipError_t hop_ctx_d2h(hop_ctx* c, void* dst, const void* src, size_t bytes) {
-  if (bytes < STAGE_MIN) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+  if (bytes < STAGE_MIN) return hop_ctx_d2h(c, dst, src, bytes);
   hipError_t e = c->stage_down.ensure(bytes);
   if (e != hipSuccess) return e;
   if ((e = hipMemcpyAsync(c->stage_down.p, src, bytes, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
@@ -849,14 +861,14 @@ int hop_set_scene(hop_ctx* c, const float* xyz, const float* nrm, const float* c
         pn[0] = sorted.nx[k], pn[1] = sorted.ny[k], pn[2] = sorted.nz[k];
       }
       HIPCHK(c, c->scene_sorted_aos_d.ensure(sizeof(float) * aos.size()));
-      HIPCHK(c, hipMemcpyAsync(c->scene_sorted_aos_d.p, aos.data(), sizeof(float) * aos.size(), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hop_ctx_h2d(c, c->scene_sorted_aos_d.p, aos.data(), sizeof(float) * aos.size()));
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     HIPCHK(c, c->scene_perm_d.ensure(sizeof(int) * 2 * (size_t)std::max(m, 1)));
     std::vector<int> inv(std::max(m, 1));
     for (int k = 0; k < m; ++k) inv[perm[k]] = k;
-    HIPCHK(c, hipMemcpyAsync(c->scene_perm_d.p, perm.data(), sizeof(int) * (size_t)std::max(m, 1), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->scene_perm_d.as<int>() + std::max(m, 1), inv.data(), sizeof(int) * (size_t)std::max(m, 1), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hop_ctx_h2d(c, c->scene_perm_d.p, perm.data(), sizeof(int) * (size_t)std::max(m, 1)));
+    HIPCHK(c, hop_ctx_h2d(c, c->scene_perm_d.as<int>() + std::max(m, 1), inv.data(), sizeof(int) * (size_t)std::max(m, 1)));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return upload_cloud(c, c->scene_d, raw);
@@ -881,7 +893,7 @@ int hop_set_ppf_keys(hop_ctx* c, const int32_t* keys4, int nkeys) {
   HIPCHK(c, hipSetDevice(c->device));
   build_key_bitmap(keys4, nkeys, c->key_bitmap, c->key_dist_bins);
   HIPCHK(c, c->key_bitmap_d.ensure(sizeof(unsigned) * c->key_bitmap.size()));
-  HIPCHK(c, hipMemcpyAsync(c->key_bitmap_d.p, c->key_bitmap.data(), sizeof(unsigned) * c->key_bitmap.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hop_ctx_h2d(c, c->key_bitmap_d.p, c->key_bitmap.data(), sizeof(unsigned) * c->key_bitmap.size()));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_keys = true;
   c->have_gen_state = false;
@@ -930,7 +942,7 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
     if (rc) return rc;
     HIPCHK(c, c->gq_unit_d.ensure(sizeof(float) * 3 * (size_t)NQ));
     for (int k = 0; k < 3; ++k)
-      HIPCHK(c, hipMemcpyAsync(c->gq_unit_d.as<float>() + (size_t)k * NQ, c->gen.gq_unit[k].data(), sizeof(float) * NQ, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hop_ctx_h2d(c, c->gq_unit_d.as<float>() + (size_t)k * NQ, c->gen.gq_unit[k].data(), sizeof(float) * NQ));
   }
   c->have_gen_state = true;
   c->have_verify_clouds = false;
@@ -975,7 +987,7 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
       float thr[32];
       if (!getenv("HOP_PPF_LITERAL") && build_angle_thresholds(thr)) {
         HIPCHK(c, c->angle_thr_d.ensure(sizeof(thr)));
-        HIPCHK(c, hipMemcpyAsync(c->angle_thr_d.p, thr, sizeof(thr), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hop_ctx_h2d(c, c->angle_thr_d.p, thr, sizeof(thr)));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->angle_thr_ok = true;
       }
@@ -1192,8 +1204,8 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
   if (rc) return rc;
   if (H > 0 && (poses16_out || lcp_out)) {
     const int m = std::min(H, cap);
-    if (poses16_out) HIPCHK(c, hipMemcpyAsync(poses16_out, c->hyp_pose.p, sizeof(float) * 16 * (size_t)m, hipMemcpyDeviceToHost, c->stream));
-    if (lcp_out) HIPCHK(c, hipMemcpyAsync(lcp_out, c->hyp_score.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    if (poses16_out) HIPCHK(c, hop_ctx_d2h(c, poses16_out, c->hyp_pose.p, sizeof(float) * 16 * (size_t)m));
+    if (lcp_out) HIPCHK(c, hop_ctx_d2h(c, lcp_out, c->hyp_score.p, sizeof(float) * (size_t)m));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   st.ms_select = ms_select;
@@ -1257,7 +1269,7 @@ int hop_verify_batch(hop_ctx* c, const float* T16, int H, float delta, int mode,
   }
   HIPCHK(c, c->tmp_pose.ensure(sizeof(float) * 16 * (size_t)H));
   HIPCHK(c, c->cand_counts_d.ensure(sizeof(int) * (size_t)H));
-  HIPCHK(c, hipMemcpyAsync(c->tmp_pose.p, T16, sizeof(float) * 16 * (size_t)H, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hop_ctx_h2d(c, c->tmp_pose.p, T16, sizeof(float) * 16 * (size_t)H));
   HIPCHK(c, hipMemsetAsync(c->cand_counts_d.p, 0, sizeof(int) * (size_t)H, c->stream));
   VerifyArgs va{};
   va.px = P.plane(0), va.py = P.plane(1), va.pz = P.plane(2), va.np = P.n;
@@ -1273,7 +1285,7 @@ int hop_verify_batch(hop_ctx* c, const float* T16, int H, float delta, int mode,
   }
   c->timing.n_verify_launches += 1;
   c->timing.pairs_verify += total * (long long)P.n;
-  HIPCHK(c, hipMemcpyAsync(count_out, c->cand_counts_d.p, sizeof(int) * (size_t)H, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hop_ctx_d2h(c, count_out, c->cand_counts_d.p, sizeof(int) * (size_t)H));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return HOP_OK;
 }
@@ -1284,12 +1296,12 @@ int hop_hypos_upload(hop_ctx* c, const float* poses16, const float* scores, int 
   HIPCHK(c, hipSetDevice(c->device));
   int rc = ensure_hyp_capacity(c, std::max(H, 1));
   if (rc) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->hyp_pose.p, poses16, sizeof(float) * 16 * (size_t)H, hipMemcpyHostToDevice, c->stream));
-  if (scores) HIPCHK(c, hipMemcpyAsync(c->hyp_score.p, scores, sizeof(float) * (size_t)H, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hop_ctx_h2d(c, c->hyp_pose.p, poses16, sizeof(float) * 16 * (size_t)H));
+  if (scores) HIPCHK(c, hop_ctx_h2d(c, c->hyp_score.p, scores, sizeof(float) * (size_t)H));
   else HIPCHK(c, hipMemsetAsync(c->hyp_score.p, 0, sizeof(float) * (size_t)H, c->stream));
   std::vector<int> ids(H);
   std::iota(ids.begin(), ids.end(), 0);
-  HIPCHK(c, hipMemcpyAsync(c->hyp_id.p, ids.data(), sizeof(int) * (size_t)H, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hop_ctx_h2d(c, c->hyp_id.p, ids.data(), sizeof(int) * (size_t)H));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->n_hyp = H;
   return HOP_OK;
@@ -1301,9 +1313,9 @@ int hop_hypos_download(hop_ctx* c, float* poses16_out, float* scores_out, int* i
   const int m = std::min(c->n_hyp, cap);
   if (n_out) *n_out = c->n_hyp;
   if (m > 0) {
-    if (poses16_out) HIPCHK(c, hipMemcpyAsync(poses16_out, c->hyp_pose.p, sizeof(float) * 16 * (size_t)m, hipMemcpyDeviceToHost, c->stream));
-    if (scores_out) HIPCHK(c, hipMemcpyAsync(scores_out, c->hyp_score.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
-    if (ids_out) HIPCHK(c, hipMemcpyAsync(ids_out, c->hyp_id.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    if (poses16_out) HIPCHK(c, hop_ctx_d2h(c, poses16_out, c->hyp_pose.p, sizeof(float) * 16 * (size_t)m));
+    if (scores_out) HIPCHK(c, hop_ctx_d2h(c, scores_out, c->hyp_score.p, sizeof(float) * (size_t)m));
+    if (ids_out) HIPCHK(c, hop_ctx_d2h(c, ids_out, c->hyp_id.p, sizeof(int) * (size_t)m));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return cap < c->n_hyp ? HOP_E_CAPACITY : HOP_OK;
@@ -1433,7 +1445,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
           HIPCHK(c, hipMemsetAsync(n_wait_d, 0, sizeof(unsigned), c->stream));
           launch_icp_lm_solve(a, hb, nb, pass == 0, n_wait_d, c->stream);
           unsigned n_wait = 0;
-          HIPCHK(c, hipMemcpyAsync(&n_wait, n_wait_d, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hop_ctx_d2h(c, &n_wait, n_wait_d, sizeof(unsigned)));
           HIPCHK(c, hipStreamSynchronize(c->stream));
           if (lm_profile) std::printf("%u%s", n_wait, n_wait ? " " : "\n");
           if (n_wait == 0) break;
@@ -1483,8 +1495,8 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     }
     launch_icp_finish(a, hb, c->icp_iters.as<int>(), c->icp_conv.as<int>(), c->stream);
   }
-  if (iterations_out) HIPCHK(c, hipMemcpyAsync(iterations_out, c->icp_iters.p, sizeof(int) * (size_t)H, hipMemcpyDeviceToHost, c->stream));
-  if (converged_out) HIPCHK(c, hipMemcpyAsync(converged_out, c->icp_conv.p, sizeof(int) * (size_t)H, hipMemcpyDeviceToHost, c->stream));
+  if (iterations_out) HIPCHK(c, hop_ctx_d2h(c, iterations_out, c->icp_iters.p, sizeof(int) * (size_t)H));
+  if (converged_out) HIPCHK(c, hop_ctx_d2h(c, converged_out, c->icp_conv.p, sizeof(int) * (size_t)H));
   if (iterations_out || converged_out) HIPCHK(c, hipStreamSynchronize(c->stream));
   return HOP_OK;
 }
@@ -1609,7 +1621,7 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
   c->timing.pairs_lcp += 2ll * H * (long long)S.n * Mo.n;
   // arg-max on the host over H floats: first strict maximum in set order (PoseEstimator.cpp:468-496, best_lcp starts at 0)
   std::vector<float> sc(H);
-  HIPCHK(c, hipMemcpyAsync(sc.data(), c->hyp_score.p, sizeof(float) * (size_t)H, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hop_ctx_d2h(c, sc.data(), c->hyp_score.p, sizeof(float) * (size_t)H));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int best = 0;
   float best_lcp = 0.f;
@@ -1618,7 +1630,7 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
   if (best_index_out) *best_index_out = best;
   if (best_score_out) *best_score_out = sc[best];
   if (best_pose16_out) {
-    HIPCHK(c, hipMemcpyAsync(best_pose16_out, c->hyp_pose.as<float>() + 16 * (size_t)best, sizeof(float) * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hop_ctx_d2h(c, best_pose16_out, c->hyp_pose.as<float>() + 16 * (size_t)best, sizeof(float) * 16));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return HOP_OK;
@@ -1663,9 +1675,9 @@ int hop_cluster_poses(hop_ctx* c, float angle_deg, float dist, const float* sym_
     i2[k] = assign_id ? (int)k : ids[keep[k]];
   }
   const int K = (int)keep.size();
-  HIPCHK(c, hipMemcpyAsync(c->hyp_pose.p, p2.data(), sizeof(float) * 16 * (size_t)K, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->hyp_score.p, s2.data(), sizeof(float) * (size_t)K, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->hyp_id.p, i2.data(), sizeof(int) * (size_t)K, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hop_ctx_h2d(c, c->hyp_pose.p, p2.data(), sizeof(float) * 16 * (size_t)K));
+  HIPCHK(c, hop_ctx_h2d(c, c->hyp_score.p, s2.data(), sizeof(float) * (size_t)K));
+  HIPCHK(c, hop_ctx_h2d(c, c->hyp_id.p, i2.data(), sizeof(int) * (size_t)K));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->n_hyp = K;
   return HOP_OK;
@@ -1680,7 +1692,7 @@ int hop_topk_pack(hop_ctx* c, int k, int id_offset, float* rows_out, int* n_rows
   HIPCHK(c, c->topk_rows.ensure(sizeof(float) * (size_t)k * HOP_TOPK_ROW_FLOATS));
   const int rc = hop_topk_pack_device(c, k, id_offset, c->topk_rows.as<float>(), n_rows_out);
   if (rc) return rc;
-  HIPCHK(c, hipMemcpyAsync(rows_out, c->topk_rows.p, sizeof(float) * (size_t)k * HOP_TOPK_ROW_FLOATS, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hop_ctx_d2h(c, rows_out, c->topk_rows.p, sizeof(float) * (size_t)k * HOP_TOPK_ROW_FLOATS));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return HOP_OK;
 }
@@ -1782,7 +1794,7 @@ int hop_hand_set_finger(hop_ctx* c, const hop_finger_args* a) {
   if (rc) return rc;
   c->finger.model_xyz = nullptr, c->finger.model_nrm = nullptr;
   HIPCHK(c, c->finger_hist_d.ensure(sizeof(float) * a->fp_num_division));
-  HIPCHK(c, hipMemcpyAsync(c->finger_hist_d.p, c->finger_hist.data(), sizeof(float) * a->fp_num_division, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hop_ctx_h2d(c, c->finger_hist_d.p, c->finger_hist.data(), sizeof(float) * a->fp_num_division));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_finger = true;
   return HOP_OK;
@@ -2040,8 +2052,8 @@ int hop_model_ppf_keys(hop_ctx* c, const float* xyz, const float* nrm, int n, in
     }
     int* ovf = reinterpret_cast<int*>(bm.as<unsigned>() + words);
     launch_model_ppf_keys(d.plane(0), d.plane(1), d.plane(2), d.plane(3), d.plane(4), d.plane(5), n, dist_bins, bm.as<unsigned>(), ovf, c->stream);
-    if (hipMemcpyAsync(host.data(), bm.p, sizeof(unsigned) * words, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipMemcpyAsync(&overflow, ovf, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+    if (hop_ctx_d2h(c, host.data(), bm.p, sizeof(unsigned) * words) != hipSuccess ||
+        hop_ctx_d2h(c, &overflow, ovf, sizeof(int)) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess)
       rc = HOP_E_HIP;
   } while (false);
@@ -2094,14 +2106,14 @@ int hop_hand_remove_surrounding(hop_ctx* c, const float* scene_xyz, const float*
   HIPCHK(c, c->sur_links.ensure(sizeof(float4) * std::max<size_t>(lp.size(), 1) + sizeof(int) * (n_links + 1) + sizeof(float) * std::max(n_links, 1)));
   HIPCHK(c, c->sur_out.ensure(sizeof(float) * 7 * N + sizeof(int) * N));
   float* in = c->sur_in.as<float>();
-  HIPCHK(c, hipMemcpyAsync(in, scene_xyz, sizeof(float) * 3 * N, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(in + 3 * N, scene_nrm, sizeof(float) * 3 * N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hop_ctx_h2d(c, in, scene_xyz, sizeof(float) * 3 * N));
+  HIPCHK(c, hop_ctx_h2d(c, in + 3 * N, scene_nrm, sizeof(float) * 3 * N));
   float4* lpd = c->sur_links.as<float4>();
   int* lsd = reinterpret_cast<int*>(lpd + std::max<size_t>(lp.size(), 1));
   float* ltd = reinterpret_cast<float*>(lsd + n_links + 1);
-  if (!lp.empty()) HIPCHK(c, hipMemcpyAsync(lpd, lp.data(), sizeof(float4) * lp.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(lsd, ls.data(), sizeof(int) * (n_links + 1), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(ltd, lt.data(), sizeof(float) * std::max(n_links, 1), hipMemcpyHostToDevice, c->stream));
+  if (!lp.empty()) HIPCHK(c, hop_ctx_h2d(c, lpd, lp.data(), sizeof(float4) * lp.size()));
+  HIPCHK(c, hop_ctx_h2d(c, lsd, ls.data(), sizeof(int) * (n_links + 1)));
+  HIPCHK(c, hop_ctx_h2d(c, ltd, lt.data(), sizeof(float) * std::max(n_links, 1)));
   M4 hb, f1, f2;
   std::memcpy(hb.m, handbase_in_cam, sizeof(float) * 16);
   std::memcpy(f1.m, finger12_in_handbase, sizeof(float) * 16);
@@ -2130,11 +2142,11 @@ int hop_hand_remove_surrounding(hop_ctx* c, const float* scene_xyz, const float*
   o.oindex = reinterpret_cast<int*>(od + 7 * N);
   launch_hand_surround_out(o, c->stream);
   int kept = 0;
-  HIPCHK(c, hipMemcpyAsync(&kept, pos + N, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(out_xyz, od, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(out_nrm, od + 3 * N, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(out_conf, od + 6 * N, sizeof(float) * N, hipMemcpyDeviceToHost, c->stream));
-  if (keep_index) HIPCHK(c, hipMemcpyAsync(keep_index, o.oindex, sizeof(int) * N, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hop_ctx_d2h(c, &kept, pos + N, sizeof(int)));
+  HIPCHK(c, hop_ctx_d2h(c, out_xyz, od, sizeof(float) * 3 * N));
+  HIPCHK(c, hop_ctx_d2h(c, out_nrm, od + 3 * N, sizeof(float) * 3 * N));
+  HIPCHK(c, hop_ctx_d2h(c, out_conf, od + 6 * N, sizeof(float) * N));
+  if (keep_index) HIPCHK(c, hop_ctx_d2h(c, keep_index, o.oindex, sizeof(int) * N));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *n_out = kept;
   return HOP_OK;

@@ -11,6 +11,8 @@
 // beside them is oracle/normals_oracle.cpp; tests compare the two and check hand-computed planes / spheres.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <string>
@@ -433,13 +435,22 @@ int hop_normals_integral_image(hop_ctx* c, const float* xyz, int H, int W, float
   const size_t n = (size_t)H * W;
   NRCHK(c, nr->xyz.ensure(sizeof(float) * 3 * n));
   NRCHK(c, nr->nrm.ensure(sizeof(float) * 3 * n));
+  static const bool prof = getenv("HOP_PROFILE_NORMALS") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = now();
   NRCHK(c, hop_ctx_h2d(c, nr->xyz.p, xyz, sizeof(float) * 3 * n));
+  if (prof) NRCHK(c, hipStreamSynchronize(st));
+  const auto t1 = now();
   float* p = nr->xyz.as<float>();
   float* q = nr->nrm.as<float>();
   const int rc = hop_normals_ii_device(c, p, p + n, p + 2 * n, H, W, max_depth_change_factor, normal_smoothing_size, depth_dependent_smoothing, q, q + n, q + 2 * n);
   if (rc) return rc;
+  if (prof) NRCHK(c, hipStreamSynchronize(st));
+  const auto t2 = now();
   NRCHK(c, hop_ctx_d2h(c, nrm_out, q, sizeof(float) * 3 * n));
   NRCHK(c, hipStreamSynchronize(st));
+  if (prof) std::printf("integral-image normals: upload %.2f ms, kernels %.2f ms, download %.2f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, now()));
   return HOP_OK;
 }
 
@@ -456,7 +467,7 @@ int hop_normals_mls(hop_ctx* c, const float* xyz, int n, float search_radius, in
   NRCHK(c, nr->out.ensure(sizeof(float) * 7 * (size_t)n));
   NRCHK(c, nr->flags.ensure(sizeof(unsigned) * (size_t)n));
   NRCHK(c, nr->scalars.ensure(sizeof(int) * 4));
-  NRCHK(c, hipMemcpyAsync(nr->xyz.p, xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+  NRCHK(c, hop_ctx_h2d(c, nr->xyz.p, xyz, sizeof(float) * 3 * (size_t)n));
   NRCHK(c, hipMemsetAsync(nr->scalars.p, 0, sizeof(int) * 4, st));
   const float* p = nr->xyz.as<float>();
   float* o = nr->out.as<float>();
@@ -468,9 +479,9 @@ int hop_normals_mls(hop_ctx* c, const float* xyz, int n, float search_radius, in
   std::vector<float> h(7 * (size_t)n);
   std::vector<unsigned> hv(n);
   int overflow = 0;
-  NRCHK(c, hipMemcpyAsync(h.data(), o, sizeof(float) * 7 * (size_t)n, hipMemcpyDeviceToHost, st));
-  NRCHK(c, hipMemcpyAsync(hv.data(), nr->flags.p, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToHost, st));
-  NRCHK(c, hipMemcpyAsync(&overflow, nr->scalars.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  NRCHK(c, hop_ctx_d2h(c, h.data(), o, sizeof(float) * 7 * (size_t)n));
+  NRCHK(c, hop_ctx_d2h(c, hv.data(), nr->flags.p, sizeof(unsigned) * (size_t)n));
+  NRCHK(c, hop_ctx_d2h(c, &overflow, nr->scalars.p, sizeof(int)));
   NRCHK(c, hipStreamSynchronize(st));
   if (overflow) return HOP_E_CAPACITY;
   int m = 0;

@@ -994,10 +994,9 @@ __global__ void __launch_bounds__(256) k_hand_height(const float* __restrict__ s
 
 // ------------------------------------------------------------------------------------------------ host helpers
 int upload_planes(hop_ctx* c, Cloud3& dst, const float* planes, int n) {
-  hipStream_t st = hop_ctx_stream(c);
   PHCHK(c, dst.buf.ensure(sizeof(float) * 3 * (size_t)std::max(n, 1)));
   dst.n = n;
-  if (n > 0) PHCHK(c, hipMemcpyAsync(dst.buf.p, planes, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+  if (n > 0) PHCHK(c, hop_ctx_h2d(c, dst.buf.p, planes, sizeof(float) * 3 * (size_t)n));
   return HOP_OK;
 }
 
@@ -1011,10 +1010,10 @@ int voxel_downsample_device(hop_ctx* c, Physics* ph, const float* x, const float
   if (!(leaf > 0)) return HOP_E_INVALID;
   PHCHK(c, ph->scalars.ensure(sizeof(unsigned) * 16));
   const unsigned init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
-  PHCHK(c, hipMemcpyAsync(ph->scalars.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+  PHCHK(c, hop_ctx_h2d(c, ph->scalars.p, init, sizeof(init)));
   k_vox_minmax<<<std::min((n + 255) / 256, 1024), 256, 0, st>>>(x, y, z, n, ph->scalars.as<unsigned>());
   unsigned sc[8];
-  PHCHK(c, hipMemcpyAsync(sc, ph->scalars.p, sizeof(sc), hipMemcpyDeviceToHost, st));
+  PHCHK(c, hop_ctx_d2h(c, sc, ph->scalars.p, sizeof(sc)));
   PHCHK(c, hipStreamSynchronize(st));
   const int n_finite = (int)sc[6];
   if (n_finite == 0) return HOP_OK;
@@ -1067,7 +1066,7 @@ int voxel_downsample_device(hop_ctx* c, Physics* ph, const float* x, const float
   PHCHK(c, prim_exclusive_sum(ph->sort_tmp.p, tmp2, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), n_finite, st));
   k_vox_starts<<<fb, 256, 0, st>>>(ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), n_finite, ph->starts.as<unsigned>(), ph->scalars.as<unsigned>() + 8);
   unsigned n_seg = 0;
-  PHCHK(c, hipMemcpyAsync(&n_seg, ph->scalars.as<unsigned>() + 8, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  PHCHK(c, hop_ctx_d2h(c, &n_seg, ph->scalars.as<unsigned>() + 8, sizeof(unsigned)));
   PHCHK(c, hipStreamSynchronize(st));
   PHCHK(c, out.buf.ensure(sizeof(float) * 3 * (size_t)n_seg));
   out.n = (int)n_seg;
@@ -1141,15 +1140,15 @@ int hop_sdf_register_mesh(hop_ctx* c, int mesh_id, const float* V, int nv, const
   PHCHK(c, ms.order_d.ensure(std::max<size_t>(sizeof(SdfOrderNode) * ot.nodes.size(), 32)));
   PHCHK(c, ms.leaf_d.ensure(std::max<size_t>(sizeof(int) * (size_t)nf, 16)));
   PHCHK(c, ms.leaf_first_d.ensure(sizeof(int) * tb.leaf_first.size()));
-  PHCHK(c, hipMemcpyAsync(ms.leaf_first_d.p, tb.leaf_first.data(), sizeof(int) * tb.leaf_first.size(), hipMemcpyHostToDevice, st));
+  PHCHK(c, hop_ctx_h2d(c, ms.leaf_first_d.p, tb.leaf_first.data(), sizeof(int) * tb.leaf_first.size()));
   PHCHK(c, ms.leaf_obb_d.ensure(std::max<size_t>(sizeof(float4) * tb.leaf_obb.size(), 16)));
-  if (!tb.leaf_obb.empty()) PHCHK(c, hipMemcpyAsync(ms.leaf_obb_d.p, tb.leaf_obb.data(), sizeof(float4) * tb.leaf_obb.size(), hipMemcpyHostToDevice, st));
+  if (!tb.leaf_obb.empty()) PHCHK(c, hop_ctx_h2d(c, ms.leaf_obb_d.p, tb.leaf_obb.data(), sizeof(float4) * tb.leaf_obb.size()));
   if (nf > 0) {
-    PHCHK(c, hipMemcpyAsync(ms.tri_d.p, tri.data(), sizeof(float4) * tri.size(), hipMemcpyHostToDevice, st));
-    PHCHK(c, hipMemcpyAsync(ms.nrm_d.p, nrm.data(), sizeof(float4) * nrm.size(), hipMemcpyHostToDevice, st));
-    PHCHK(c, hipMemcpyAsync(ms.nodes_d.p, tb.nodes.data(), sizeof(SdfNode) * tb.nodes.size(), hipMemcpyHostToDevice, st));
-    PHCHK(c, hipMemcpyAsync(ms.order_d.p, ot.nodes.data(), sizeof(SdfOrderNode) * ot.nodes.size(), hipMemcpyHostToDevice, st));
-    PHCHK(c, hipMemcpyAsync(ms.leaf_d.p, ot.face_leaf.data(), sizeof(int) * (size_t)nf, hipMemcpyHostToDevice, st));
+    PHCHK(c, hop_ctx_h2d(c, ms.tri_d.p, tri.data(), sizeof(float4) * tri.size()));
+    PHCHK(c, hop_ctx_h2d(c, ms.nrm_d.p, nrm.data(), sizeof(float4) * nrm.size()));
+    PHCHK(c, hop_ctx_h2d(c, ms.nodes_d.p, tb.nodes.data(), sizeof(SdfNode) * tb.nodes.size()));
+    PHCHK(c, hop_ctx_h2d(c, ms.order_d.p, ot.nodes.data(), sizeof(SdfOrderNode) * ot.nodes.size()));
+    PHCHK(c, hop_ctx_h2d(c, ms.leaf_d.p, ot.face_leaf.data(), sizeof(int) * (size_t)nf));
   }
   PHCHK(c, hipStreamSynchronize(st));
   ms.dev.tri = ms.tri_d.as<float4>(), ms.dev.nrm = ms.nrm_d.as<float4>(), ms.dev.nodes = ms.nodes_d.as<SdfNode>();
@@ -1189,7 +1188,7 @@ int hop_sdf_register_mesh(hop_ctx* c, int mesh_id, const float* V, int nv, const
     PHCHK(c, prim_exclusive_sum(ph->sort_tmp.p, tmp, ph->pos.as<unsigned>(), ph->starts.as<unsigned>(), nvox + 1, st));
     k_face_cells_pack<<<(nvox + 256) / 256, 256, 0, st>>>(count, ph->starts.as<unsigned>(), nvox, ms.cell_start_d.as<int>());
     unsigned total = 0;
-    PHCHK(c, hipMemcpyAsync(&total, ph->starts.as<unsigned>() + nvox, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    PHCHK(c, hop_ctx_d2h(c, &total, ph->starts.as<unsigned>() + nvox, sizeof(unsigned)));
     PHCHK(c, hipStreamSynchronize(st));
     PHCHK(c, ms.cell_faces_d.ensure(sizeof(int) * std::max<size_t>(total, 4)));
     k_face_cells<true><<<nvox, 64, 0, st>>>(ms.dev, g, margin, nullptr, reinterpret_cast<const int*>(ph->starts.as<unsigned>()), ms.cell_faces_d.as<int>());
@@ -1240,8 +1239,8 @@ int hop_sdf_signed_distance(hop_ctx* c, int mesh_id, const float* pts_xyz, int n
     k_sdf_query<<<(n + SDF_BLOCK - 1) / SDF_BLOCK, SDF_BLOCK, 0, st>>>(ph->mesh[mesh_id].dev, ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), n,
                                                                        nullptr, S, I);
     PHCHK(c, hipGetLastError());
-    PHCHK(c, hipMemcpyAsync(dists, S, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
-    if (faces) PHCHK(c, hipMemcpyAsync(faces, I, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+    PHCHK(c, hop_ctx_d2h(c, dists, S, sizeof(float) * (size_t)n));
+    if (faces) PHCHK(c, hop_ctx_d2h(c, faces, I, sizeof(int) * (size_t)n));
     PHCHK(c, hipStreamSynchronize(st));
     mn = INFINITY, mx = -INFINITY;  // S.minCoeff() / S.maxCoeff(), NaN (points on the surface) skipped
     for (int i = 0; i < n; ++i)
@@ -1266,7 +1265,7 @@ int hop_voxel_downsample(hop_ctx* c, const float* xyz, int n, float leaf, float*
   if (m > cap) return HOP_E_CAPACITY;
   if (m > 0 && out_xyz)
     for (int a = 0; a < 3; ++a)
-      PHCHK(c, hipMemcpyAsync(out_xyz + (size_t)a * cap, ph->tmp_cloud2.buf.as<float>() + (size_t)a * m, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
+      PHCHK(c, hop_ctx_d2h(c, out_xyz + (size_t)a * cap, ph->tmp_cloud2.buf.as<float>() + (size_t)a * m, sizeof(float) * (size_t)m));
   PHCHK(c, hipStreamSynchronize(st));
   return HOP_OK;
 }
@@ -1332,11 +1331,11 @@ static int scene_from_depth_impl(hop_ctx* c, const uint16_t* depth_raw, int H, i
   if (rc) return rc;
   const int m = ph->tmp_cloud2.n;
   unsigned n_valid = 0, kept = 0;
-  PHCHK(c, hipMemcpyAsync(&n_valid, ph->scalars.as<unsigned>() + 12, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  PHCHK(c, hop_ctx_d2h(c, &n_valid, ph->scalars.as<unsigned>() + 12, sizeof(unsigned)));
   if (m > 0) {
     PHCHK(c, ph->mats.ensure(sizeof(float) * 16 * 5));
-    PHCHK(c, hipMemcpyAsync(ph->mats.as<float>(), cam_in_handbase, sizeof(float) * 16, hipMemcpyHostToDevice, st));
-    PHCHK(c, hipMemcpyAsync(ph->mats.as<float>() + 16, handbase_in_cam, sizeof(float) * 16, hipMemcpyHostToDevice, st));
+    PHCHK(c, hop_ctx_h2d(c, ph->mats.as<float>(), cam_in_handbase, sizeof(float) * 16));
+    PHCHK(c, hop_ctx_h2d(c, ph->mats.as<float>() + 16, handbase_in_cam, sizeof(float) * 16));
     PHCHK(c, ph->tmp_cloud.buf.ensure(sizeof(float) * 6 * (size_t)m));
     PHCHK(c, ph->flags.ensure(sizeof(unsigned) * (size_t)m));
     PHCHK(c, ph->pos.ensure(sizeof(unsigned) * (size_t)m));
@@ -1351,11 +1350,11 @@ static int scene_from_depth_impl(hop_ctx* c, const uint16_t* depth_raw, int H, i
     PHCHK(c, prim_exclusive_sum(ph->sort_tmp.p, tmp, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), m, st));
     k_compact3<<<(m + 255) / 256, 256, 0, st>>>(a, a + m, a + 2 * (size_t)m, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), m, b, b + m, b + 2 * (size_t)m, m,
                                                ph->scalars.as<unsigned>() + 13);
-    PHCHK(c, hipMemcpyAsync(&kept, ph->scalars.as<unsigned>() + 13, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    PHCHK(c, hop_ctx_d2h(c, &kept, ph->scalars.as<unsigned>() + 13, sizeof(unsigned)));
     PHCHK(c, hipStreamSynchronize(st));
     if ((int)kept <= cap && out_xyz)
       for (int k = 0; k < 3; ++k)
-        PHCHK(c, hipMemcpyAsync(out_xyz + (size_t)k * cap, b + (size_t)k * m, sizeof(float) * (size_t)kept, hipMemcpyDeviceToHost, st));
+        PHCHK(c, hop_ctx_d2h(c, out_xyz + (size_t)k * cap, b + (size_t)k * m, sizeof(float) * (size_t)kept));
     if (with_normals && out_nrm && (int)kept <= cap) {
       PHCHK(c, hipStreamSynchronize(st));
       const float* vn = ph->tmp_nrm2.buf.as<float>();
@@ -1363,7 +1362,7 @@ static int scene_from_depth_impl(hop_ctx* c, const uint16_t* depth_raw, int H, i
       k_compact3<<<(m + 255) / 256, 256, 0, st>>>(a, a + m, a + 2 * (size_t)m, ph->flags.as<unsigned>(), ph->pos.as<unsigned>(), m, b, b + m, b + 2 * (size_t)m, m,
                                                  ph->scalars.as<unsigned>() + 14);
       for (int k = 0; k < 3; ++k)
-        PHCHK(c, hipMemcpyAsync(out_nrm + (size_t)k * cap, b + (size_t)k * m, sizeof(float) * (size_t)kept, hipMemcpyDeviceToHost, st));
+        PHCHK(c, hop_ctx_d2h(c, out_nrm + (size_t)k * cap, b + (size_t)k * m, sizeof(float) * (size_t)kept));
     }
   }
   PHCHK(c, hipStreamSynchronize(st));
@@ -1385,7 +1384,7 @@ int hop_object_segment(hop_ctx* c, const float* xyz, const float* nrm, const flo
   rc = upload_planes(c, ph->tmp_nrm, nrm, n);
   if (rc) return rc;
   PHCHK(c, ph->gather.ensure(sizeof(float) * (size_t)n));
-  PHCHK(c, hipMemcpyAsync(ph->gather.p, conf, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, st));
+  PHCHK(c, hop_ctx_h2d(c, ph->gather.p, conf, sizeof(float) * (size_t)n));
   rc = voxel_downsample_device(c, ph, ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), n, leaf, ph->tmp_cloud2, ph->tmp_nrm.buf.as<float>(), &ph->tmp_nrm2);
   if (rc) return rc;
   const int m = ph->tmp_cloud2.n;
@@ -1398,10 +1397,10 @@ int hop_object_segment(hop_ctx* c, const float* xyz, const float* nrm, const flo
                                                ph->tmp_cloud.y(), ph->tmp_cloud.z(), ph->gather.as<float>(), n, ph->tmp_pose.as<float>());
   PHCHK(c, hipGetLastError());
   for (int k = 0; k < 3; ++k) {
-    if (out_xyz) PHCHK(c, hipMemcpyAsync(out_xyz + (size_t)k * cap, ph->tmp_cloud2.buf.as<float>() + (size_t)k * m, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
-    if (out_nrm) PHCHK(c, hipMemcpyAsync(out_nrm + (size_t)k * cap, on + (size_t)k * m, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
+    if (out_xyz) PHCHK(c, hop_ctx_d2h(c, out_xyz + (size_t)k * cap, ph->tmp_cloud2.buf.as<float>() + (size_t)k * m, sizeof(float) * (size_t)m));
+    if (out_nrm) PHCHK(c, hop_ctx_d2h(c, out_nrm + (size_t)k * cap, on + (size_t)k * m, sizeof(float) * (size_t)m));
   }
-  if (out_conf) PHCHK(c, hipMemcpyAsync(out_conf, ph->tmp_pose.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
+  if (out_conf) PHCHK(c, hop_ctx_d2h(c, out_conf, ph->tmp_pose.p, sizeof(float) * (size_t)m));
   PHCHK(c, hipStreamSynchronize(st));
   return HOP_OK;
 }
@@ -1418,7 +1417,7 @@ int hop_hand_scene_filters(hop_ctx* c, const float* xyz, const float* nrm, int n
   rc = upload_planes(c, ph->tmp_nrm, nrm, n);
   if (rc) return rc;
   PHCHK(c, ph->mats.ensure(sizeof(float) * 16 * 5));
-  PHCHK(c, hipMemcpyAsync(ph->mats.p, cam_in_handbase, sizeof(float) * 16, hipMemcpyHostToDevice, st));
+  PHCHK(c, hop_ctx_h2d(c, ph->mats.p, cam_in_handbase, sizeof(float) * 16));
   PHCHK(c, ph->tmp_cloud2.buf.ensure(sizeof(float) * 3 * (size_t)n));
   PHCHK(c, ph->tmp_nrm2.buf.ensure(sizeof(float) * 3 * (size_t)n));
   ph->tmp_cloud2.n = n;
@@ -1437,8 +1436,8 @@ int hop_hand_scene_filters(hop_ctx* c, const float* xyz, const float* nrm, int n
   k_sor_mean<<<(n + 3) / 4, 256, 0, st>>>(hb, hb + n, hb + 2 * (size_t)n, n, live2, dist);  // :307-313
   std::vector<float> dh(n);
   std::vector<unsigned char> lh(n);
-  PHCHK(c, hipMemcpyAsync(dh.data(), dist, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
-  PHCHK(c, hipMemcpyAsync(lh.data(), live2, (size_t)n, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hop_ctx_d2h(c, dh.data(), dist, sizeof(float) * (size_t)n));
+  PHCHK(c, hop_ctx_d2h(c, lh.data(), live2, (size_t)n));
   PHCHK(c, hipStreamSynchronize(st));
   // mean and standard deviation of the per-point mean distances, in double, in point order (statistical_outlier_removal.hpp)
   double sum = 0, sq_sum = 0;
@@ -1454,10 +1453,10 @@ int hop_hand_scene_filters(hop_ctx* c, const float* xyz, const float* nrm, int n
   }
   k_sor_apply<<<(n + 255) / 256, 256, 0, st>>>(hb, n, live2, dist, thr, use_sor, live0, sw);
   PHCHK(c, hipGetLastError());
-  PHCHK(c, hipMemcpyAsync(hb_xyz, hb, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
-  PHCHK(c, hipMemcpyAsync(hb_nrm, hbn, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
-  PHCHK(c, hipMemcpyAsync(keep_noise, live0, (size_t)n, hipMemcpyDeviceToHost, st));
-  PHCHK(c, hipMemcpyAsync(keep_swivel, sw, (size_t)n, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hop_ctx_d2h(c, hb_xyz, hb, sizeof(float) * 3 * (size_t)n));
+  PHCHK(c, hop_ctx_d2h(c, hb_nrm, hbn, sizeof(float) * 3 * (size_t)n));
+  PHCHK(c, hop_ctx_d2h(c, keep_noise, live0, (size_t)n));
+  PHCHK(c, hop_ctx_d2h(c, keep_swivel, sw, (size_t)n));
   PHCHK(c, hipStreamSynchronize(st));
   return HOP_OK;
 }
@@ -1479,8 +1478,8 @@ int hop_voxel_downsample_normals(hop_ctx* c, const float* xyz, const float* nrm,
   *n_out = m;
   if (m > cap) return HOP_E_CAPACITY;
   for (int k = 0; k < 3 && m > 0; ++k) {
-    if (out_xyz) PHCHK(c, hipMemcpyAsync(out_xyz + (size_t)k * cap, ph->tmp_cloud2.buf.as<float>() + (size_t)k * m, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
-    if (out_nrm) PHCHK(c, hipMemcpyAsync(out_nrm + (size_t)k * cap, ph->tmp_nrm2.buf.as<float>() + (size_t)k * m, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, st));
+    if (out_xyz) PHCHK(c, hop_ctx_d2h(c, out_xyz + (size_t)k * cap, ph->tmp_cloud2.buf.as<float>() + (size_t)k * m, sizeof(float) * (size_t)m));
+    if (out_nrm) PHCHK(c, hop_ctx_d2h(c, out_nrm + (size_t)k * cap, ph->tmp_nrm2.buf.as<float>() + (size_t)k * m, sizeof(float) * (size_t)m));
   }
   PHCHK(c, hipStreamSynchronize(st));
   return HOP_OK;
@@ -1498,7 +1497,7 @@ int hop_handbase_region(hop_ctx* c, const float* xyz, const float* nrm, int n, c
   rc = upload_planes(c, ph->tmp_nrm, nrm, n);
   if (rc) return rc;
   PHCHK(c, ph->mats.ensure(sizeof(float) * 16 * 5));
-  PHCHK(c, hipMemcpyAsync(ph->mats.p, cam_in_handbase, sizeof(float) * 16, hipMemcpyHostToDevice, st));
+  PHCHK(c, hop_ctx_h2d(c, ph->mats.p, cam_in_handbase, sizeof(float) * 16));
   PHCHK(c, ph->tmp_cloud2.buf.ensure(sizeof(float) * 3 * (size_t)n));
   PHCHK(c, ph->tmp_nrm2.buf.ensure(sizeof(float) * 3 * (size_t)n));
   PHCHK(c, ph->flags.ensure((size_t)n + 16));
@@ -1506,9 +1505,9 @@ int hop_handbase_region(hop_ctx* c, const float* xyz, const float* nrm, int n, c
   k_handbase_region<<<(n + 255) / 256, 256, 0, st>>>(ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), nn, nn + n, nn + 2 * (size_t)n, n, ph->mats.as<float>(), y1, z1,
                                                     y2, z2, ph->tmp_cloud2.buf.as<float>(), ph->tmp_nrm2.buf.as<float>(), ph->flags.as<unsigned char>());
   PHCHK(c, hipGetLastError());
-  PHCHK(c, hipMemcpyAsync(hb_xyz, ph->tmp_cloud2.buf.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
-  PHCHK(c, hipMemcpyAsync(hb_nrm, ph->tmp_nrm2.buf.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
-  PHCHK(c, hipMemcpyAsync(keep, ph->flags.p, (size_t)n, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hop_ctx_d2h(c, hb_xyz, ph->tmp_cloud2.buf.p, sizeof(float) * 3 * (size_t)n));
+  PHCHK(c, hop_ctx_d2h(c, hb_nrm, ph->tmp_nrm2.buf.p, sizeof(float) * 3 * (size_t)n));
+  PHCHK(c, hop_ctx_d2h(c, keep, ph->flags.p, (size_t)n));
   PHCHK(c, hipStreamSynchronize(st));
   return HOP_OK;
 }
@@ -1534,14 +1533,14 @@ int hop_hand_height_matches(hop_ctx* c, const float* scene_xyz, const float* sce
   PHCHK(c, ph->scalars.ensure(sizeof(unsigned) * 16));
   PHCHK(c, ph->mats.ensure(sizeof(float) * 16 * 5));
   PHCHK(c, ph->gather.ensure(sizeof(int) * 64));
-  PHCHK(c, hipMemcpyAsync(ph->mats.p, heights, sizeof(float) * (size_t)n_heights, hipMemcpyHostToDevice, st));
+  PHCHK(c, hop_ctx_h2d(c, ph->mats.p, heights, sizeof(float) * (size_t)n_heights));
   PHCHK(c, hipMemsetAsync(ph->gather.p, 0, sizeof(int) * 64, st));
   const float *sn = ph->tmp_nrm.buf.as<float>(), *hn = ph->tmp_nrm2.buf.as<float>();
   k_hand_height<<<dim3((n_hand + 3) / 4, n_heights), 256, 0, st>>>(ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), sn, sn + n_scene, sn + 2 * (size_t)n_scene, n_scene,
                                                                   ph->tmp_cloud2.x(), ph->tmp_cloud2.y(), ph->tmp_cloud2.z(), hn, hn + n_hand, hn + 2 * (size_t)n_hand, n_hand,
                                                                   ph->mats.as<float>(), ph->gather.as<int>());
   PHCHK(c, hipGetLastError());
-  PHCHK(c, hipMemcpyAsync(counts, ph->gather.p, sizeof(int) * (size_t)n_heights, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hop_ctx_d2h(c, counts, ph->gather.p, sizeof(int) * (size_t)n_heights));
   PHCHK(c, hipStreamSynchronize(st));
   return HOP_OK;
 }
@@ -1593,7 +1592,7 @@ int hop_physics_set_frame(hop_ctx* c, const hop_physics_args* a) {
     const int n = a->finger_n[k];
     int rc = upload_planes(c, ph->tmp_cloud, a->finger_xyz[k], n);
     if (rc) return rc;
-    PHCHK(c, hipMemcpyAsync(ph->mats.as<float>() + 16 * k, a->finger2handbase[k], sizeof(float) * 16, hipMemcpyHostToDevice, st));
+    PHCHK(c, hop_ctx_h2d(c, ph->mats.as<float>() + 16 * k, a->finger2handbase[k], sizeof(float) * 16));
     float* o = ph->fingers.buf.as<float>() + P.finger_off[k];
     k_transform_cloud<<<(n + 255) / 256, 256, 0, st>>>(ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), n, ph->mats.as<float>() + 16 * k, o, o + total,
                                                        o + 2 * (size_t)total);
@@ -1606,7 +1605,7 @@ int hop_physics_set_frame(hop_ctx* c, const hop_physics_args* a) {
     if (rc) return rc;
     PHCHK(c, ph->tmp_cloud2.buf.ensure(sizeof(float) * 3 * (size_t)std::max(n, 1)));
     ph->tmp_cloud2.n = n;
-    PHCHK(c, hipMemcpyAsync(ph->mats.as<float>() + 64, a->cam2handbase, sizeof(float) * 16, hipMemcpyHostToDevice, st));
+    PHCHK(c, hop_ctx_h2d(c, ph->mats.as<float>() + 64, a->cam2handbase, sizeof(float) * 16));
     if (n > 0) {
       float* o = ph->tmp_cloud2.buf.as<float>();
       k_transform_cloud<<<(n + 255) / 256, 256, 0, st>>>(ph->tmp_cloud.x(), ph->tmp_cloud.y(), ph->tmp_cloud.z(), n, ph->mats.as<float>() + 64, o, o + n,
@@ -1665,8 +1664,8 @@ int hop_reject_by_collision(hop_ctx* c, unsigned char* keep_out, float* diag8_ou
   PHCHK(c, hipGetLastError());
   PHCHK(c, hipEventRecord(ph->ev[1], st));
   std::vector<int> stg(H);
-  PHCHK(c, hipMemcpyAsync(stg.data(), stage, sizeof(int) * (size_t)H, hipMemcpyDeviceToHost, st));
-  if (diag8_out) PHCHK(c, hipMemcpyAsync(diag8_out, diag, sizeof(float) * 8 * (size_t)H, hipMemcpyDeviceToHost, st));
+  PHCHK(c, hop_ctx_d2h(c, stg.data(), stage, sizeof(int) * (size_t)H));
+  if (diag8_out) PHCHK(c, hop_ctx_d2h(c, diag8_out, diag, sizeof(float) * 8 * (size_t)H));
   PHCHK(c, hipStreamSynchronize(st));
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ph->ev[0], ph->ev[1]);
@@ -1684,7 +1683,7 @@ int hop_reject_by_collision(hop_ctx* c, unsigned char* keep_out, float* diag8_ou
     PHCHK(c, ph->tmp_pose.ensure(sizeof(float) * 16 * (size_t)K));
     PHCHK(c, ph->tmp_score.ensure(sizeof(float) * (size_t)K));
     PHCHK(c, ph->tmp_id.ensure(sizeof(int) * (size_t)K));
-    PHCHK(c, hipMemcpyAsync(ph->gather.p, src.data(), sizeof(int) * (size_t)K, hipMemcpyHostToDevice, st));
+    PHCHK(c, hop_ctx_h2d(c, ph->gather.p, src.data(), sizeof(int) * (size_t)K));
     k_phys_gather<<<(K * 16 + 255) / 256, 256, 0, st>>>(ph->gather.as<int>(), K, hv.pose, hv.score, hv.id, ph->tmp_pose.as<float>(), ph->tmp_score.as<float>(),
                                                         ph->tmp_id.as<int>());
     PHCHK(c, hipMemcpyAsync(hv.pose, ph->tmp_pose.p, sizeof(float) * 16 * (size_t)K, hipMemcpyDeviceToDevice, st));

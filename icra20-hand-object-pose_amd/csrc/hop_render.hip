@@ -378,8 +378,8 @@ int hop_render_set_frame(hop_ctx* c, const uint16_t* depth_raw, int H, int W, do
   if (hand_nf > 0) {
     RDCHK(c, r->hand_V.ensure(sizeof(float) * 3 * (size_t)hand_nv));
     RDCHK(c, r->hand_F.ensure(sizeof(int) * 3 * (size_t)hand_nf));
-    RDCHK(c, hipMemcpyAsync(r->hand_V.p, hand_V, sizeof(float) * 3 * (size_t)hand_nv, hipMemcpyHostToDevice, st));
-    RDCHK(c, hipMemcpyAsync(r->hand_F.p, hand_F, sizeof(int) * 3 * (size_t)hand_nf, hipMemcpyHostToDevice, st));
+    RDCHK(c, hop_ctx_h2d(c, r->hand_V.p, hand_V, sizeof(float) * 3 * (size_t)hand_nv));
+    RDCHK(c, hop_ctx_h2d(c, r->hand_F.p, hand_F, sizeof(int) * 3 * (size_t)hand_nf));
     rc = run_raster(c, r, r->hand_V.as<float>(), r->hand_F.as<int>(), hand_nf, nullptr, 1, r->hand_z.as<unsigned>());
     if (rc) return rc;
   }
@@ -398,8 +398,8 @@ int hop_render_set_object(hop_ctx* c, const float* V, int nv, const int32_t* F, 
   hipStream_t st = hop_ctx_stream(c);
   RDCHK(c, r->obj_V.ensure(sizeof(float) * 3 * (size_t)nv));
   RDCHK(c, r->obj_F.ensure(sizeof(int) * 3 * (size_t)nf));
-  RDCHK(c, hipMemcpyAsync(r->obj_V.p, V, sizeof(float) * 3 * (size_t)nv, hipMemcpyHostToDevice, st));
-  RDCHK(c, hipMemcpyAsync(r->obj_F.p, F, sizeof(int) * 3 * (size_t)nf, hipMemcpyHostToDevice, st));
+  RDCHK(c, hop_ctx_h2d(c, r->obj_V.p, V, sizeof(float) * 3 * (size_t)nv));
+  RDCHK(c, hop_ctx_h2d(c, r->obj_F.p, F, sizeof(int) * 3 * (size_t)nf));
   RDCHK(c, hipStreamSynchronize(st));
   r->obj_nv = nv, r->obj_nf = nf, r->have_object = true;
   return HOP_OK;
@@ -418,7 +418,7 @@ int hop_render_depth(hop_ctx* c, const float* pose16, float* depth_m_out, unsign
   if (pose16) {
     RDCHK(c, r->zbuf.ensure(sizeof(unsigned) * npx));
     RDCHK(c, r->poses.ensure(sizeof(float) * 16));
-    RDCHK(c, hipMemcpyAsync(r->poses.p, pose16, sizeof(float) * 16, hipMemcpyHostToDevice, st));
+    RDCHK(c, hop_ctx_h2d(c, r->poses.p, pose16, sizeof(float) * 16));
     int rc = fill_clear(c, r->zbuf.p, npx);
     if (rc) return rc;
     rc = run_raster(c, r, r->obj_V.as<float>(), r->obj_F.as<int>(), r->obj_nf, r->poses.as<float>(), 1, r->zbuf.as<unsigned>());
@@ -427,8 +427,8 @@ int hop_render_depth(hop_ctx* c, const float* pose16, float* depth_m_out, unsign
   }
   k_compose_image<<<(unsigned)((npx + 255) / 256), 256, 0, st>>>(r->hand_z.as<unsigned>(), oz, (int)npx, r->out_depth.as<float>(), r->out_owner.as<unsigned char>());
   RDCHK(c, hipGetLastError());
-  RDCHK(c, hipMemcpyAsync(depth_m_out, r->out_depth.p, sizeof(float) * npx, hipMemcpyDeviceToHost, st));
-  if (owner_out) RDCHK(c, hipMemcpyAsync(owner_out, r->out_owner.p, npx, hipMemcpyDeviceToHost, st));
+  RDCHK(c, hop_ctx_d2h(c, depth_m_out, r->out_depth.p, sizeof(float) * npx));
+  if (owner_out) RDCHK(c, hop_ctx_d2h(c, owner_out, r->out_owner.p, npx));
   RDCHK(c, hipStreamSynchronize(st));
   return HOP_OK;
 }
@@ -466,13 +466,13 @@ int hop_reject_by_render(hop_ctx* c, float roi_weight, float keep_ratio, int sum
     }
     RDCHK(c, hipGetLastError());
   }
-  RDCHK(c, hipMemcpyAsync(wrong.data(), r->sums.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+  RDCHK(c, hop_ctx_d2h(c, wrong.data(), r->sums.p, sizeof(float) * (size_t)n));
   // the survivors, ascending wrong ratio (ties by position; NaN -- no object pixel -- last), gathered on the host: n is small
   std::vector<float> pose((size_t)16 * n), score(n);
   std::vector<int> id(n);
-  RDCHK(c, hipMemcpyAsync(pose.data(), hv.pose, sizeof(float) * 16 * (size_t)n, hipMemcpyDeviceToHost, st));
-  RDCHK(c, hipMemcpyAsync(score.data(), hv.score, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
-  RDCHK(c, hipMemcpyAsync(id.data(), hv.id, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+  RDCHK(c, hop_ctx_d2h(c, pose.data(), hv.pose, sizeof(float) * 16 * (size_t)n));
+  RDCHK(c, hop_ctx_d2h(c, score.data(), hv.score, sizeof(float) * (size_t)n));
+  RDCHK(c, hop_ctx_d2h(c, id.data(), hv.id, sizeof(int) * (size_t)n));
   RDCHK(c, hipStreamSynchronize(st));
   int num_to_keep = std::max((int)(keep_ratio * n), 10);
   num_to_keep = std::min(num_to_keep, n);
@@ -490,9 +490,9 @@ int hop_reject_by_render(hop_ctx* c, float roi_weight, float keep_ratio, int sum
     s2[k] = score[order[k]], i2[k] = id[order[k]];
     if (keep_index_out) keep_index_out[k] = order[k];
   }
-  RDCHK(c, hipMemcpyAsync(hv.pose, p2.data(), sizeof(float) * 16 * (size_t)num_to_keep, hipMemcpyHostToDevice, st));
-  RDCHK(c, hipMemcpyAsync(hv.score, s2.data(), sizeof(float) * (size_t)num_to_keep, hipMemcpyHostToDevice, st));
-  RDCHK(c, hipMemcpyAsync(hv.id, i2.data(), sizeof(int) * (size_t)num_to_keep, hipMemcpyHostToDevice, st));
+  RDCHK(c, hop_ctx_h2d(c, hv.pose, p2.data(), sizeof(float) * 16 * (size_t)num_to_keep));
+  RDCHK(c, hop_ctx_h2d(c, hv.score, s2.data(), sizeof(float) * (size_t)num_to_keep));
+  RDCHK(c, hop_ctx_h2d(c, hv.id, i2.data(), sizeof(int) * (size_t)num_to_keep));
   RDCHK(c, hipStreamSynchronize(st));
   hop_ctx_hyp_set_count(c, num_to_keep);
   if (wrong_ratio_out) std::copy(wrong.begin(), wrong.end(), wrong_ratio_out);

@@ -284,53 +284,15 @@ def test_c2_hand_search_at_size_against_the_oracle(ctx, api, orc, synth):
         assert abs(ang.value - true["finger_1_1"]) < 0.18
 
 
-def test_device_resident_topk_exchange_and_frame_gather_single_rank(ctx, api, synth):
+def test_device_resident_topk_exchange_and_frame_gather_single_rank():
     """the top-k table stays on the device from hop_topk_pack_device through ncclAllGather to the merge kernel (a
     communicator of one rank: RCCL refuses two ranks on one GPU; world 2 is covered with gloo in tests/test_distributed_cpu.py), and
-    the C4 gather of per-frame poses.  Same rows as the host path (hop_topk_pack = HypoCompare order, ties by id)."""
-    import ctypes as C
-    hip = C.CDLL("libamdhip64.so")     # a 9 KB device buffer without PyTorch (whose bundled HIP / RCCL must not mix with the system's here)
-    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    hip.hipFree.argtypes = [C.c_void_p]
-    dbuf = C.c_void_p()
-    assert hip.hipMalloc(C.byref(dbuf), 128 * api.TOPK_ROW_FLOATS * 4) == 0
-
-    def dev_rows():
-        out = np.zeros((128, api.TOPK_ROW_FLOATS), np.float32)
-        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), dbuf, out.nbytes, 2) == 0   # hipMemcpyDeviceToHost
-        return out
-    sc = synth.make_scene(2000, seed=7)
-    poses = synth.replay_poses(sc.gt_pose, 500, seed=1)
-    scores = np.random.default_rng(0).random(500).astype(np.float32)
-    scores[10] = scores[20] = scores[30]
-    ctx.hypos_upload(poses, scores)
-    rows_h, n = ctx.topk_pack(128, id_offset=1000)
-    p, s, i = ctx.hypos_download()
-    order = np.lexsort((i, -s))[:128]
-    assert n == 128 and np.array_equal(rows_h[:, 0], s[order]) and np.array_equal(rows_h[:, 1].copy().view(np.int32), i[order] + 1000)
-    assert np.array_equal(rows_h[:, 2:], p[order].reshape(-1, 16))
-    try:
-        comm = api.Comm(0, api.Comm.unique_id(), 0, 1)
-    except api.HopError as e:
-        pytest.skip(f"RCCL not loadable here: {e}")
-    try:
-        assert ctx.topk_pack_device(128, 1000, dbuf.value) == 128
-        assert np.array_equal(dev_rows(), rows_h)
-        m, nm = comm.topk_allgather_device(dbuf.value, 128)
-        m2, _ = comm.topk_allgather(rows_h, 128)
-        assert nm == 128 and np.array_equal(m, m2) and np.array_equal(m, rows_h)
-        ctx.hypos_upload(poses[:5], scores[:5])         # fewer hypotheses than k: padding rows carry id -1 and sort last
-        ctx.topk_pack_device(128, 0, dbuf.value)
-        m, nm = comm.topk_allgather_device(dbuf.value, 128)
-        assert nm == 5 and (m[5:, 1].copy().view(np.int32) == -1).all() and (np.diff(m[:5, 0]) <= 0).all()
-        fr = np.zeros((3, api.FRAME_ROW_FLOATS), np.float32)
-        fr[:, 0] = [4, 9, 2]
-        fr[:, 1:] = np.random.default_rng(1).normal(size=(3, 16))
-        g = comm.frames_allgather(fr, 5, 1)
-        assert np.array_equal(g[:3], fr) and (g[3:, 0] == -1).all()
-        nr, us, cnt = comm.info()
-        assert nr == 1 and cnt == 3
-    finally:
-        comm.close()
-        hip.hipFree(dbuf)
+    the C4 gather of per-frame poses.  Same rows as the host path (hop_topk_pack = HypoCompare order, ties by id).
+    Runs in a process of its own (tests/exchange_child.py): RCCL's helper threads then live and die with that process, and the system
+    ROCm it loads never meets the HIP runtime PyTorch bundles (pytest imports torch while collecting the CPU tests)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "exchange_child.py")], capture_output=True, text=True, timeout=300)
+    if "SKIP" in r.stdout:
+        pytest.skip(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 0 and "EXCHANGE OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
