@@ -141,7 +141,7 @@ struct hop_ctx {
   int n_hyp = 0;
 
   // scoring workspaces
-  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv, icp_corr_idx, icp_hist, icp_lm, pose_inv, topk_rows;
+  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv, icp_corr_idx, icp_corr16, icp_hist, icp_lm, pose_inv, topk_rows;
 
   // hand
   CloudDevice hand_scene_d, hand_lookup_d, hand_swivel_d, hand_model_d;
@@ -761,7 +761,7 @@ void hop_ctx_destroy(hop_ctx* c) {
                     &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
                     &c->hyp_score, &c->hyp_id, &c->hyp_key, &c->hyp_inv, &c->tmp_pose, &c->tmp_score, &c->tmp_id, &c->sort_keys_alt,
                     &c->sort_vals, &c->sort_vals_alt, &c->sort_tmp, &c->lcp_rev_idx, &c->lcp_rev_d2, &c->lcp_terms, &c->icp_moved,
-                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->icp_corr_idx, &c->icp_hist, &c->icp_lm, &c->pose_inv, &c->topk_rows, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
+                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->icp_corr_idx, &c->icp_corr16, &c->icp_hist, &c->icp_lm, &c->pose_inv, &c->topk_rows, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
                     &c->hand_swivel_d.buf, &c->hand_model_d.buf, &c->finger_hist_d, &c->pso_particles_d, &c->pso_match_d,
                     &c->pso_terms_d, &c->pso_sum_d, &c->pso_cnt_d};
   for (DevBuf* b : bufs) b->release();
@@ -1400,6 +1400,11 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
       HIPCHK(c, c->icp_lm.ensure(sizeof(LmDev) * (size_t)HB + 64));
       a.lm = c->icp_lm.as<LmDev>();
     }
+    static const bool icp_split = getenv("HOP_ICP_SPLIT") != nullptr && atoi(getenv("HOP_ICP_SPLIT")) != 0;
+    if (lm6_mode && icp_split) {
+      HIPCHK(c, c->icp_corr16.ensure(sizeof(unsigned short) * (size_t)S.n * HB + 64));
+      a.corr16 = c->icp_corr16.as<unsigned short>();
+    }
     if (lm_mode || lm6_mode) {
       // PCL's gates (correspondence_estimation.hpp: double max_dist_sqr = max_distance * max_distance, skip if distance > it;
       // correspondence_rejection_surface_normal: double(dot) > std::cos(angle / 180.0 * M_PI), Utils.cpp:205) against float values:
@@ -1460,7 +1465,8 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
         a.iter = it;
         {
           SpanGuard sg(c, T_ICP_NN);
-          launch_icp_fusedq_mom(a, hb, c->stream);
+          if (a.corr16) launch_icp_scan_accum(a, hb, c->stream);
+          else launch_icp_fusedq_mom(a, hb, c->stream);
         }
         {
           SpanGuard sg(c, T_ICP_SOLVE);

@@ -250,6 +250,7 @@ struct IcpArgs {
   const float* pose_inv;  // nn_mode 2: [H][12] inverse of the input poses
   const float4 *s_pts4, *s_nrm4;  // nn_mode 3/4: the Morton-ordered source as AoS float4 (two 16-byte loads per point)
   LmDev* lm;                      // nn_mode 5: [hb]
+  unsigned short* corr16;         // nn_mode 6, split form: [hb][ns] list position of the accepted correspondence (0xFFFF: none)
 };
 
 struct PsoParticle {
@@ -348,6 +349,7 @@ void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_sum_t(const LcpArgs& a, int hb, hipStream_t s);
 int lcp_cells_row_stride(int hb);
 int icp_blocks_per_hyp(int ns, bool cells);
+void launch_icp_scan_accum(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_fusedq_mom(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_lm6_solve(const IcpArgs& a, int hb, int nblocks, hipStream_t s);
 void launch_icp_lm_begin(const IcpArgs& a, int hb, hipStream_t s);

@@ -2072,6 +2072,38 @@ __device__ __forceinline__ bool cells_nnq(const CellListDev& c, V3 qg, const flo
 //   final_tf = T_k * ... * T_1 (IcpState, float products) with fused multiply-adds.  Positions differ from the chain by
 //   float rounding (<= 1e-7 relative), so a correspondence at an exact tie or a residual at the gate can differ:
 //   same iteration counts, poses within the tolerances tests/test_gpu_parity.py::test_icp_composed_increments states.
+// The per-lane float sums of a 256-thread block added in double, NV of them: a transposition through LDS instead of NV butterfly
+// reductions (74 of those cost 888 ds_bpermute + 444 v_add_f64 per wavefront -- a fifth of k_icp_fusedq_mom's time).  Sixteen sums at a
+// time: every thread writes its sixteen floats to a row of the tile (stride 17: conflict-free), thread (g, k) adds the sixteen rows of
+// group g for sum k in double, two shuffles join the four groups of a wavefront, a 4 x 16 table the wavefronts.  out[k] = the block's sum.
+struct BlockSumLds {
+  float tile[256][17];
+  double part[4][16];
+};
+template <int NV>
+__device__ __forceinline__ void block_sum_floats(const float (&acc)[NV], BlockSumLds& L, double* __restrict__ out) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int k = t & 15, g = t >> 4;
+#pragma unroll
+  for (int c = 0; c < (NV + 15) / 16; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 16; ++v)
+      if (c * 16 + v < NV) L.tile[t][v] = acc[c * 16 + v];
+    __syncthreads();
+    double pd = 0.0;
+    if (c * 16 + k < NV) {
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) pd += (double)L.tile[g * 16 + s2][k];
+    }
+    pd += __shfl_xor(pd, 16);
+    pd += __shfl_xor(pd, 32);
+    if (lane < 16) L.part[wave][lane] = pd;
+    __syncthreads();
+    if (t < 16 && c * 16 + t < NV) out[c * 16 + t] = (L.part[0][t] + L.part[1][t]) + (L.part[2][t] + L.part[3][t]);
+  }
+}
+
 #ifndef HOP_ICP_W
 #define HOP_ICP_W 7
 #endif
@@ -2137,11 +2169,16 @@ __device__ __forceinline__ int icp_fusedq_point(const IcpArgs& a, int i, const f
 }
 template <bool COMPOSED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPOSED ? HOP_ICP_W : 4))) void k_icp_fusedq(IcpArgs a, int R) {
-  __shared__ double red[4][ICP_NACC];
+  __shared__ double red[COMPOSED ? 1 : 4][ICP_NACC];
+  __shared__ int n_cnt[4];
   // nn_mode 4: lookups that need the exact re-scan (0.6 % of them, but a fifth of the wavefronts held one) are queued per
   // wavefront and run afterwards densely packed, instead of every such wavefront walking its lists again for one or two lanes.
   // The queue is filled by ballot (no atomics): its order, and with it every float sum, is the same in every run.
-  __shared__ unsigned short defer_i[COMPOSED ? 4 : 1][COMPOSED ? 64 * ICP_ACCUM_R : 1];
+  // (the queue and the tile of the final block sum share their bytes: the queue is drained before the sums leave the registers)
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[COMPOSED ? sizeof(BlockSumLds) : 16];
+  static_assert(sizeof(BlockSumLds) >= sizeof(unsigned short) * 4 * 64 * ICP_ACCUM_R, "the queue fits the tile");
+  unsigned short(*defer_i)[64 * ICP_ACCUM_R] = reinterpret_cast<unsigned short(*)[64 * ICP_ACCUM_R]>(lds_raw);
+  BlockSumLds& bs = *reinterpret_cast<BlockSumLds*>(lds_raw);
   const int hl = blockIdx.y, h = a.h0 + hl;
   const IcpState& st = a.state[hl];
   if (!st.active) return;
@@ -2176,15 +2213,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPOSED ? 
     for (int t = lane; t < nd; t += 64)
       n_wave += __popcll(__ballot(icp_fusedq_point<COMPOSED, false, acc_t>(a, base + defer_i[wave][t], pose, sTi, hist, F, acc) == ICP_PT_ACCEPTED));
   }
+  if constexpr (COMPOSED) {  // float per-lane sums: the block sum through LDS (block_sum_floats below the moment kernel's notes)
+    double* __restrict__ out = a.partial + ((size_t)hl * gridDim.x + blockIdx.x) * ICP_NACC;
+    if (lane == 0) n_cnt[wave] = n_wave;
+    block_sum_floats<ICP_NACC>(acc, bs, out);
+    __syncthreads();
+    if (threadIdx.x == 0) out[28] = (double)((n_cnt[0] + n_cnt[1]) + (n_cnt[2] + n_cnt[3]));
+  } else {
 #pragma unroll
-  for (int k = 0; k < ICP_NACC; ++k) {
-    const double s = (COMPOSED && k == 28) ? (double)n_wave : icp_wave_sum(acc[k]);
-    if (lane == 0) red[wave][k] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < ICP_NACC) {
-    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NACC + threadIdx.x] = s;
+    for (int k = 0; k < ICP_NACC; ++k) {
+      const double s = icp_wave_sum(acc[k]);
+      if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < ICP_NACC) {
+      const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+      a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NACC + threadIdx.x] = s;
+    }
   }
 }
 template __global__ void k_icp_fusedq<false>(IcpArgs, int);
@@ -2255,8 +2300,10 @@ __device__ __forceinline__ int icp_fusedq_point_mom(const IcpArgs& a, int i, con
 #define HOP_ICP_MOM_W 4
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM_W))) void k_icp_fusedq_mom(IcpArgs a, int R) {
-  __shared__ double red[4][ICP_NMOM + 1];
-  __shared__ unsigned short defer_i[4][64 * ICP_ACCUM_R];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[sizeof(BlockSumLds)];  // the queue, then the tile of the block sum
+  __shared__ int n_cnt[4];
+  unsigned short(*defer_i)[64 * ICP_ACCUM_R] = reinterpret_cast<unsigned short(*)[64 * ICP_ACCUM_R]>(lds_raw);
+  BlockSumLds& bs = *reinterpret_cast<BlockSumLds*>(lds_raw);
   const int hl = blockIdx.y, h = a.h0 + hl;
   const IcpState& st = a.state[hl];
   if (!st.active) return;
@@ -2282,17 +2329,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM
   const int nd = __builtin_amdgcn_readfirstlane(n_def);
   for (int t = lane; t < nd; t += 64)
     n_wave += __popcll(__ballot(icp_fusedq_point_mom<false>(a, base + defer_i[wave][t], pose, sTi, F, ctr, acc) == ICP_PT_ACCEPTED));
-#pragma unroll
-  for (int k = 0; k < ICP_NMOM; ++k) {
-    const double s = wave_sum((double)acc[k]);
-    if (lane == 0) red[wave][k] = s;
-  }
-  if (lane == 0) red[wave][ICP_NMOM] = (double)n_wave;
-  __syncthreads();
-  if (threadIdx.x <= ICP_NMOM) {
-    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NMOM_STRIDE + threadIdx.x] = s;
-  }
+  double* __restrict__ out = a.partial + ((size_t)hl * gridDim.x + blockIdx.x) * ICP_NMOM_STRIDE;
+  if (lane == 0) n_cnt[wave] = n_wave;
+  block_sum_floats<ICP_NMOM>(acc, bs, out);  // (its barriers order n_cnt as well)
+  if (threadIdx.x == 0) out[ICP_NMOM] = (double)((n_cnt[0] + n_cnt[1]) + (n_cnt[2] + n_cnt[3]));
 }
 #else
 // EXPERIMENT (tools/build_variant.sh mfma -DHOP_ICP_MOM_MFMA; measured SLOWER): the moment matrix on the
@@ -2447,6 +2487,145 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM
   }
 }
 #endif
+// ------------------------------------------------------------------------------------------------
+// nn_mode 6 in two kernels (HOP_ICP_SPLIT, see hop_icp_refine): k_icp_scan does the lookups and PCL's two gates of k_icp_fusedq_mom and
+// writes the accepted correspondence of every (hypothesis, source point) as a 16-bit list position (0xFFFF: none) -- no accumulators,
+// so it runs at twice the occupancy --; k_icp_mom_accum walks the same (block, lane, r) partition, rebuilds the operands from that index
+// with the same float expressions and adds the 74 sums.  2 B per point and hypothesis of extra traffic (132 MB per launch at C2).
+// ------------------------------------------------------------------------------------------------
+template <bool DEFER>
+__device__ __forceinline__ int icp_scan_point(const IcpArgs& a, int i, const float* __restrict__ pose, const float* __restrict__ sTi,
+                                               const float* __restrict__ F, int& jout) {
+  const float4 p4 = a.s_pts4[i];
+  V3 q = v3(p4.x, p4.y, p4.z);
+  if (a.iter > 0) q = m4_point_fma(F, q);
+  float d2 = 3.0e38f;
+  int j = -1;
+  V3 tq;
+  if (cells_nnq<DEFER>(a.cells, m4_point_fma(sTi, q), pose, q, d2, j, tq)) return ICP_PT_DEFERRED;
+  if (j < 0 || !(d2 <= a.max_d2)) return ICP_PT_REJECTED;
+  const float4 tn = a.cells.nrm_idx[j];
+  const float4 n4 = a.s_nrm4[i];
+  V3 qn = v3(n4.x, n4.y, n4.z);
+  if (a.iter > 0) qn = m4_dir_fma(F, qn);
+  const V3 nt = m4_dir(pose, v3(tn.x, tn.y, tn.z));
+  if (!(((qn.x * nt.x + qn.y * nt.y) + qn.z * nt.z) > a.cos_thr)) return ICP_PT_REJECTED;
+  jout = j;
+  return ICP_PT_ACCEPTED;
+}
+#ifndef HOP_ICP_SCAN_W
+#define HOP_ICP_SCAN_W 8
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_SCAN_W))) void k_icp_scan(IcpArgs a, int R) {
+  __shared__ unsigned short defer_i[4][64 * ICP_ACCUM_R];
+  const int hl = blockIdx.y, h = a.h0 + hl;
+  const IcpState& st = a.state[hl];
+  if (!st.active) return;
+  const float* __restrict__ pose = a.pose + (size_t)h * 16;
+  const float* __restrict__ sTi = a.pose_inv + (size_t)h * 12;
+  const float* __restrict__ F = st.final_tf;
+  unsigned short* __restrict__ corr = a.corr16 + (size_t)hl * a.ns;
+  int n_def = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int base = blockIdx.x * (256 * R);
+  for (int r = 0; r < R; ++r) {
+    const int li = r * 256 + threadIdx.x, i = base + li;
+    int j = 0xFFFF;
+    const int res = i < a.ns ? icp_scan_point<true>(a, i, pose, sTi, F, j) : ICP_PT_REJECTED;
+    const unsigned long long dm = __ballot(res == ICP_PT_DEFERRED);
+    if (res == ICP_PT_DEFERRED) defer_i[wave][n_def + __popcll(dm & ((1ull << lane) - 1ull))] = (unsigned short)li;
+    else if (i < a.ns) corr[i] = (unsigned short)(res == ICP_PT_ACCEPTED ? j : 0xFFFF);
+    n_def += __popcll(dm);
+  }
+  const int nd = __builtin_amdgcn_readfirstlane(n_def);
+  for (int t = lane; t < nd; t += 64) {
+    const int i = base + defer_i[wave][t];
+    int j = 0xFFFF;
+    const int res = icp_scan_point<false>(a, i, pose, sTi, F, j);
+    corr[i] = (unsigned short)(res == ICP_PT_ACCEPTED ? j : 0xFFFF);
+  }
+}
+#ifndef HOP_ICP_ACC_U
+#define HOP_ICP_ACC_U 4
+#endif
+__global__ __launch_bounds__(256) void k_icp_mom_accum(IcpArgs a, int R) {
+  __shared__ BlockSumLds bs;
+  __shared__ int n_cnt[4];
+  const int hl = blockIdx.y, h = a.h0 + hl;
+  const IcpState& st = a.state[hl];
+  if (!st.active) return;
+  const float* __restrict__ pose = a.pose + (size_t)h * 16;
+  const float* __restrict__ F = st.final_tf;
+  const unsigned short* __restrict__ corr = a.corr16 + (size_t)hl * a.ns;
+  const V3 ctr = v3(pose[3], pose[7], pose[11]);
+  float acc[ICP_NMOM];
+#pragma unroll
+  for (int k = 0; k < ICP_NMOM; ++k) acc[k] = 0.f;
+  int n_wave = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int base = blockIdx.x * (256 * R);
+  // branch-free over HOP_ICP_ACC_U points per trip: the index, then the three gathers of every point of the trip are in flight together
+  // (a lane without a correspondence reads entry 0 and adds zeros: fma(0, x, s) and s + 0 leave s as it is)
+  for (int r0i = 0; r0i < R; r0i += HOP_ICP_ACC_U) {
+    int jj[HOP_ICP_ACC_U];
+    bool okk[HOP_ICP_ACC_U];
+#pragma unroll
+    for (int u = 0; u < HOP_ICP_ACC_U; ++u) {
+      const int i = base + (r0i + u) * 256 + threadIdx.x;
+      const int j = (r0i + u < R && i < a.ns) ? (int)corr[i] : 0xFFFF;
+      okk[u] = j != 0xFFFF, jj[u] = okk[u] ? j : 0;
+    }
+    float4 p4[HOP_ICP_ACC_U], w4[HOP_ICP_ACC_U], t4[HOP_ICP_ACC_U];
+#pragma unroll
+    for (int u = 0; u < HOP_ICP_ACC_U; ++u) {
+      const int i = min(base + (r0i + u) * 256 + (int)threadIdx.x, a.ns - 1);
+      p4[u] = a.s_pts4[i], w4[u] = a.cells.pts_idx[jj[u]], t4[u] = a.cells.nrm_idx[jj[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < HOP_ICP_ACC_U; ++u) {
+      const bool ok = okk[u];
+      n_wave += __popcll(__ballot(ok));
+      V3 q = v3(p4[u].x, p4[u].y, p4[u].z);
+      if (a.iter > 0) q = m4_point_fma(F, q);
+      const V3 tq = m4_point(pose, v3(w4[u].x, w4[u].y, w4[u].z));
+      const float d2 = ok ? sqdist_flann(q, tq) : 0.f;
+      V3 nt = m4_dir(pose, v3(t4[u].x, t4[u].y, t4[u].z));
+      nt = ok ? nt : v3(0.f, 0.f, 0.f);
+      const V3 pc = q - ctr;
+      const float r0 = vdot(q - tq, nt);
+      const float nn[6] = {nt.x * nt.x, nt.x * nt.y, nt.x * nt.z, nt.y * nt.y, nt.y * nt.z, nt.z * nt.z};
+      const float pp[6] = {pc.x * pc.x, pc.x * pc.y, pc.x * pc.z, pc.y * pc.y, pc.y * pc.z, pc.z * pc.z};
+      const float pv[3] = {pc.x, pc.y, pc.z}, nv[3] = {nt.x, nt.y, nt.z};
+#pragma unroll
+      for (int x = 0; x < 6; ++x) {
+#pragma unroll
+        for (int v = 0; v < 6; ++v) acc[x * 6 + v] = __builtin_fmaf(nn[x], pp[v], acc[x * 6 + v]);
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) acc[36 + x * 3 + b2] = __builtin_fmaf(nn[x], pv[b2], acc[36 + x * 3 + b2]);
+        acc[54 + x] += nn[x];
+      }
+#pragma unroll
+      for (int c2 = 0; c2 < 3; ++c2) {
+        const float nr = nv[c2] * r0;
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) acc[60 + c2 * 3 + b2] = __builtin_fmaf(nr, pv[b2], acc[60 + c2 * 3 + b2]);
+        acc[69 + c2] += nr;
+      }
+      acc[72] = __builtin_fmaf(r0, r0, acc[72]);
+      acc[73] += d2;
+    }
+  }
+  double* __restrict__ out = a.partial + ((size_t)hl * gridDim.x + blockIdx.x) * ICP_NMOM_STRIDE;
+  if (lane == 0) n_cnt[wave] = n_wave;
+  block_sum_floats<ICP_NMOM>(acc, bs, out);
+  if (threadIdx.x == 0) out[ICP_NMOM] = (double)((n_cnt[0] + n_cnt[1]) + (n_cnt[2] + n_cnt[3]));
+}
+void launch_icp_scan_accum(const IcpArgs& a, int hb, hipStream_t s) {
+  const int nb = icp_blocks_per_hyp(a.ns, true);
+  const int R = (a.ns + 256 * nb - 1) / (256 * nb);
+  hipLaunchKernelGGL(k_icp_scan, dim3(nb, hb), dim3(256), 0, s, a, R);
+  hipLaunchKernelGGL(k_icp_mom_accum, dim3(nb, hb), dim3(256), 0, s, a, R);
+}
 void launch_icp_fusedq_mom(const IcpArgs& a, int hb, hipStream_t s) {
   const int nb = icp_blocks_per_hyp(a.ns, true);
   const int R = (a.ns + 256 * nb - 1) / (256 * nb);
