@@ -617,3 +617,34 @@ def test_adjust_hand_height_vs_oracle(ctx, orc, synth, api):
     h._component_status["handbase"] = True
     same, b2, c2 = h.adjustHandHeight(rx, rn, reported)
     assert np.array_equal(same, reported) and c2 is None
+
+
+def test_registering_the_same_mesh_again_reuses_its_structures_and_a_changed_mesh_does_not(ctx, orc, synth):
+    """the reference registers the object mesh once per frame (PoseEstimator.cpp:505-508); the same triangles find their tree and face cells
+    standing (a fresh registration also clears hop_sdf_set_mesh_pose), one moved vertex or another pose rebuilds them"""
+    import time
+    rng = np.random.default_rng(5)
+    V, F = synth.ellipsoid_mesh(subdiv=4)
+    P = (V[rng.integers(0, len(V), 8000)] + rng.normal(scale=0.006, size=(8000, 3))).astype(np.float32)
+    t0 = time.perf_counter()
+    ctx.sdf_register_mesh(12, V, F)
+    t_first = time.perf_counter() - t0
+    d0, f0, _, _ = ctx.sdf_signed_distance(12, P)
+    T = synth.se3(synth.random_rotation(rng), [0.02, 0.01, -0.03]).astype(np.float32)
+    ctx.sdf_set_mesh_pose(12, T)
+    t0 = time.perf_counter()
+    ctx.sdf_register_mesh(12, V.copy(), F.copy())          # same content in other arrays
+    t_again = time.perf_counter() - t0
+    d1, f1, _, _ = ctx.sdf_signed_distance(12, P)           # ... and the pose set in between is gone, as after a fresh registration
+    assert np.array_equal(d0.view(np.int32), d1.view(np.int32)) and np.array_equal(f0, f1)
+    assert t_again < 0.25 * t_first
+    V2 = V.copy()
+    V2[17] *= 1.2                                           # one vertex moved: the structures are rebuilt
+    ctx.sdf_register_mesh(12, V2, F)
+    d2, f2, _, _ = ctx.sdf_signed_distance(12, P)
+    S2, I2 = orc.sdf_signed_distance(P, V2, F)
+    assert np.array_equal(d2.view(np.int32), S2.view(np.int32)) and np.array_equal(f2, I2) and not np.array_equal(d2, d0)
+    ctx.sdf_register_mesh(12, V2, F, T)                     # the same triangles under a pose: rebuilt as well
+    d3, f3, _, _ = ctx.sdf_signed_distance(12, P)
+    S3, I3 = orc.sdf_signed_distance(P, V2, F, pose=T)
+    assert np.array_equal(d3.view(np.int32), S3.view(np.int32)) and np.array_equal(f3, I3)
