@@ -1,0 +1,85 @@
+"""The C++ host's file readers (host/Frame.h: its own 16-bit PNG decoder on zlib, Utils::parsePoseTxt, the calibration chain of
+run_real_all.cpp:116-133) against the Python mirror on the same files -- CPU only: nothing here creates a context."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    lib = os.path.join(ROOT, "icra20-hand-object-pose_amd", "lib")
+    if not os.path.exists(os.path.join(lib, "libhop.so")):
+        pytest.skip("libhop.so is not built")
+    exe = str(tmp_path_factory.mktemp("hostio") / "host_io_check")
+    subprocess.run(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "host_io_check.cpp"), "-o", exe, "-L" + lib, "-lhop", "-lz",
+                    "-Wl,-rpath," + lib], check=True, capture_output=True)
+    return exe
+
+
+@pytest.mark.parametrize("kind", ["smooth16", "noise16", "gray8"])
+def test_cpp_png_pose_and_calibration_readers_equal_the_python_mirror(checker, hop, tmp_path, kind):
+    from PIL import Image
+    import yaml
+    from hop_amd import config as hop_config
+    from hop_amd import run_real_all as rr
+    rng = np.random.default_rng(3)
+    H, W = 97, 131                                       # odd sizes: every PNG filter type sees a partial last group
+    if kind == "smooth16":                               # gradients: PIL's encoder picks Sub / Up / Average / Paeth rows
+        img = (np.add.outer(np.arange(H) * 37, np.arange(W) * 11) % 60000).astype(np.uint16)
+    elif kind == "noise16":
+        img = rng.integers(0, 65536, (H, W)).astype(np.uint16)
+    else:
+        img = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    png = str(tmp_path / "depth.png")
+    Image.fromarray(img).save(png)
+    cfg = hop_config.load_config()
+    cfg["cam_K"] = [615.5, 0.0, 322.25, 0.0, 614.75, 241.5, 0.0, 0.0, 1.0]
+    q = rng.normal(size=4)
+    cfg["cam1_in_leftarm"] = [0.11, -0.03, 0.27] + [float(v) for v in q / np.linalg.norm(q)]
+    hp = np.eye(4)
+    hp[:3, 3] = [0.01, -0.02, 0.13]
+    cfg["handbase_in_palm"] = [float(v) for v in hp.reshape(16)]
+    cfg_path = str(tmp_path / "config.yaml")
+    with open(cfg_path, "w") as f:
+        class _Dumper(yaml.SafeDumper):
+            pass
+        _Dumper.add_representer(list, lambda d, data: d.represent_sequence("tag:yaml.org,2002:seq", data, flow_style=True))
+        yaml.dump(cfg, f, Dumper=_Dumper, default_flow_style=False)
+
+    def pose(seed):
+        r = np.random.default_rng(seed)
+        A = np.linalg.qr(r.normal(size=(3, 3)))[0]
+        T = np.eye(4)
+        T[:3, :3] = A * np.sign(np.linalg.det(A))
+        T[:3, 3] = r.normal(size=3) * 0.3
+        return T
+    arm, palm = pose(1), pose(2)
+    fmt = lambda T: "\n".join(" ".join(repr(float(v)) for v in row) for row in T) + "\n"
+    open(tmp_path / "arm.txt", "w").write(fmt(arm))
+    open(tmp_path / "palm.txt", "w").write(fmt(palm))
+    r = subprocess.run([checker, cfg_path, png, str(tmp_path / "arm.txt"), str(tmp_path / "palm.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.strip().splitlines()}
+    flat = img.astype(np.uint64).reshape(-1)
+    wsum = int((flat * (np.arange(flat.size, dtype=np.uint64) % np.uint64(9973) + np.uint64(1))).sum())
+    assert [int(v) for v in lines["png"]] == [H, W, int(flat.sum()), wsum, int(flat[0]), int(flat[-1])]
+    assert np.array_equal(rr.read_depth_png(png).astype(np.uint64).reshape(-1), flat)
+    cfg2 = hop_config.load_config(cfg_path)
+    K, _, _ = rr.calibration(cfg2)
+    assert np.allclose(np.array([float(v) for v in lines["K"]], np.float32), np.asarray(K, np.float32).reshape(9), rtol=0, atol=0)
+    hb_py = rr.handbase_in_cam_of(cfg2, rr.parse_pose_txt(str(tmp_path / "arm.txt")), rr.parse_pose_txt(str(tmp_path / "palm.txt")))
+    hb_cpp = np.array([float(v) for v in lines["handbase"]], np.float32).reshape(4, 4)
+    assert np.abs(hb_cpp - np.asarray(hb_py, np.float32)).max() < 2e-6
+    # and against the plain matrix product in double
+    q4 = np.array(cfg["cam1_in_leftarm"][3:])
+    x, y, z, w = q4 / np.linalg.norm(q4)
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    C = np.eye(4)
+    C[:3, :3], C[:3, 3] = R, cfg["cam1_in_leftarm"][:3]
+    ref = np.linalg.inv(C) @ (np.linalg.inv(arm) @ palm @ hp)
+    assert np.abs(hb_cpp - ref).max() < 1e-5
