@@ -7,6 +7,16 @@
 #include "../../icra20-hand-object-pose_amd/host/Frame.h"
 
 int main(int argc, char** argv) {
+  if (argc == 3 && std::string(argv[2]) == "dump") {  // every key the parser holds, "key<TAB>value"
+    try {
+      ConfigParser cfg(argv[1]);
+      for (const auto& kv : cfg.all()) std::printf("%s\t%s\n", kv.first.c_str(), kv.second.c_str());
+      return 0;
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "error: %s\n", e.what());
+      return 3;
+    }
+  }
   if (argc < 5) return 2;
   try {
     ConfigParser cfg(argv[1]);
