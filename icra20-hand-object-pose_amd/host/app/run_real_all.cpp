@@ -144,8 +144,10 @@ int main(int argc, char** argv) {
       }
     };
     std::vector<std::thread> pool;
-    for (int w = 1; w < std::min<int>(inflight, (int)std::max<size_t>(jobs.size(), 1)); ++w) pool.emplace_back(worker);
-    worker();
+    if (!jobs.empty()) {  // (nothing left to do: no estimator, no context, no device is touched)
+      for (int w = 1; w < std::min<int>(inflight, (int)jobs.size()); ++w) pool.emplace_back(worker);
+      worker();
+    }
     for (std::thread& t : pool) t.join();
     if (!first_error.empty()) throw std::runtime_error(first_error);
     const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();

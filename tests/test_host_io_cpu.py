@@ -116,3 +116,27 @@ def test_cpp_config_parser_reads_the_shipped_yaml_like_pyyaml(checker, hop):
         else:
             assert cpp[k].strip().strip('"').strip("'") == str(v), k
     assert hop_config.load_config(path)["model_name"] == cpp["model_name"].strip()
+
+
+def test_cpp_dataset_driver_resumes_and_shards_without_touching_a_device(hop, tmp_path):
+    """host/app/run_real_all on a record whose frames all have results: it lists the reference's layout (run_real_all.cpp:72-104), takes
+    this rank's share (frame index mod WORLD_SIZE) and, with nothing left to compute, creates no context -- so this runs without a GPU"""
+    from hop_amd import run_real_all as rr
+    exe = os.path.join(ROOT, "icra20-hand-object-pose_amd", "lib", "run_real_all")
+    if not os.path.exists(exe):
+        pytest.skip("run_real_all is not built")
+    base = str(tmp_path / "auto_collect")
+    rec = os.path.join(base, "ellipse", "rec_000")
+    os.makedirs(rec)
+    for k in (0, 1, 2, 5, 12):
+        open(os.path.join(rec, f"rgb{k}.png"), "wb").write(b"")          # only the names are read when every frame is done
+        os.makedirs(os.path.join(rec, "predict", str(k)))
+        open(os.path.join(rec, "predict", str(k), "model2scene.txt"), "w").write("1 0 0 0\n0 1 0 0\n0 0 1 0\n0 0 0 1\n")
+    open(os.path.join(rec, "notes.txt"), "w").write("not a frame")
+    cfg_path = os.path.join(ROOT, "icra20-hand-object-pose_amd", "config", "config_autodataset.yaml")
+    adir = rr.write_assets_dir(rr.Assets(), str(tmp_path / "assets"))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "HOP_FORCE")}
+    r = subprocess.run([exe, cfg_path, adir, base, "ellipse"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "rank 0 of 1: 0 frames written" in r.stdout and "5 resumed" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([exe, cfg_path, adir, base, "ellipse"], capture_output=True, text=True, env=dict(env, RANK="1", WORLD_SIZE="2", HOP_INFLIGHT="4"))
+    assert r.returncode == 0 and "rank 1 of 2: 0 frames written" in r.stdout and "2 resumed" in r.stdout, r.stdout + r.stderr   # frames 1 and 5
