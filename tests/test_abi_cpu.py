@@ -35,6 +35,17 @@ def test_library_exports_every_declared_symbol(api):
     assert L.hop_abi_version() == 1
 
 
+def test_every_entry_point_is_bound_in_integration_md_and_cites_the_reference():
+    """The drop-in boundary is documented entry point by entry point: INTEGRATION.md names every function of include/hop.h, and the
+    header cites reference files (file:line) throughout."""
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in _header_functions() if not re.search(r"\b" + n + r"\b", integ)]
+    assert not missing, f"not named in INTEGRATION.md: {missing}"
+    header = open(os.path.join(ROOT, "include", "hop.h")).read()
+    cites = re.findall(r"[A-Za-z0-9_]+\.(?:cpp|hpp|h|yaml|py):\d+", header)
+    assert len(cites) >= 60, len(cites)
+
+
 def test_library_contains_gfx950_code_object(api):
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", api.LIB_PATH], capture_output=True, text=True)
     blob = open(api.LIB_PATH, "rb").read()
