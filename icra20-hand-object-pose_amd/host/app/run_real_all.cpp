@@ -6,6 +6,11 @@
 //   RANK / WORLD_SIZE in the environment shard the frames (frame index mod world, as the Python runner does; the reference is one process);
 //   HOP_FORCE=1 recomputes frames whose result exists (default: resume); HOP_INFLIGHT=N keeps N frames in flight on the device (N host
 //   threads, each with its own estimator / hand / contexts; default 1 = the reference's sequential loop); LOCAL_RANK picks the device.
+//   HOP_GATHER=1 (BASELINE configs[3], "frames sharded over the GPUs, RCCL gather of per-frame best pose"): at the end of its shard every
+//   rank contributes its frames' poses to ONE hop_frames_allgather (ncclAllGather inside libhop.so); rank 0 writes them all to
+//   <base>/<model>/model2scene_all.txt ("record index m00 ... m33" per frame).  The 128-byte RCCL id travels through the file
+//   HOP_COMM_ID_FILE (default <base>/<model>/.hop_comm_id[.<MASTER_PORT>]: the ranks share the dataset directory already); one rank
+//   needs no communicator.  Same table as run_real_all.gather_frame_poses of the Python runner.
 // assets_dir holds what the reference loads from PLY / OBJ / Boost archive / URDF files (download links): see hop::Assets (host/Frame.h).
 #include <dirent.h>
 #include <sys/stat.h>
@@ -17,6 +22,8 @@
 #include <mutex>
 #include <regex>
 #include <thread>
+
+#include <unistd.h>
 
 #include "../Frame.h"
 
@@ -52,6 +59,36 @@ struct FrameJob {
   int idx;
 };
 
+// The launcher's side of hop_comm_unique_id / hop_comm_create (include/hop.h: "the launcher hands the 128 bytes to the other ranks (any
+// channel)"): rank 0 publishes the id in a file next to the frames (written under another name and renamed, so a reader never sees half
+// of it), the others wait for it.  Rank 0 removes a file left by a killed run when it starts and its own once the collective has
+// returned -- by then every rank has read it.
+static hop_comm* comm_through_file(const std::string& id_file, int device, int rank, int world) {
+  unsigned char id[HOP_COMM_ID_BYTES];
+  if (rank == 0) {
+    if (hop_comm_unique_id(id) != HOP_OK) throw std::runtime_error(std::string("hop_comm_unique_id: ") + hop_comm_last_error(nullptr));
+    {
+      std::ofstream f(id_file + ".tmp", std::ios::binary);
+      f.write(reinterpret_cast<const char*>(id), sizeof id);
+      if (!f) throw std::runtime_error("cannot write " + id_file);
+    }
+    if (std::rename((id_file + ".tmp").c_str(), id_file.c_str()) != 0) throw std::runtime_error("cannot publish " + id_file);
+  } else {
+    const double wait_s = std::getenv("HOP_COMM_WAIT_S") ? std::atof(std::getenv("HOP_COMM_WAIT_S")) : 3600.0;  // rank 0 may still be in its shard
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      std::ifstream f(id_file, std::ios::binary);
+      if (f && f.read(reinterpret_cast<char*>(id), sizeof id)) break;
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_s)
+        throw std::runtime_error("rank 0 did not publish the RCCL id in " + id_file);
+      usleep(20000);
+    }
+  }
+  hop_comm* comm = nullptr;
+  if (hop_comm_create(device, id, rank, world, &comm) != HOP_OK) throw std::runtime_error(std::string("hop_comm_create: ") + hop_comm_last_error(nullptr));
+  return comm;
+}
+
 int main(int argc, char** argv) {
   if (argc < 4) {
     std::cout << "usage: run_real_all <config.yaml> <assets_dir> <base_dir> [model_name]\n";
@@ -67,8 +104,12 @@ int main(int argc, char** argv) {
     const int device = std::getenv("LOCAL_RANK") ? std::atoi(std::getenv("LOCAL_RANK")) : 0;
     const std::string mdir = base + "/" + model_name;
     // this rank's frames that have no result yet (the reference walks the same directories in the same order, :70-115)
-    std::vector<FrameJob> jobs;
+    std::vector<FrameJob> jobs, all_frames, mine;  // all_frames: every rank lists the same directory, so its order numbers the frames for all
     int n_skipped = 0;
+    const bool gather = std::getenv("HOP_GATHER") != nullptr;
+    std::string id_file = std::getenv("HOP_COMM_ID_FILE") ? std::getenv("HOP_COMM_ID_FILE") : mdir + "/.hop_comm_id";
+    if (!std::getenv("HOP_COMM_ID_FILE") && std::getenv("MASTER_PORT")) id_file += std::string(".") + std::getenv("MASTER_PORT");
+    if (gather && world > 1 && rank == 0) std::remove(id_file.c_str());
     const std::regex rgb_re("rgb([0-9]+)\\..*");
     for (const std::string& record : list_dir(mdir, true)) {
       const std::string rec = mdir + "/" + record;
@@ -79,7 +120,9 @@ int main(int argc, char** argv) {
       }
       std::sort(frames.begin(), frames.end());
       for (int idx : frames) {
+        all_frames.push_back({record, rec, idx});
         if (idx % world != rank) continue;
+        mine.push_back({record, rec, idx});
         std::ifstream ex(rec + "/predict/" + std::to_string(idx) + "/model2scene.txt");
         if (ex && !force) ++n_skipped;
         else jobs.push_back({record, rec, idx});
@@ -156,6 +199,57 @@ int main(int argc, char** argv) {
                 nd ? ms_total / nd : 0.0, inflight, nd ? wall / nd : 0.0, n_skipped);
     if (std::getenv("HOP_APP_TIMING") && nd)
       for (const auto& st : stage_total) std::printf("  %-45s %8.2f ms per frame\n", st.first.c_str(), st.second / nd);
+    if (gather) {
+      // rows { frame number, pose[16] } of this rank's frames (computed now or by an earlier, resumed run: the result files are the
+      // record of both), padded by the library to the largest shard, which every rank derives from the same list and the same rule
+      std::vector<int> counts(world, 0);
+      for (const FrameJob& j : all_frames) ++counts[j.idx % world];
+      const int rows_per_rank = std::max(1, *std::max_element(counts.begin(), counts.end()));
+      std::vector<float> rows(mine.size() * HOP_FRAME_ROW_FLOATS);
+      size_t r = 0, number = 0;
+      for (const FrameJob& j : all_frames) {
+        if (j.idx % world == rank) {
+          const Mat4 T = hop::parse_pose_txt(j.rec + "/predict/" + std::to_string(j.idx) + "/model2scene.txt");
+          rows[r * HOP_FRAME_ROW_FLOATS] = (float)number;
+          std::copy(T.m, T.m + 16, rows.begin() + r * HOP_FRAME_ROW_FLOATS + 1);
+          ++r;
+        }
+        ++number;
+      }
+      std::vector<float> table;
+      if (world == 1) table = rows;  // one rank: its rows are the table
+      else {
+        hop_comm* comm = comm_through_file(id_file, device, rank, world);
+        table.assign((size_t)world * rows_per_rank * HOP_FRAME_ROW_FLOATS, 0.f);
+        const int rc = hop_frames_allgather(comm, rows.data(), (int)mine.size(), rows_per_rank, table.data());
+        const std::string why = rc == HOP_OK ? "" : std::string(hop_strerror(rc)) + " " + hop_comm_last_error(comm);
+        hop_comm_destroy(comm);
+        if (rank == 0) std::remove(id_file.c_str());
+        if (rc != HOP_OK) throw std::runtime_error("hop_frames_allgather: " + why);
+      }
+      std::vector<const float*> by_number(all_frames.size(), nullptr);
+      for (size_t q = 0; q < table.size() / HOP_FRAME_ROW_FLOATS; ++q) {
+        const float* row = table.data() + q * HOP_FRAME_ROW_FLOATS;
+        if (row[0] >= 0 && (size_t)row[0] < by_number.size()) by_number[(size_t)row[0]] = row;
+      }
+      size_t n_have = 0;
+      for (const float* row : by_number) n_have += row != nullptr;
+      if (n_have != all_frames.size()) throw std::runtime_error("the gathered table holds " + std::to_string(n_have) + " of " + std::to_string(all_frames.size()) + " frames");
+      if (rank == 0) {
+        const std::string out = mdir + "/model2scene_all.txt";
+        {
+          std::ofstream ff(out + ".tmp");
+          ff.precision(9);
+          for (size_t q = 0; q < all_frames.size(); ++q) {
+            ff << all_frames[q].record << " " << all_frames[q].idx;
+            for (int e = 0; e < 16; ++e) ff << " " << by_number[q][1 + e];
+            ff << "\n";
+          }
+        }
+        std::rename((out + ".tmp").c_str(), out.c_str());
+      }
+      std::printf("rank %d of %d: poses of %zu frames gathered (%zu from this rank, %d rows per rank)\n", rank, world, all_frames.size(), mine.size(), rows_per_rank);
+    }
     return 0;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());

@@ -140,3 +140,45 @@ def test_cpp_dataset_driver_resumes_and_shards_without_touching_a_device(hop, tm
     assert r.returncode == 0 and "rank 0 of 1: 0 frames written" in r.stdout and "5 resumed" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([exe, cfg_path, adir, base, "ellipse"], capture_output=True, text=True, env=dict(env, RANK="1", WORLD_SIZE="2", HOP_INFLIGHT="4"))
     assert r.returncode == 0 and "rank 1 of 2: 0 frames written" in r.stdout and "2 resumed" in r.stdout, r.stdout + r.stderr   # frames 1 and 5
+    assert not os.path.exists(os.path.join(base, "ellipse", "model2scene_all.txt"))     # no gather unless asked for
+
+
+def test_cpp_dataset_driver_gathers_the_frame_poses(hop, tmp_path):
+    """HOP_GATHER=1 (BASELINE configs[3], "gather of per-frame best pose"): the driver turns its frames' results into the rows of
+    hop_frames_allgather, numbers them by the directory listing every rank shares, and rank 0 writes the table.  One rank needs no
+    communicator (and, every frame being done, no device): rows, numbering and the written table are what this checks; the collective
+    itself is hop_frames_allgather (tests/test_distributed_cpu.py, tests/exchange_child.py)."""
+    from hop_amd import run_real_all as rr
+    exe = os.path.join(ROOT, "icra20-hand-object-pose_amd", "lib", "run_real_all")
+    if not os.path.exists(exe):
+        pytest.skip("run_real_all is not built")
+    base = str(tmp_path / "auto_collect")
+    rng = np.random.default_rng(11)
+    truth = {}
+    for record, frames in (("rec_000", (0, 3, 10, 2)), ("rec_001", (7, 1))):
+        rec = os.path.join(base, "ellipse", record)
+        os.makedirs(rec)
+        for k in frames:
+            open(os.path.join(rec, f"rgb{k}.png"), "wb").write(b"")
+            os.makedirs(os.path.join(rec, "predict", str(k)))
+            T = np.eye(4, dtype=np.float32)
+            T[:3, :] = rng.normal(size=(3, 4)).astype(np.float32)
+            truth[(record, k)] = T
+            with open(os.path.join(rec, "predict", str(k), "model2scene.txt"), "w") as f:
+                for row in T:
+                    f.write(" ".join(f"{v:.9g}" for v in row) + "\n")
+    cfg_path = os.path.join(ROOT, "icra20-hand-object-pose_amd", "config", "config_autodataset.yaml")
+    adir = rr.write_assets_dir(rr.Assets(), str(tmp_path / "assets"))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "HOP_FORCE", "MASTER_PORT", "HOP_COMM_ID_FILE")}
+    r = subprocess.run([exe, cfg_path, adir, base, "ellipse"], capture_output=True, text=True, env=dict(env, HOP_GATHER="1"))
+    assert r.returncode == 0 and "poses of 6 frames gathered (6 from this rank, 6 rows per rank)" in r.stdout, r.stdout + r.stderr
+    lines = open(os.path.join(base, "ellipse", "model2scene_all.txt")).read().strip().splitlines()
+    got = [(ln.split()[0], int(ln.split()[1])) for ln in lines]
+    assert got == sorted(truth), "frames in the order of the listing: record, then frame index"
+    for ln in lines:
+        t = ln.split()
+        assert np.array_equal(np.array(t[2:], np.float32).reshape(4, 4), truth[(t[0], int(t[1]))])    # %.9g round-trips a float
+    # a rank other than 0 waits for rank 0's RCCL id in the shared directory and says so when it never comes
+    r = subprocess.run([exe, cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=60,
+                       env=dict(env, HOP_GATHER="1", RANK="1", WORLD_SIZE="2", MASTER_PORT="29999", HOP_COMM_WAIT_S="0.3"))
+    assert r.returncode == 3 and "rank 0 did not publish the RCCL id in" in r.stderr and ".hop_comm_id.29999" in r.stderr, r.stdout + r.stderr
