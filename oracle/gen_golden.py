@@ -36,6 +36,12 @@ CASES = [
     # BASELINE configs[0] ("C1-synthetic-model"): the hand-region cloud of the reference's example/depth7.png
     # (tests/golden/depth7_hand_region.npz, made by tools/make_depth7_fixture.py) against the synthetic ellipse
     ("depth7", -1, 0, 1, 100, 10),
+    # BASELINE configs[2] stand-ins (synth.OBJECT_SYMMETRY): the inputs of tests/test_gpu_objects.py's as-shipped chain -- the object's
+    # 5 mm model, its own PPF key table, a 1500-point scene of it -- through the reference's generator
+    ("obj_cuboid", 1500, 31, 1, 100, 10),
+    ("obj_cylinder", 1500, 31, 1, 100, 10),
+    ("obj_tless3", 1500, 31, 1, 100, 10),
+    ("obj_mustard", 1500, 31, 1, 100, 10),
 ]
 
 
@@ -57,7 +63,11 @@ def canonical_hypos(pose, lcp):
 def gen_case(name, n_scene, seed, n_calls, sample_size, succ):
     mx, mn = synth.ellipsoid_model_spacing(0.005)
     keys = synth.ppf_key_table()
-    if n_scene < 0:
+    if name.startswith("obj_"):
+        mx, mn = synth.object_model(name[4:], 0.005)
+        keys = orc.model_ppf_keys(mx, mn)
+        sc = synth.make_object_scene(name[4:], n_scene, seed=seed)
+    elif n_scene < 0:
         g = np.load(os.path.join(OUT, "depth7_hand_region.npz"))
 
         class Real:

@@ -66,7 +66,10 @@ def test_kat_rigid(orc, golden_dir):
             assert np.array_equal(T, g["rigid_T"][k])   # bit-equal transform
 
 
-@pytest.mark.parametrize("case", ["case1", "case2", "case3", "depth7"])
+OBJECT_CASES = ["obj_cuboid", "obj_cylinder", "obj_tless3", "obj_mustard"]   # BASELINE configs[2] stand-ins through the reference build
+
+
+@pytest.mark.parametrize("case", ["case1", "case2", "case3", "depth7"] + OBJECT_CASES)
 def test_generator_matches_reference(orc, golden_dir, case):
     g = np.load(os.path.join(golden_dir, f"s4pcs_{case}.npz"))
     sample_size, succ, n_calls = (int(v) for v in g["opts"])
@@ -103,7 +106,12 @@ def test_generator_matches_reference(orc, golden_dir, case):
     # Verify KATs on the state left by the run
     for T, v in zip(g["verify_T"], g["verify_lcp"]):
         assert o.verify(T) == v
-    assert st["n_quat_fallback"] == 0  # the JacobiSVD fallback was not exercised here
+    # Quaternion::setFromTwoVectors' JacobiSVD branch (an analytic perpendicular here).  The ellipse cases never reach it;
+    # the cylinder's end caps and the mustard stand-in do (pairs along -z), and everything above still equals the reference build.
+    if case in ("obj_cylinder", "obj_mustard"):
+        assert st["n_quat_fallback"] > 0
+    else:
+        assert st["n_quat_fallback"] == 0
 
 
 def test_verify_brute_equals_tree(orc, golden_dir):
