@@ -386,6 +386,38 @@ def cpu_baseline(w, budget_s):
                      f"{best['hypotheses_in_sample']} best of them with {best['threads']} OpenMP threads; each stage the median of 5 after a warm-up; "
                      f"end-to-end = H / (t_gen B/{n_bases_s} + H (t_icp + t_lcp) / {best['hypotheses_in_sample']}) with H = {H}")
     out["what_cannot_be_timed"] = "the reference's own PCL / Armadillo path (libraries absent); its OpenGR generator was timed in the build container: profiles/r03_ref_generator_c2.json"
+    # kind "reference" for the one stage whose reference code builds: the reference's OWN generator (its OpenGR fork compiled in place in
+    # the build container, g++ -O2, oracle/_ref/libref_s4pcs_o2.so travels with the snapshot) on the same C2 clouds on this box's host
+    # cores, one thread, ONE ComputeTransformation call = its 30 base trials (congruentSetExplorationBase.hpp:90-100), beside the port.
+    o2 = os.path.join(ROOT, "oracle", "_ref", "libref_s4pcs_o2.so")
+    if os.path.exists(o2):
+        saved = (orc.REF_SO, orc._ref)
+        try:
+            threads(1)
+            orc.REF_SO, orc._ref = o2, None
+            P, Pn, Pc = sc.xyz[keep], sc.nrm[keep], sc.conf[keep]
+
+            def ref_gen():
+                r = orc.RefS4PCS(success_quadrilaterals=10 ** 6, record_pairs=False, plain=True)
+                r.set_keys(w.keys)
+                with orc.quiet_stdout():
+                    return r.run(P, Pn, Pc, mx, mn, 1)
+
+            def port_gen():
+                oo = orc.OracleS4PCS(success_quadrilaterals=10 ** 6)
+                oo.set_keys(w.keys)
+                return oo.run(P, Pn, Pc, mx, mn, 1)
+            t_ref, n_ref = med5(ref_gen)
+            t_port, n_port = med5(port_gen)
+            out["reference_generator"] = {"kind": "reference", "what": "the reference's OpenGR matcher (g++ -O2 build of its own sources), untouched, one thread, 30 base trials, same clouds",
+                                          "hypotheses": int(n_ref), "median_s": t_ref, "R_gen_hyp_per_s": n_ref / t_ref,
+                                          "port_same_inputs": {"hypotheses": int(n_port), "median_s": t_port, "R_gen_hyp_per_s": n_port / t_port},
+                                          "same_hypothesis_count": int(n_ref) == int(n_port)}
+        except Exception as e:  # the line must survive a box where the prebuilt file does not load
+            out["reference_generator"] = {"kind": "reference", "failed": f"{type(e).__name__}: {e}"}
+        finally:
+            orc.REF_SO, orc._ref = saved
+            threads(logical)
     return out
 
 

@@ -63,6 +63,10 @@ def quiet_stdout():
     try:
         yield
     finally:
+        try:
+            C.CDLL(None).fflush(None)   # what the C++ side left in stdio's buffer goes to /dev/null too, not to the caller's stdout at exit
+        except (OSError, AttributeError):
+            pass
         os.dup2(saved, 1)
         os.close(devnull)
         os.close(saved)
