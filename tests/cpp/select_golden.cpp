@@ -37,6 +37,12 @@ int main(int argc, char** argv) {
   o.max_time_seconds = 0, o.n_trials = 30, o.random_seed = 5489u, o.max_normal_difference = -1, o.max_color_distance = -1, o.verify_mode = 0;
   GenHost G(&gen, o);
   G.init_clouds();
+  // MatchBase::init's state (sampling.h:67-144, matchBase.hpp:380-462): sampled, centred Q; centroids; diameter -- as bit patterns
+  std::printf("state %d %08x %08x %08x %08x %08x %08x %08x\n", gen.gq_h.n, f2u(gen.centroid_p[0]), f2u(gen.centroid_p[1]), f2u(gen.centroid_p[2]),
+              f2u(gen.centroid_q[0]), f2u(gen.centroid_q[1]), f2u(gen.centroid_q[2]), f2u(gen.diameter));
+  for (int k = 0; k < gen.gq_h.n; ++k)
+    std::printf("q %08x %08x %08x %08x %08x %08x\n", f2u(gen.gq_h.x[k]), f2u(gen.gq_h.y[k]), f2u(gen.gq_h.z[k]), f2u(gen.gq_h.nx[k]), f2u(gen.gq_h.ny[k]),
+                f2u(gen.gq_h.nz[k]));
   std::vector<unsigned> bitmap;
   int dist_bins = 0;
   build_key_bitmap(keys.data(), nkeys, bitmap, dist_bins);

@@ -55,6 +55,13 @@ def test_product_host_selection_against_the_reference_build(select_golden_exe, g
         ids = np.array([[int(v) for v in x[:4]] for x in rows], np.int32).reshape(-1, 4)
         inv = np.array([[int(v, 16) for v in x[4:]] for x in rows], np.uint32).reshape(-1, 2).view(np.float32)
         outs.append((ids, inv))
+        # sampling, centring, diameter (rows B0 / B2): bit-equal to the reference build
+        st = [ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith("state ")][0]
+        f32 = lambda xs: np.array([int(v, 16) for v in xs], np.uint32).view(np.float32)
+        assert int(st[0]) == len(g["Qs"])
+        assert np.array_equal(f32(st[1:4]), g["cP"]) and np.array_equal(f32(st[4:7]), g["cQ"]) and f32(st[7:8])[0] == g["diameter"]
+        q = np.array([[int(v, 16) for v in ln.split()[1:]] for ln in r.stdout.splitlines() if ln.startswith("q ")], np.uint32).view(np.float32)
+        assert np.array_equal(q[:, :3], g["Qs"]) and np.array_equal(q[:, 3:], g["Qs_nrm"])
         k, skipped = 0, 0
         for b, iv in zip(g["base_ids"], g["base_inv"]):
             while k < len(ids) and not (np.array_equal(ids[k], b) and np.array_equal(inv[k], iv)):
