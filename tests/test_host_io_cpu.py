@@ -175,6 +175,10 @@ def test_cpp_dataset_driver_gathers_the_frame_poses(hop, tmp_path):
     lines = open(os.path.join(base, "ellipse", "model2scene_all.txt")).read().strip().splitlines()
     got = [(ln.split()[0], int(ln.split()[1])) for ln in lines]
     assert got == sorted(truth), "frames in the order of the listing: record, then frame index"
+    # the Python runner numbers the frames of its gather from the same listing (run_real_all.py main): rows of the two drivers are interchangeable
+    mdir = os.path.join(base, "ellipse")
+    py_keys = [(rec, i) for rec in sorted(d for d in os.listdir(mdir) if os.path.isdir(os.path.join(mdir, d))) for i in rr.raw_frame_indices(os.path.join(mdir, rec))]
+    assert py_keys == got
     for ln in lines:
         t = ln.split()
         assert np.array_equal(np.array(t[2:], np.float32).reshape(4, 4), truth[(t[0], int(t[1]))])    # %.9g round-trips a float
