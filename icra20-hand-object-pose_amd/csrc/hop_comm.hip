@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/hop.h"
+#include "hop_math.h"
 
 namespace {
 
@@ -103,22 +104,49 @@ struct DeviceGuard {
     if (prev >= 0) (void)hipSetDevice(prev);
   }
 };
-std::string& process_error() {
+// errors that have no communicator to hang on (hop_comm_unique_id, hop_comm_create): one string per process, written and read under a
+// lock (several host threads may create communicators at once); the reader gets a thread-local copy, so the pointer it hands out stays
+// valid while another thread writes
+std::mutex& process_error_lock() {
+  static std::mutex m;
+  return m;
+}
+std::string& process_error_unlocked() {
   static std::string e;
   return e;
+}
+void set_process_error(const std::string& e) {
+  std::lock_guard<std::mutex> lk(process_error_lock());
+  process_error_unlocked() = e;
+}
+const char* process_error_cstr() {
+  static thread_local std::string copy;
+  std::lock_guard<std::mutex> lk(process_error_lock());
+  copy = process_error_unlocked();
+  return copy.c_str();
 }
 std::string nccl_err(const char* what, int rc) {
   Rccl& r = rccl();
   return std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "error") + " (" + std::to_string(rc) + ")";
 }
 
+// a HIP call inside an exchange: on failure the communicator's error string says which call and why, and the stream is drained so
+// that nothing queued before the failure still runs when the caller reacts
+#define COMM_HIP(c, call)                                                                  \
+  do {                                                                                     \
+    const hipError_t e__ = (call);                                                         \
+    if (e__ != hipSuccess) {                                                               \
+      (c)->last_error = std::string(#call) + ": " + hipGetErrorString(e__);                \
+      (void)hipStreamSynchronize((c)->stream);                                             \
+      return HOP_E_HIP;                                                                    \
+    }                                                                                      \
+  } while (0)
+
 // HypoCompare key of a row: descending score, then ascending id, as one ascending 64-bit key; empty rows (id < 0) last
 __device__ __forceinline__ unsigned long long row_key(const float* row) {
   const int id = __float_as_int(row[1]);
   if (id < 0) return ~0ull;
-  unsigned u = __float_as_uint(row[0]);
-  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-  return ((unsigned long long)(~u) << 32) | (unsigned)id;
+  return ((unsigned long long)(~hop::score_order_key(row[0])) << 32) | (unsigned)id;
 }
 // merge of the gathered tables on the device: one workgroup sorts the n_rows (<= 4096) keys with their row numbers (bitonic, LDS)
 // and writes the k best rows -- the order hop_topk_merge produces on the host (stable_sort by the same comparator; ids are unique)
@@ -166,12 +194,12 @@ int hop_comm_unique_id(unsigned char id_out[HOP_COMM_ID_BYTES]) {
   if (!id_out) return HOP_E_INVALID;
   Rccl& r = rccl();
   if (!r.ok) {
-    process_error() = r.error;
+    set_process_error(r.error);
     return HOP_E_COMM;
   }
   NcclId id;
   if (const int rc = r.GetUniqueId(&id)) {
-    process_error() = nccl_err("ncclGetUniqueId", rc);
+    set_process_error(nccl_err("ncclGetUniqueId", rc));
     return HOP_E_COMM;
   }
   std::memcpy(id_out, id.internal, HOP_COMM_ID_BYTES);
@@ -183,7 +211,7 @@ int hop_comm_create(int device, const unsigned char id[HOP_COMM_ID_BYTES], int r
   *out = nullptr;
   Rccl& r = rccl();
   if (!r.ok) {
-    process_error() = r.error;
+    set_process_error(r.error);
     return HOP_E_COMM;
   }
   DeviceGuard dg(device);
@@ -195,7 +223,7 @@ int hop_comm_create(int device, const unsigned char id[HOP_COMM_ID_BYTES], int r
   const int rc = r.CommInitRank(&c->comm, world, nid, rank);
   hipError_t he = hipSuccess;
   if (rc != 0 || (he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
-    process_error() = rc != 0 ? nccl_err("ncclCommInitRank", rc) : std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(he);
+    set_process_error(rc != 0 ? nccl_err("ncclCommInitRank", rc) : std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(he));
     if (c->comm) r.CommDestroy(c->comm);
     delete c;
     return HOP_E_COMM;
@@ -221,7 +249,8 @@ void hop_comm_destroy(hop_comm* c) {
 
 const char* hop_comm_last_error(const hop_comm* c) {
   if (c) return c->last_error.c_str();
-  return process_error().empty() ? rccl().error.c_str() : process_error().c_str();
+  const char* e = process_error_cstr();
+  return *e ? e : rccl().error.c_str();
 }
 
 // ranks of the communicator as RCCL reports them (ncclCommCount), and the mean wall time of the exchanges so far
@@ -243,8 +272,10 @@ static int ensure_topk_buffers(hop_comm* c, int k) {
     if (c->merged) (void)hipFree(c->merged);
     c->send = c->recv = c->merged = nullptr;
     if (hipMalloc(&c->send, sizeof(float) * row_floats) != hipSuccess || hipMalloc(&c->recv, sizeof(float) * row_floats * c->world) != hipSuccess ||
-        hipMalloc(&c->merged, sizeof(float) * row_floats) != hipSuccess)
+        hipMalloc(&c->merged, sizeof(float) * row_floats) != hipSuccess) {
+      c->last_error = "hipMalloc of the exchange buffers failed";
       return HOP_E_ALLOC;
+    }
     c->k_cap = k;
   }
   return HOP_OK;
@@ -257,21 +288,25 @@ int hop_topk_allgather_device(hop_comm* c, const float* rows_dev, int k, float* 
   if (!c || !rows_dev || !merged_out || k <= 0) return HOP_E_INVALID;
   Rccl& r = rccl();
   DeviceGuard dg(c->device);
-  if (!dg.ok) return HOP_E_HIP;
+  if (!dg.ok) {
+    c->last_error = "hipSetDevice failed for the communicator's device";
+    return HOP_E_HIP;
+  }
   if (const int rc = ensure_topk_buffers(c, k)) return rc;
   const size_t row_floats = (size_t)k * HOP_TOPK_ROW_FLOATS;
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = r.AllGather(rows_dev, c->recv, row_floats, 7 /* ncclFloat32 */, c->comm, c->stream);
   if (rc != 0) {
     c->last_error = nccl_err("ncclAllGather", rc);
+    (void)hipStreamSynchronize(c->stream);
     return HOP_E_COMM;
   }
   const int n_rows = k * c->world;
   int status = HOP_OK;
   if (n_rows <= MERGE_MAX) {
     hipLaunchKernelGGL(k_topk_merge, dim3(1), dim3(1024), 0, c->stream, c->recv, n_rows, k, c->merged);
-    if (hipMemcpyAsync(merged_out, c->merged, sizeof(float) * row_floats, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return HOP_E_HIP;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return HOP_E_HIP;
+    COMM_HIP(c, hipMemcpyAsync(merged_out, c->merged, sizeof(float) * row_floats, hipMemcpyDeviceToHost, c->stream));
+    COMM_HIP(c, hipStreamSynchronize(c->stream));
     if (n_rows_out) {
       int m = 0;
       for (int q = 0; q < k; ++q) {
@@ -283,8 +318,8 @@ int hop_topk_allgather_device(hop_comm* c, const float* rows_dev, int k, float* 
     }
   } else {
     std::vector<float> all(row_floats * c->world);
-    if (hipMemcpyAsync(all.data(), c->recv, sizeof(float) * row_floats * c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return HOP_E_HIP;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return HOP_E_HIP;
+    COMM_HIP(c, hipMemcpyAsync(all.data(), c->recv, sizeof(float) * row_floats * c->world, hipMemcpyDeviceToHost, c->stream));
+    COMM_HIP(c, hipStreamSynchronize(c->stream));
     status = hop_topk_merge(all.data(), c->world, k, merged_out, n_rows_out);
   }
   c->exchange_us_sum += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -300,26 +335,33 @@ int hop_frames_allgather(hop_comm* c, const float* rows_local, int n_local, int 
   if (!c || !all_out || n_local < 0 || rows_per_rank <= 0 || n_local > rows_per_rank || (n_local > 0 && !rows_local)) return HOP_E_INVALID;
   Rccl& r = rccl();
   DeviceGuard dg(c->device);
-  if (!dg.ok) return HOP_E_HIP;
+  if (!dg.ok) {
+    c->last_error = "hipSetDevice failed for the communicator's device";
+    return HOP_E_HIP;
+  }
   const size_t nf = (size_t)rows_per_rank * HOP_FRAME_ROW_FLOATS;
   if (nf > c->f_cap) {
     if (c->fsend) (void)hipFree(c->fsend);
     if (c->frecv) (void)hipFree(c->frecv);
     c->fsend = c->frecv = nullptr;
-    if (hipMalloc(&c->fsend, sizeof(float) * nf) != hipSuccess || hipMalloc(&c->frecv, sizeof(float) * nf * c->world) != hipSuccess) return HOP_E_ALLOC;
+    if (hipMalloc(&c->fsend, sizeof(float) * nf) != hipSuccess || hipMalloc(&c->frecv, sizeof(float) * nf * c->world) != hipSuccess) {
+      c->last_error = "hipMalloc of the frame-table buffers failed";
+      return HOP_E_ALLOC;
+    }
     c->f_cap = nf;
   }
   std::vector<float> pad(nf, 0.f);
   for (int q = 0; q < rows_per_rank; ++q) pad[(size_t)q * HOP_FRAME_ROW_FLOATS] = -1.f;
   if (n_local > 0) std::memcpy(pad.data(), rows_local, sizeof(float) * (size_t)n_local * HOP_FRAME_ROW_FLOATS);
-  if (hipMemcpyAsync(c->fsend, pad.data(), sizeof(float) * nf, hipMemcpyHostToDevice, c->stream) != hipSuccess) return HOP_E_HIP;
+  COMM_HIP(c, hipMemcpyAsync(c->fsend, pad.data(), sizeof(float) * nf, hipMemcpyHostToDevice, c->stream));
   const int rc = r.AllGather(c->fsend, c->frecv, nf, 7 /* ncclFloat32 */, c->comm, c->stream);
   if (rc != 0) {
     c->last_error = nccl_err("ncclAllGather", rc);
+    (void)hipStreamSynchronize(c->stream);
     return HOP_E_COMM;
   }
-  if (hipMemcpyAsync(all_out, c->frecv, sizeof(float) * nf * c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return HOP_E_HIP;
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return HOP_E_HIP;
+  COMM_HIP(c, hipMemcpyAsync(all_out, c->frecv, sizeof(float) * nf * c->world, hipMemcpyDeviceToHost, c->stream));
+  COMM_HIP(c, hipStreamSynchronize(c->stream));
   return HOP_OK;
 }
 
@@ -330,19 +372,23 @@ int hop_topk_allgather(hop_comm* c, const float* rows_in, int k, float* merged_o
   if (!c || !rows_in || !merged_out || k <= 0) return HOP_E_INVALID;
   Rccl& r = rccl();
   DeviceGuard dg(c->device);
-  if (!dg.ok) return HOP_E_HIP;
+  if (!dg.ok) {
+    c->last_error = "hipSetDevice failed for the communicator's device";
+    return HOP_E_HIP;
+  }
   if (const int rc = ensure_topk_buffers(c, k)) return rc;
   const size_t row_floats = (size_t)k * HOP_TOPK_ROW_FLOATS;
   std::vector<float> all(row_floats * c->world);
   const auto t0 = std::chrono::steady_clock::now();
-  if (hipMemcpyAsync(c->send, rows_in, sizeof(float) * row_floats, hipMemcpyHostToDevice, c->stream) != hipSuccess) return HOP_E_HIP;
+  COMM_HIP(c, hipMemcpyAsync(c->send, rows_in, sizeof(float) * row_floats, hipMemcpyHostToDevice, c->stream));
   const int rc = r.AllGather(c->send, c->recv, row_floats, 7 /* ncclFloat32 */, c->comm, c->stream);
   if (rc != 0) {
     c->last_error = nccl_err("ncclAllGather", rc);
+    (void)hipStreamSynchronize(c->stream);
     return HOP_E_COMM;
   }
-  if (hipMemcpyAsync(all.data(), c->recv, sizeof(float) * row_floats * c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return HOP_E_HIP;
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return HOP_E_HIP;
+  COMM_HIP(c, hipMemcpyAsync(all.data(), c->recv, sizeof(float) * row_floats * c->world, hipMemcpyDeviceToHost, c->stream));
+  COMM_HIP(c, hipStreamSynchronize(c->stream));
   c->exchange_us_sum += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   c->exchange_count += 1;
   return hop_topk_merge(all.data(), c->world, k, merged_out, n_rows_out);

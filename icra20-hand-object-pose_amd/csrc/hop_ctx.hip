@@ -1747,8 +1747,8 @@ int hop_topk_merge(const float* tables, int n_tables, int k, float* rows_out, in
       if (id >= 0) rows.push_back(row);
     }
   std::stable_sort(rows.begin(), rows.end(), [](const float* a, const float* b) {
-    if (a[0] > b[0]) return true;
-    if (a[0] < b[0]) return false;
+    const uint32_t ka = score_order_key(a[0]), kb = score_order_key(b[0]);  // (the key the device sorts by: -0 = +0, NaN last)
+    if (ka != kb) return ka > kb;
     int ia, ib;
     std::memcpy(&ia, &a[1], 4);
     std::memcpy(&ib, &b[1], 4);

@@ -779,13 +779,11 @@ __global__ void k_iota(unsigned* p, int n) {
   if (t < n) p[t] = (unsigned)t;
 }
 __global__ void k_score_keys(const float* __restrict__ score, const int* __restrict__ ids, int n, unsigned long long* __restrict__ key) {
-  // descending score, then ascending id, as one ascending 64-bit key (scores are finite and >= 0 here;
-  // negative scores are ordered correctly by the sign-flip trick)
+  // descending score, then ascending id, as one ascending 64-bit key (score_order_key: -0 = +0, NaN below every number -- the
+  // same key the host's hop_topk_merge and the device merge of hop_comm.hip order by)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  unsigned u = __float_as_uint(score[t]);
-  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending float order
-  key[t] = ((unsigned long long)(~u) << 32) | (unsigned)ids[t];
+  key[t] = ((unsigned long long)(~score_order_key(score[t])) << 32) | (unsigned)ids[t];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -55,6 +55,21 @@ HOP_HD float sqdist_flann(V3 a, V3 b) {
   return (dx * dx + dy * dy) + dz * dz;
 }
 
+// HypoCompare order of a score as an unsigned key that ASCENDS with the score: used by every sort / merge of (score, id) rows on the
+// device and on the host, so the two cannot disagree.  Canonical form: -0 counts as +0 and a NaN score as lower than every number
+// (float comparison would make NaN "equal" to everything, which is no order at all).
+HOP_HD uint32_t score_order_key(float s) {
+  if (s != s) return 0u;
+  if (s == 0.f) s = 0.f;  // (-0 -> +0)
+  uint32_t u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  u = __float_as_uint(s);
+#else
+  memcpy(&u, &s, 4);
+#endif
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 struct M4 {
   float m[16];  // row-major
 };

@@ -40,7 +40,11 @@ inline void read_png16(const std::string& path, std::vector<uint16_t>& raw, int&
     const size_t data = pos + 8;
     if (data + len + 4 > buf.size()) throw std::runtime_error("truncated PNG: " + path);
     if (type == "IHDR") {
-      W = (int)be32(data), H = (int)be32(data + 4);
+      if (len != 13) throw std::runtime_error("PNG with an IHDR chunk of " + std::to_string(len) + " bytes (13 expected): " + path);
+      const uint32_t w32 = be32(data), h32 = be32(data + 4);
+      // (bounded before anything is sized from them: a corrupt header must not turn into a multi-gigabyte allocation)
+      if (w32 == 0 || h32 == 0 || w32 > 16384u || h32 > 16384u) throw std::runtime_error("PNG with implausible dimensions " + std::to_string(w32) + " x " + std::to_string(h32) + ": " + path);
+      W = (int)w32, H = (int)h32;
       depth = buf[data + 8], ctype = buf[data + 9], interlace = buf[data + 12];
     } else if (type == "IDAT")
       idat.insert(idat.end(), buf.begin() + data, buf.begin() + data + len);

@@ -9,8 +9,8 @@
 //   HOP_GATHER=1 (BASELINE configs[3], "frames sharded over the GPUs, RCCL gather of per-frame best pose"): at the end of its shard every
 //   rank contributes its frames' poses to ONE hop_frames_allgather (ncclAllGather inside libhop.so); rank 0 writes them all to
 //   <base>/<model>/model2scene_all.txt ("record index m00 ... m33" per frame).  The 128-byte RCCL id travels through the file
-//   HOP_COMM_ID_FILE (default <base>/<model>/.hop_comm_id[.<MASTER_PORT>]: the ranks share the dataset directory already); one rank
-//   needs no communicator.  Same table as run_real_all.gather_frame_poses of the Python runner.
+//   HOP_COMM_ID_FILE (default <base>/<model>/.hop_comm_id[.<MASTER_PORT>][.<HOP_RUN_ID>]: the ranks share the dataset directory already;
+//   see comm_through_file for how a stale file and a failed rank are handled); one rank needs no communicator.  Same table as run_real_all.gather_frame_poses of the Python runner.
 // assets_dir holds what the reference loads from PLY / OBJ / Boost archive / URDF files (download links): see hop::Assets (host/Frame.h).
 #include <dirent.h>
 #include <sys/stat.h>
@@ -61,11 +61,43 @@ struct FrameJob {
 
 // The launcher's side of hop_comm_unique_id / hop_comm_create (include/hop.h: "the launcher hands the 128 bytes to the other ranks (any
 // channel)"): rank 0 publishes the id in a file next to the frames (written under another name and renamed, so a reader never sees half
-// of it), the others wait for it.  Rank 0 removes a file left by a killed run when it starts and its own once the collective has
-// returned -- by then every rank has read it.
+// of it), the others wait for it.  What keeps a file of ANOTHER run from being taken for this one's:
+//   * the name carries the launch's MASTER_PORT and, if the launcher sets one, HOP_RUN_ID (a per-launch nonce);
+//   * a waiting rank only accepts a file written after its own start minus HOP_COMM_STALE_S (default 120 s: the ranks of one launch start
+//     together) -- the 128 bytes a killed run left behind are older than that and are ignored even if rank 0 has not yet removed them;
+//   * rank 0 removes a left-over file when it starts and its own once the collective has returned (every rank has read it by then).
+// A rank that fails in its shard publishes <id_file>.abort with the reason: ranks still waiting for the id stop with that reason instead of
+// sitting out HOP_COMM_WAIT_S, and rank 0 does not publish an id any more (no rank is led into a collective that cannot complete).
+static double file_age_before(const std::string& path, double t_ref) {  // seconds by which the file's mtime precedes t_ref (< 0: written later)
+  struct stat st;
+  if (stat(path.c_str(), &st) != 0) return 1e300;
+  return t_ref - ((double)st.st_mtim.tv_sec + 1e-9 * (double)st.st_mtim.tv_nsec);
+}
+static double wall_now() {
+  timespec ts;
+  clock_gettime(CLOCK_REALTIME, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static const double g_start = wall_now();
+static double stale_s() { return std::getenv("HOP_COMM_STALE_S") ? std::atof(std::getenv("HOP_COMM_STALE_S")) : 120.0; }
+static bool abort_published(const std::string& id_file, std::string& why) {
+  const std::string a = id_file + ".abort";
+  if (file_age_before(a, g_start) > stale_s()) return false;  // none, or one an earlier run left
+  std::ifstream f(a);
+  std::getline(f, why);
+  return true;
+}
+static void publish_abort(const std::string& id_file, int rank, const std::string& why) {
+  std::ofstream f(id_file + ".abort.tmp" + std::to_string(rank));
+  f << "rank " << rank << ": " << why << "\n";
+  f.close();
+  std::rename((id_file + ".abort.tmp" + std::to_string(rank)).c_str(), (id_file + ".abort").c_str());
+}
 static hop_comm* comm_through_file(const std::string& id_file, int device, int rank, int world) {
   unsigned char id[HOP_COMM_ID_BYTES];
+  std::string why;
   if (rank == 0) {
+    if (abort_published(id_file, why)) throw std::runtime_error("another rank gave up before the gather: " + why);
     if (hop_comm_unique_id(id) != HOP_OK) throw std::runtime_error(std::string("hop_comm_unique_id: ") + hop_comm_last_error(nullptr));
     {
       std::ofstream f(id_file + ".tmp", std::ios::binary);
@@ -77,8 +109,11 @@ static hop_comm* comm_through_file(const std::string& id_file, int device, int r
     const double wait_s = std::getenv("HOP_COMM_WAIT_S") ? std::atof(std::getenv("HOP_COMM_WAIT_S")) : 3600.0;  // rank 0 may still be in its shard
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
-      std::ifstream f(id_file, std::ios::binary);
-      if (f && f.read(reinterpret_cast<char*>(id), sizeof id)) break;
+      if (abort_published(id_file, why)) throw std::runtime_error("another rank gave up before the gather: " + why);
+      if (file_age_before(id_file, g_start) <= stale_s()) {  // (an older file is a killed run's: not this launch's id)
+        std::ifstream f(id_file, std::ios::binary);
+        if (f && f.read(reinterpret_cast<char*>(id), sizeof id)) break;
+      }
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_s)
         throw std::runtime_error("rank 0 did not publish the RCCL id in " + id_file);
       usleep(20000);
@@ -88,6 +123,9 @@ static hop_comm* comm_through_file(const std::string& id_file, int device, int r
   if (hop_comm_create(device, id, rank, world, &comm) != HOP_OK) throw std::runtime_error(std::string("hop_comm_create: ") + hop_comm_last_error(nullptr));
   return comm;
 }
+
+static std::string g_id_file;  // set once the gather of a multi-rank run is known to be wanted: where a failure is announced
+static int g_rank = 0;
 
 int main(int argc, char** argv) {
   if (argc < 4) {
@@ -109,7 +147,10 @@ int main(int argc, char** argv) {
     const bool gather = std::getenv("HOP_GATHER") != nullptr;
     std::string id_file = std::getenv("HOP_COMM_ID_FILE") ? std::getenv("HOP_COMM_ID_FILE") : mdir + "/.hop_comm_id";
     if (!std::getenv("HOP_COMM_ID_FILE") && std::getenv("MASTER_PORT")) id_file += std::string(".") + std::getenv("MASTER_PORT");
-    if (gather && world > 1 && rank == 0) std::remove(id_file.c_str());
+    if (!std::getenv("HOP_COMM_ID_FILE") && std::getenv("HOP_RUN_ID")) id_file += std::string(".") + std::getenv("HOP_RUN_ID");
+    g_id_file = gather && world > 1 ? id_file : std::string();
+    g_rank = rank;
+    if (gather && world > 1 && rank == 0) std::remove(id_file.c_str()), std::remove((id_file + ".abort").c_str());
     const std::regex rgb_re("rgb([0-9]+)\\..*");
     for (const std::string& record : list_dir(mdir, true)) {
       const std::string rec = mdir + "/" + record;
@@ -253,6 +294,7 @@ int main(int argc, char** argv) {
     return 0;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
+    if (!g_id_file.empty()) publish_abort(g_id_file, g_rank, e.what());  // the ranks waiting for the gather stop too
     return 3;
   }
 }

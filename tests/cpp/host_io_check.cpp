@@ -18,6 +18,20 @@ int main(int argc, char** argv) {
     }
   }
   if (argc < 5) return 2;
+  if (std::string(argv[1]) == "-") {  // the PNG reader alone: "png H W sum"
+    try {
+      std::vector<uint16_t> d;
+      int H = 0, W = 0;
+      hop::read_png16(argv[2], d, H, W);
+      uint64_t sum = 0;
+      for (uint16_t v : d) sum += v;
+      std::printf("png %d %d %" PRIu64 "\n", H, W, sum);
+      return 0;
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "error: %s\n", e.what());
+      return 3;
+    }
+  }
   try {
     ConfigParser cfg(argv[1]);
     const hop::Calibration cal(cfg);

@@ -107,6 +107,22 @@ def test_topk_merge_is_hypocompare_order(api):
     assert [(float(s), int(i)) for s, i in zip(score, ids)] == [(float(a), b) for a, b in exp]
 
 
+def test_topk_merge_orders_by_the_canonical_key(api):
+    """the device merge sorts by a bit-pattern key, the host by float comparison -- they disagreed on -0 vs +0 and on NaN.  Both
+    now order by hop::score_order_key (csrc/hop_math.h): -0 counts as +0 (ties by id), a NaN score sorts below every number; this is
+    the host side (the device side: tests/test_gpu_pipeline.py, same rows)."""
+    k = 6
+    scores = [0.0, -0.0, float("nan"), 1.5, -2.0, float("-inf")]
+    ids = [5, 4, 1, 9, 2, 3]
+    t = np.zeros((1, k, api.TOPK_ROW_FLOATS), np.float32)
+    for r, (sc, i) in enumerate(zip(scores, ids)):
+        t[0, r, 0] = sc
+        t[0, r, 1:2] = np.array([i], np.int32).view(np.float32)
+    out, n = api.topk_merge(t, k)
+    assert n == k
+    assert out.reshape(k, -1)[:, 1].copy().view(np.int32).tolist() == [9, 4, 5, 2, 3, 1]   # 1.5 | -0 (id 4) before +0 (id 5) | -2 | -inf | NaN last
+
+
 def test_cluster_poses_host_matches_oracle(api, orc, hop):
     synth = hop.synth
     sc = synth.make_scene(200, seed=3)

@@ -2,6 +2,7 @@
 run_real_all.cpp:116-133) against the Python mirror on the same files -- CPU only: nothing here creates a context."""
 import os
 import subprocess
+import time
 
 import numpy as np
 import pytest
@@ -118,6 +119,31 @@ def test_cpp_config_parser_reads_the_shipped_yaml_like_pyyaml(checker, hop):
     assert hop_config.load_config(path)["model_name"] == cpp["model_name"].strip()
 
 
+def test_cpp_png_reader_rejects_corrupt_headers(checker, tmp_path):
+    """A short IHDR chunk or absurd dimensions end in an error message, not in a read past the buffer or a multi-gigabyte allocation
+    (Frame.h read_png16 trusted both)."""
+    import struct
+    import zlib
+
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xffffffff)
+    sig = b"\x89PNG\r\n\x1a\n"
+    good_ihdr = struct.pack(">IIBBBBB", 4, 2, 16, 0, 0, 0, 0)
+    idat = zlib.compress(b"".join(b"\x00" + bytes(8) for _ in range(2)))
+    cases = {"short_ihdr": sig + chunk(b"IHDR", good_ihdr[:9]) + chunk(b"IEND", b""),          # IHDR as the last bytes of the file, too short
+             "huge": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 0x7fffffff, 0x7fffffff, 16, 0, 0, 0, 0)) + chunk(b"IDAT", idat) + chunk(b"IEND", b""),
+             "zero": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 0, 2, 16, 0, 0, 0, 0)) + chunk(b"IDAT", idat) + chunk(b"IEND", b"")}
+    for name, blob in cases.items():
+        png = tmp_path / f"{name}.png"
+        png.write_bytes(blob)
+        r = subprocess.run([checker, "-", str(png), "-", "-"], capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and ("IHDR" in r.stderr or "implausible" in r.stderr), (name, r.stdout, r.stderr)
+    ok = tmp_path / "ok.png"
+    ok.write_bytes(sig + chunk(b"IHDR", good_ihdr) + chunk(b"IDAT", idat) + chunk(b"IEND", b""))
+    r = subprocess.run([checker, "-", str(ok), "-", "-"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.split()[:3] == ["png", "2", "4"], r.stdout + r.stderr
+
+
 def test_cpp_dataset_driver_resumes_and_shards_without_touching_a_device(hop, tmp_path):
     """host/app/run_real_all on a record whose frames all have results: it lists the reference's layout (run_real_all.cpp:72-104), takes
     this rank's share (frame index mod WORLD_SIZE) and, with nothing left to compute, creates no context -- so this runs without a GPU"""
@@ -186,3 +212,17 @@ def test_cpp_dataset_driver_gathers_the_frame_poses(hop, tmp_path):
     r = subprocess.run([exe, cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=60,
                        env=dict(env, HOP_GATHER="1", RANK="1", WORLD_SIZE="2", MASTER_PORT="29999", HOP_COMM_WAIT_S="0.3"))
     assert r.returncode == 3 and "rank 0 did not publish the RCCL id in" in r.stderr and ".hop_comm_id.29999" in r.stderr, r.stdout + r.stderr
+    # ... it says so too when the only id in the directory is the one a killed run left behind (older than this launch: ADVICE r03) ...
+    stale = os.path.join(mdir, ".hop_comm_id.29999.launch7")
+    open(stale, "wb").write(bytes(128))
+    old = time.time() - 600
+    os.utime(stale, (old, old))
+    r = subprocess.run([exe, cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=60,
+                       env=dict(env, HOP_GATHER="1", RANK="1", WORLD_SIZE="2", MASTER_PORT="29999", HOP_RUN_ID="launch7", HOP_COMM_WAIT_S="0.3"))
+    assert r.returncode == 3 and "rank 0 did not publish the RCCL id in" in r.stderr and ".hop_comm_id.29999.launch7" in r.stderr, r.stdout + r.stderr
+    assert open(os.path.join(mdir, ".hop_comm_id.29999.launch7.abort")).read().startswith("rank 1: rank 0 did not publish"), "a rank that gives up announces it"
+    # ... and a rank that finds another rank's announcement stops at once with that rank's reason instead of waiting
+    t0 = time.time()
+    r = subprocess.run([exe, cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=60,
+                       env=dict(env, HOP_GATHER="1", RANK="1", WORLD_SIZE="2", MASTER_PORT="29999", HOP_RUN_ID="launch7", HOP_COMM_WAIT_S="30"))
+    assert r.returncode == 3 and "another rank gave up before the gather: rank 1: rank 0 did not publish" in r.stderr and time.time() - t0 < 10, r.stdout + r.stderr
