@@ -1355,12 +1355,13 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
   const bool cells = o->nn_mode >= 2;
   bool lm_mode = o->nn_mode == 5;   // the reference's Levenberg-Marquardt minimiser (csrc/hop_icp_lm.hip), float-faithful, one pass per evaluation
   bool lm6_mode = o->nn_mode == 6;  // the same minimiser from the moment matrix of the correspondences: one pass per ICP iteration
-  if (o->nn_mode < 0 || o->nn_mode > 6) return HOP_E_INVALID;
+  bool lm7_mode = o->nn_mode == 7;  // the moment form with integer-exact sums and IEEE operations only: the bits the oracle's minimiser 7 returns
+  if (o->nn_mode < 0 || o->nn_mode > 7) return HOP_E_INVALID;
   const size_t per_h = cells ? sizeof(int) * (size_t)S.n : sizeof(float) * 6 * (size_t)S.n;
   const size_t ws_cap = cells ? ((size_t)4 << 30) : ((size_t)1 << 30);
   const int HB = (int)std::max<size_t>(1, std::min<size_t>((size_t)H, ws_cap / per_h));
   if (!cells) HIPCHK(c, c->icp_moved.ensure(per_h * HB));
-  HIPCHK(c, c->icp_partial.ensure(sizeof(double) * (size_t)std::max(ICP_NACC, ICP_NMOM_STRIDE) * (size_t)nb * HB));
+  HIPCHK(c, c->icp_partial.ensure(sizeof(double) * (size_t)std::max(std::max(ICP_NACC, ICP_NMOM_STRIDE), ICP_NMOMI_STRIDE) * (size_t)nb * HB));
   HIPCHK(c, c->icp_state.ensure(sizeof(IcpState) * (size_t)HB));
   HIPCHK(c, c->icp_iters.ensure(sizeof(int) * (size_t)H));
   HIPCHK(c, c->icp_conv.ensure(sizeof(int) * (size_t)H));
@@ -1386,7 +1387,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
   } else if (cells) {
     // cells of a sixth of the gating distance for the plain lists (nn_mode 2), a seventh for the packed ones (measured:
     // 6 / 7 / 8 / 10 / 12 -> 819 / 784 / 789 / 845 / 925 us per launch at C2)
-    const bool packed_mode = o->nn_mode == 3 || o->nn_mode == 4 || lm6_mode;
+    const bool packed_mode = o->nn_mode == 3 || o->nn_mode == 4 || lm6_mode || lm7_mode;
     float cell = o->max_corr_dist / (packed_mode ? 7.f : 6.f);
     if (const char* e = getenv("HOP_ICP_CELL_DIV")) cell = o->max_corr_dist / (float)atof(e);
     CellListStore& cs = c->model_cells[HOP_MODEL_5MM];
@@ -1398,7 +1399,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     a.cells = cs.c;
     // nn_mode 6 needs the packed lists; a model of >= 65535 points or a list outside the 16-bit frame has none: the per-evaluation form
     // (nn_mode 5) runs the same minimiser on the plain lists
-    if (lm6_mode && !cs.c.rec) lm6_mode = false, lm_mode = true;
+    if ((lm6_mode || lm7_mode) && !cs.c.rec) lm6_mode = lm7_mode = false, lm_mode = true;
     if (o->nn_mode == 2 || lm_mode) HIPCHK(c, c->icp_corr_idx.ensure(sizeof(int) * (size_t)S.n * HB));  // the fused kernels keep no correspondence array
     if (lm_mode) {
       HIPCHK(c, c->icp_lm.ensure(sizeof(LmDev) * (size_t)HB + 64));
@@ -1409,7 +1410,20 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
       HIPCHK(c, c->icp_corr16.ensure(sizeof(unsigned short) * (size_t)S.n * HB + 64));
       a.corr16 = c->icp_corr16.as<unsigned short>();
     }
-    if (lm_mode || lm6_mode) {
+    if (lm7_mode) {
+      // the grid of the moment form (oracle: mom_spec): powers of two from the model's radius about its origin and the gate
+      const CloudHost& mh = c->gen.model_h[HOP_MODEL_5MM];
+      double r2 = 0;
+      for (int i = 0; i < mh.n; ++i) r2 = std::max(r2, (double)mh.x[i] * (double)mh.x[i] + (double)mh.y[i] * (double)mh.y[i] + (double)mh.z[i] * (double)mh.z[i]);
+      const double radius = std::sqrt(r2), gate = (double)o->max_corr_dist, lim = std::ldexp(1.0, ICP_MOM_BITS), lim_d = 16777216.0;
+      a.mom_k_n = ICP_MOM_BITS;
+      a.mom_k_np = std::ilogb(lim / ((radius + gate) * 1.01));
+      a.mom_k_r = std::ilogb(lim / gate);
+      a.mom_k_d = std::ilogb(lim_d / (gate * gate));
+      a.mom_s_n = std::ldexp(1.0f, a.mom_k_n), a.mom_s_np = std::ldexp(1.0f, a.mom_k_np), a.mom_s_r = std::ldexp(1.0f, a.mom_k_r), a.mom_s_d = std::ldexp(1.0f, a.mom_k_d);
+      a.mom_lim = (float)lim, a.mom_lim_d = (float)lim_d;
+    }
+    if (lm_mode || lm6_mode || lm7_mode) {
       // PCL's gates (correspondence_estimation.hpp: double max_dist_sqr = max_distance * max_distance, skip if distance > it;
       // correspondence_rejection_surface_normal: double(dot) > std::cos(angle / 180.0 * M_PI), Utils.cpp:205) against float values:
       // d <= m and d > c for a float d and double m, c are d <= (largest float <= m) and d > (largest float <= c)
@@ -1464,17 +1478,19 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
       launch_icp_finish(a, hb, c->icp_iters.as<int>(), c->icp_conv.as<int>(), c->stream);
       continue;
     }
-    if (lm6_mode) {
+    if (lm6_mode || lm7_mode) {
       for (int it = 0; it < o->max_iter; ++it) {
         a.iter = it;
         {
           SpanGuard sg(c, T_ICP_NN);
-          if (a.corr16) launch_icp_scan_accum(a, hb, c->stream);
+          if (lm7_mode) launch_icp_fusedq_momi(a, hb, c->stream);
+          else if (a.corr16) launch_icp_scan_accum(a, hb, c->stream);
           else launch_icp_fusedq_mom(a, hb, c->stream);
         }
         {
           SpanGuard sg(c, T_ICP_SOLVE);
-          launch_icp_lm6_solve(a, hb, nb, c->stream);
+          if (lm7_mode) launch_icp_lm7_solve(a, hb, nb, c->stream);
+          else launch_icp_lm6_solve(a, hb, nb, c->stream);
         }
         c->timing.n_icp_nn_launches += 1;
       }

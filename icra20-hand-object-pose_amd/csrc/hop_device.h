@@ -15,6 +15,9 @@ constexpr int ICP_NACC = 32;   // 21 (lower triangle of J^T J) + 6 (J^T r) + mse
 constexpr int FIT_QUEUES = 64;    // sub-queues between the quadrilateral test and fit stages (power of two)
 constexpr int ICP_NMOM = 74;         // nn_mode 6: 73 distinct entries of the 13 x 13 moment matrix + the sum of squared correspondence distances
 constexpr int ICP_NMOM_STRIDE = 76;  // + the accepted count, padded
+constexpr int ICP_NMOMI = 92;         // nn_mode 7: the 91 entries of the lower triangle of the integer moment matrix + the gridded squared distances
+constexpr int ICP_NMOMI_STRIDE = 94;  // (64-bit words per block and hypothesis) + the accepted count, padded
+constexpr int ICP_MOM_BITS = 12;      // nn_mode 7: |gridded component| <= 2^12, products <= 2^24: a lane may add 127 of them in 32 bits (it adds <= 2 ICP_ACCUM_R)
 constexpr int ICP_ACCUM_R = 32;  // points per thread of the accumulation kernel of the cell-list path
 constexpr float GRID_MARGIN = 1.0e-5f;  // metres; bounds | ||T^-1 s - m|| - ||s - T m|| | for rigid float poses
 constexpr int MAX_RING = 64;   // samples on the normal cone (normalset.hpp:208-210; <= 2*ceil(2*pi*atan(pi)*3.5) = 56)
@@ -220,14 +223,7 @@ struct LmDev {
   double mse_sum;                 // sum of squared correspondence distances of this ICP iteration
   int iter, nfev, status, phase, cnt, waiting;
   static constexpr bool fast_lmpar = false;  // nn_mode 5 keeps the oracle's operation sequence
-};
-
-struct LmDev6 {  // nn_mode 6: the same state without the per-pass warp tables (lives in registers)
-  float x[6], xc[6], p[6];
-  double A[21], g[6], ff;
-  double diag[6], delta, par, xnorm, fnorm, gnorm, pnorm;
-  int iter, nfev, status, phase;
-  static constexpr bool fast_lmpar = true;  // lmpar2's common case in registers (hop_icp_lm.hip lm_par_fast)
+  static constexpr bool regs_lmpar = false;  // ... and lmpar2 in its general, pivoted form (the oracle's lm_par)
 };
 
 struct IcpArgs {
@@ -251,6 +247,10 @@ struct IcpArgs {
   const float4 *s_pts4, *s_nrm4;  // nn_mode 3/4: the Morton-ordered source as AoS float4 (two 16-byte loads per point)
   LmDev* lm;                      // nn_mode 5: [hb]
   unsigned short* corr16;         // nn_mode 6, split form: [hb][ns] list position of the accepted correspondence (0xFFFF: none)
+  // nn_mode 7: the grid of the moment form -- powers of two (as floats, and their exponents) that scale n_a p'_b, n_a, r0 and the squared
+  // correspondence distance to integers, and the clamps (oracle: mom_spec)
+  float mom_s_np, mom_s_n, mom_s_r, mom_s_d, mom_lim, mom_lim_d;
+  int mom_k_np, mom_k_n, mom_k_r, mom_k_d;
 };
 
 struct PsoParticle {
@@ -349,6 +349,8 @@ void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_sum_t(const LcpArgs& a, int hb, hipStream_t s);
 int lcp_cells_row_stride(int hb);
 int icp_blocks_per_hyp(int ns, bool cells);
+void launch_icp_fusedq_momi(const IcpArgs& a, int hb, hipStream_t s);
+void launch_icp_lm7_solve(const IcpArgs& a, int hb, int nblocks, hipStream_t s);
 void launch_icp_scan_accum(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_fusedq_mom(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_lm6_solve(const IcpArgs& a, int hb, int nblocks, hipStream_t s);

@@ -2486,6 +2486,131 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM
 }
 #endif
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// nn_mode 7: the moment form with INTEGER-EXACT sums -- the result no longer depends on which lane, wavefront or workgroup adds which
+// correspondence, so the CPU statement of the algorithm (oracle minimiser 7) returns the same bits.
+// The 13 components of u = (n_a p'_b, n_a, r0) are scaled by powers of two chosen from the model's radius and the gate (IcpArgs::mom_*,
+// hop_icp_refine), rounded to the nearest integer (v_rndne_f32: ties to even), clamped to +-2^ICP_MOM_BITS; M = sum U U^T (91 entries,
+// lower triangle) is accumulated per lane with v_mad_i32_i24 -- products <= 2^24, a lane adds at most 2 ICP_ACCUM_R = 64 of them -- and
+// lanes / wavefronts / workgroups are added in 64 bits.  The squared correspondence distances of the MSE stop rule go the same way.
+// Lookups, gates and the deferred-lookup queue are those of k_icp_fusedq_mom; the grid costs 13 x (mul, rndne, med3, cvt) per accepted
+// point and 18 more accumulators than the symmetric float form (the rounding breaks the (n_a n_c)(p_b p_d) symmetry).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int momi_q(float v, float s, float lim) {
+  const float t = __builtin_rintf(v * s);  // s is a power of two: the product is exact
+  return (int)__builtin_amdgcn_fmed3f(t, -lim, lim);
+}
+template <bool DEFER>
+__device__ __forceinline__ int icp_fusedq_point_momi(const IcpArgs& a, int i, const float* __restrict__ pose, const float* __restrict__ sTi,
+                                                      const float* __restrict__ F, V3 ctr, int (&acc)[ICP_NMOMI]) {
+  const float4 p4 = a.s_pts4[i];
+  V3 q = v3(p4.x, p4.y, p4.z);
+  if (a.iter > 0) q = m4_point_fma(F, q);
+  float d2 = 3.0e38f;
+  int j = -1;
+  V3 tq;
+  if (cells_nnq<DEFER>(a.cells, m4_point_fma(sTi, q), pose, q, d2, j, tq)) return ICP_PT_DEFERRED;
+  if (j < 0 || !(d2 <= a.max_d2)) return ICP_PT_REJECTED;
+  const float4 tn = a.cells.nrm_idx[j];
+  const float4 n4 = a.s_nrm4[i];
+  V3 qn = v3(n4.x, n4.y, n4.z);
+  if (a.iter > 0) qn = m4_dir_fma(F, qn);
+  const V3 nt = m4_dir(pose, v3(tn.x, tn.y, tn.z));
+  if (!(((qn.x * nt.x + qn.y * nt.y) + qn.z * nt.z) > a.cos_thr)) return ICP_PT_REJECTED;
+  const V3 pc = q - ctr;
+  const float r0 = vdot(q - tq, nt);
+  const float pv[3] = {pc.x, pc.y, pc.z}, nv[3] = {nt.x, nt.y, nt.z};
+  int U[13];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) U[3 * c + b] = momi_q(nv[c] * pv[b], a.mom_s_np, a.mom_lim);
+    U[9 + c] = momi_q(nv[c], a.mom_s_n, a.mom_lim);
+  }
+  U[12] = momi_q(r0, a.mom_s_r, a.mom_lim);
+  int k = 0;
+#pragma unroll
+  for (int u = 0; u < 13; ++u)
+#pragma unroll
+    for (int v = 0; v <= u; ++v) {
+      acc[k] = __mul24(U[u], U[v]) + acc[k];  // v_mad_i32_i24
+      ++k;
+    }
+  acc[91] += momi_q(d2, a.mom_s_d, a.mom_lim_d);
+  return ICP_PT_ACCEPTED;
+}
+// the per-lane 32-bit sums of a 256-thread block added in 64 bits: block_sum_floats with integers (same tile, same steps)
+template <int NV>
+__device__ __forceinline__ void block_sum_ints(const int (&acc)[NV], BlockSumLds& L, long long* __restrict__ out) {
+  int(*tile)[17] = reinterpret_cast<int(*)[17]>(L.tile);
+  long long(*part)[16] = reinterpret_cast<long long(*)[16]>(L.part);
+  static_assert(sizeof(L.tile) == sizeof(int) * 256 * 17 && sizeof(L.part) == sizeof(long long) * 4 * 16, "same bytes");
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int k = t & 15, g = t >> 4;
+#pragma unroll
+  for (int c = 0; c < (NV + 15) / 16; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 16; ++v)
+      if (c * 16 + v < NV) tile[t][v] = acc[c * 16 + v];
+    __syncthreads();
+    long long pd = 0;
+    if (c * 16 + k < NV) {
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) pd += (long long)tile[g * 16 + s2][k];
+    }
+    pd += __shfl_xor(pd, 16);
+    pd += __shfl_xor(pd, 32);
+    if (lane < 16) part[wave][lane] = pd;
+    __syncthreads();
+    if (t < 16 && c * 16 + t < NV) out[c * 16 + t] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+  }
+}
+#ifndef HOP_ICP_MOMI_W
+#define HOP_ICP_MOMI_W 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOMI_W))) void k_icp_fusedq_momi(IcpArgs a, int R) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[sizeof(BlockSumLds)];  // the queue, then the tile of the block sum
+  __shared__ int n_cnt[4];
+  unsigned short(*defer_i)[64 * ICP_ACCUM_R] = reinterpret_cast<unsigned short(*)[64 * ICP_ACCUM_R]>(lds_raw);
+  BlockSumLds& bs = *reinterpret_cast<BlockSumLds*>(lds_raw);
+  const int hl = blockIdx.y, h = a.h0 + hl;
+  const IcpState& st = a.state[hl];
+  if (!st.active) return;
+  const float* __restrict__ pose = a.pose + (size_t)h * 16;
+  const float* __restrict__ sTi = a.pose_inv + (size_t)h * 12;
+  const float* __restrict__ F = st.final_tf;
+  const V3 ctr = v3(pose[3], pose[7], pose[11]);
+  int acc[ICP_NMOMI];
+#pragma unroll
+  for (int k = 0; k < ICP_NMOMI; ++k) acc[k] = 0;
+  int n_wave = 0, n_def = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int base = blockIdx.x * (256 * R);
+  for (int r = 0; r < R; ++r) {
+    const int li = r * 256 + threadIdx.x, i = base + li;
+    if (i >= a.ns) continue;
+    const int res = icp_fusedq_point_momi<true>(a, i, pose, sTi, F, ctr, acc);
+    const unsigned long long dm = __ballot(res == ICP_PT_DEFERRED);
+    if (res == ICP_PT_DEFERRED) defer_i[wave][n_def + __popcll(dm & ((1ull << lane) - 1ull))] = (unsigned short)li;
+    n_def += __popcll(dm);
+    n_wave += __popcll(__ballot(res == ICP_PT_ACCEPTED));
+  }
+  const int nd = __builtin_amdgcn_readfirstlane(n_def);
+  for (int t = lane; t < nd; t += 64)
+    n_wave += __popcll(__ballot(icp_fusedq_point_momi<false>(a, base + defer_i[wave][t], pose, sTi, F, ctr, acc) == ICP_PT_ACCEPTED));
+  long long* __restrict__ out = reinterpret_cast<long long*>(a.partial) + ((size_t)hl * gridDim.x + blockIdx.x) * ICP_NMOMI_STRIDE;
+  if (lane == 0) n_cnt[wave] = n_wave;
+  block_sum_ints<ICP_NMOMI>(acc, bs, out);  // (its barriers order n_cnt as well)
+  if (threadIdx.x == 0) out[ICP_NMOMI] = (long long)((n_cnt[0] + n_cnt[1]) + (n_cnt[2] + n_cnt[3]));
+}
+void launch_icp_fusedq_momi(const IcpArgs& a, int hb, hipStream_t s) {
+  const int nb = icp_blocks_per_hyp(a.ns, true);
+  const int R = (a.ns + 256 * nb - 1) / (256 * nb);
+  static_assert(2 * ICP_ACCUM_R * (1 << (2 * ICP_MOM_BITS)) < (1ll << 31), "a lane's 32-bit sums cannot overflow");
+  hipLaunchKernelGGL(k_icp_fusedq_momi, dim3(nb, hb), dim3(256), 0, s, a, R);
+}
+
 // nn_mode 6 in two kernels (HOP_ICP_SPLIT, see hop_icp_refine): k_icp_scan does the lookups and PCL's two gates of k_icp_fusedq_mom and
 // writes the accepted correspondence of every (hypothesis, source point) as a 16-bit list position (0xFFFF: none) -- no accumulators,
 // so it runs at twice the occupancy --; k_icp_mom_accum walks the same (block, lane, r) partition, rebuilds the operands from that index

@@ -1397,7 +1397,9 @@ struct LmState {
   double diag[6], delta, par, xnorm, fnorm, gnorm, pnorm;
   float p[6];
   int iter, nfev, status, phase;
+  bool chol_first = false;  // the moment form (minimiser 7): lmpar2 through the unpivoted Cholesky factor when the Jacobian is comfortably of full rank
 };
+bool lm_par_chol(const double A[6][6], const double g[6], const double diag[6], double delta, double& par, double x[6]);
 void lm_begin(LmState& s) {
   for (int j = 0; j < 6; ++j) s.x[j] = s.xc[j] = 0.f;
   s.phase = 0, s.status = LM_STATUS_RUNNING, s.iter = 0, s.nfev = 0, s.par = 0, s.delta = 0, s.xnorm = 0, s.fnorm = 0, s.gnorm = 0, s.pnorm = 0;
@@ -1410,7 +1412,7 @@ inline double lm_scaled_norm(const double diag[6], const float v[6]) {
 // the do { lmpar; candidate } part of minimizeOneStep (LevenbergMarquardt.h:262-275): leaves the candidate in xc
 void lm_inner(LmState& s) {
   double xs[6];
-  lm_par(s.cur.A, s.cur.g, s.diag, s.delta, s.par, xs);
+  if (!(s.chol_first && lm_par_chol(s.cur.A, s.cur.g, s.diag, s.delta, s.par, xs))) lm_par(s.cur.A, s.cur.g, s.diag, s.delta, s.par, xs);
   for (int j = 0; j < 6; ++j) {
     s.p[j] = -(float)xs[j];        // wa1 = -wa1
     s.xc[j] = s.x[j] + s.p[j];     // wa2 = x + wa1 (float)
@@ -1518,6 +1520,279 @@ bool lm_point_to_plane(const std::vector<V3>& P, const std::vector<V3>& Q, const
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The moment form of the same minimiser (minimiser 7; what the GPU's nn_mode 7 computes, bit for bit).
+//
+// PCL's residual f_i(x) = n_i . (R(x) p_i + t - q_i) (transformation_estimation_point_to_plane.h:77-84) is linear in the twelve entries
+// of [R | t].  With c a fixed point near the object (the translation of the hypothesis: conditioning only), p' = p - c,
+//   u_i = (n_a p'_b [9 entries, a major], n_a [3], r0_i),  r0_i = n_i . (p_i - q_i),   w(x) = (R - I [9], t + (R - I) c [3], 1):
+//   f_i(x) = w(x) . u_i,
+// so sum f^2, J^T J and J^T f of EVERY parameter vector Eigen's minimiser evaluates -- NumericalDiff's six forward-difference columns
+// included -- are quadratic forms in the 13 x 13 moment matrix M = sum_i u_i u_i^T of the ICP iteration's correspondences: one pass over
+// the points per ICP iteration instead of one per function evaluation, and the algorithm is evaluated in exact arithmetic where PCL
+// rounds every residual to float (lm_pass_exact above is the per-point statement of that; profiles/r0*_icp_lm_deltas.json measures both
+// against Eigen's own run).
+//
+// What makes the form reproducible on ANY summation order (a GPU adds the terms of M in the order its lanes, wavefronts and workgroups
+// happen to be laid out): u is put on a fixed binary grid first -- each component class scaled by a power of two chosen from the model's
+// radius and the correspondence gate, rounded to the nearest integer (ties to even), |integer| <= 2^bits -- and M is the EXACT integer
+// matrix sum_i U_i U_i^T (products < 2^(2 bits), sums in 64 bits).  Integer addition is associative: every order gives the same M.  The
+// grid is far below what the float run carries as rounding noise in its Jacobian (13 bits: 15 um on p', 1e-4 on n, 2 um on r0; the
+// reference's forward differences carry 1e-3 relative), and the squared correspondence distances of the MSE stop rule are summed the
+// same way.  From M on, every operation is an IEEE double operation (+ - * / sqrt fma) in a fixed order, stated once here and once in
+// csrc/hop_lm_core.h -- two texts, same doubles.
+// Differences to minimiser 6 (lm_pass_exact), all at rounding level: (a) the grid; (b) the moved source point of ICP iteration k is
+// final_k p0 with final_k the float product of the increments so far, applied with fused multiply-adds (PCL moves a stored cloud once
+// per iteration: T_k(...T_1(p0))); (c) lmpar2 runs on the unpivoted Cholesky factor of J^T J when it is comfortably of full rank.
+// ------------------------------------------------------------------------------------------------
+struct MomSpec {
+  int k_np, k_n, k_r, k_d;  // power-of-two scales of n_a p'_b, n_a, r0 and of the squared distance
+  float lim, lim_d;         // clamps (2^bits; 2^24 for the distances)
+};
+// largest power of two 2^k with bound * 2^k <= lim
+inline int mom_scale_exp(double lim, double bound) { return std::ilogb(lim / bound); }
+MomSpec mom_spec(double model_radius, float max_corr_dist, int bits) {
+  MomSpec q;
+  q.lim = std::ldexp(1.0f, bits), q.lim_d = 16777216.0f;
+  const double gate = (double)max_corr_dist;
+  q.k_n = bits;                                                     // |n_a| <= 1
+  q.k_np = mom_scale_exp((double)q.lim, (model_radius + gate) * 1.01);  // |n_a p'_b| <= |p'| <= model radius + gate (p' is within the gate of a posed model point)
+  q.k_r = mom_scale_exp((double)q.lim, gate);                       // |r0| <= |p - q| <= gate
+  q.k_d = mom_scale_exp((double)q.lim_d, gate * gate);
+  return q;
+}
+inline int32_t mom_quant(float v, int k, float lim) {
+  float s = std::ldexp(v, k);  // exact (power of two)
+  s = std::nearbyintf(s);      // ties to even
+  s = std::min(std::max(s, -lim), lim);
+  return (int32_t)s;
+}
+struct MomSums {
+  int64_t M[13][13];  // lower triangle used
+  int64_t d2q;
+  int cnt;
+  void clear() {
+    std::memset(M, 0, sizeof M);
+    d2q = 0, cnt = 0;
+  }
+};
+// one accepted correspondence: p moved source point, q its target (posed model point), n the target's posed normal, d2 their squared distance
+inline void mom_add(MomSums& m, const MomSpec& sp, V3 p, V3 q, V3 n, V3 ctr, float d2) {
+  const float pc[3] = {p.x - ctr.x, p.y - ctr.y, p.z - ctr.z}, nv[3] = {n.x, n.y, n.z};
+  const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+  const float r0 = dx * n.x + (dy * n.y + dz * n.z);
+  int32_t U[13];
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) U[3 * a + b] = mom_quant(nv[a] * pc[b], sp.k_np, sp.lim);
+    U[9 + a] = mom_quant(nv[a], sp.k_n, sp.lim);
+  }
+  U[12] = mom_quant(r0, sp.k_r, sp.lim);
+  for (int i = 0; i < 13; ++i)
+    for (int j = 0; j <= i; ++j) m.M[i][j] += (int64_t)U[i] * (int64_t)U[j];
+  m.d2q += (int64_t)mom_quant(d2, sp.k_d, sp.lim_d);
+  m.cnt += 1;
+}
+inline int mom_exp_of(const MomSpec& sp, int i) { return i < 9 ? sp.k_np : i < 12 ? sp.k_n : sp.k_r; }
+// the moment matrix in metres etc.: exact (an integer below 2^53 times a power of two)
+void mom_to_double(const MomSums& m, const MomSpec& sp, double Md[13][13]) {
+  for (int i = 0; i < 13; ++i)
+    for (int j = 0; j <= i; ++j) Md[i][j] = Md[j][i] = std::ldexp((double)m.M[i][j], -(mom_exp_of(sp, i) + mom_exp_of(sp, j)));
+}
+
+// w(x) = (R(x) - I, t + (R(x) - I) c, 1); R from the quaternion as WarpPointRigid6D::setParam forms it (|q| = 1 in exact arithmetic)
+void mom_w(const float x[6], const double c[3], double w[13]) {
+  const double qx = (double)x[3], qy = (double)x[4], qz = (double)x[5];
+  const double qw2 = 1.0 - (qx * qx + qy * qy + qz * qz);
+  const double qw = std::sqrt(qw2);
+  const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+  const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  w[0] = -(tyy + tzz), w[1] = txy - twz, w[2] = txz + twy;
+  w[3] = txy + twz, w[4] = -(txx + tzz), w[5] = tyz - twx;
+  w[6] = txz - twy, w[7] = tyz + twx, w[8] = -(txx + tyy);
+  for (int a = 0; a < 3; ++a) w[9 + a] = (double)x[a] + (w[3 * a] * c[0] + w[3 * a + 1] * c[1] + w[3 * a + 2] * c[2]);
+  w[12] = 1.0;
+}
+// sum f^2, J^T J, J^T f at xc from M, with NumericalDiff's forward differences (NumericalDiff.h:64-122): column j of the Jacobian as a
+// functional on u is d_j = (w(xc + h_j e_j) - w(xc)) / h_j, h_j = sqrt(eps) |xc_j| (or sqrt(eps)), the step taken in float as the
+// reference takes it.  For the three translations d_j = s_j e_{9+j} with s_j = (float step actually taken) / h_j.
+void lm_eval_moments(const double M[13][13], const double c[3], const float xc[6], LmSums& s) {
+  double w0[13], d[3][12], st[3];
+  mom_w(xc, c, w0);
+  for (int j = 0; j < 6; ++j) {
+    float xx[6];
+    std::copy(xc, xc + 6, xx);
+    float h = LM_SQRT_EPS * std::fabs(xc[j]);
+    if (h == 0.f) h = LM_SQRT_EPS;
+    xx[j] += h;
+    const double hinv = 1.0 / (double)h;
+    if (j < 3) st[j] = ((double)xx[j] - (double)xc[j]) * hinv;
+    else {
+      double wj[13];
+      mom_w(xx, c, wj);
+      for (int k = 0; k < 12; ++k) d[j - 3][k] = (wj[k] - w0[k]) * hinv;
+    }
+  }
+  double ff = 0, gr[3] = {0, 0, 0}, Arr[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gt[3], Atr[3][3], Att[3][3];
+  for (int i = 0; i < 13; ++i) {
+    const double* row = M[i];
+    double y0 = 0, z[3] = {0, 0, 0};
+    for (int k = 0; k < 13; ++k) y0 += row[k] * w0[k];
+    for (int v = 0; v < 3; ++v)
+      for (int k = 0; k < 12; ++k) z[v] += row[k] * d[v][k];
+    ff += w0[i] * y0;
+    if (i < 12)
+      for (int u = 0; u < 3; ++u) {
+        gr[u] += d[u][i] * y0;
+        for (int v = 0; v <= u; ++v) Arr[u][v] += d[u][i] * z[v];
+      }
+    if (i >= 9 && i < 12) {
+      const int t = i - 9;
+      gt[t] = st[t] * y0;
+      for (int v = 0; v < 3; ++v) Atr[t][v] = st[t] * z[v];
+      for (int t2 = 0; t2 <= t; ++t2) Att[t][t2] = st[t] * st[t2] * row[9 + t2];
+    }
+  }
+  for (int u = 0; u < 6; ++u)
+    for (int v = 0; v <= u; ++v) {
+      double a;
+      if (u < 3) a = Att[u][v];
+      else if (v < 3) a = Atr[v][u - 3];
+      else a = Arr[u - 3][v - 3];
+      s.A[u][v] = s.A[v][u] = a;
+    }
+  for (int u = 0; u < 6; ++u) s.g[u] = u < 3 ? gt[u] : gr[u - 3];
+  s.ff = std::max(ff, 0.0);
+}
+
+// lmpar2 (lmpar.h:163-293) when J^T J is comfortably positive definite (smallest Cholesky pivot above 2e-5 of the largest; Eigen's rank
+// decision would call it full rank down to 7e-7): the triangular solves against R are solves against L, L L^T = A, and qrsolv's problem
+// [R; sqrt(par) D] is the factor of A + par D^2.  Reciprocals of the pivots are formed once and multiplied with (one IEEE division per
+// pivot).  false: not that case -- the caller runs the general, pivoted lm_par.
+static bool canon_chol(const double A[6][6], const double diag[6], double par, double L[6][6], double Linv[6]) {
+  double lmin = 1e300, lmax = 0;
+  bool ok = true;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double v = A[i][j];
+      if (i == j) v = std::fma(par * diag[i], diag[i], v);
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+      if (i == j) {
+        ok = ok && v > 1e-290;
+        const double d = std::sqrt(std::fmax(v, 1e-290));
+        L[i][i] = d;
+        Linv[i] = 1.0 / d;
+        lmin = std::fmin(lmin, d), lmax = std::fmax(lmax, d);
+      } else
+        L[i][j] = v * Linv[j];
+    }
+  return ok && lmin > 2e-5 * lmax;
+}
+static void canon_fwd(const double L[6][6], const double Linv[6], const double b[6], double y[6]) {
+  for (int i = 0; i < 6; ++i) {
+    double v = b[i];
+    for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
+    y[i] = v * Linv[i];
+  }
+}
+static void canon_bwd(const double L[6][6], const double Linv[6], const double y[6], double x[6]) {
+  for (int i = 5; i >= 0; --i) {
+    double v = y[i];
+    for (int k = i + 1; k < 6; ++k) v -= L[k][i] * x[k];
+    x[i] = v * Linv[i];
+  }
+}
+static double canon_dnorm(const double diag[6], const double x[6], double wa2[6]) {
+  double q = 0;
+  for (int j = 0; j < 6; ++j) {
+    wa2[j] = diag[j] * x[j];
+    q = std::fma(wa2[j], wa2[j], q);
+  }
+  return q > 1e-290 ? std::sqrt(q) : 0.0;
+}
+bool lm_par_chol(const double A[6][6], const double g[6], const double diag[6], double delta, double& par_io, double x[6]) {
+  const double dwarf = (double)FLT_MIN, p1 = (double)0.1f;
+  double L[6][6] = {}, Linv[6], y[6], xs[6], wa2[6], w[6];
+  if (!canon_chol(A, diag, 0.0, L, Linv)) return false;
+  canon_fwd(L, Linv, g, y);
+  canon_bwd(L, Linv, y, xs);
+  double dxnorm = canon_dnorm(diag, xs, wa2);
+  double fp = dxnorm - delta;
+  if (fp <= p1 * delta) {
+    std::copy(xs, xs + 6, x);
+    par_io = 0;
+    return true;
+  }
+  const double dinv = 1.0 / delta;
+  {
+    const double ninv = 1.0 / dxnorm;
+    for (int j = 0; j < 6; ++j) w[j] = diag[j] * wa2[j] * ninv;
+    canon_fwd(L, Linv, w, y);
+  }
+  double t2 = 0;
+  for (int j = 0; j < 6; ++j) t2 = std::fma(y[j], y[j], t2);
+  double parl = fp * dinv * (1.0 / t2);
+  double gq = 0;
+  for (int j = 0; j < 6; ++j) {
+    const double v = g[j] * (1.0 / diag[j]);
+    gq = std::fma(v, v, gq);
+  }
+  const double gnorm = gq > 1e-290 ? std::sqrt(gq) : 0.0;
+  double paru = gnorm * dinv;
+  if (paru == 0) paru = dwarf / std::fmin(delta, p1);
+  double par = std::fmin(std::fmax(par_io, parl), paru);
+  if (par == 0) par = gnorm * (1.0 / dxnorm);
+  for (int iter = 1;; ++iter) {
+    if (par == 0) par = std::fmax(dwarf, (double)0.001f * paru);
+    if (!canon_chol(A, diag, par, L, Linv)) return false;
+    canon_fwd(L, Linv, g, y);
+    canon_bwd(L, Linv, y, xs);
+    dxnorm = canon_dnorm(diag, xs, wa2);
+    const double temp = fp;
+    fp = dxnorm - delta;
+    if (std::fabs(fp) <= p1 * delta || (parl == 0 && fp <= temp && temp < 0) || iter == 10) break;
+    const double ninv = 1.0 / dxnorm;
+    for (int j = 0; j < 6; ++j) w[j] = diag[j] * (wa2[j] * ninv);
+    canon_fwd(L, Linv, w, y);
+    double t3 = 0;
+    for (int j = 0; j < 6; ++j) t3 = std::fma(y[j], y[j], t3);
+    const double parc = fp * dinv * (1.0 / t3);
+    if (fp > 0) parl = std::fmax(parl, par);
+    if (fp < 0) paru = std::fmin(paru, par);
+    par = std::fmax(parl, par + parc);
+  }
+  std::copy(xs, xs + 6, x);
+  par_io = par;
+  return true;
+}
+
+// estimateRigidTransformation from the moment matrix (cnt >= 4 correspondences went into it)
+void lm_point_to_plane_moments(const double M[13][13], const double c[3], M4& T, float x_out[6] = nullptr, int* stats = nullptr) {
+  LmState s;
+  lm_begin(s);
+  s.chol_first = true;
+  LmSums sums;
+  do lm_eval_moments(M, c, s.xc, sums);
+  while (lm_advance(s, sums));
+  T = lm_warp6(s.x);
+  if (x_out) std::copy(s.x, s.x + 6, x_out);
+  if (stats) stats[0] = s.status, stats[1] = s.nfev, stats[2] = s.iter;
+}
+// the composed form of the moved source: final p0 with fused multiply-adds (what the GPU's fused kernels evaluate)
+inline V3 fma_transform_point(const M4& T, V3 p) {
+  V3 r;
+  r.x = std::fma(T.m[0][0], p.x, std::fma(T.m[0][1], p.y, std::fma(T.m[0][2], p.z, T.m[0][3])));
+  r.y = std::fma(T.m[1][0], p.x, std::fma(T.m[1][1], p.y, std::fma(T.m[1][2], p.z, T.m[1][3])));
+  r.z = std::fma(T.m[2][0], p.x, std::fma(T.m[2][1], p.y, std::fma(T.m[2][2], p.z, T.m[2][3])));
+  return r;
+}
+inline V3 fma_rotate_normal(const M4& T, V3 n) {
+  V3 r;
+  r.x = std::fma(T.m[0][0], n.x, std::fma(T.m[0][1], n.y, T.m[0][2] * n.z));
+  r.y = std::fma(T.m[1][0], n.x, std::fma(T.m[1][1], n.y, T.m[1][2] * n.z));
+  r.z = std::fma(T.m[2][0], n.x, std::fma(T.m[2][1], n.y, T.m[2][2] * n.z));
+  return r;
+}
+
 // hook for the minimiser compiled from the reference's vendored Eigen (oracle/_ref/libref_icp.so, ref_lm_point_to_plane);
 // set from oracle/orc.py in the build container (and wherever the prebuilt file travelled)
 typedef int (*lm_estimator_fn)(int m, const float* src_xyz, const float* tgt_xyz, const float* tgt_nrm, float* T16_out, float* x6_out,
@@ -1555,8 +1830,14 @@ struct IcpResult {
 // translation (< 1 mm) and are equally close to the ground truth, but the pose the chain finally SELECTS can differ by
 // degrees between any two of them -- also between 2 and 3, which compute the same minimiser -- because the early MSE stop
 // and the argmax over near-equivalent cluster heads amplify 1e-6 differences on this near-symmetric object.
+//   minimiser 4 / 5 / 6: the reference's Levenberg-Marquardt -- restated in float / Eigen's own code (hook) / in exact arithmetic per point
+//   minimiser 7: the moment form with integer-exact sums (see "The moment form" above): needs the hypothesis' translation (ctr), the
+//             model's radius about its origin and the grid's bits
 struct IcpVariant {
   int minimiser = 0, strict_normal = 0, relative_stop = 1;
+  float ctr[3] = {0, 0, 0};
+  double model_radius = 0;
+  int mom_bits = 12;
 };
 constexpr int ICP_INNER_MAX = 3;
 constexpr double ICP_INNER_W = 1.0e-3;
@@ -1580,6 +1861,8 @@ IcpResult run_icp(const Cloud& src, const Cloud& tgt, bool use_tree, int max_ite
   std::vector<V3> sp = src.pos, sn = src.nrm;  // moved source
   double mse_prev = std::numeric_limits<double>::max();
   M4 T_lm = identity4();  // transformation_: survives an iteration whose estimator returns early (fewer than 4 correspondences)
+  const MomSpec mspec = mom_spec(var.model_radius, max_corr_dist, var.mom_bits);
+  MomSums mom;
   while (true) {
     // correspondences
     double A[6][6] = {}, b[6] = {};
@@ -1587,6 +1870,7 @@ IcpResult run_icp(const Cloud& src, const Cloud& tgt, bool use_tree, int max_ite
     double cs[3] = {0, 0, 0};  // sum of the matched source points
     int cnt = 0;
     std::vector<V3> corr_p, corr_q, corr_n;  // minimiser 2 keeps the correspondences
+    mom.clear();
     for (size_t i = 0; i < sp.size(); ++i) {
       float d2 = FLT_MAX;
       int idx = -1;
@@ -1598,7 +1882,8 @@ IcpResult run_icp(const Cloud& src, const Cloud& tgt, bool use_tree, int max_ite
       if (pcl_gates) {
         if (!((double)((sn[i].x * nt.x + sn[i].y * nt.y) + sn[i].z * nt.z) > cos_thr_d)) continue;
       } else if (var.strict_normal ? !(dot(sn[i], nt) > cos_thr) : !(dot(sn[i], nt) >= cos_thr)) continue;
-      if (var.minimiser >= 2) corr_p.push_back(sp[i]), corr_q.push_back(tgt.pos[idx]), corr_n.push_back(nt);
+      if (var.minimiser == 7) mom_add(mom, mspec, sp[i], tgt.pos[idx], nt, V3{var.ctr[0], var.ctr[1], var.ctr[2]}, d2);
+      else if (var.minimiser >= 2) corr_p.push_back(sp[i]), corr_q.push_back(tgt.pos[idx]), corr_n.push_back(nt);
       ++cnt;
       mse += (double)d2;
       cs[0] += (double)sp[i].x, cs[1] += (double)sp[i].y, cs[2] += (double)sp[i].z;
@@ -1668,6 +1953,14 @@ IcpResult run_icp(const Cloud& src, const Cloud& tgt, bool use_tree, int max_ite
         }
         float T16[16];
         if (g_ref_lm_estimator(cnt, a.data(), bq.data(), cn.data(), T16, nullptr, nullptr, nullptr) == 0) T_lm = load4(T16);
+      } else if (var.minimiser == 7) {
+        if (cnt >= 4) {
+          double Md[13][13];
+          mom_to_double(mom, mspec, Md);
+          const double cd[3] = {(double)var.ctr[0], (double)var.ctr[1], (double)var.ctr[2]};
+          lm_point_to_plane_moments(Md, cd, T_lm);
+        }
+        mse = std::ldexp((double)mom.d2q, -mspec.k_d);  // the exact sum of the gridded squared distances
       } else
         lm_point_to_plane(corr_p, corr_q, corr_n, T_lm, nullptr, nullptr, var.minimiser == 6);  // 6: the same minimiser in exact arithmetic
       T = T_lm;
@@ -1784,10 +2077,17 @@ IcpResult run_icp(const Cloud& src, const Cloud& tgt, bool use_tree, int max_ite
         T.m[i][3] = (float)xv[i];
       }
     }
-    for (size_t i = 0; i < sp.size(); ++i) {
-      sp[i] = pcl_transform_point(T, sp[i]);
-      sn[i] = pcl_rotate_normal(T, sn[i]);
-    }
+    if (var.minimiser == 7) {  // the composed form: final p0, not T_k(...T_1(p0))
+      const M4 F = mul4(T, res.final_tf);
+      for (size_t i = 0; i < sp.size(); ++i) {
+        sp[i] = fma_transform_point(F, src.pos[i]);
+        sn[i] = fma_rotate_normal(F, src.nrm[i]);
+      }
+    } else
+      for (size_t i = 0; i < sp.size(); ++i) {
+        sp[i] = pcl_transform_point(T, sp[i]);
+        sn[i] = pcl_rotate_normal(T, sn[i]);
+      }
     res.final_tf = mul4(T, res.final_tf);
     res.iterations++;
     mse /= cnt;
@@ -2126,15 +2426,26 @@ void orc_icp_refine_batch(const float* Sxyz, const float* Snrm, int nS, const fl
   }
 }
 
+// radius of a cloud about its origin: sqrt of the largest squared norm, both in double from the float coordinates
+double cloud_radius(const std::vector<V3>& p) {
+  double m = 0;
+  for (const V3& v : p) m = std::max(m, (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z);
+  return std::sqrt(m);
+}
+int g_mom_bits = 12;  // grid of the moment form (minimiser 7); orc_set_mom_bits: precision experiments only
+void orc_set_mom_bits(int bits) { g_mom_bits = bits; }
 void orc_icp_refine_batch_variant(const float* Sxyz, const float* Snrm, int nS, const float* Mxyz, const float* Mnrm, int nM, float* pose16, int H,
                                   int max_iter, float angle_deg, float max_corr_dist, int minimiser, int strict_normal, int relative_stop,
                                   int* iters_out, int* converged_out) {
   const Cloud scene = load_cloud(Sxyz, Snrm, nS), model = load_cloud(Mxyz, Mnrm, nM);
-  IcpVariant var;
-  var.minimiser = minimiser, var.strict_normal = strict_normal, var.relative_stop = relative_stop;
+  IcpVariant var0;
+  var0.minimiser = minimiser, var0.strict_normal = strict_normal, var0.relative_stop = relative_stop;
+  var0.model_radius = cloud_radius(model.pos), var0.mom_bits = g_mom_bits;
 #pragma omp parallel for schedule(dynamic)
   for (int h = 0; h < H; ++h) {
     const M4 pose = load4(pose16 + 16 * h);
+    IcpVariant var = var0;
+    var.ctr[0] = pose.m[0][3], var.ctr[1] = pose.m[1][3], var.ctr[2] = pose.m[2][3];
     Cloud mt;
     mt.pos.resize(nM), mt.nrm.resize(nM);
     for (int i = 0; i < nM; ++i) {
@@ -2164,6 +2475,34 @@ int orc_lm_point_to_plane(int m, const float* src_xyz, const float* tgt_xyz, con
   if (!lm_point_to_plane(P, Q, Nn, T, x6_out, stats)) return -1;
   store4(T, T16_out);
   return 0;
+}
+/* the moment form alone (minimiser 7): Eigen's minimiser from a 13 x 13 moment matrix (row-major, symmetric) and the centre c */
+void orc_lm_point_to_plane_moments(const double* M169, const double* c3, float* T16_out, float* x6_out, int* stats) {
+  double M[13][13];
+  for (int i = 0; i < 13; ++i)
+    for (int j = 0; j < 13; ++j) M[i][j] = M169[13 * i + j];
+  M4 T = identity4();
+  lm_point_to_plane_moments(M, c3, T, x6_out, stats);
+  if (T16_out) store4(T, T16_out);
+}
+/* the integer moment sums of m correspondences (AoS m x 3 inputs; d2[m]); M169_out: the exact integer matrix, Md169_out: in metres */
+void orc_mom_accumulate(int m, const float* src_xyz, const float* tgt_xyz, const float* tgt_nrm, const float* d2, const float* ctr3, double model_radius,
+                        float max_corr_dist, int bits, long long* M169_out, long long* d2q_out, double* Md169_out, int* scales4_out) {
+  const MomSpec sp = mom_spec(model_radius, max_corr_dist, bits);
+  MomSums ms;
+  ms.clear();
+  for (int i = 0; i < m; ++i)
+    mom_add(ms, sp, V3{src_xyz[3 * i], src_xyz[3 * i + 1], src_xyz[3 * i + 2]}, V3{tgt_xyz[3 * i], tgt_xyz[3 * i + 1], tgt_xyz[3 * i + 2]},
+            V3{tgt_nrm[3 * i], tgt_nrm[3 * i + 1], tgt_nrm[3 * i + 2]}, V3{ctr3[0], ctr3[1], ctr3[2]}, d2[i]);
+  double Md[13][13];
+  mom_to_double(ms, sp, Md);
+  for (int i = 0; i < 13; ++i)
+    for (int j = 0; j < 13; ++j) {
+      if (M169_out) M169_out[13 * i + j] = ms.M[std::max(i, j)][std::min(i, j)];
+      if (Md169_out) Md169_out[13 * i + j] = Md[i][j];
+    }
+  if (d2q_out) *d2q_out = ms.d2q;
+  if (scales4_out) scales4_out[0] = sp.k_np, scales4_out[1] = sp.k_n, scales4_out[2] = sp.k_r, scales4_out[3] = sp.k_d;
 }
 void orc_lm_warp6(const float* x6, float* T16) { store4(lm_warp6(x6), T16); }
 /* f(x) and NumericalDiff's Jacobian at x (row-major m x 6) */

@@ -178,6 +178,10 @@ def lib():
         L.orc_lm_point_to_plane.restype = C.c_int
         L.orc_lm_point_to_plane.argtypes = [C.c_int, fp, fp, fp, fp, fp, ip]
         L.orc_lm_warp6.argtypes = [fp, fp]
+        llp = C.POINTER(C.c_longlong)
+        L.orc_set_mom_bits.argtypes = [C.c_int]
+        L.orc_lm_point_to_plane_moments.argtypes = [dp, dp, fp, fp, ip]
+        L.orc_mom_accumulate.argtypes = [C.c_int, fp, fp, fp, fp, fp, C.c_double, C.c_float, C.c_int, llp, llp, dp, ip]
         L.orc_lm_residuals_jacobian.argtypes = [C.c_int, fp, fp, fp, fp, fp, fp]
         L.orc_euler_zyx.argtypes = [fp, fp]
         L.orc_geodesic.restype = C.c_float
@@ -384,7 +388,7 @@ def icp_refine_batch_variant(S, Sn, M, Mn, poses, max_iter=10, angle_deg=45.0, m
 
 
 # ---- the reference's ICP minimiser (Eigen::LevenbergMarquardt from the reference's vendored Eigen) --------------------------
-MIN_GN, MIN_LM_RESTATED, MIN_LM_REF, MIN_LM_EXACT = 0, 4, 5, 6
+MIN_GN, MIN_LM_RESTATED, MIN_LM_REF, MIN_LM_EXACT, MIN_LM_MOMENT = 0, 4, 5, 6, 7
 _ref_icp = None
 _ref_icp_native = None
 
@@ -470,13 +474,45 @@ def lm_residuals_jacobian(src, tgt, nrm, x6, ref=False):
     return f, J
 
 
-def icp_refine_batch_lm(S, Sn, M, Mn, poses, max_iter=10, angle_deg=45.0, max_corr_dist=0.01, ref=False, exact=False):
+def set_mom_bits(bits):
+    """grid of the moment form (minimiser 7): |integer| <= 2^bits; 13 is what the GPU's nn_mode 7 uses -- other values: precision experiments"""
+    lib().orc_set_mom_bits(int(bits))
+
+
+def lm_point_to_plane_moments(M, c):
+    """Eigen's minimiser from a 13 x 13 moment matrix (the moment form, minimiser 7) -> (T, x, (status, nfev, iter))"""
+    Md = np.ascontiguousarray(M, np.float64).reshape(169)
+    cd = np.ascontiguousarray(c, np.float64).reshape(3)
+    T = np.zeros(16, np.float32)
+    x = np.zeros(6, np.float32)
+    st = np.zeros(3, np.int32)
+    lib().orc_lm_point_to_plane_moments(Md.ctypes.data_as(dp), cd.ctypes.data_as(dp), F(T), F(x), I(st))
+    return T.reshape(4, 4), x, tuple(int(v) for v in st)
+
+
+def mom_accumulate(src, tgt, nrm, d2, ctr, model_radius, max_corr_dist=0.01, bits=13):
+    """integer moment sums of the given correspondences -> (M int64 13x13, d2q, M in metres float64 13x13, (k_np, k_n, k_r, k_d))"""
+    a, b, c = (np.ascontiguousarray(v, np.float32).reshape(-1, 3) for v in (src, tgt, nrm))
+    d = np.ascontiguousarray(d2, np.float32).reshape(-1)
+    ct = np.ascontiguousarray(ctr, np.float32).reshape(3)
+    Mi = np.zeros(169, np.int64)
+    Md = np.zeros(169, np.float64)
+    dq = C.c_longlong(0)
+    sc = np.zeros(4, np.int32)
+    lib().orc_mom_accumulate(len(a), F(a), F(b), F(c), F(d), F(ct), C.c_double(model_radius), C.c_float(max_corr_dist), int(bits),
+                             Mi.ctypes.data_as(C.POINTER(C.c_longlong)), C.byref(dq), Md.ctypes.data_as(C.POINTER(C.c_double)), I(sc))
+    return Mi.reshape(13, 13), int(dq.value), Md.reshape(13, 13), tuple(int(v) for v in sc)
+
+
+def icp_refine_batch_lm(S, Sn, M, Mn, poses, max_iter=10, angle_deg=45.0, max_corr_dist=0.01, ref=False, exact=False, moment=False):
     """refineByICP with the reference's minimiser: PCL's gates and stopping rules (strict normal test, absolute MSE only)
     around Levenberg-Marquardt -- ref=True: Eigen's own code from the reference tree (needs oracle/_ref/libref_icp.so),
-    False: the restatement (what the GPU's nn_mode 5 is compared with)."""
+    False: the restatement (what the GPU's nn_mode 5 is compared with); exact=True: the same with every residual in double (nn_mode 6);
+    moment=True: the moment form with integer-exact sums (nn_mode 7: the GPU returns these bits)."""
     if ref:
         ref_icp()
-    return icp_refine_batch_variant(S, Sn, M, Mn, poses, max_iter, angle_deg, max_corr_dist, minimiser=MIN_LM_REF if ref else (MIN_LM_EXACT if exact else MIN_LM_RESTATED),
+    return icp_refine_batch_variant(S, Sn, M, Mn, poses, max_iter, angle_deg, max_corr_dist,
+                                    minimiser=MIN_LM_REF if ref else (MIN_LM_MOMENT if moment else (MIN_LM_EXACT if exact else MIN_LM_RESTATED)),
                                     strict_normal=True, relative_stop=False)
 
 
