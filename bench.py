@@ -44,9 +44,11 @@ def parse():
     ap.add_argument("--particles", type=int, default=200)
     ap.add_argument("--hand-scene", type=int, default=20000)
     ap.add_argument("--verify-mode", type=int, default=2, help="0 brute-force LDS scan, 1 voxel grid, 2 EXIST-mode cell lists (identical counts)")
-    ap.add_argument("--nn-mode", type=int, default=6, help="ICP nearest neighbour: 0 brute force, 1 voxel grids, 2 NN cell lists, 3 packed NN cell lists "
+    ap.add_argument("--nn-mode", type=int, default=7, help="ICP: 0 brute force, 1 voxel grids, 2 NN cell lists, 3 packed NN cell lists "
                     "with search and accumulation in one kernel (identical correspondences in modes 0-3), 4 = 3 with the increments "
-                    "composed into one transform per iteration (poses equal to ~1e-6, tests/test_gpu_fullsize.py)")
+                    "composed into one transform per iteration (poses equal to ~1e-6, tests/test_gpu_fullsize.py) -- modes 0-4: one Gauss-Newton "
+                    "step per iteration; 5 / 6 / 7: the reference's Levenberg-Marquardt minimiser (float-faithful passes / float moment sums / "
+                    "integer-exact moment sums + IEEE solve = the oracle's bits: the default and what the mirrors run)")
     ap.add_argument("--lcp-mode", type=int, default=3, help="computeLCP: 0 brute force, 1 voxel grids, 2 NN cell lists with the reference's ordered "
                     "float sum (bit-equal scores in modes 0-2), 3 NN cell lists with in-wave partial sums (scores within 1e-4 relative)")
     ap.add_argument("--pso-sum-mode", type=int, default=1, help="outer-side penalty of objFuncPSO: 0 added in scene order (the reference's float "
@@ -590,8 +592,9 @@ def main():
     alt = {}
     if not strong and not args.no_alt_modes:
         base_cfg = (args.nn_mode, args.lcp_mode, args.pso_sum_mode)
-        for label, cfg in (("icp_one_gauss_newton_step_nn_mode4", (4, args.lcp_mode, args.pso_sum_mode)),
-                           ("bit_exact_order_nn_mode3_lcp_mode2_pso_sum_mode0", (3, 2, 0))):
+        for label, cfg in (("icp_float_moment_sums_nn_mode6", (6, args.lcp_mode, args.pso_sum_mode)),
+                           ("icp_one_gauss_newton_step_nn_mode4", (4, args.lcp_mode, args.pso_sum_mode)),
+                           ("oracle_bits_every_stage_nn_mode7_lcp_mode2_pso_sum_mode0", (7, 2, 0))):
             if cfg == base_cfg:
                 continue
             args.nn_mode, args.lcp_mode, args.pso_sum_mode = cfg
@@ -656,11 +659,11 @@ def main():
                 kern["k_icp_nn"] = kern.pop("k_icp_corr_cells")
                 kern.pop("k_icp_accum")
             elif args.nn_mode >= 3:
-                # nn_mode 6: lookups + the 13 x 13 moment sums in one kernel, then the whole Levenberg-Marquardt run per hypothesis
-                kern["k_icp_fusedq_mom" if args.nn_mode == 6 else "k_icp_fusedq"] = kern.pop("k_icp_corr_cells")
+                # nn_mode 6 / 7: lookups + the 13 x 13 moment sums in one kernel, then the whole Levenberg-Marquardt run per hypothesis
+                kern[{6: "k_icp_fusedq_mom", 7: "k_icp_fusedq_momi"}.get(args.nn_mode, "k_icp_fusedq")] = kern.pop("k_icp_corr_cells")
                 kern.pop("k_icp_accum")
                 if args.nn_mode >= 5:
-                    kern["k_icp_lm6_solve" if args.nn_mode == 6 else "k_icp_lm_pass+solve"] = (tmx["ms_icp_solve"], tmx["n_icp_nn_launches"], 0.0, 0.0)
+                    kern[{6: "k_icp_lm6_solve", 7: "k_icp_lm7_solve"}.get(args.nn_mode, "k_icp_lm_pass+solve")] = (tmx["ms_icp_solve"], tmx["n_icp_nn_launches"], 0.0, 0.0)
             return kern
 
         def roofline_of(kern, dom, frames):
@@ -746,9 +749,10 @@ def main():
         out["config"]["icp_minimiser"] = ("Levenberg-Marquardt on (t, quaternion) to Eigen's stopping rule per ICP iteration = the reference's "
                                           "(PCL TransformationEstimationPointToPlane, Utils.cpp:200-216)" if args.nn_mode >= 5 else
                                           "one Gauss-Newton step per ICP iteration (NOT the reference's minimiser; see alt_modes / --nn-mode 6)")
-        out["config"]["parity_note"] = ("ICP nn_mode 6: the reference's minimiser evaluated from moment sums (exact arithmetic where PCL rounds residuals to float); "
+        out["config"]["parity_note"] = ("ICP nn_mode 7: the reference's minimiser evaluated from integer-exact moment sums with an IEEE-only solve -- the refined "
+                                        "poses are the oracle's (minimiser 7) bit for bit, whatever the launch shape; nn_mode 6 is the float-sum variant of r03. "
                                         "computeLCP lcp_mode 3 and objFuncPSO sum mode 1 re-associate float sums (<= 1e-4 / 1e-5 relative). "
-                                        "alt_modes.bit_exact_order_* is the configuration whose stages follow the oracle's operation order bit for bit.")
+                                        "alt_modes.oracle_bits_every_stage_* is the configuration in which every stage returns the oracle's bits.")
         if not args.no_cpu_baseline and world == 1 and not strong:
             try:
                 out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget_s)

@@ -51,7 +51,9 @@ class S4pcsStats(C.Structure):
                 ("ms_select", C.c_double), ("ms_device", C.c_double)]
 
 
-ICP_NN_MODE_REFERENCE = 6  # hop_icp_opts.nn_mode of the mirrors: Levenberg-Marquardt on (t, quaternion) to its stopping rule per ICP iteration
+HOP_ABI_VERSION = 2
+ICP_NN_MODE_REFERENCE = 7  # hop_icp_opts.nn_mode of the mirrors: the reference's Levenberg-Marquardt on (t, quaternion) to its stopping rule per ICP iteration,
+                           # from integer-exact moment sums with an IEEE-only solve: the poses the CPU oracle (minimiser 7) returns, bit for bit
 ICP_NN_MODE_GN = 4         # one Gauss-Newton step per ICP iteration (faster; not what PCL computes)
 
 
@@ -204,6 +206,8 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if L.hop_abi_version() != HOP_ABI_VERSION:  # the struct layouts and entry points this binding was written for (include/hop.h)
+            raise HopError(-1, "load", f"{LIB_PATH} has ABI version {L.hop_abi_version()}, this binding expects {HOP_ABI_VERSION}: rebuild")
         _lib = L
     return _lib
 
@@ -953,7 +957,7 @@ class PoseEstimator:
         self.ctx.cluster_poses(angle_diff, dist_diff, [s["x"], s["y"], s["z"]], assign_id)
 
     def refineByICP(self):
-        # nn_mode 6: the reference's minimiser (PCL's point-to-plane estimator = Eigen's Levenberg-Marquardt, Utils.cpp:200-216)
+        # nn_mode 7: the reference's minimiser (PCL's point-to-plane estimator = Eigen's Levenberg-Marquardt, Utils.cpp:200-216)
         self.ctx.icp_refine(10, float(self.cfg["icp_angle_thres"]), float(self.cfg["icp_dist_thres"]), max_hypotheses=100, nn_mode=ICP_NN_MODE_REFERENCE)
 
     def selectBest(self):

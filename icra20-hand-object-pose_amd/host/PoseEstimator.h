@@ -108,8 +108,9 @@ class PoseEstimator {
 
   // refineByICP (PoseEstimator.cpp:235-275)
   void refineByICP() {
-    // nn_mode 6: the reference's minimiser (PCL's TransformationEstimationPointToPlane = Eigen's Levenberg-Marquardt, Utils.cpp:200-216)
-    hop_icp_opts o{10, cfg->getf("icp_angle_thres"), cfg->getf("icp_dist_thres"), 100, 6};
+    // nn_mode 7: the reference's minimiser (PCL's TransformationEstimationPointToPlane = Eigen's Levenberg-Marquardt, Utils.cpp:200-216) from
+    // integer-exact moment sums with an IEEE-only solve: the refined poses are the CPU oracle's, bit for bit
+    hop_icp_opts o{10, cfg->getf("icp_angle_thres"), cfg->getf("icp_dist_thres"), 100, 7};
     hop::check(hop_icp_refine(ctx_, &o, nullptr, nullptr), ctx_, "hop_icp_refine");
   }
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define HOP_ABI_VERSION 1
+#define HOP_ABI_VERSION 2 /* 2: hop_frames_allgather, hop_topk_pack_device, hop_topk_allgather_device, hop_comm_info, hop_cluster_pose_terms (round 3); icp nn_mode 7 */
 
 typedef enum {
   HOP_OK = 0,
@@ -144,7 +144,14 @@ typedef struct {
                       * 6: the same minimiser evaluated from the 13 x 13 moment matrix of the correspondences (the residual is
                       * linear in [R | t]): ONE pass per ICP iteration, the whole Levenberg-Marquardt run per hypothesis in the
                       * solve kernel.  Exact arithmetic where PCL rounds each residual to float; closer to the reference's
-                      * default build than its -march=native build is (profiles/r03_icp_lm_deltas.json). */
+                      * default build than its -march=native build is (profiles/r03_icp_lm_deltas.json).  Per-lane float sums,
+                      * reciprocal estimates in the solve: results reproducible on the GPU, not on a CPU.
+                      * 7: the moment form made REPRODUCIBLE ANYWHERE -- the 13 components of u are put on a power-of-two grid
+                      * (12 bits: 30 um on positions, 2e-4 on normals, 4 um on the residual -- two orders below the noise of the
+                      * reference's float forward differences), the moment matrix is their exact integer sum (any order of the
+                      * lanes / wavefronts / workgroups gives the same 64-bit integers), and the solve uses IEEE + - * / sqrt fma in
+                      * a fixed order: the CPU statement of the algorithm (oracle minimiser 7) returns the same bits, so the chain
+                      * above it returns the same pose.  As close to the reference's run as mode 6. */
 } hop_icp_opts;
 int hop_icp_refine(hop_ctx* ctx, const hop_icp_opts* opts, int* iterations_out /*H or NULL*/,
                    int* converged_out /*H or NULL*/);

@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--scene", type=int, default=2000)
     ap.add_argument("--no-oracle", action="store_true")
     ap.add_argument("--model", default="ellipse", help="stand-in object (hop_amd.synth.OBJECT_SYMMETRY): ellipse, cuboid, cylinder, tless3, mustard")
-    ap.add_argument("--icp-mode", type=int, default=6, help="hop_icp_opts.nn_mode: 6 / 5 the reference's Levenberg-Marquardt minimiser, 3 / 4 one Gauss-Newton step")
+    ap.add_argument("--icp-mode", type=int, default=7, help="hop_icp_opts.nn_mode: 7 / 6 / 5 the reference's Levenberg-Marquardt minimiser (7: integer-exact moment sums, what the mirrors run), 3 / 4 one Gauss-Newton step")
     args = ap.parse_args()
     import hop_loader
     hop = hop_loader.load()
@@ -95,9 +95,9 @@ def main():
             if len(ol):
                 keep = orc.cluster_poses(op, ol, np.arange(len(ol)), 30.0, 0.015, sym)
                 p1, l1 = op[keep][:100], ol[keep][:100]
-                if args.icp_mode >= 5:  # the reference's minimiser (Levenberg-Marquardt), exact-arithmetic form for nn_mode 6, float form for 5
+                if args.icp_mode >= 5:  # the reference's minimiser (Levenberg-Marquardt): the moment form for nn_mode 7 (same bits), exact-arithmetic form for 6, float form for 5
                     keep_s = sc.conf >= 0.8
-                    p2, _, _ = orc.icp_refine_batch_lm(sc.xyz[keep_s], sc.nrm[keep_s], mx5, mn5, p1, 10, 45.0, 0.01, exact=(args.icp_mode == 6))
+                    p2, _, _ = orc.icp_refine_batch_lm(sc.xyz[keep_s], sc.nrm[keep_s], mx5, mn5, p1, 10, 45.0, 0.01, exact=(args.icp_mode == 6), moment=(args.icp_mode == 7))
                 else:
                     p2, _, _ = orc.icp_refine_batch(sc.xyz, sc.nrm, mx5, mn5, p1, 10, 45.0, 0.01)
                 keep2 = orc.cluster_poses(p2, l1, np.arange(len(l1)), 5.0, 0.003, sym)
@@ -108,6 +108,7 @@ def main():
                 ob = np.eye(4, dtype=np.float32)
             t_cpu += time.perf_counter() - t0
             row["adi_cpu"] = adi(mx1, ob.astype(np.float64), sc.gt_pose.astype(np.float64))
+            row["bit_equal"] = bool(np.array_equal(np.ascontiguousarray(best, np.float32).view(np.int32), np.ascontiguousarray(ob, np.float32).view(np.int32)))
             row["dt_mm"] = 1e3 * float(np.linalg.norm(best[:3, 3] - ob[:3, 3]))
             row["drot_deg"] = min(rot_err_deg(best[:3, :3].astype(np.float64), ob[:3, :3].astype(np.float64) @ S) for S in sym_rots)
         rows.append(row)
@@ -119,7 +120,7 @@ def main():
         b = np.array([r["adi_cpu"] for r in rows])
         agree = np.array([(r["dt_mm"] < 1.0 and r["drot_deg"] < 1.0) for r in rows])
         out.update({"recall_adi_5mm_cpu": float((b < 0.005).mean()), "recall_adi_10mm_cpu": float((b < 0.010).mean()),
-                    "frames_gpu_pose_within_1mm_1deg_of_cpu": int(agree.sum()), "cpu_s_per_frame": t_cpu / args.frames,
+                    "frames_gpu_pose_within_1mm_1deg_of_cpu": int(agree.sum()), "frames_gpu_pose_bit_equal_to_cpu": int(sum(r["bit_equal"] for r in rows)), "cpu_s_per_frame": t_cpu / args.frames,
                     "max_dt_mm": float(max(r["dt_mm"] for r in rows)), "max_drot_deg": float(max(r["drot_deg"] for r in rows))})
     print(json.dumps(out))
 

@@ -206,6 +206,13 @@ def test_c5_subsample_against_the_oracle_at_size(ctx, api, orc, synth):
     assert np.median(d6) < 2e-6 and np.percentile(d6, 90) < 5e-5
     for a, b in zip(p6, ref6):
         assert np.linalg.norm(a[:3, 3] - b[:3, 3]) < 1e-3 and _rot_err_deg(a[:3, :3], b[:3, :3]) < 1.0
+    # nn_mode 7 (what the mirrors and the bench run): the oracle's bits at this size too
+    ref7, rit7, rcv7 = orc.icp_refine_batch_lm(sc.xyz, sc.nrm, mx, mn, poses, 10, 45.0, 0.01, moment=True)
+    ctx.hypos_upload(poses)
+    it7, cv7 = ctx.icp_refine(10, 45.0, 0.01, nn_mode=7, want_stats=True)
+    p7 = ctx.hypos_download()[0].copy()
+    assert np.array_equal(cv7, rcv7) and np.array_equal(it7, rit7)
+    assert np.array_equal(p7.view(np.int32), np.ascontiguousarray(ref7, np.float32).view(np.int32))
     sref = orc.compute_lcp_batch(sc.xyz, sc.nrm, mx, mn, ref, 0.001, 10.0, use_tree=True)
     ctx.hypos_upload(ref)
     _, _, i2 = ctx.lcp_select_best(0.001, 10.0, 2)

@@ -499,8 +499,8 @@ def test_handbase_icp_pieces_and_mirror(ctx, orc, synth, api):
     assert dt < 1.5e-3 and math.degrees(math.acos(min(1.0, c))) < 0.6, (dt, c)
     # the same chain through the oracle
     bx, bn = hand.clouds["base_link"]
-    # (Utils::runICP's minimiser is PCL's Levenberg-Marquardt: the mirror runs hop_icp_refine nn_mode 6, the oracle its exact-arithmetic form)
-    poses, it, cv = orc.icp_refine_batch_lm(gx[keep_o], gn[keep_o], bx, bn, np.eye(4, dtype=np.float32)[None], 50, 30.0, 0.03, exact=True)
+    # (Utils::runICP's minimiser is PCL's Levenberg-Marquardt: the mirror runs hop_icp_refine nn_mode 7, the oracle the same moment form)
+    poses, it, cv = orc.icp_refine_batch_lm(gx[keep_o], gn[keep_o], bx, bn, np.eye(4, dtype=np.float32)[None], 50, 30.0, 0.03, moment=True)
     off_o = np.linalg.inv(poses[0].astype(np.float64))
     assert np.abs(off_o - offset).max() < 2e-4
     # a 13 degree error is found by the ICP but not accepted (rot_diff >= 10, Hand.cpp:752-756): the offset is reset

@@ -178,6 +178,25 @@ def test_icp_with_the_minimiser_in_exact_arithmetic_vs_the_reference_builds(orc,
     assert_as_close_as_the_other_build(p, g, slack=5)
 
 
+def test_icp_in_the_moment_form_vs_the_reference_builds(orc, hop, golden_dir):
+    """The moment form with integer-exact sums (minimiser 7 = the GPU's nn_mode 7, the form the mirrors run): the 12-bit grid and the
+    composed source transform change nothing that can be seen at the scale of the reference's own build-to-build spread -- as close to
+    Eigen's default build as the exact-arithmetic form, iteration counts and convergence flags equal on the C2-style subset."""
+    g = np.load(os.path.join(golden_dir, "icp_lm_c2sub.npz"))
+    S, Sn, mx5, mn5 = c2sub_inputs(hop)
+    p, it, cv = orc.icp_refine_batch_lm(S, Sn, mx5, mn5, g["poses_in"], 10, 45.0, 0.01, moment=True)
+    mine, native = assert_as_close_as_the_other_build(p, g, slack=3)
+    assert mine[0] >= 88 and (it == g["iterations"]).sum() >= 88 and np.array_equal(cv, g["converged"])
+    pe, ite, cve = orc.icp_refine_batch_lm(S, Sn, mx5, mn5, g["poses_in"], 10, 45.0, 0.01, exact=True)
+    t, r = pose_deltas(p, pe)
+    assert ((t < 0.05) & (r < 0.5)).sum() >= len(t) - 3 and (it == ite).sum() >= len(t) - 2   # against the per-point exact form: the grid is invisible
+    g = np.load(os.path.join(golden_dir, "icp_lm_c1.npz"))
+    S, Sn, mx5, mn5 = c1_inputs(hop, golden_dir)
+    p, it, cv = orc.icp_refine_batch_lm(S, Sn, mx5, mn5, g["poses_in"], 10, 45.0, 0.01, moment=True)
+    assert_as_close_as_the_other_build(p, g, slack=5)
+    assert (cv == g["converged"]).sum() >= 88
+
+
 @pytest.mark.skipif(not os.path.exists("/root/reference"), reason="the reference tree (build container only)")
 def test_goldens_are_what_the_reference_build_returns_now(orc, hop, golden_dir, kat):
     """regenerates a slice of the vectors from oracle/_ref/libref_icp.so and compares (guards stale fixtures)"""
