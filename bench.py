@@ -486,6 +486,12 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
+            # self-check before anything is timed: the communicator RCCL built spans exactly WORLD_SIZE ranks (a line whose exchange ran on
+            # fewer ranks than the launch asked for would misreport the job)
+            nr = comm.info()[0]
+            if nr != world:
+                raise SystemExit(f"bench.py: ncclCommCount reports {nr} ranks on rank {rank}, WORLD_SIZE is {world}: refusing to time a partial job "
+                                 f"(check HSA_ENABLE_IPC_MODE_LEGACY=0 and that every rank owns its own GPU)")
             exchange_kind = "hop_topk_pack_device + hop_topk_allgather_device (RCCL inside libhop.so; table on the device end to end)"
         elif comm is not None:
             comm.close()

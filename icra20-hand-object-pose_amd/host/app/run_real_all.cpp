@@ -10,7 +10,8 @@
 //   rank contributes its frames' poses to ONE hop_frames_allgather (ncclAllGather inside libhop.so); rank 0 writes them all to
 //   <base>/<model>/model2scene_all.txt ("record index m00 ... m33" per frame).  The 128-byte RCCL id travels through the file
 //   HOP_COMM_ID_FILE (default <base>/<model>/.hop_comm_id[.<MASTER_PORT>][.<HOP_RUN_ID>]: the ranks share the dataset directory already;
-//   see comm_through_file for how a stale file and a failed rank are handled); one rank needs no communicator.  Same table as run_real_all.gather_frame_poses of the Python runner.
+//   see comm_through_file for how a stale file and a failed rank are handled); one rank needs no communicator (HOP_GATHER_COMM=1
+//   builds a 1-rank one all the same: the RCCL leg on a single-GPU box).  Same table as run_real_all.gather_frame_poses of the Python runner.
 // assets_dir holds what the reference loads from PLY / OBJ / Boost archive / URDF files (download links): see hop::Assets (host/Frame.h).
 #include <dirent.h>
 #include <sys/stat.h>
@@ -148,9 +149,12 @@ int main(int argc, char** argv) {
     std::string id_file = std::getenv("HOP_COMM_ID_FILE") ? std::getenv("HOP_COMM_ID_FILE") : mdir + "/.hop_comm_id";
     if (!std::getenv("HOP_COMM_ID_FILE") && std::getenv("MASTER_PORT")) id_file += std::string(".") + std::getenv("MASTER_PORT");
     if (!std::getenv("HOP_COMM_ID_FILE") && std::getenv("HOP_RUN_ID")) id_file += std::string(".") + std::getenv("HOP_RUN_ID");
-    g_id_file = gather && world > 1 ? id_file : std::string();
+    // HOP_GATHER_COMM=1: go through the communicator even with ONE rank (the ncclAllGather leg then runs on a 1-rank RCCL communicator:
+    // what a single-GPU box can exercise of configs[3]'s collective)
+    const bool use_comm = gather && (world > 1 || std::getenv("HOP_GATHER_COMM") != nullptr);
+    g_id_file = use_comm ? id_file : std::string();
     g_rank = rank;
-    if (gather && world > 1 && rank == 0) std::remove(id_file.c_str()), std::remove((id_file + ".abort").c_str());
+    if (use_comm && rank == 0) std::remove(id_file.c_str()), std::remove((id_file + ".abort").c_str());
     const std::regex rgb_re("rgb([0-9]+)\\..*");
     for (const std::string& record : list_dir(mdir, true)) {
       const std::string rec = mdir + "/" + record;
@@ -258,7 +262,7 @@ int main(int argc, char** argv) {
         ++number;
       }
       std::vector<float> table;
-      if (world == 1) table = rows;  // one rank: its rows are the table
+      if (!use_comm) table = rows;  // one rank: its rows are the table
       else {
         hop_comm* comm = comm_through_file(id_file, device, rank, world);
         table.assign((size_t)world * rows_per_rank * HOP_FRAME_ROW_FLOATS, 0.f);
@@ -289,7 +293,8 @@ int main(int argc, char** argv) {
         }
         std::rename((out + ".tmp").c_str(), out.c_str());
       }
-      std::printf("rank %d of %d: poses of %zu frames gathered (%zu from this rank, %d rows per rank)\n", rank, world, all_frames.size(), mine.size(), rows_per_rank);
+      std::printf("rank %d of %d: poses of %zu frames gathered (%zu from this rank, %d rows per rank%s)\n", rank, world, all_frames.size(), mine.size(), rows_per_rank,
+                  use_comm ? ", through hop_frames_allgather" : "");
     }
     return 0;
   } catch (const std::exception& e) {
