@@ -525,10 +525,11 @@ __device__ __forceinline__ void quad_fit_emit(const QuadArgs& a, const BaseDev& 
 // (query) per wave at a time -- wave-uniform, read once -- against all first pairs (elements), 64 per step, read
 // coalesced.  The ~0.2 % that pass go into a device-wide queue (one wave-aggregated atomic per step that has any), so that
 // the long rigid-fit code of stage 2 always runs with full lanes whatever the per-wave yield.
-__global__ __launch_bounds__(256) void k_quads(QuadArgs a) {
+__global__ __launch_bounds__(256) void k_quads(QuadArgs a, int n1_above) {
   __shared__ int queue_s[4][2][128];  // per wave: accepted (id1, id2) on their way to the device-wide queue
   const int b = blockIdx.y;
   const int n1 = min(a.cnt1[b], a.cap), n2 = min(a.cnt2[b], a.cap);
+  if (n1 <= n1_above) return;  // (bases k_quads_hash takes)
   const int eg = a.geom.eg_size;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -578,6 +579,104 @@ __global__ __launch_bounds__(256) void k_quads(QuadArgs a) {
         flush(qn - 64, 64);
         qn -= 64;
         __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  if (qn > 0) flush(0, qn);
+  if (lane == 0 && nq_wave) atomicAdd(&a.nquads[b], nq_wave);
+}
+
+// The same stage the way the reference does it (IndexedNormalSet: first pairs binned by the cell of their invariant point, a second pair
+// looks into the 27 cells around its own, FunctorSuper4pcs.h:131-293) instead of every second pair against every first pair: a block
+// hashes the base's first pairs by cell into LDS (chained, open hashing on the three cell coordinates), then one second pair per lane
+// walks the chains of its 27 neighbour cells.  ~30 x fewer instructions than k_quads at C2's ~600 x 600 pairs per base; bases with more
+// than QH_MAX first pairs are left to k_quads.  The accepted pairs reach the fit queue in another order; quad_fit_emit's canonical key
+// orders the candidates afterwards, as it already had to (the queue is filled through atomics).
+constexpr int QH_MAX = 4096, QH_SLOTS = 4096;
+__device__ __forceinline__ int qh_hash(int cx, int cy, int cz) {
+  return (int)(((unsigned)cx * 73856093u) ^ ((unsigned)cy * 19349663u) ^ ((unsigned)cz * 83492791u)) & (QH_SLOTS - 1);
+}
+__global__ __launch_bounds__(256) void k_quads_hash(QuadArgs a) {
+  __shared__ int head[QH_SLOTS];
+  __shared__ unsigned short nxt[QH_MAX];
+  __shared__ uint2 ekey[QH_MAX];
+  __shared__ int queue_s[4][2][128];
+  const int b = blockIdx.y;
+  const int n1 = min(a.cnt1[b], a.cap), n2 = min(a.cnt2[b], a.cap);
+  if (n1 > QH_MAX || n1 == 0 || n2 == 0) return;
+  const int eg = a.geom.eg_size;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const char* __restrict__ eb = reinterpret_cast<const char*>(a.elems + (size_t)b * a.cap);
+  static_assert(sizeof(QuadElem) == 20, "an element's first two words and its position are read by offset");
+  for (int i = threadIdx.x; i < QH_SLOTS; i += 256) head[i] = -1;
+  __syncthreads();
+  for (int id1 = threadIdx.x; id1 < n1; id1 += 256) {
+    const unsigned* w = reinterpret_cast<const unsigned*>(eb + (size_t)id1 * 20);
+    const unsigned w0 = w[0], w1 = w[1];
+    ekey[id1] = make_uint2(w0, w1);
+    const int ecx = (short)(w0 & 0xffffu), ecy = (short)(w0 >> 16), ecz = (short)(w1 & 0xffffu), nid = (short)(w1 >> 16);
+    int old = -1;
+    const bool valid = ecx >= 0 && ecx < eg && ecy >= 0 && ecy < eg && ecz >= 0 && ecz < eg && nid >= 0 && nid < 343;
+    if (valid) old = atomicExch(&head[qh_hash(ecx, ecy, ecz)], id1);
+    nxt[id1] = (unsigned short)(old < 0 ? 0xFFFF : old);
+  }
+  __syncthreads();
+  int* queue1 = queue_s[wave][0];
+  int* queue2 = queue_s[wave][1];
+  int nq_wave = 0, qn = 0;
+  const int qi = (blockIdx.y * gridDim.x + blockIdx.x) & (FIT_QUEUES - 1);
+  auto flush = [&](int from, int count) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(a.fit_count + qi, count);
+    base = __shfl(base, 0);
+    if (lane < count) {
+      const int at = base + lane;
+      if (at < a.fit_cap) a.fit_queue[(size_t)qi * a.fit_cap + at] = make_int4(b, queue1[from + lane], queue2[from + lane], 0);
+      else *a.overflow = 1;
+    }
+  };
+  const int tiles = (n2 + 63) >> 6;
+  for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
+    const int id2 = tile * 64 + lane;
+    const QuadQuery* __restrict__ qq = a.queries + (size_t)b * a.cap + min(id2, n2 - 1);
+    const int qcx = qq->cx, qcy = qq->cy, qcz = qq->cz;
+    const bool qok = id2 < n2 && qcx >= 0 && qcx < eg && qcy >= 0 && qcy < eg && qcz >= 0 && qcz < eg;
+    const V3 qp = v3(qq->px, qq->py, qq->pz);
+    for (int nb = 0; nb < 27; ++nb) {
+      const int ncx = qcx + nb % 3 - 1, ncy = qcy + (nb / 3) % 3 - 1, ncz = qcz + nb / 9 - 1;
+      int cur = -1;
+      if (qok && ncx >= 0 && ncx < eg && ncy >= 0 && ncy < eg && ncz >= 0 && ncz < eg) cur = head[qh_hash(ncx, ncy, ncz)];
+      while (__ballot(cur >= 0)) {  // (wave-uniform: the lanes whose chain has ended idle)
+        bool ok = false;
+        const int id1 = cur;
+        if (cur >= 0) {
+          const uint2 k = ekey[cur];
+          const int ecx = (short)(k.x & 0xffffu), ecy = (short)(k.x >> 16), ecz = (short)(k.y & 0xffffu), nid = (short)(k.y >> 16);
+          const unsigned short nx = nxt[cur];
+          cur = nx == 0xFFFF ? -1 : (int)nx;
+          ok = ecx == ncx && ecy == ncy && ecz == ncz;  // (a chain holds every cell that hashes to its slot)
+          if (ok) ok = (qq->mask[nid >> 5] >> (nid & 31)) & 1u;
+          if (ok) {
+            const float* pp = reinterpret_cast<const float*>(eb + (size_t)id1 * 20 + 8);
+            const V3 d = qp - v3(pp[0], pp[1], pp[2]);
+            ok = vsqn(d) <= a.dist_thr2;  // squared norm vs the UNSQUARED threshold (FunctorSuper4pcs.h:277)
+          }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (!m) continue;
+        if (ok) {
+          const int at = qn + __popcll(m & ((1ull << lane) - 1ull));
+          queue1[at] = id1, queue2[at] = id2;
+        }
+        qn += __popcll(m);
+        nq_wave += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= 64) {
+          flush(qn - 64, 64);
+          qn -= 64;
+          __builtin_amdgcn_wave_barrier();
+        }
       }
     }
   }
@@ -3337,7 +3436,13 @@ void launch_quad_prep(const QuadPrepArgs& a, int nbases, int max_items, hipStrea
 }
 void launch_quads(const QuadArgs& a, int nbases, int blocks_per_base, hipStream_t s) {
   dim3 grid(blocks_per_base, nbases);
-  hipLaunchKernelGGL(k_quads, grid, dim3(256), 0, s, a);
+  static const bool hashed = getenv("HOP_QUADS_HASH") != nullptr && atoi(getenv("HOP_QUADS_HASH")) != 0;
+  if (hashed) {
+    hipLaunchKernelGGL(k_quads_hash, dim3(4, nbases), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_quads, grid, dim3(256), 0, s, a, (int)QH_MAX);  // the bases it left (more first pairs than its table holds)
+  } else {
+    hipLaunchKernelGGL(k_quads, grid, dim3(256), 0, s, a, -1);
+  }
   hipLaunchKernelGGL(k_quad_fit, dim3(8, FIT_QUEUES), dim3(256), 0, s, a);
 }
 void launch_verify_cells(const VerifyArgs& a, const CellListDev& cl, int blocks, hipStream_t s) {

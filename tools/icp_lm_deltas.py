@@ -12,6 +12,8 @@ ICP minimiser switched, everything else identical (CPU oracle):
     lm         the restatement of that algorithm (oracle/hop_oracle.cpp lm_*; what the GPU's nn_mode 5 computes)
     lm_exact   the same minimiser with every residual in exact (double) arithmetic instead of float -- what the GPU's nn_mode 6 computes
                from the 13 x 13 moment matrix of the correspondences, one pass per ICP iteration
+    lm_moment  the moment form with integer-exact sums on a 12-bit grid and an IEEE-only solve (oracle minimiser 7) -- what the GPU's
+               nn_mode 7 returns BIT FOR BIT (the mode the mirrors and the bench run)
     gn         one Gauss-Newton step about the matched centroid per ICP iteration (nn_mode 0-4)
 and reports, against `ref`: per refined hypothesis (all <= 100 per frame) and for the SELECTED pose, translation / rotation
 differences.  `ref_native` vs `ref` is the reference's own build-to-build spread: no implementation can be asked to be closer to
@@ -86,6 +88,7 @@ def main():
         "ref_native": v_ref(True),
         "lm": lambda S, Sn, M, Mn, P: orc.icp_refine_batch_lm(S, Sn, M, Mn, P, 10, 45.0, 0.01, ref=False),
         "lm_exact": lambda S, Sn, M, Mn, P: orc.icp_refine_batch_lm(S, Sn, M, Mn, P, 10, 45.0, 0.01, exact=True),
+        "lm_moment": lambda S, Sn, M, Mn, P: orc.icp_refine_batch_lm(S, Sn, M, Mn, P, 10, 45.0, 0.01, moment=True),
         "gn": lambda S, Sn, M, Mn, P: orc.icp_refine_batch(S, Sn, M, Mn, P, 10, 45.0, 0.01),
     }
     if args.gpu:
@@ -102,6 +105,7 @@ def main():
             return f
         variants["gpu_lm_nn_mode5"] = v_gpu(5)
         variants["gpu_lm_moments_nn_mode6"] = v_gpu(6)
+        variants["gpu_lm_integer_moments_nn_mode7"] = v_gpu(7)
         variants["gpu_gn_nn_mode3"] = v_gpu(3)
     frames = []
     g = np.load(os.path.join(ROOT, "tests", "golden", "depth7_hand_region.npz"))
