@@ -1,0 +1,32 @@
+#!/bin/bash
+# First thing to run on an MI355X box when GPU access (re)opens (VERDICT r03 "next round" item 1): everything the driver runs at round
+# end, with the logs KEPT under gpurun_out/<tag>/ so that the summaries can be committed to profiles/.
+#   gpurun --timeout 3000 -- 'bash tools/gpu_round_check.sh r04'
+#     gputest.log      python -m pytest tests -m gpu  (no -x: every red test is listed; durations of the slowest 20)
+#     smoke.log        __graft_entry__.smoke()
+#     bench.json/.err  python bench.py --gpus 1 --steps 20 --warmup 5   (the driver's command)
+#     bench_alt*.json  the same with nn_mode 6 (round 3's default) for the comparison DESIGN.md section 4 needs
+# Profiles (rocprofv3 kernel stats, PMC passes) are a second call: tools/gpu_profile.sh <tag>.
+TAG=${1:-r04}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+python -m pytest tests -m gpu -q -p no:cacheprovider --durations=20 > $OUT/gputest.log 2>&1
+echo "pytest exit $?" >> $OUT/gputest.log
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+echo "smoke exit $?" >> $OUT/smoke.log
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --gpus 1 --steps 20 --warmup 5 --nn-mode 6 --no-cpu-baseline --no-next-rows --no-alt-modes > $OUT/bench_nn_mode6.json 2> $OUT/bench_nn_mode6.err
+HOP_QUADS_HASH=1 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-next-rows --no-alt-modes > $OUT/bench_quads_hash.json 2> $OUT/bench_quads_hash.err
+tail -15 $OUT/gputest.log
+tail -2 $OUT/smoke.log
+head -c 1500 $OUT/bench.json
+echo
+python - <<PY
+import json
+for f in ("bench", "bench_nn_mode6", "bench_quads_hash"):
+    try:
+        d = json.loads(open("$OUT/%s.json" % f).read().strip().splitlines()[-1])
+        print(f, d["value"], d["unit"], d["ms_per_step"], "ms/step", d.get("roofline", {}).get("kernel"), d.get("roofline", {}).get("frac"))
+    except Exception as e:
+        print(f, "unreadable:", e)
+PY
