@@ -2031,9 +2031,13 @@ template __global__ void k_icp_fused<ICP_ACCUM_R>(IcpArgs);
 // quantisation error q_eq of a candidate position added to `tol`).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+#if defined(HOP_EMU)  // (tests/emu: the kernel text compiled for the CPU model -- no gfx950 instruction there)
+  return max(min(a, b), min(max(a, b), c));
+#else
   unsigned r;
   asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
+#endif
 }
 __device__ __forceinline__ V3 m4_point_fma(const float* T, V3 p) {
   return v3(__builtin_fmaf(T[0], p.x, __builtin_fmaf(T[1], p.y, __builtin_fmaf(T[2], p.z, T[3]))),
@@ -2073,8 +2077,12 @@ struct Q3 {
 __device__ __forceinline__ unsigned q_rank(Q3 l, unsigned lo, unsigned hi) {
   const int dx = l.x - (int)(lo & 0xffffu), dy = l.y - (int)(lo >> 16), dz = l.z - (int)(hi & 0xffffu);
   unsigned d = (unsigned)__mul24(dz, dz);
+#if defined(HOP_EMU)
+  d += (unsigned)__mul24(dy, dy) + (unsigned)__mul24(dx, dx);
+#else
   asm("v_mad_i32_i24 %0, %1, %1, %0" : "+v"(d) : "v"(dy));  // (the compiler prefers three multiplies and v_add3)
   asm("v_mad_i32_i24 %0, %1, %1, %0" : "+v"(d) : "v"(dx));
+#endif
   return d;
 }
 #define Q_L(v) (int)(v)

@@ -24,6 +24,14 @@
 #define LM_COUNT(slot, v) do { } while (0)
 #endif
 
+// (std::max) / (std::min) as Eigen's LevenbergMarquardt.h and lmpar.h call them -- NOT fmax / fmin: when a trial step leaves the unit ball
+// of the quaternion its residuals are NaN, and what the minimiser does next (Eigen: the comparison with NaN is false, the step is refused
+// and the trust region shrinks) depends on which operand a maximum with NaN returns.  fmax would return the number: round 3's
+// `fmax(ff, 0)` turned a NaN sum of squares into 0, "a perfect step", and nn_mode 6 accepted it (found in round 4 by running this text on
+// the CPU model against the oracle on the C1 frame, hypothesis 78).
+HOP_LM_INL double lm_max(double a, double b) { return (a < b) ? b : a; }
+HOP_LM_INL double lm_min(double a, double b) { return (b < a) ? b : a; }
+
 // state of the minimiser for one hypothesis, register-resident (nn_mode 6 / 7: no per-pass warp tables)
 struct LmDev6 {
   float x[6], xc[6], p[6];
@@ -77,7 +85,7 @@ HOP_LM_DEV void piv_chol(const double A[6][6], PivChol& c) {
     }
     const double d = sqrt(S[k][k]);
     c.R[k][k] = d;
-    maxpiv = fmax(maxpiv, d);
+    maxpiv = lm_max(maxpiv, d);
     for (int j = k + 1; j < 6; ++j) c.R[k][j] = S[k][j] / d;
     for (int i = k + 1; i < 6; ++i)
       for (int j = k + 1; j < 6; ++j) S[i][j] -= c.R[k][i] * c.R[k][j];
@@ -178,13 +186,13 @@ HOP_LM_NOINL void lm_par(const double A[6][6], const double g[6], const double d
   for (int j = 0; j < 6; ++j) wa1[j] = g[j] / diag[j];
   const double gnorm = norm6(wa1);
   double paru = gnorm / delta;
-  if (paru == 0) paru = dwarf / fmin(delta, p1);
-  par = fmax(par, parl);
-  par = fmin(par, paru);
+  if (paru == 0) paru = dwarf / lm_min(delta, p1);
+  par = lm_max(par, parl);
+  par = lm_min(par, paru);
   if (par == 0) par = gnorm / dxnorm;
   while (true) {
     ++iter;
-    if (par == 0) par = fmax(dwarf, (double)0.001f * paru);
+    if (par == 0) par = lm_max(dwarf, (double)0.001f * paru);
     double M[6][6];
     for (int i = 0; i < 6; ++i)
       for (int j = 0; j < 6; ++j) M[i][j] = A[i][j] + (i == j ? par * diag[i] * diag[i] : 0.0);
@@ -201,9 +209,9 @@ HOP_LM_NOINL void lm_par(const double A[6][6], const double g[6], const double d
     for (int j = 0; j < 6; ++j) t2 += w[j] * u[j];
     temp = sqrt(t2);
     const double parc = fp / delta / temp / temp;
-    if (fp > 0) parl = fmax(parl, par);
-    if (fp < 0) paru = fmin(paru, par);
-    par = fmax(parl, par + parc);
+    if (fp > 0) parl = lm_max(parl, par);
+    if (fp < 0) paru = lm_min(paru, par);
+    par = lm_max(parl, par + parc);
   }
   if (iter == 0) par = 0;
 }
@@ -268,10 +276,10 @@ HOP_LM_INL bool chol6_regs(const double* __restrict__ a21, const double* __restr
       if (i == j) {
         ok = ok && v > 1e-290;
         double d, r;
-        LmOps<FAST>::root(fmax(v, 1e-290), d, r);
+        LmOps<FAST>::root(lm_max(v, 1e-290), d, r);
         L[i * (i + 1) / 2 + i] = d;
         Linv[i] = r;
-        lmin = fmin(lmin, d), lmax = fmax(lmax, d);
+        lmin = lm_min(lmin, d), lmax = lm_max(lmax, d);
       } else
         L[i * (i + 1) / 2 + j] = v * Linv[j];
     }
@@ -343,11 +351,11 @@ HOP_LM_INL bool lm_par_regs(const double* __restrict__ a21, const double* __rest
   }
   const double gnorm = gq > 1e-290 ? LmOps<FAST>::sqrt_pos(gq) : 0.0;
   double paru = gnorm * dinv;
-  if (paru == 0) paru = dwarf / fmin(delta, p1);
-  double par = fmin(fmax(par_io, parl), paru);
+  if (paru == 0) paru = dwarf / lm_min(delta, p1);
+  double par = lm_min(lm_max(par_io, parl), paru);
   if (par == 0) par = gnorm * LmOps<FAST>::rcp(dxnorm);
   for (int iter = 1;; ++iter) {
-    if (par == 0) par = fmax(dwarf, (double)0.001f * paru);
+    if (par == 0) par = lm_max(dwarf, (double)0.001f * paru);
     if (!chol6_regs<FAST>(a21, diag, par, L, Linv)) return false;  // (A + par D^2 is better conditioned than A: does not happen)
     chol6_fwd(L, Linv, g, y);
     chol6_bwd(L, Linv, y, xs);
@@ -363,9 +371,9 @@ HOP_LM_INL bool lm_par_regs(const double* __restrict__ a21, const double* __rest
 #pragma unroll
     for (int j = 0; j < 6; ++j) t3 = fma(y[j], y[j], t3);
     const double parc = fp * dinv * LmOps<FAST>::rcp(t3);
-    if (fp > 0) parl = fmax(parl, par);
-    if (fp < 0) paru = fmin(paru, par);
-    par = fmax(parl, par + parc);
+    if (fp > 0) parl = lm_max(parl, par);
+    if (fp < 0) paru = lm_min(paru, par);
+    par = lm_max(parl, par + parc);
   }
 #pragma unroll
   for (int j = 0; j < 6; ++j) x[j] = xs[j];
@@ -402,7 +410,7 @@ HOP_LM_DEV void lm_inner(LS& s) {
     s.xc[j] = s.x[j] + s.p[j];
   }
   s.pnorm = lm_scaled_norm(s.diag, s.p);
-  if (s.iter == 1) s.delta = fmin(s.delta, s.pnorm);
+  if (s.iter == 1) s.delta = lm_min(s.delta, s.pnorm);
   s.phase = 1;
 }
 // head of minimizeOneStep (LevenbergMarquardt.h:219-260); false = finished
@@ -432,11 +440,11 @@ HOP_LM_DEV bool lm_outer(LS& s) {
       const double finv = rcp_nr(s.fnorm);
 #pragma unroll
       for (int j = 0; j < 6; ++j)
-        if (wa2[j] != 0) s.gnorm = fmax(s.gnorm, fabs(s.g[j] * finv * wa2inv[j]));
+        if (wa2[j] != 0) s.gnorm = lm_max(s.gnorm, fabs(s.g[j] * finv * wa2inv[j]));
     } else {
 #pragma unroll
       for (int j = 0; j < 6; ++j)
-        if (wa2[j] != 0) s.gnorm = fmax(s.gnorm, fabs(s.g[j] / s.fnorm / wa2[j]));
+        if (wa2[j] != 0) s.gnorm = lm_max(s.gnorm, fabs(s.g[j] / s.fnorm / wa2[j]));
     }
   }
   if (s.gnorm <= 0) {
@@ -444,7 +452,7 @@ HOP_LM_DEV bool lm_outer(LS& s) {
     return false;
   }
 #pragma unroll
-  for (int j = 0; j < 6; ++j) s.diag[j] = fmax(s.diag[j], wa2[j]);
+  for (int j = 0; j < 6; ++j) s.diag[j] = lm_max(s.diag[j], wa2[j]);
   lm_inner(s);
   return true;
 }
@@ -480,12 +488,12 @@ HOP_LM_DEV bool lm_advance(LS& s, const double* cand) {
     fnorm1 = c27 > 1e-290 ? c27 * rsqrt_nr(c27) : 0.0;
     const double finv = rcp_nr(s.fnorm), r1 = fnorm1 * finv;
     if (p1 * fnorm1 < s.fnorm) actred = 1.0 - r1 * r1;
-    temp1 = fmax(jp2, 0.0) * finv * finv;
+    temp1 = lm_max(jp2, 0.0) * finv * finv;
     temp2 = s.par * (s.pnorm * finv) * (s.pnorm * finv);
   } else {
     fnorm1 = sqrt(cand[27]);
     if (p1 * fnorm1 < s.fnorm) actred = 1.0 - (fnorm1 / s.fnorm) * (fnorm1 / s.fnorm);
-    const double t1r = sqrt(fmax(jp2, 0.0)) / s.fnorm, t2r = sqrt(s.par) * s.pnorm / s.fnorm;
+    const double t1r = sqrt(lm_max(jp2, 0.0)) / s.fnorm, t2r = sqrt(s.par) * s.pnorm / s.fnorm;
     temp1 = t1r * t1r, temp2 = t2r * t2r;
   }
   const double prered = temp1 + temp2 / p5, dirder = -(temp1 + temp2);
@@ -495,7 +503,7 @@ HOP_LM_DEV bool lm_advance(LS& s, const double* cand) {
     double temp = p5;
     if (actred < 0) temp = p5 * dirder / (dirder + p5 * actred);
     if (p1 * fnorm1 >= s.fnorm || temp < p1) temp = p1;
-    s.delta = temp * fmin(s.delta, s.pnorm / p1);
+    s.delta = temp * lm_min(s.delta, s.pnorm / p1);
     s.par /= temp;
   } else if (!(s.par != 0 && ratio < p75)) {
     s.delta = s.pnorm / p5;
@@ -618,7 +626,7 @@ HOP_LM_DEV void lm6_eval(const double* __restrict__ Mlds /* + lane, stride MSTRI
     }
 #pragma unroll
   for (int u = 0; u < 6; ++u) cand[21 + u] = u < 3 ? gt[u] : gr[u - 3];
-  cand[27] = fmax(ff, 0.0);
+  cand[27] = lm_max(ff, 0.0);
 }
 
 

@@ -1678,10 +1678,10 @@ static bool canon_chol(const double A[6][6], const double diag[6], double par, d
       for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
       if (i == j) {
         ok = ok && v > 1e-290;
-        const double d = std::sqrt(std::fmax(v, 1e-290));
+        const double d = std::sqrt(std::max(v, 1e-290));
         L[i][i] = d;
         Linv[i] = 1.0 / d;
-        lmin = std::fmin(lmin, d), lmax = std::fmax(lmax, d);
+        lmin = std::min(lmin, d), lmax = std::max(lmax, d);
       } else
         L[i][j] = v * Linv[j];
     }
@@ -1738,11 +1738,11 @@ bool lm_par_chol(const double A[6][6], const double g[6], const double diag[6], 
   }
   const double gnorm = gq > 1e-290 ? std::sqrt(gq) : 0.0;
   double paru = gnorm * dinv;
-  if (paru == 0) paru = dwarf / std::fmin(delta, p1);
-  double par = std::fmin(std::fmax(par_io, parl), paru);
+  if (paru == 0) paru = dwarf / std::min(delta, p1);
+  double par = std::min(std::max(par_io, parl), paru);
   if (par == 0) par = gnorm * (1.0 / dxnorm);
   for (int iter = 1;; ++iter) {
-    if (par == 0) par = std::fmax(dwarf, (double)0.001f * paru);
+    if (par == 0) par = std::max(dwarf, (double)0.001f * paru);
     if (!canon_chol(A, diag, par, L, Linv)) return false;
     canon_fwd(L, Linv, g, y);
     canon_bwd(L, Linv, y, xs);
@@ -1756,9 +1756,9 @@ bool lm_par_chol(const double A[6][6], const double g[6], const double diag[6], 
     double t3 = 0;
     for (int j = 0; j < 6; ++j) t3 = std::fma(y[j], y[j], t3);
     const double parc = fp * dinv * (1.0 / t3);
-    if (fp > 0) parl = std::fmax(parl, par);
-    if (fp < 0) paru = std::fmin(paru, par);
-    par = std::fmax(parl, par + parc);
+    if (fp > 0) parl = std::max(parl, par);
+    if (fp < 0) paru = std::min(paru, par);
+    par = std::max(parl, par + parc);
   }
   std::copy(xs, xs + 6, x);
   par_io = par;

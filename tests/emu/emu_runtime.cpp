@@ -1,0 +1,299 @@
+// tests/emu/emu_runtime.cpp -- TEST INFRASTRUCTURE: the scheduler and the runtime calls of the functional HIP model (hip/hip_runtime.h).
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "hip/hip_runtime.h"
+
+emu_uint3 threadIdx, blockIdx;
+dim3 blockDim, gridDim;
+
+// A context switch without the signal-mask system calls of swapcontext (a launch of a few hundred thousand small workgroups makes tens of
+// millions of them): callee-saved registers on the old stack, stack pointers exchanged.  x86-64 System V.
+extern "C" void emu_swap(void** save_sp, void* load_sp);
+__asm__(
+    ".text\n"
+    ".globl emu_swap\n"
+    ".type emu_swap,@function\n"
+    "emu_swap:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size emu_swap,.-emu_swap\n");
+
+namespace emu {
+namespace {
+constexpr size_t STACK_BYTES = 512 << 10;
+enum State { ST_READY = 0, ST_BLOCKED, ST_DONE };
+struct Fiber {
+  void* sp = nullptr;
+  char* stack = nullptr;
+  State state = ST_DONE;
+  Kind kind = K_NONE;
+  int site = 0, arg = 0, arg2 = 0;
+  unsigned long long payload = 0, result = 0;
+  emu_uint3 tid;
+};
+std::vector<Fiber> g_fibers;
+void* g_sched_sp = nullptr;
+int g_current = -1;
+const std::function<void()>* g_body = nullptr;
+std::recursive_mutex g_launch_lock;  // the model runs one launch at a time (host threads of the product may launch concurrently)
+std::vector<std::string> g_files;
+std::mutex g_site_lock;
+bool g_strict = getenv("EMU_STRICT_CONVERGENCE") != nullptr;
+
+void fiber_entry() {
+  (*g_body)();
+  g_fibers[g_current].state = ST_DONE;
+  emu_swap(&g_fibers[g_current].sp, g_sched_sp);
+  std::abort();  // (a finished work-item is never resumed)
+}
+void prepare_fiber(Fiber& f) {
+  // stack as emu_swap expects to find it: six callee-saved registers, then the address it returns to; above that the slot a call would
+  // have pushed, so that the entry function sees the alignment of an ordinary call
+  uintptr_t top = (reinterpret_cast<uintptr_t>(f.stack) + STACK_BYTES) & ~(uintptr_t)15;
+  void** sp = reinterpret_cast<void**>(top);
+  *--sp = nullptr;
+  *--sp = reinterpret_cast<void*>(&fiber_entry);
+  for (int i = 0; i < 6; ++i) *--sp = nullptr;
+  f.sp = sp;
+}
+void run_fiber(int t) {
+  g_current = t;
+  threadIdx = g_fibers[t].tid;
+  emu_swap(&g_sched_sp, g_fibers[t].sp);
+  g_current = -1;
+}
+[[noreturn]] void die(const char* what, int nthreads) {
+  std::fprintf(stderr, "emu: %s\n", what);
+  std::map<std::pair<int, int>, int> hist;
+  for (int t = 0; t < nthreads; ++t)
+    if (g_fibers[t].state == ST_BLOCKED) hist[{(int)g_fibers[t].kind, g_fibers[t].site}]++;
+  for (auto& kv : hist)
+    std::fprintf(stderr, "  %d work-items wait in kind %d at %s:%d\n", kv.second, kv.first.first, g_files[kv.first.second >> 20].c_str(), kv.first.second & 0xFFFFF);
+  std::abort();
+}
+}  // namespace
+
+int site_of(const char* file, int line) {
+  std::lock_guard<std::mutex> lk(g_site_lock);
+  size_t f = 0;
+  for (; f < g_files.size(); ++f)
+    if (g_files[f] == file) break;
+  if (f == g_files.size()) g_files.push_back(file);
+  return (int)(f << 20) | line;
+}
+
+unsigned long long collective(Kind kind, int site, unsigned long long payload, int arg, int arg2) {
+  if (g_current < 0) {
+    std::fprintf(stderr, "emu: collective outside a kernel\n");
+    std::abort();
+  }
+  Fiber& f = g_fibers[g_current];
+  f.kind = kind, f.site = site, f.payload = payload, f.arg = arg, f.arg2 = arg2;
+  f.state = ST_BLOCKED;
+  emu_swap(&f.sp, g_sched_sp);
+  threadIdx = f.tid;
+  return f.result;
+}
+
+// resolves one wavefront's waiting lanes; true if any were released
+static bool resolve_wave(int t0, int t1) {
+  int site = -1;
+  Kind kind = K_NONE;
+  int n_sites = 0, last_site = -1;
+  for (int t = t0; t < t1; ++t) {
+    Fiber& f = g_fibers[t];
+    if (f.state == ST_READY) return false;  // (cannot happen after a run phase)
+    if (f.state != ST_BLOCKED || f.kind == K_SYNC) continue;
+    if (f.site != last_site) ++n_sites, last_site = f.site;
+    if (site < 0 || f.site < site) site = f.site, kind = f.kind;
+  }
+  if (site < 0) return false;
+  if (g_strict && n_sites > 1) die("EMU_STRICT_CONVERGENCE: a wavefront waits at more than one call site", t1);
+  unsigned long long mask = 0;
+  int first = -1;
+  for (int t = t0; t < t1; ++t) {
+    Fiber& f = g_fibers[t];
+    if (f.state == ST_BLOCKED && f.kind != K_SYNC && f.site == site) {
+      mask |= 1ull << (t - t0);
+      if (first < 0) first = t;
+    }
+  }
+  unsigned long long ballot = 0;
+  if (kind == K_BALLOT)
+    for (int t = t0; t < t1; ++t)
+      if ((mask >> (t - t0)) & 1ull && g_fibers[t].payload) ballot |= 1ull << (t - t0);
+  for (int t = t0; t < t1; ++t) {
+    if (!((mask >> (t - t0)) & 1ull)) continue;
+    Fiber& f = g_fibers[t];
+    const int lane = t - t0;
+    switch (kind) {
+      case K_BALLOT: f.result = ballot; break;
+      case K_WAVE_BARRIER: f.result = 0; break;
+      case K_FIRSTLANE: f.result = g_fibers[first].payload; break;
+      case K_SHFL: {
+        const int mode = f.arg2 & 0xFF, width = std::max(1, f.arg2 >> 8);
+        const int seg = lane / width * width;
+        int src;
+        if (mode == 0) src = seg + (f.arg & (width - 1));
+        else if (mode == 1) src = lane ^ f.arg;
+        else if (mode == 2) src = lane + f.arg;
+        else src = lane - f.arg;
+        const bool in_seg = src >= seg && src < seg + width && src < 64 && src >= 0;
+        // a source lane outside the segment or not taking part returns the caller's own value (HIP: own value / undefined)
+        f.result = (in_seg && ((mask >> src) & 1ull)) ? g_fibers[t0 + src].payload : f.payload;
+        break;
+      }
+      default: f.result = 0;
+    }
+  }
+  for (int t = t0; t < t1; ++t)
+    if ((mask >> (t - t0)) & 1ull) g_fibers[t].state = ST_READY;
+  return true;
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+  std::lock_guard<std::recursive_mutex> lk(g_launch_lock);
+  const int nthreads = (int)(block.x * block.y * block.z);
+  if (nthreads <= 0 || grid.x * grid.y * grid.z == 0) return;
+  if ((int)g_fibers.size() < nthreads) g_fibers.resize(nthreads);
+  for (int t = 0; t < nthreads; ++t)
+    if (!g_fibers[t].stack) g_fibers[t].stack = static_cast<char*>(std::malloc(STACK_BYTES));
+  const emu_uint3 save_t = threadIdx, save_b = blockIdx;
+  const dim3 save_bd = blockDim, save_gd = gridDim;
+  const std::function<void()>* save_body = g_body;
+  g_body = &body;
+  blockDim = block, gridDim = grid;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        blockIdx = emu_uint3{bx, by, bz};
+        for (int t = 0; t < nthreads; ++t) {
+          Fiber& f = g_fibers[t];
+          f.tid = emu_uint3{(unsigned)t % block.x, (unsigned)t / block.x % block.y, (unsigned)t / (block.x * block.y)};
+          f.state = ST_READY, f.kind = K_NONE;
+          prepare_fiber(f);
+        }
+        int live = nthreads;
+        while (live > 0) {
+          bool progressed = false;
+          for (int t = 0; t < nthreads; ++t)
+            if (g_fibers[t].state == ST_READY) {
+              run_fiber(t);
+              progressed = true;
+            }
+          live = 0;
+          for (int t = 0; t < nthreads; ++t) live += g_fibers[t].state != ST_DONE;
+          if (live == 0) break;
+          bool released = false;
+          for (int t0 = 0; t0 < nthreads; t0 += 64) released |= resolve_wave(t0, std::min(nthreads, t0 + 64));
+          if (!released) {
+            bool all_sync = true;
+            for (int t = 0; t < nthreads; ++t)
+              if (g_fibers[t].state == ST_BLOCKED && g_fibers[t].kind != K_SYNC) all_sync = false;
+            if (!all_sync) die("deadlock: work-items wait in a wavefront operation that cannot complete", nthreads);
+            for (int t = 0; t < nthreads; ++t)
+              if (g_fibers[t].state == ST_BLOCKED) g_fibers[t].state = ST_READY, g_fibers[t].result = 0;
+            released = true;
+          }
+          (void)progressed;
+        }
+      }
+  g_body = save_body;
+  threadIdx = save_t, blockIdx = save_b, blockDim = save_bd, gridDim = save_gd;
+}
+}  // namespace emu
+
+// ---- runtime ---------------------------------------------------------------------------------------------------------------------------
+struct emu_stream {
+  int id;
+};
+struct emu_event {
+  std::chrono::steady_clock::time_point t;
+};
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : e == hipErrorOutOfMemory ? "out of memory" : e == hipErrorInvalidDevice ? "invalid device ordinal" : "invalid value"; }
+hipError_t hipGetDeviceCount(int* n) {
+  *n = 1;
+  return hipSuccess;
+}
+static thread_local int g_device = 0;
+hipError_t hipSetDevice(int d) {
+  if (d != 0) return hipErrorInvalidDevice;
+  g_device = d;
+  return hipSuccess;
+}
+hipError_t hipGetDevice(int* d) {
+  *d = g_device;
+  return hipSuccess;
+}
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipGetLastError() { return hipSuccess; }
+hipError_t emu_malloc(void** p, size_t bytes) {
+  *p = std::aligned_alloc(256, (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255);
+  if (!*p) return hipErrorOutOfMemory;
+  std::memset(*p, 0xCD, std::min<size_t>(bytes, 1 << 20));  // (device memory is not zeroed: make reads of unwritten memory visible)
+  return hipSuccess;
+}
+hipError_t hipFree(void* p) {
+  std::free(p);
+  return hipSuccess;
+}
+hipError_t hipHostFree(void* p) {
+  std::free(p);
+  return hipSuccess;
+}
+hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+hipError_t hipHostUnregister(void*) { return hipSuccess; }
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) {
+  std::memmove(dst, src, bytes);
+  return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind, hipStream_t) {
+  std::memmove(dst, src, bytes);
+  return hipSuccess;
+}
+hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t) {
+  std::memset(dst, value, bytes);
+  return hipSuccess;
+}
+hipError_t hipMemset(void* dst, int value, size_t bytes) {
+  std::memset(dst, value, bytes);
+  return hipSuccess;
+}
+hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int value, size_t count, hipStream_t) {
+  int* p = static_cast<int*>(dst);
+  for (size_t i = 0; i < count; ++i) p[i] = value;
+  return hipSuccess;
+}
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+  *s = new emu_stream{1};
+  return hipSuccess;
+}
+hipError_t hipStreamCreate(hipStream_t* s) { return hipStreamCreateWithFlags(s, 0); }
+hipError_t hipStreamDestroy(hipStream_t s) {
+  delete s;
+  return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) {
+  *e = new emu_event{std::chrono::steady_clock::now()};
+  return hipSuccess;
+}
+hipError_t hipEventDestroy(hipEvent_t e) {
+  delete e;
+  return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+  e->t = std::chrono::steady_clock::now();
+  return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+  return hipSuccess;
+}
