@@ -201,10 +201,19 @@ def test_stage_min_switch_has_an_effect(api, hop, orc):
     directly.  A child process with HOP_STAGE_MIN set far above every transfer runs a small ICP and returns the same bits."""
     import subprocess
     import sys
-    code = ("import sys, numpy as np; sys.path.insert(0, %r); import hop_loader; hop = hop_loader.load(); from hop_amd import api; s = hop.synth;"
-            "sc = s.make_scene(500, seed=3); mx, mn = s.ellipsoid_model_spacing(0.005); c = api.Context(0); c.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8);"
-            "c.set_model(api.HOP_MODEL_5MM, mx, mn); c.hypos_upload(s.replay_poses(sc.gt_pose, 9, seed=1, max_rot_deg=8.0, max_trans=0.004));"
-            "c.icp_refine(10, 45.0, 0.01, nn_mode=7); p = c.hypos_download()[0]; print(p.view(np.int32).sum(dtype=np.int64))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "\n".join([
+        "import os, sys, numpy as np",
+        "sys.path.insert(0, %r)" % root,
+        "import hop_loader; hop = hop_loader.load()",
+        "from hop_amd import api",
+        "if os.environ.get('HOP_TEST_EMU'):   # (tests/emu: the same child on the CPU model)",
+        "    api.LIB_PATH = %r; api._lib = None" % os.path.join(root, "tests", "emu", "_build", "libhop_emu.so"),
+        "s = hop.synth; sc = s.make_scene(500, seed=3); mx, mn = s.ellipsoid_model_spacing(0.005)",
+        "c = api.Context(0); c.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8); c.set_model(api.HOP_MODEL_5MM, mx, mn)",
+        "c.hypos_upload(s.replay_poses(sc.gt_pose, 9, seed=1, max_rot_deg=8.0, max_trans=0.004))",
+        "c.icp_refine(10, 45.0, 0.01, nn_mode=7); p = c.hypos_download()[0]",
+        "print(p.view(np.int32).sum(dtype=np.int64))"])
     env = dict(os.environ)
     outs = []
     for v in (None, "1000000000", "1"):
