@@ -26,6 +26,8 @@ def hop():
         from hop_amd import api
         api.LIB_PATH = EMU_LIB
         api._lib = None
+        # the C++ host applications (lib/main_realdata_auto, lib/run_real_all: RUNPATH $ORIGIN) find the model under the name libhop.so first
+        os.environ["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(EMU_LIB), "as_libhop") + os.pathsep + os.environ.get("LD_LIBRARY_PATH", "")
     return mod
 
 
@@ -39,3 +41,16 @@ def orc():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def config_for_run(path, tmp_dir):
+    """The configuration file a test hands to the mirrors and the C++ applications.  On the MI355X: `path` itself.  On the CPU model
+    (HOP_TEST_EMU, ~1000x slower than the device) a copy whose generator time budget -- `super4pcs_max_time_seconds: 1`, a WALL-CLOCK limit as
+    in the reference -- is raised: it would otherwise end the base trials at a different point in every process."""
+    if not os.environ.get("HOP_TEST_EMU"):
+        return path
+    import re
+    text = re.sub(r"(?m)^super4pcs_max_time_seconds:.*$", "super4pcs_max_time_seconds: 100000", open(path).read())
+    out = os.path.join(str(tmp_dir), "config_emu_" + os.path.basename(path))
+    open(out, "w").write(text)
+    return out

@@ -473,7 +473,8 @@ def test_cpp_host_app_equals_python_mirror(api, hop, synth, tmp_path):
     """The C++ host above the C-ABI (host/app/main_realdata_auto.cpp: the reference driver's call order,
     main_realdata_auto.cpp:99-205) and the Python mirror run the same frame: same finger angles, same best pose."""
     import subprocess
-    cfg_path = os.path.join(ROOT, "icra20-hand-object-pose_amd", "config", "config_autodataset.yaml")
+    from conftest import config_for_run
+    cfg_path = config_for_run(os.path.join(ROOT, "icra20-hand-object-pose_amd", "config", "config_autodataset.yaml"), tmp_path)
     from hop_amd import config as hop_config
     cfg = hop_config.load_config(cfg_path)
     exe = os.path.join(ROOT, "icra20-hand-object-pose_amd", "lib", "main_realdata_auto")
@@ -507,7 +508,7 @@ def test_cpp_host_app_equals_python_mirror(api, hop, synth, tmp_path):
     _write_cloud(frame / "hand_region.bin", hxyz, hnrm)
     _write_cloud(frame / "hand_swivel.bin", swivel)
     (frame / "cam_side.txt").write_text("1\n")
-    r = subprocess.run([exe, cfg_path, str(frame), str(out)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, cfg_path, str(frame), str(out)], capture_output=True, text=True, timeout=3000)
     assert r.returncode == 0, r.stdout + r.stderr
     cpp_pose = np.loadtxt(out / "model2scene.txt").astype(np.float32)
     cpp_angles = {ln.split()[0]: float(ln.split()[1]) for ln in (out / "finger_angles.txt").read_text().splitlines()}
