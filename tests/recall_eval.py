@@ -50,6 +50,9 @@ def main():
     import hop_loader
     hop = hop_loader.load()
     from hop_amd import api
+    if os.environ.get("HOP_TEST_EMU"):   # (tests/emu: the same tool with the kernels executed by the CPU model -- see tests/emu/README.md)
+        api.LIB_PATH = os.path.join(ROOT, "tests", "emu", "_build", "libhop_emu.so")
+        api._lib = None
     synth = hop.synth
     if args.model == "ellipse":
         mx5, mn5 = synth.ellipsoid_model_spacing(0.005)

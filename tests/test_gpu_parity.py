@@ -709,10 +709,11 @@ def test_recall_tool_gpu_matches_oracle_on_synthetic_frames():
     import subprocess
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "recall_eval.py"), "--frames", "6", "--scene", "1500"],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=6000 if os.environ.get("HOP_TEST_EMU") else 600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["frames_gpu_pose_within_1mm_1deg_of_cpu"] == 6
+    assert out["icp_nn_mode"] == 7 and out["frames_gpu_pose_bit_equal_to_cpu"] == 6     # the shipped ICP mode returns the oracle's bits
     assert out["recall_adi_10mm_gpu"] == out["recall_adi_10mm_cpu"] and out["recall_adi_5mm_gpu"] == out["recall_adi_5mm_cpu"]
     assert out["recall_adi_10mm_gpu"] >= 0.8
 
