@@ -54,3 +54,14 @@ def config_for_run(path, tmp_dir):
     out = os.path.join(str(tmp_dir), "config_emu_" + os.path.basename(path))
     open(out, "w").write(text)
     return out
+
+
+def model_time_budget_in_place(cfg_file):
+    """the same for a configuration file a test has just written (run_real_all.write_synthetic_record): rewritten in place on the CPU model"""
+    if os.environ.get("HOP_TEST_EMU"):
+        import re
+        text = re.sub(r"(?m)^super4pcs_max_time_seconds:.*$", "super4pcs_max_time_seconds: 100000", open(cfg_file).read())
+        open(cfg_file, "w").write(text)
+
+
+CHILD_TIMEOUT = 6000 if os.environ.get("HOP_TEST_EMU") else 600   # seconds a test waits for a C++ host application

@@ -285,7 +285,8 @@ def test_cpp_host_app_with_physics_equals_python_mirror(api, hop, synth, tmp_pat
     import math
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cfg_path = os.path.join(root, "icra20-hand-object-pose_amd", "config", "config_autodataset.yaml")
+    from conftest import config_for_run
+    cfg_path = config_for_run(os.path.join(root, "icra20-hand-object-pose_amd", "config", "config_autodataset.yaml"), tmp_path)
     from hop_amd import config as hop_config
     cfg = hop_config.load_config(cfg_path)
     exe = os.path.join(root, "icra20-hand-object-pose_amd", "lib", "main_realdata_auto")
@@ -330,7 +331,7 @@ def test_cpp_host_app_with_physics_equals_python_mirror(api, hop, synth, tmp_pat
     _write_cloud(frame / "hand_region.bin", hxyz, hnrm)
     _write_cloud(frame / "hand_swivel.bin", swivel)
     (frame / "cam_side.txt").write_text("1\n")
-    r = subprocess.run([exe, cfg_path, str(frame), str(out)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, cfg_path, str(frame), str(out)], capture_output=True, text=True, timeout=3000)
     assert r.returncode == 0, r.stdout + r.stderr
     cpp_pose = np.loadtxt(out / "model2scene.txt").astype(np.float32)
     cpp_left = int([ln for ln in r.stdout.splitlines() if ln.startswith("hypotheses after physics:")][0].split(":")[1])

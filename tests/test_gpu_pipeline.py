@@ -9,6 +9,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import CHILD_TIMEOUT, model_time_budget_in_place
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -120,6 +122,7 @@ def test_dataset_runner_on_the_reference_layout(hop, tmp_path):
     from hop_amd import run_real_all as rr
     base = str(tmp_path / "auto_collect")
     rec = rr.write_synthetic_record(base, "ellipse", n_frames=3)
+    model_time_budget_in_place(os.path.join(base, "config_autodataset.yaml"))
     cfg = hop_config.load_config(os.path.join(base, "config_autodataset.yaml"))
     done = rr.run_raw(base, cfg, rank=0, world=1)
     assert done == {"synthetic_000": [0, 1, 2]}
@@ -143,6 +146,7 @@ def test_cpp_drivers_from_the_depth_image_equal_the_python_mirror(hop, tmp_path)
     lib = os.path.join(ROOT, "icra20-hand-object-pose_amd", "lib")
     base = str(tmp_path / "auto_collect")
     rec = rr.write_synthetic_record(base, "ellipse", n_frames=2)
+    model_time_budget_in_place(os.path.join(base, "config_autodataset.yaml"))
     cfg_path = os.path.join(base, "config_autodataset.yaml")
     cfg = hop_config.load_config(cfg_path)
     assets = rr.Assets()
@@ -158,18 +162,18 @@ def test_cpp_drivers_from_the_depth_image_equal_the_python_mirror(hop, tmp_path)
         py[idx] = (rr.process_frame(ctx, cfg, assets, rr.read_depth_png(os.path.join(rec, f"depth{idx}.png")), K, hb, info=info), info, hb)
     ctx.close()
     # C++ dataset driver
-    r = subprocess.run([os.path.join(lib, "run_real_all"), cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([os.path.join(lib, "run_real_all"), cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=CHILD_TIMEOUT)
     assert r.returncode == 0, r.stdout + r.stderr
     for idx in (0, 1):
         cpp = np.loadtxt(os.path.join(rec, "predict", str(idx), "model2scene.txt")).astype(np.float32)
         assert np.abs(cpp - py[idx][0]).max() < 2e-6, (idx, cpp, py[idx][0])
-    r2 = subprocess.run([os.path.join(lib, "run_real_all"), cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=600)
+    r2 = subprocess.run([os.path.join(lib, "run_real_all"), cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=CHILD_TIMEOUT)
     assert r2.returncode == 0 and "0 frames written" in r2.stdout and "2 resumed" in r2.stdout            # resume
     ev = rr.eval_raw(base, "ellipse", assets.model001[0])
     assert ev["total"] == 2 and ev["recall_10mm"] >= 0.5
     # frames in flight from the C++ host (HOP_INFLIGHT workers, each with its own estimator / hand / contexts): the same files
     seq = {idx: open(os.path.join(rec, "predict", str(idx), "model2scene.txt")).read() for idx in (0, 1)}
-    r4 = subprocess.run([os.path.join(lib, "run_real_all"), cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=600,
+    r4 = subprocess.run([os.path.join(lib, "run_real_all"), cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=CHILD_TIMEOUT,
                         env=dict(os.environ, HOP_INFLIGHT="2", HOP_FORCE="1"))
     assert r4.returncode == 0 and "2 frames written" in r4.stdout and "2 in flight" in r4.stdout, r4.stdout + r4.stderr
     for idx in (0, 1):
@@ -177,7 +181,7 @@ def test_cpp_drivers_from_the_depth_image_equal_the_python_mirror(hop, tmp_path)
     # the driver's own end-of-shard gather through RCCL (BASELINE configs[3]): HOP_GATHER_COMM=1 builds the communicator with ONE rank too, so the
     # id file, hop_comm_create, ncclAllGather inside hop_frames_allgather and the table rank 0 writes all run on this box
     env_g = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "HOP_COMM_ID_FILE")}
-    r5 = subprocess.run([os.path.join(lib, "run_real_all"), cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=600,
+    r5 = subprocess.run([os.path.join(lib, "run_real_all"), cfg_path, adir, base, "ellipse"], capture_output=True, text=True, timeout=CHILD_TIMEOUT,
                         env=dict(env_g, HOP_GATHER="1", HOP_GATHER_COMM="1", MASTER_PORT="29411", HOP_RUN_ID="gputest"))
     assert r5.returncode == 0 and "poses of 2 frames gathered (2 from this rank, 2 rows per rank, through hop_frames_allgather)" in r5.stdout, r5.stdout + r5.stderr
     rows_all = open(os.path.join(base, "ellipse", "model2scene_all.txt")).read().strip().splitlines()
@@ -191,7 +195,7 @@ def test_cpp_drivers_from_the_depth_image_equal_the_python_mirror(hop, tmp_path)
     hbf = tmp_path / "hb.txt"
     hbf.write_text("\n".join(" ".join(repr(float(v)) for v in row) for row in py[0][2]) + "\n")
     r3 = subprocess.run([os.path.join(lib, "main_realdata_auto"), cfg_path, "--depth", adir, os.path.join(rec, "depth0.png"), str(hbf), str(out)],
-                        capture_output=True, text=True, timeout=600)
+                        capture_output=True, text=True, timeout=CHILD_TIMEOUT)
     assert r3.returncode == 0, r3.stdout + r3.stderr
     assert np.abs(np.loadtxt(out / "model2scene.txt").astype(np.float32) - py[0][0]).max() < 2e-6
     assert np.abs(np.loadtxt(out / "handbase_in_cam.txt").astype(np.float32) - py[0][1]["handbase_in_cam"]).max() < 2e-6
