@@ -116,7 +116,8 @@ def main():
             row["drot_deg"] = min(rot_err_deg(best[:3, :3].astype(np.float64), ob[:3, :3].astype(np.float64) @ S) for S in sym_rots)
         rows.append(row)
     a = np.array([r["adi_gpu"] for r in rows])
-    out = {"model": args.model, "object_symmetry": sym, "icp_nn_mode": args.icp_mode, "frames": args.frames, "scene_points": args.scene, "data": "synthetic substitute (seeds 1000+f)",
+    out = {"model": args.model, "object_symmetry": sym, "icp_nn_mode": args.icp_mode,
+           "kernels_executed_on": "tests/emu CPU model of the HIP execution model (NOT hardware: semantics only, timings meaningless)" if os.environ.get("HOP_TEST_EMU") else "MI355X", "frames": args.frames, "scene_points": args.scene, "data": "synthetic substitute (seeds 1000+f)",
            "recall_adi_5mm_gpu": float((a < 0.005).mean()), "recall_adi_10mm_gpu": float((a < 0.010).mean()),
            "gpu_s_per_frame": t_gpu / args.frames}
     if orc is not None:
