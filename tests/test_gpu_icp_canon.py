@@ -225,3 +225,19 @@ def test_stage_min_switch_has_an_effect(api, hop, orc):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] == outs[2]
+
+
+def test_device_sort_and_host_merge_order_scores_the_same_way(ctx, api):
+    """the device sorted (score, id) rows by a bit-pattern key, the host merge by float comparison; they disagreed on -0 vs +0 and
+    on NaN.  One key now (score_order_key, csrc/hop_math.h: -0 = +0, NaN below every number): hop_topk_pack (k_score_keys + radix sort on the
+    device) and hop_topk_merge (host) return the same order for the same rows."""
+    scores = np.array([0.0, -0.0, np.nan, 1.5, -2.0, -np.inf, 1.5, 0.25], np.float32)
+    poses = np.tile(np.eye(4, dtype=np.float32), (len(scores), 1, 1))
+    poses[:, 0, 3] = np.arange(len(scores))            # (tells the rows apart)
+    ctx.hypos_upload(poses, scores)
+    rows, n = ctx.topk_pack(len(scores))
+    assert n == len(scores)
+    dev_ids = rows[:, 1].copy().view(np.int32).tolist()
+    assert dev_ids == [3, 6, 7, 0, 1, 4, 5, 2]          # 1.5 (ids 3, 6) | 0.25 | +-0 by id | -2 | -inf | NaN last
+    merged, m = api.topk_merge(rows[None], len(scores))
+    assert m == len(scores) and merged.reshape(len(scores), -1)[:, 1].copy().view(np.int32).tolist() == dev_ids
