@@ -74,3 +74,105 @@ def test_icp_with_the_references_minimiser_on_the_model(emu_lib):
     ball among them) too"""
     sel = [os.path.join("tests", "test_gpu_icp_canon.py")]
     assert _child_pytest(sel, "not_converged or c1_depth7_bits", timeout=1500) == 2
+
+
+def _emu_env(emu_lib, **extra):
+    """children that find the model under the name libhop.so and the file-based stand-in for RCCL (tests/emu/fake_rccl.cpp) under librccl.so"""
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HOP_FORCE", "HOP_COMM_ID_FILE", "HOP_GATHER")}
+    e["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(emu_lib), "as_libhop") + os.pathsep + e.get("LD_LIBRARY_PATH", "")
+    e.update(extra)
+    return e
+
+
+def test_cpp_dataset_driver_gathers_with_two_ranks_on_the_model(emu_lib, tmp_path):
+    """BASELINE configs[3] ("frames sharded over the GPUs, RCCL gather of per-frame best pose") with MORE THAN ONE RANK: two processes of the C++
+    dataset driver (host/app/run_real_all.cpp) share a record whose frames are already done, meet through the id file (run nonce in its
+    name), build their communicators, run ONE hop_frames_allgather and rank 0 writes the table -- the product's exchange code end to end,
+    the RCCL calls answered by the inter-process stand-in of tests/emu (files in /dev/shm) and device memory by the model.  The collective on
+    real hardware has only ever run with one rank; this is the rank arithmetic, padding and numbering it will run with."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import hop_loader
+    hop_loader.load()
+    from hop_amd import run_real_all as rr
+    exe = os.path.join(ROOT, "icra20-hand-object-pose_amd", "lib", "run_real_all")
+    if not os.path.exists(exe):
+        pytest.skip("run_real_all is not built")
+    base = str(tmp_path / "auto_collect")
+    rng = np.random.default_rng(23)
+    truth = {}
+    for record, frames in (("rec_000", (0, 3, 10, 2, 5)), ("rec_001", (7, 1))):          # rank 0 owns 0, 10, 2 ; rank 1 owns 3, 5, 7, 1
+        rec = os.path.join(base, "ellipse", record)
+        os.makedirs(rec)
+        for k in frames:
+            open(os.path.join(rec, f"rgb{k}.png"), "wb").write(b"")
+            os.makedirs(os.path.join(rec, "predict", str(k)))
+            T = np.eye(4, dtype=np.float32)
+            T[:3, :] = rng.normal(size=(3, 4)).astype(np.float32)
+            truth[(record, k)] = T
+            with open(os.path.join(rec, "predict", str(k), "model2scene.txt"), "w") as f:
+                for row in T:
+                    f.write(" ".join(f"{v:.9g}" for v in row) + "\n")
+    cfg_path = os.path.join(ROOT, "icra20-hand-object-pose_amd", "config", "config_autodataset.yaml")
+    adir = rr.write_assets_dir(rr.Assets(), str(tmp_path / "assets"))
+    procs = [subprocess.Popen([exe, cfg_path, adir, base, "ellipse"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=_emu_env(emu_lib, HOP_GATHER="1", RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_PORT="29517", HOP_RUN_ID="twoRanks",
+                                           HOP_COMM_WAIT_S="60")) for r in (1, 0)]          # (rank 1 first: it waits for rank 0's id)
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so + se
+    assert "rank 1 of 2: poses of 7 frames gathered (4 from this rank, 4 rows per rank, through hop_frames_allgather)" in outs[0][0], outs[0][0]
+    assert "rank 0 of 2: poses of 7 frames gathered (3 from this rank, 4 rows per rank, through hop_frames_allgather)" in outs[1][0], outs[1][0]
+    lines = open(os.path.join(base, "ellipse", "model2scene_all.txt")).read().strip().splitlines()
+    assert [(ln.split()[0], int(ln.split()[1])) for ln in lines] == sorted(truth)
+    for ln in lines:
+        t = ln.split()
+        assert np.array_equal(np.array(t[2:], np.float32).reshape(4, 4), truth[(t[0], int(t[1]))])
+    assert not [n for n in os.listdir(os.path.join(base, "ellipse")) if n.startswith(".hop_comm_id")], "rank 0 removes its id file"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_topk_exchange_with_several_ranks_on_the_model(emu_lib, tmp_path, world):
+    """BASELINE configs[4]'s exchange with more than one rank: every rank packs its shard's table on the "device", one all-gather, the merge
+    kernel (one workgroup, bitonic sort of the gathered keys in LDS) -- against the host merge (hop_topk_merge) of the same tables: identical
+    rows on every rank, in HypoCompare order with the canonical key (equal scores across ranks, -0, a NaN, shards with fewer than k rows,
+    an empty shard)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import hop_loader
+    hop_loader.load()
+    from hop_amd import api
+    rng = np.random.default_rng(world)
+    k = 16
+    cases = {}
+    sizes = [200, 37, 5, 64]
+    for c, n in enumerate(sizes):
+        poses = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+        poses[:, :3, 3] = rng.normal(size=(n, 3)).astype(np.float32)
+        scores = (rng.integers(0, 12, n) / 4.0).astype(np.float32)          # many ties across the shards
+        if c == 1:
+            scores[3], scores[20], scores[30] = -0.0, 0.0, np.nan
+        cases[f"poses{c}"], cases[f"scores{c}"] = poses, scores
+    if world == 3:
+        cases["poses2"], cases["scores2"] = cases["poses2"][:2], cases["scores2"][:2]     # two hypotheses for three ranks: an empty shard
+    cases["n_cases"] = np.array(len(sizes))
+    path = str(tmp_path / "cases.npz")
+    np.savez(path, **cases)
+    child = os.path.join(EMU_DIR, "exchange_rank.py")
+    id_file = str(tmp_path / "id.bin")
+    procs = [subprocess.Popen([sys.executable, child, str(r), str(world), id_file, str(k), path, emu_lib], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=_emu_env(emu_lib)) for r in reversed(range(world))]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-2000:] + se[-3000:]
+    per_rank = [[ln.split() for ln in so.strip().splitlines() if ln.startswith("case")] for so, _ in reversed(outs)]      # rank order
+    for c in range(len(sizes)):
+        merged = [np.frombuffer(bytes.fromhex(pr[c][3]), np.uint32).reshape(k, -1) for pr in per_rank]
+        tables = np.stack([np.frombuffer(bytes.fromhex(pr[c][4]), np.uint32).view(np.float32).reshape(k, -1) for pr in per_rank])
+        for m in merged[1:]:
+            assert np.array_equal(m, merged[0]), "every rank holds the same merged table"
+        host, n = api.topk_merge(tables, k)           # (host function: no device, no model)
+        assert int(per_rank[0][c][2]) == n
+        assert np.array_equal(host.view(np.uint32).reshape(k, -1)[:n], merged[0][:n]), c
+        ids = merged[0][:n, 1].view(np.int32)
+        assert len(set(ids.tolist())) == n and ids.min() >= 0
