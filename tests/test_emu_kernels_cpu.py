@@ -68,6 +68,13 @@ def test_generator_kernels_against_the_reference_built_goldens_on_the_model(emu_
     assert _child_pytest(sel, "generator_matches_reference_golden and case1", env={"HOP_QUADS_HASH": "1"}) == 3
 
 
+def test_render_and_normals_kernels_on_the_model(emu_lib):
+    """csrc/hop_render.hip (rasteriser with near-plane clipping and the workgroup-per-big-triangle path, image composition, ordered and reduced
+    score sums) and csrc/hop_normals.hip (integral-image normals incl. the reference's example/depth7.png, moving least squares) against their
+    oracles: every test of tests/test_gpu_render.py and tests/test_gpu_normals.py"""
+    assert _child_pytest([os.path.join("tests", "test_gpu_render.py"), os.path.join("tests", "test_gpu_normals.py")]) == 12
+
+
 def test_icp_with_the_references_minimiser_on_the_model(emu_lib):
     """k_icp_fusedq_momi + k_icp_lm7_solve (nn_mode 7, what the mirrors run): refined poses, iteration counts and convergence flags equal to the
     oracle's BIT FOR BIT, hypotheses that do not converge included; the C1 frame's 100 hypotheses (a trial step outside the quaternion's unit
