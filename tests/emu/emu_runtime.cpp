@@ -45,6 +45,32 @@ std::recursive_mutex g_launch_lock;  // the model runs one launch at a time (hos
 std::vector<std::string> g_files;
 std::mutex g_site_lock;
 bool g_strict = getenv("EMU_STRICT_CONVERGENCE") != nullptr;
+// EMU_ORDER=reverse | shuffle:<seed>: the order in which the workgroups of a launch run and in which the runnable work-items of a workgroup
+// are resumed.  The hardware promises neither; a result that changes with it (slots handed out by atomics that are not re-ordered later, a
+// read of another wavefront's LDS without a barrier) is a result that depends on scheduling.
+int g_order_mode = 0;  // 0 ascending, 1 reverse, 2 shuffled
+unsigned long long g_order_state = 0x9E3779B97F4A7C15ull;
+struct OrderInit {
+  OrderInit() {
+    const char* e = getenv("EMU_ORDER");
+    if (!e) return;
+    if (!std::strcmp(e, "reverse")) g_order_mode = 1;
+    else if (!std::strncmp(e, "shuffle", 7)) {
+      g_order_mode = 2;
+      if (e[7] == ':') g_order_state ^= std::strtoull(e + 8, nullptr, 10) * 0xD1342543DE82EF95ull;
+    }
+  }
+} g_order_init;
+unsigned long long next_rand() {  // xorshift64*
+  g_order_state ^= g_order_state >> 12, g_order_state ^= g_order_state << 25, g_order_state ^= g_order_state >> 27;
+  return g_order_state * 0x2545F4914F6CDD1Dull;
+}
+void make_order(std::vector<int>& o, int n) {
+  o.resize(n);
+  for (int i = 0; i < n; ++i) o[i] = g_order_mode == 1 ? n - 1 - i : i;
+  if (g_order_mode == 2)
+    for (int i = n - 1; i > 0; --i) std::swap(o[i], o[(int)(next_rand() % (unsigned long long)(i + 1))]);
+}
 
 void fiber_entry() {
   (*g_body)();
@@ -169,9 +195,10 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   const std::function<void()>* save_body = g_body;
   g_body = &body;
   blockDim = block, gridDim = grid;
-  for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
+  std::vector<int> block_order, thread_order;
+  make_order(block_order, (int)(grid.x * grid.y * grid.z));
+  for (int bi : block_order) {
+        const unsigned bx = (unsigned)bi % grid.x, by = (unsigned)bi / grid.x % grid.y, bz = (unsigned)bi / (grid.x * grid.y);
         blockIdx = emu_uint3{bx, by, bz};
         for (int t = 0; t < nthreads; ++t) {
           Fiber& f = g_fibers[t];
@@ -182,7 +209,8 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
         int live = nthreads;
         while (live > 0) {
           bool progressed = false;
-          for (int t = 0; t < nthreads; ++t)
+          make_order(thread_order, nthreads);
+          for (int t : thread_order)
             if (g_fibers[t].state == ST_READY) {
               run_fiber(t);
               progressed = true;
