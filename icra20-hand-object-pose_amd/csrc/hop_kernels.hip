@@ -2596,20 +2596,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM
 // ------------------------------------------------------------------------------------------------
 // nn_mode 7: the moment form with INTEGER-EXACT sums -- the result no longer depends on which lane, wavefront or workgroup adds which
 // correspondence, so the CPU statement of the algorithm (oracle minimiser 7) returns the same bits.
-// The 13 components of u = (n_a p'_b, n_a, r0) are scaled by powers of two chosen from the model's radius and the gate (IcpArgs::mom_*,
-// hop_icp_refine), rounded to the nearest integer (v_rndne_f32: ties to even), clamped to +-2^ICP_MOM_BITS; M = sum U U^T (91 entries,
-// lower triangle) is accumulated per lane with v_mad_i32_i24 -- products <= 2^24, a lane adds at most 2 ICP_ACCUM_R = 64 of them -- and
-// lanes / wavefronts / workgroups are added in 64 bits.  The squared correspondence distances of the MSE stop rule go the same way.
-// Lookups, gates and the deferred-lookup queue are those of k_icp_fusedq_mom; the grid costs 13 x (mul, rndne, med3, cvt) per accepted
-// point and 18 more accumulators than the symmetric float form (the rounding breaks the (n_a n_c)(p_b p_d) symmetry).
+// The 13 components of u = (n_a p'_b, n_a, r0) are put on a power-of-two grid chosen from the model's radius and the gate (IcpArgs::mom_*,
+// hop_icp_refine): U = the EXACT value of n_a (p'_b 2^k) (or n_a 2^12, r0 2^k_r) rounded to the nearest integer, ties to even, clamped to
+// +-2^ICP_MOM_BITS.  One v_fma_f32 does the product and the rounding: x y + 1.5 2^23 is rounded ONCE, to a float whose unit is 1 (|x y| < 2^22),
+// so its mantissa bits are the integer (the oracle: nearbyint of the product formed exactly in double).
+// M = sum U U^T (91 entries, lower triangle): a lane handles its points two at a time, packs the two vectors into 16-bit halves
+// (v_cvt_pk_i16_i32) and adds both outer products with 91 v_dot2_i32_i16 -- products <= 2^24, a lane adds at most 2 ICP_ACCUM_R = 64 of them in
+// 32 bits -- lanes / wavefronts / workgroups are then added in 64 bits.  The squared correspondence distances of the MSE stop rule go the
+// same way.  Lookups, gates and the deferred-lookup queue are those of k_icp_fusedq_mom.
+// Per accepted correspondence (ISA count): 3 scalings + 13 x (fma, sub, med3) + 6.5 packs + 45.5 dot2 = 94 vector instructions; the float form
+// of nn_mode 6 needs ~60 (its 73 FMAs go two to a v_pk_fma_f32); the first integer form of this round (one point at a time, mul / rndne / med3 /
+// cvt, 91 v_mad_i32_i24) needed 152.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int momi_q(float v, float s, float lim) {
+__device__ __forceinline__ int momi_q(float v, float s, float lim) {  // rint(v s) for values beyond the fma form's range (the squared distance)
   const float t = __builtin_rintf(v * s);  // s is a power of two: the product is exact
   return (int)__builtin_amdgcn_fmed3f(t, -lim, lim);
 }
+constexpr float MOMI_MAGIC = 12582912.0f;      // 1.5 * 2^23: floats in [2^23, 2^24) have unit 1
+constexpr int MOMI_MAGIC_BITS = 0x4B400000;
+__device__ __forceinline__ int momi_qp(float x, float y, int lim) {  // nearest integer (ties to even) of the exact product x y, |x y| < 2^22; clamped
+  const float t = __builtin_fmaf(x, y, MOMI_MAGIC);
+  const int v = __float_as_int(t) - MOMI_MAGIC_BITS;
+  return min(max(v, -lim), lim);
+}
+// two signed 16-bit integers in one register / the sum of the two products of the halves added to c
+#if defined(HOP_EMU)  // (tests/emu: the kernel text compiled for the CPU model -- no gfx950 builtins there)
+__device__ __forceinline__ unsigned momi_pack(int a, int b) { return ((unsigned)a & 0xffffu) | ((unsigned)b << 16); }
+__device__ __forceinline__ int momi_dot2(unsigned a, unsigned b, int c) {
+  return c + (int)(short)(a & 0xffffu) * (int)(short)(b & 0xffffu) + (int)(short)(a >> 16) * (int)(short)(b >> 16);
+}
+#else
+typedef short momi_v2i16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned momi_pack(int a, int b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(a, b)); }  // (|a|, |b| <= 4096: no saturation)
+__device__ __forceinline__ int momi_dot2(unsigned a, unsigned b, int c) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(momi_v2i16, a), __builtin_bit_cast(momi_v2i16, b), c, false);
+}
+#endif
+// one source point of a hypothesis: lookup, PCL's two gates, and -- if accepted -- its gridded u in U[13] and its gridded squared distance in dq
+// (both left untouched otherwise: the caller zeroes them)
 template <bool DEFER>
 __device__ __forceinline__ int icp_fusedq_point_momi(const IcpArgs& a, int i, const float* __restrict__ pose, const float* __restrict__ sTi,
-                                                      const float* __restrict__ F, V3 ctr, int (&acc)[ICP_NMOMI]) {
+                                                      const float* __restrict__ F, V3 ctr, int (&U)[13], int& dq) {
   const float4 p4 = a.s_pts4[i];
   V3 q = v3(p4.x, p4.y, p4.z);
   if (a.iter > 0) q = m4_point_fma(F, q);
@@ -2626,25 +2653,32 @@ __device__ __forceinline__ int icp_fusedq_point_momi(const IcpArgs& a, int i, co
   if (!(((qn.x * nt.x + qn.y * nt.y) + qn.z * nt.z) > a.cos_thr)) return ICP_PT_REJECTED;
   const V3 pc = q - ctr;
   const float r0 = vdot(q - tq, nt);
-  const float pv[3] = {pc.x, pc.y, pc.z}, nv[3] = {nt.x, nt.y, nt.z};
-  int U[13];
+  const float ps[3] = {pc.x * a.mom_s_np, pc.y * a.mom_s_np, pc.z * a.mom_s_np};  // (powers of two: exact)
+  const float nv[3] = {nt.x, nt.y, nt.z};
+  const int lim = 1 << ICP_MOM_BITS;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
 #pragma unroll
-    for (int b = 0; b < 3; ++b) U[3 * c + b] = momi_q(nv[c] * pv[b], a.mom_s_np, a.mom_lim);
-    U[9 + c] = momi_q(nv[c], a.mom_s_n, a.mom_lim);
+    for (int b = 0; b < 3; ++b) U[3 * c + b] = momi_qp(nv[c], ps[b], lim);
+    U[9 + c] = momi_qp(nv[c], a.mom_s_n, lim);
   }
-  U[12] = momi_q(r0, a.mom_s_r, a.mom_lim);
+  U[12] = momi_qp(r0, a.mom_s_r, lim);
+  dq = momi_q(d2, a.mom_s_d, a.mom_lim_d);
+  return ICP_PT_ACCEPTED;
+}
+// the outer products of two gridded vectors (either may be zero: a point that was not accepted) added to the lane's 91 sums
+__device__ __forceinline__ void momi_accumulate_pair(const int (&UA)[13], const int (&UB)[13], int (&acc)[ICP_NMOMI]) {
+  unsigned P[13];
+#pragma unroll
+  for (int u = 0; u < 13; ++u) P[u] = momi_pack(UA[u], UB[u]);
   int k = 0;
 #pragma unroll
   for (int u = 0; u < 13; ++u)
 #pragma unroll
     for (int v = 0; v <= u; ++v) {
-      acc[k] = __mul24(U[u], U[v]) + acc[k];  // v_mad_i32_i24
+      acc[k] = momi_dot2(P[u], P[v], acc[k]);
       ++k;
     }
-  acc[91] += momi_q(d2, a.mom_s_d, a.mom_lim_d);
-  return ICP_PT_ACCEPTED;
 }
 // the per-lane 32-bit sums of a 256-thread block added in 64 bits: block_sum_floats with integers (same tile, same steps)
 template <int NV>
@@ -2694,18 +2728,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM
   int n_wave = 0, n_def = 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int base = blockIdx.x * (256 * R);
-  for (int r = 0; r < R; ++r) {
-    const int li = r * 256 + threadIdx.x, i = base + li;
-    if (i >= a.ns) continue;
-    const int res = icp_fusedq_point_momi<true>(a, i, pose, sTi, F, ctr, acc);
-    const unsigned long long dm = __ballot(res == ICP_PT_DEFERRED);
-    if (res == ICP_PT_DEFERRED) defer_i[wave][n_def + __popcll(dm & ((1ull << lane) - 1ull))] = (unsigned short)li;
-    n_def += __popcll(dm);
-    n_wave += __popcll(__ballot(res == ICP_PT_ACCEPTED));
+  // the lane's points two at a time (trips r and r + 1): one lookup after the other, both outer products in one pass of 91 v_dot2.
+  // Every lane of the wavefront makes every trip (a point past the end of the cloud counts as rejected): the ballots see all 64 lanes.
+  for (int r = 0; r < R; r += 2) {
+    int UA[13], UB[13], dA = 0, dB = 0;
+#pragma unroll
+    for (int u = 0; u < 13; ++u) UA[u] = 0, UB[u] = 0;
+    int res[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int li = (r + half) * 256 + threadIdx.x, i = base + li;
+      int rs = ICP_PT_REJECTED;
+      if (r + half < R && i < a.ns) rs = half ? icp_fusedq_point_momi<true>(a, i, pose, sTi, F, ctr, UB, dB) : icp_fusedq_point_momi<true>(a, i, pose, sTi, F, ctr, UA, dA);
+      const unsigned long long dm = __ballot(rs == ICP_PT_DEFERRED);
+      if (rs == ICP_PT_DEFERRED) defer_i[wave][n_def + __popcll(dm & ((1ull << lane) - 1ull))] = (unsigned short)li;
+      n_def += __popcll(dm);
+      n_wave += __popcll(__ballot(rs == ICP_PT_ACCEPTED));
+      res[half] = rs;
+    }
+    if (res[0] == ICP_PT_ACCEPTED || res[1] == ICP_PT_ACCEPTED) {
+      momi_accumulate_pair(UA, UB, acc);
+      acc[91] += dA + dB;
+    }
   }
   const int nd = __builtin_amdgcn_readfirstlane(n_def);
-  for (int t = lane; t < nd; t += 64)
-    n_wave += __popcll(__ballot(icp_fusedq_point_momi<false>(a, base + defer_i[wave][t], pose, sTi, F, ctr, acc) == ICP_PT_ACCEPTED));
+  for (int t0 = 0; t0 < nd; t0 += 128) {  // the deferred lookups densely packed, again two to a lane
+    int UA[13], UB[13], dA = 0, dB = 0;
+#pragma unroll
+    for (int u = 0; u < 13; ++u) UA[u] = 0, UB[u] = 0;
+    int res[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int t = t0 + half * 64 + lane;
+      int rs = ICP_PT_REJECTED;
+      if (t < nd) rs = half ? icp_fusedq_point_momi<false>(a, base + defer_i[wave][t], pose, sTi, F, ctr, UB, dB) : icp_fusedq_point_momi<false>(a, base + defer_i[wave][t], pose, sTi, F, ctr, UA, dA);
+      n_wave += __popcll(__ballot(rs == ICP_PT_ACCEPTED));
+      res[half] = rs;
+    }
+    if (res[0] == ICP_PT_ACCEPTED || res[1] == ICP_PT_ACCEPTED) {
+      momi_accumulate_pair(UA, UB, acc);
+      acc[91] += dA + dB;
+    }
+  }
   long long* __restrict__ out = reinterpret_cast<long long*>(a.partial) + ((size_t)hl * gridDim.x + blockIdx.x) * ICP_NMOMI_STRIDE;
   if (lane == 0) n_cnt[wave] = n_wave;
   block_sum_ints<ICP_NMOMI>(acc, bs, out);  // (its barriers order n_cnt as well)

@@ -1581,12 +1581,18 @@ inline void mom_add(MomSums& m, const MomSpec& sp, V3 p, V3 q, V3 n, V3 ctr, flo
   const float pc[3] = {p.x - ctr.x, p.y - ctr.y, p.z - ctr.z}, nv[3] = {n.x, n.y, n.z};
   const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
   const float r0 = dx * n.x + (dy * n.y + dz * n.z);
+  // U = the EXACT product n_a (p'_b 2^k) -- two floats: 48 bits, exact in a double -- rounded to the nearest integer, ties to even (the GPU
+  // obtains it with one fused multiply-add onto 1.5 2^23; see csrc/hop_kernels.hip momi_qp), clamped
+  auto q_exact = [&](float x, float y_scaled) -> int32_t {
+    const double r = std::nearbyint((double)x * (double)y_scaled);
+    return (int32_t)std::min(std::max(r, -(double)sp.lim), (double)sp.lim);
+  };
   int32_t U[13];
   for (int a = 0; a < 3; ++a) {
-    for (int b = 0; b < 3; ++b) U[3 * a + b] = mom_quant(nv[a] * pc[b], sp.k_np, sp.lim);
-    U[9 + a] = mom_quant(nv[a], sp.k_n, sp.lim);
+    for (int b = 0; b < 3; ++b) U[3 * a + b] = q_exact(nv[a], std::ldexp(pc[b], sp.k_np));
+    U[9 + a] = q_exact(nv[a], std::ldexp(1.0f, sp.k_n));
   }
-  U[12] = mom_quant(r0, sp.k_r, sp.lim);
+  U[12] = q_exact(r0, std::ldexp(1.0f, sp.k_r));
   for (int i = 0; i < 13; ++i)
     for (int j = 0; j <= i; ++j) m.M[i][j] += (int64_t)U[i] * (int64_t)U[j];
   m.d2q += (int64_t)mom_quant(d2, sp.k_d, sp.lim_d);
