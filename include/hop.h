@@ -147,7 +147,7 @@ typedef struct {
                       * default build than its -march=native build is (profiles/r03_icp_lm_deltas.json).  Per-lane float sums,
                       * reciprocal estimates in the solve: results reproducible on the GPU, not on a CPU.
                       * 7: the moment form made REPRODUCIBLE ANYWHERE -- the 13 components of u are put on a power-of-two grid
-                      * (12 bits: 30 um on positions, 2e-4 on normals, 4 um on the residual -- two orders below the noise of the
+                      * (12 bits, nearest integer of the exact product: 30 um on positions, 2e-4 on normals, 4 um on the residual -- two orders below the noise of the
                       * reference's float forward differences), the moment matrix is their exact integer sum (any order of the
                       * lanes / wavefronts / workgroups gives the same 64-bit integers), and the solve uses IEEE + - * / sqrt fma in
                       * a fixed order: the CPU statement of the algorithm (oracle minimiser 7) returns the same bits, so the chain

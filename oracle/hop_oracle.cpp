@@ -1535,9 +1535,9 @@ bool lm_point_to_plane(const std::vector<V3>& P, const std::vector<V3>& Q, const
 //
 // What makes the form reproducible on ANY summation order (a GPU adds the terms of M in the order its lanes, wavefronts and workgroups
 // happen to be laid out): u is put on a fixed binary grid first -- each component class scaled by a power of two chosen from the model's
-// radius and the correspondence gate, rounded to the nearest integer (ties to even), |integer| <= 2^bits -- and M is the EXACT integer
+// radius and the correspondence gate, the EXACT scaled value rounded to the nearest integer (ties to even), |integer| <= 2^bits -- and M is the EXACT integer
 // matrix sum_i U_i U_i^T (products < 2^(2 bits), sums in 64 bits).  Integer addition is associative: every order gives the same M.  The
-// grid is far below what the float run carries as rounding noise in its Jacobian (13 bits: 15 um on p', 1e-4 on n, 2 um on r0; the
+// grid is far below what the float run carries as rounding noise in its Jacobian (12 bits: 30 um on p', 2e-4 on n, 4 um on r0; the
 // reference's forward differences carry 1e-3 relative), and the squared correspondence distances of the MSE stop rule are summed the
 // same way.  From M on, every operation is an IEEE double operation (+ - * / sqrt fma) in a fixed order, stated once here and once in
 // csrc/hop_lm_core.h -- two texts, same doubles.
