@@ -83,7 +83,9 @@ static const double g_start = wall_now();
 static double stale_s() { return std::getenv("HOP_COMM_STALE_S") ? std::atof(std::getenv("HOP_COMM_STALE_S")) : 120.0; }
 static bool abort_published(const std::string& id_file, std::string& why) {
   const std::string a = id_file + ".abort";
-  if (file_age_before(a, g_start) > stale_s()) return false;  // none, or one an earlier run left
+  // none, or one an earlier run left: a rank of THIS launch gives up after it has started, i.e. at most a launcher's start-up spread before
+  // this rank's own start (10 s allowed) -- the id file's 120 s would let a re-launch right after a failure trip over the old marker
+  if (file_age_before(a, g_start) > std::min(stale_s(), 10.0)) return false;
   std::ifstream f(a);
   std::getline(f, why);
   return true;
