@@ -133,3 +133,47 @@ def test_product_minimiser_text_equals_the_oracle_bit_for_bit(orc, kat, core_hos
         n_par += st[1] > 8
         assert np.isfinite(x).all(), k
     assert len(cases) > 150 and n_par > 100 and len(statuses) >= 2, (len(cases), n_par, statuses)
+
+
+def test_product_minimiser_text_equals_the_oracle_on_random_problems(orc, core_host, tmp_path):
+    """1 500 random point-to-plane problems -- surface patches of random extent and curvature, increments from 0.01 to 30 degrees / 0.1 to 40 mm
+    (the large ones drive trial steps through the trust-region logic and, now and then, outside the quaternion's unit ball), noise from 0 to
+    3 mm, 4 to 400 correspondences: parameters, status and evaluation count of the product's text equal the oracle's bit for bit"""
+    rng = np.random.default_rng(99)
+    cases = []
+    for k in range(1500):
+        m = int(rng.integers(4, 400))
+        ext = rng.uniform(0.005, 0.08, 3)
+        P = (rng.normal(size=(m, 3)) * ext).astype(np.float32)
+        if k % 7 == 0:
+            P[:, 2] = (0.5 * rng.uniform(-20, 20) * (P[:, 0] ** 2 + P[:, 1] ** 2)).astype(np.float32)      # a curved sheet
+        N = P / np.maximum(ext ** 2, 1e-9) + rng.normal(size=(m, 3)) * 0.05
+        N = (N / np.linalg.norm(N, axis=1, keepdims=True)).astype(np.float32)
+        ang = np.radians(10 ** rng.uniform(-2, np.log10(30.0)))
+        ax = rng.normal(size=3)
+        ax /= np.linalg.norm(ax)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+        t = rng.normal(size=3) * 10 ** rng.uniform(-4, np.log10(0.04))
+        ctr0 = rng.normal(size=3) * 0.3
+        Q = ((P.astype(np.float64) @ R.T + t) + rng.normal(size=(m, 3)) * rng.uniform(0, 0.003) * (k % 3 > 0) + ctr0).astype(np.float32)
+        Pm = (P + ctr0).astype(np.float32)
+        cases.append(_moments(orc, Pm, Q, N)[1:3])
+    path = tmp_path / "fuzz.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", len(cases)))
+        for Md, ctr in cases:
+            f.write(np.ascontiguousarray(Md, np.float64).tobytes())
+            f.write(np.asarray(ctr, np.float64).tobytes())
+    r = subprocess.run([core_host, str(path)], capture_output=True, text=True, check=True)
+    lines = r.stdout.strip().splitlines()
+    counts = [int(v) for v in lines.pop().split()[1:]]
+    assert len(lines) == len(cases) and min(counts) > 0, counts
+    statuses = {}
+    for k, ((Md, ctr), ln) in enumerate(zip(cases, lines)):
+        t = ln.split()
+        x_host = np.array([int(v, 16) for v in t[:6]], np.uint32).view(np.float32)
+        _, x, st = orc.lm_point_to_plane_moments(Md, ctr)
+        assert np.array_equal(x_host.view(np.uint32), x.view(np.uint32)) and tuple(int(v) for v in t[6:9]) == st, (k, x_host, x, t[6:9], st)
+        statuses[st[0]] = statuses.get(st[0], 0) + 1
+    assert len(statuses) >= 3, statuses
