@@ -1035,12 +1035,17 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
   HIPCHK(c, c->cand_counts_d.ensure(sizeof(int) * (size_t)cand_cap));
   HIPCHK(c, c->counters_d.ensure(sizeof(int) * 16));
   HIPCHK(c, c->fit_queue_d.ensure(sizeof(int4) * (size_t)cand_cap * 4));  // FIT_QUEUES sub-queues of cand_cap/FIT_QUEUES*4 entries
-  HIPCHK(c, c->fit_count_d.ensure(sizeof(int) * FIT_QUEUES));
+  // per flushed batch: its candidate count and the FIT_QUEUES sub-queue counts (a flush carries at least one base: <= n_trials of them) --
+  // zeroed ONCE per frame below instead of by two fill kernels before every batch (~32 of the ~100 fills of a C2 frame)
+  const size_t batch_cnt_stride = 1 + FIT_QUEUES;
+  HIPCHK(c, c->fit_count_d.ensure(sizeof(int) * batch_cnt_stride * ((size_t)n_trials + 1)));
   int rc = ensure_hyp_capacity(c, hyp_cap);
   if (rc) return rc;
-  int* counters = c->counters_d.as<int>();  // [0] cand_count, [1] hyp_count, [2] overflow
+  int* counters = c->counters_d.as<int>();  // [1] hyp_count, [2] overflow, [3] candidates in total ([0]: unused since the batches count their own)
   HIPCHK(c, hipMemsetAsync(counters, 0, sizeof(int) * 16, c->stream));
   HIPCHK(c, hipMemsetAsync(c->cnt_d.p, 0, sizeof(int) * 3 * (size_t)n_trials, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->fit_count_d.p, 0, sizeof(int) * batch_cnt_stride * ((size_t)n_trials + 1), c->stream));
+  int n_flushed = 0;
   int* cnt1_all = c->cnt_d.as<int>();
   int* cnt2_all = cnt1_all + n_trials;
   const NsetGeom geom = make_nset_geom(opts->delta / c->gen.ratio);
@@ -1068,8 +1073,10 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
     HIPCHK(c, hipEventRecord(stage_ev[flip], c->stream));
     stage_used[flip] = true;
     flip ^= 1;
-    HIPCHK(c, hipMemsetAsync(counters, 0, sizeof(int), c->stream));      // cand_count
-    HIPCHK(c, hipMemsetAsync(c->fit_count_d.p, 0, sizeof(int) * FIT_QUEUES, c->stream));
+    if (n_flushed > n_trials) return HOP_E_STATE;
+    int* cand_count = c->fit_count_d.as<int>() + batch_cnt_stride * (size_t)n_flushed;  // this batch's own, still zero from the frame's one fill
+    int* fit_count = cand_count + 1;
+    ++n_flushed;
     int* cnt1 = cnt1_all + batch_first_trace;
     int* cnt2 = cnt2_all + batch_first_trace;
     {
@@ -1091,10 +1098,10 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
       qa.bases = pa.bases, qa.qx = qx, qa.qy = qy, qa.qz = qz, qa.pairs1 = pa.pairs1, qa.pairs2 = pa.pairs2;
       qa.cnt1 = cnt1, qa.cnt2 = cnt2, qa.cap = pair_cap, qa.geom = geom, qa.elems = qp.elems, qa.queries = qp.queries;
       qa.dist_thr2 = 1.0f * opts->delta, qa.delta = 1.0f * opts->delta, qa.base_index0 = batch_first_trace;
-      qa.cands = c->cands_d.as<Candidate>(), qa.cand_counts = c->cand_counts_d.as<int>(), qa.cand_count = counters, qa.cand_cap = cand_cap;
+      qa.cands = c->cands_d.as<Candidate>(), qa.cand_counts = c->cand_counts_d.as<int>(), qa.cand_count = cand_count, qa.cand_cap = cand_cap;
       qa.nquads = nquads_all + batch_first_trace;
       qa.overflow = counters + 2;
-      qa.fit_queue = c->fit_queue_d.as<int4>(), qa.fit_count = c->fit_count_d.as<int>(), qa.fit_cap = cand_cap / FIT_QUEUES * 4;
+      qa.fit_queue = c->fit_queue_d.as<int4>(), qa.fit_count = fit_count, qa.fit_cap = cand_cap / FIT_QUEUES * 4;
       {
         SpanGuard sq(c, T_QUADS);
         launch_quads(qa, nb, 64, c->stream);
@@ -1105,7 +1112,7 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
     va.px = c->gp_d.plane(0), va.py = c->gp_d.plane(1), va.pz = c->gp_d.plane(2), va.np = N;
     va.qx = qx, va.qy = qy, va.qz = qz, va.nq = NQ;
     va.T = reinterpret_cast<const float*>(c->cands_d.p), va.t_stride = sizeof(Candidate) / sizeof(float);
-    va.n_cand_ptr = counters, va.n_cand = 0, va.cand_cap = cand_cap;
+    va.n_cand_ptr = cand_count, va.n_cand = 0, va.cand_cap = cand_cap;
     va.sq_eps = opts->delta * opts->delta, va.counts = c->cand_counts_d.as<int>();
     {
       SpanGuard sg(c, T_VERIFY);
@@ -1116,7 +1123,7 @@ int hop_s4pcs_generate(hop_ctx* c, const hop_s4pcs_opts* opts, float* poses16_ou
     {
       SpanGuard sg(c, T_GEN_OTHER);
       EmitArgs ea{};
-      ea.cands = c->cands_d.as<Candidate>(), ea.cand_counts = c->cand_counts_d.as<int>(), ea.cand_count = counters, ea.cand_cap = cand_cap;
+      ea.cands = c->cands_d.as<Candidate>(), ea.cand_counts = c->cand_counts_d.as<int>(), ea.cand_count = cand_count, ea.cand_cap = cand_cap;
       for (int k = 0; k < 3; ++k) ea.cp[k] = c->gen.centroid_p[k], ea.cq[k] = c->gen.centroid_q[k];
       ea.nq = NQ, ea.pose = c->hyp_pose.as<float>(), ea.score = c->hyp_score.as<float>(), ea.key = c->hyp_key.as<unsigned long long>();
       ea.inv_count = c->hyp_inv.as<unsigned>(), ea.hyp_count = counters + 1, ea.hyp_cap = hyp_cap, ea.cand_total = counters + 3;
