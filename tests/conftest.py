@@ -12,7 +12,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-EMU_LIB = os.path.join(ROOT, "tests", "emu", "_build", "libhop_emu.so")
+EMU_LIB = os.environ.get("HOP_TEST_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "_build", "libhop_emu.so")   # (override: e.g. an AddressSanitizer build of the model)
 
 
 @pytest.fixture(scope="session")
