@@ -676,7 +676,7 @@ hipError_t hop_ctx_h2d(hop_ctx* c, void* dst, const void* src, size_t bytes) {
   char* at = static_cast<char*>(c->stage_up.p) + c->stage_cur;
   static const bool prof = getenv("HOP_PROFILE_STAGE") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  std::memcpy(at, src, bytes);
+  if (bytes) std::memcpy(at, src, bytes);
   const auto t1 = std::chrono::steady_clock::now();
   c->stage_cur += need;
   const hipError_t e = hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, c->stream);

@@ -999,19 +999,14 @@ template __global__ void k_lcp_forward<4>(LcpArgs);
 __global__ __launch_bounds__(64) void k_lcp_sum(LcpArgs a, int hb) {
   const int hl = blockIdx.x * blockDim.x + threadIdx.x;
   if (hl >= hb) return;
-  const float4* t = reinterpret_cast<const float4*>(a.terms + (size_t)hl * a.ns * 2);
+  // (forward term, reciprocal term) of a scene point: 8-byte pairs -- a hypothesis' row starts at a multiple of 8 bytes whatever ns is (16-byte
+  // loads would be misaligned for odd hypotheses when ns is odd: found by the UBSan build of the CPU model)
+  const float2* t = reinterpret_cast<const float2*>(a.terms + (size_t)hl * a.ns * 2);
   float cp = 0.f;
-  const int n4 = (a.ns * 2) / 4;
-  for (int k = 0; k < n4; ++k) {
-    const float4 v = t[k];
+  for (int k = 0; k < a.ns; ++k) {
+    const float2 v = t[k];
     if (v.x >= 0.f) cp += v.x;
     if (v.y >= 0.f) cp += v.y;
-    if (v.z >= 0.f) cp += v.z;
-    if (v.w >= 0.f) cp += v.w;
-  }
-  for (int k = n4 * 4; k < a.ns * 2; ++k) {
-    const float v = a.terms[(size_t)hl * a.ns * 2 + k];
-    if (v >= 0.f) cp += v;
   }
   a.score[a.h0 + hl] = cp;
 }
