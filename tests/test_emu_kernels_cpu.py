@@ -66,6 +66,10 @@ def test_generator_kernels_against_the_reference_built_goldens_on_the_model(emu_
     sel = [os.path.join("tests", "test_gpu_parity.py")]
     assert _child_pytest(sel, "generator_matches_reference_golden and case1") == 3
     assert _child_pytest(sel, "generator_matches_reference_golden and case1", env={"HOP_QUADS_HASH": "1"}) == 3
+    # ... and with the workgroups and work-items of every launch scheduled in a shuffled order (the queues are filled through atomics: the
+    # emitted multiset must not depend on who gets which slot)
+    assert _child_pytest(sel, "generator_matches_reference_golden and case1", env={"HOP_QUADS_HASH": "1", "EMU_ORDER": "shuffle:5"}) == 3
+    assert _child_pytest(sel, "generator_matches_reference_golden and case1", env={"EMU_ORDER": "reverse"}) == 3
 
 
 def test_render_and_normals_kernels_on_the_model(emu_lib):
