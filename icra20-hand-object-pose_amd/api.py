@@ -52,8 +52,10 @@ class S4pcsStats(C.Structure):
 
 
 HOP_ABI_VERSION = 2
-ICP_NN_MODE_REFERENCE = 7  # hop_icp_opts.nn_mode of the mirrors: the reference's Levenberg-Marquardt on (t, quaternion) to its stopping rule per ICP iteration,
-                           # from integer-exact moment sums with an IEEE-only solve: the poses the CPU oracle (minimiser 7) returns, bit for bit
+# hop_icp_opts.nn_mode of the mirrors: 7 = the reference's Levenberg-Marquardt on (t, quaternion) to its stopping rule per ICP iteration, from
+# integer-exact moment sums with an IEEE-only solve: the poses the CPU oracle (minimiser 7) returns, bit for bit.  HOP_ICP_NN_MODE overrides it
+# without a rebuild (host/PoseEstimator.h icp_nn_mode_reference: e.g. 6, the float-sum form round 3 measured on hardware).
+ICP_NN_MODE_REFERENCE = int(os.environ.get("HOP_ICP_NN_MODE", "7"))
 ICP_NN_MODE_GN = 4         # one Gauss-Newton step per ICP iteration (faster; not what PCL computes)
 
 

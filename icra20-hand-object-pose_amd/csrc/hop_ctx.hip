@@ -1404,9 +1404,14 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
       if (rc) return rc;
     }
     a.cells = cs.c;
-    // nn_mode 6 needs the packed lists; a model of >= 65535 points or a list outside the 16-bit frame has none: the per-evaluation form
-    // (nn_mode 5) runs the same minimiser on the plain lists
-    if ((lm6_mode || lm7_mode) && !cs.c.rec) lm6_mode = lm7_mode = false, lm_mode = true;
+    // nn_mode 6 / 7 need the packed lists; a model of >= 65535 points or a list outside the 16-bit frame has none.  nn_mode 6 then runs the
+    // same minimiser in its per-evaluation form on the plain lists (nn_mode 5: the float results of that form); nn_mode 7 promises the
+    // oracle's bits and has no other form that returns them: it refuses instead of answering with another arithmetic.
+    if (lm7_mode && !cs.c.rec) {
+      hop_ctx_set_error(c, "hop_icp_refine: nn_mode 7 needs the packed cell lists (HOP_MODEL_5MM of < 65535 points, lists inside the 16-bit cell frame); use nn_mode 5");
+      return HOP_E_STATE;
+    }
+    if (lm6_mode && !cs.c.rec) lm6_mode = false, lm_mode = true;
     if (o->nn_mode == 2 || lm_mode) HIPCHK(c, c->icp_corr_idx.ensure(sizeof(int) * (size_t)S.n * HB));  // the fused kernels keep no correspondence array
     if (lm_mode) {
       HIPCHK(c, c->icp_lm.ensure(sizeof(LmDev) * (size_t)HB + 64));

@@ -485,7 +485,8 @@ HOP_LM_DEV bool lm_advance(LS& s, const double* cand) {
   if (LS::fast_lmpar) {
     // the same quantities without the square roots that are squared again: (|J p| / |f|)^2 = p^T A p / |f|^2
     const double c27 = cand[27];
-    fnorm1 = c27 > 1e-290 ? c27 * rsqrt_nr(c27) : 0.0;
+    // (a NaN sum of squares -- a trial step outside the quaternion's unit ball -- stays NaN: Eigen's `0.1 * fnorm1 < fnorm` is then false and the step is refused)
+    fnorm1 = c27 != c27 ? c27 : (c27 > 1e-290 ? c27 * rsqrt_nr(c27) : 0.0);
     const double finv = rcp_nr(s.fnorm), r1 = fnorm1 * finv;
     if (p1 * fnorm1 < s.fnorm) actred = 1.0 - r1 * r1;
     temp1 = lm_max(jp2, 0.0) * finv * finv;

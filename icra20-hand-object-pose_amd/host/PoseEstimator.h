@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -27,6 +28,13 @@ struct Mesh {             // what igl::readOBJ / pcl::PolygonMesh hold: vertices
   int nv() const { return (int)(V.size() / 3); }
   int nf() const { return (int)(F.size() / 3); }
 };
+// hop_icp_opts.nn_mode of the mirrors: 7 (the oracle's bits).  HOP_ICP_NN_MODE=<0..7> overrides it without a rebuild -- e.g. 6, the float-sum
+// form that round 3 measured on hardware, should a device disagree with nn_mode 7's CPU-verified bits.
+inline int icp_nn_mode_reference() {
+  const char* e = std::getenv("HOP_ICP_NN_MODE");
+  const int m = e ? std::atoi(e) : 7;
+  return (m < 0 || m > 7) ? 7 : m;
+}
 inline void check(int rc, hop_ctx* c, const char* where) {
   if (rc != HOP_OK) throw std::runtime_error(std::string(where) + ": " + hop_strerror(rc) + " " + (c ? hop_last_error(c) : ""));
 }
@@ -110,7 +118,7 @@ class PoseEstimator {
   void refineByICP() {
     // nn_mode 7: the reference's minimiser (PCL's TransformationEstimationPointToPlane = Eigen's Levenberg-Marquardt, Utils.cpp:200-216) from
     // integer-exact moment sums with an IEEE-only solve: the refined poses are the CPU oracle's, bit for bit
-    hop_icp_opts o{10, cfg->getf("icp_angle_thres"), cfg->getf("icp_dist_thres"), 100, 7};
+    hop_icp_opts o{10, cfg->getf("icp_angle_thres"), cfg->getf("icp_dist_thres"), 100, hop::icp_nn_mode_reference()};
     hop::check(hop_icp_refine(ctx_, &o, nullptr, nullptr), ctx_, "hop_icp_refine");
   }
 

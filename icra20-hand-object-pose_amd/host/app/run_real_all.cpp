@@ -156,7 +156,12 @@ int main(int argc, char** argv) {
     const bool use_comm = gather && (world > 1 || std::getenv("HOP_GATHER_COMM") != nullptr);
     g_id_file = use_comm ? id_file : std::string();
     g_rank = rank;
-    if (use_comm && rank == 0) std::remove(id_file.c_str()), std::remove((id_file + ".abort").c_str());
+    if (use_comm && rank == 0) {
+      std::remove(id_file.c_str());
+      // the abort marker only if it is an EARLIER run's (the age rule abort_published reads it by): a peer of this launch that failed at once
+      // may have published its reason before rank 0 got here, and removing it would leave every rank waiting for a collective that cannot complete
+      if (file_age_before(id_file + ".abort", g_start) > std::min(stale_s(), 10.0)) std::remove((id_file + ".abort").c_str());
+    }
     const std::regex rgb_re("rgb([0-9]+)\\..*");
     for (const std::string& record : list_dir(mdir, true)) {
       const std::string rec = mdir + "/" + record;

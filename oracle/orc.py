@@ -475,7 +475,7 @@ def lm_residuals_jacobian(src, tgt, nrm, x6, ref=False):
 
 
 def set_mom_bits(bits):
-    """grid of the moment form (minimiser 7): |integer| <= 2^bits; 13 is what the GPU's nn_mode 7 uses -- other values: precision experiments"""
+    """grid of the moment form (minimiser 7): |integer| <= 2^bits; 12 (csrc/hop_device.h ICP_MOM_BITS, the oracle's default) is what the GPU's nn_mode 7 uses -- other values: precision experiments"""
     lib().orc_set_mom_bits(int(bits))
 
 
@@ -490,7 +490,10 @@ def lm_point_to_plane_moments(M, c):
     return T.reshape(4, 4), x, tuple(int(v) for v in st)
 
 
-def mom_accumulate(src, tgt, nrm, d2, ctr, model_radius, max_corr_dist=0.01, bits=13):
+MOM_BITS = 12  # = csrc/hop_device.h ICP_MOM_BITS = the oracle's g_mom_bits (tests/test_abi_cpu.py keeps the three in step)
+
+
+def mom_accumulate(src, tgt, nrm, d2, ctr, model_radius, max_corr_dist=0.01, bits=MOM_BITS):
     """integer moment sums of the given correspondences -> (M int64 13x13, d2q, M in metres float64 13x13, (k_np, k_n, k_r, k_d))"""
     a, b, c = (np.ascontiguousarray(v, np.float32).reshape(-1, 3) for v in (src, tgt, nrm))
     d = np.ascontiguousarray(d2, np.float32).reshape(-1)

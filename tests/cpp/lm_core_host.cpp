@@ -1,8 +1,10 @@
 // CPU build of the PRODUCT's minimiser text (icra20-hand-object-pose_amd/csrc/hop_lm_core.h -- the header k_icp_lm7_solve runs on the GPU), driven
 // the way the kernel drives it.  tests/test_lm_core_cpu.py compares what it returns with the oracle's independent statement of the same
 // algorithm (oracle/hop_oracle.cpp lm_point_to_plane_moments) bit for bit: the arithmetic of nn_mode 7's solve is checked without a GPU.
-//   lm_core_host <cases.bin> -> one line per case: x[6] as hex floats, status, nfev, iter; then "counts <general lmpar2> <register, par = 0> <register, iterated>"
+//   lm_core_host <cases.bin> [6] -> one line per case: x[6] as hex floats, status, nfev, iter; then "counts <general lmpar2> <register, par = 0> <register, iterated>"
 //   cases.bin: int32 n, then n x (169 doubles M row-major, 3 doubles c)
+//   "6": the fast-arithmetic machine of nn_mode 6 (LmDev6, lm6_eval<true>: on the host its reciprocal estimates are IEEE operations) -- the
+//   same state machine through its other branches; no oracle states it, the test checks what it does with a NaN evaluation
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -16,18 +18,19 @@ long g_count[8];  // the header's statistics hooks: [2] general (pivoted) lmpar2
 constexpr float LM_SQRT_EPS_F = 3.4526698300124393e-04f;  // (csrc/hop_device.h)
 #include "../../icra20-hand-object-pose_amd/csrc/hop_lm_core.h"
 
-// the loop of k_icp_lm7_solve (csrc/hop_icp_lm.hip) on one moment matrix
+// the loop of k_icp_lm7_solve / k_icp_lm6_solve (csrc/hop_icp_lm.hip) on one moment matrix
+template <class LS, bool FAST>
 void solve(const double* M169, const double* c, float x_out[6], int st_out[3]) {
   double M[91];
   for (int i = 0; i < 13; ++i)
     for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] = M169[13 * i + j];
-  LmDev7 s;
+  LS s;
   for (int j = 0; j < 6; ++j) s.x[j] = s.xc[j] = 0.f, s.p[j] = 0.f;
   s.phase = 0, s.status = -1, s.iter = 0, s.nfev = 0;
   s.par = s.delta = s.xnorm = s.fnorm = s.gnorm = s.pnorm = 0.0;
   double cand[28];
   for (int guard = 0; guard < 420; ++guard) {
-    lm6_eval<false, 1>(M, c, s.xc, cand);
+    lm6_eval<FAST, 1>(M, c, s.xc, cand);
     if (!lm_advance(s, cand)) break;
   }
   for (int j = 0; j < 6; ++j) x_out[j] = s.x[j];
@@ -37,6 +40,7 @@ void solve(const double* M169, const double* c, float x_out[6], int st_out[3]) {
 
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
+  const bool mode6 = argc > 2 && argv[2][0] == '6';
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) return 3;
   int32_t n = 0;
@@ -46,7 +50,8 @@ int main(int argc, char** argv) {
     if (std::fread(buf.data(), sizeof(double), 172, f) != 172) return 3;
     float x[6];
     int st[3];
-    hop_host::solve(buf.data(), buf.data() + 169, x, st);
+    if (mode6) hop_host::solve<hop_host::LmDev6, true>(buf.data(), buf.data() + 169, x, st);
+    else hop_host::solve<hop_host::LmDev7, false>(buf.data(), buf.data() + 169, x, st);
     for (int j = 0; j < 6; ++j) {
       uint32_t u;
       std::memcpy(&u, &x[j], 4);

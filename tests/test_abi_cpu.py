@@ -194,3 +194,16 @@ def test_reference_config_as_shipped_is_accepted(hop):
     assert kv["model_name"] == "ellipse" and float(kv["super4pcs_dispersion"]) == 0.5
     assert len(kv["cam_K"].replace("[", " ").replace("]", " ").replace(",", " ").split()) == 9
     assert len(kv["handbase_in_palm"].replace("[", " ").replace("]", " ").replace(",", " ").split()) == 16
+
+
+def test_moment_grid_width_is_one_number(orc):
+    """the grid of nn_mode 7's moment form is stated in three places -- the product (csrc/hop_device.h ICP_MOM_BITS), the oracle's
+    default (g_mom_bits) and orc.py's helper default; a test that calls orc.mom_accumulate with its default must compare the kernel's grid."""
+    dev = open(os.path.join(ROOT, "icra20-hand-object-pose_amd", "csrc", "hop_device.h")).read()
+    bits = int(re.search(r"constexpr int ICP_MOM_BITS = (\d+);", dev).group(1))
+    ora = open(os.path.join(ROOT, "oracle", "hop_oracle.cpp")).read()
+    assert int(re.search(r"int g_mom_bits = (\d+);", ora).group(1)) == bits
+    assert int(re.search(r"int mom_bits = (\d+);", ora).group(1)) == bits
+    assert orc.MOM_BITS == bits
+    import inspect
+    assert inspect.signature(orc.mom_accumulate).parameters["bits"].default == bits

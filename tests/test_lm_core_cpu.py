@@ -135,6 +135,30 @@ def test_product_minimiser_text_equals_the_oracle_bit_for_bit(orc, kat, core_hos
     assert len(cases) > 150 and n_par > 100 and len(statuses) >= 2, (len(cases), n_par, statuses)
 
 
+def test_fast_arithmetic_machine_refuses_a_nan_step_too(orc, core_host, tmp_path):
+    """nn_mode 6's branch of lm_advance mapped a NaN sum of squares to fnorm1 = 0 ("a perfect step") after round 4 had fixed the
+    same defect in lm6_eval.  The nine moment matrices of C1 hypothesis 78 (the last sends a trial step outside the quaternion's unit ball)
+    through LmDev6 on the host: the step must be refused as Eigen refuses it -- finite parameters, the status and evaluation count of the
+    IEEE machine (258 evaluations, status 1; the defect stopped at 16 with status 4 and NaN parameters)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "lm_moment_c1_hyp78.npz"))
+    path = tmp_path / "hyp78.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", len(g["M"])))
+        for Md, ctr in zip(g["M"], g["c"]):
+            f.write(np.ascontiguousarray(Md, np.float64).tobytes())
+            f.write(np.asarray(ctr, np.float64).tobytes())
+    out = {}
+    for mode in ("7", "6"):
+        r = subprocess.run([core_host, str(path)] + (["6"] if mode == "6" else []), capture_output=True, text=True, check=True)
+        out[mode] = [ln.split() for ln in r.stdout.strip().splitlines()[:-1]]
+    for k, (t7, t6) in enumerate(zip(out["7"], out["6"])):
+        x6 = np.array([int(v, 16) for v in t6[:6]], np.uint32).view(np.float32)
+        x7 = np.array([int(v, 16) for v in t7[:6]], np.uint32).view(np.float32)
+        assert np.isfinite(x6).all(), (k, x6)
+        assert t6[6:9] == t7[6:9], (k, t6[6:9], t7[6:9])       # same status, evaluations and iterations as the IEEE machine
+        assert np.abs(x6 - x7).max() <= 1e-6, (k, x6, x7)      # (on the host the two differ by the order of a few double operations)
+
+
 def test_product_minimiser_text_equals_the_oracle_on_random_problems(orc, core_host, tmp_path):
     """1 500 random point-to-plane problems -- surface patches of random extent and curvature, increments from 0.01 to 30 degrees / 0.1 to 40 mm
     (the large ones drive trial steps through the trust-region logic and, now and then, outside the quaternion's unit ball), noise from 0 to

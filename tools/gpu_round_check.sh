@@ -8,18 +8,18 @@
 #     bench_alt*.json  the same with nn_mode 6 (round 3's default) for the comparison DESIGN.md section 4 needs
 #     icp_bench_*.json the ICP stage alone: nn_mode 4 / 6 / 7 and the 4-waves-per-SIMD build of nn_mode 7
 # Profiles (rocprofv3 kernel stats, PMC passes) are a second call: tools/gpu_profile.sh <tag>.
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-python -m pytest tests -m gpu -q -p no:cacheprovider --durations=20 > $OUT/gputest.log 2>&1
-echo "pytest exit $?" >> $OUT/gputest.log
-python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
 echo "smoke exit $?" >> $OUT/smoke.log
-python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
-python bench.py --gpus 1 --steps 20 --warmup 5 --nn-mode 6 --no-cpu-baseline --no-next-rows --no-alt-modes > $OUT/bench_nn_mode6.json 2> $OUT/bench_nn_mode6.err
-HOP_QUADS_HASH=1 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-next-rows --no-alt-modes > $OUT/bench_quads_hash.json 2> $OUT/bench_quads_hash.err
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=20 --timeout 900 > $OUT/gputest.log 2>&1
+echo "pytest exit $?" >> $OUT/gputest.log
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --nn-mode 6 --no-cpu-baseline --no-next-rows --no-alt-modes > $OUT/bench_nn_mode6.json 2> $OUT/bench_nn_mode6.err
+HOP_QUADS_HASH=1 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-next-rows --no-alt-modes > $OUT/bench_quads_hash.json 2> $OUT/bench_quads_hash.err
 # the ICP stage alone (one frame at a time, HIP events): nn_mode 4 / 6 / 7, and nn_mode 7 built for 4 waves per SIMD (151 VGPRs -> 128: spills?)
-python tools/icp_bench.py --reps 3 --icp-modes 4,6,7 --lcp-modes 3 > $OUT/icp_bench_modes_4_6_7.json 2> $OUT/icp_bench.err
+timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 4,6,7 --lcp-modes 3 > $OUT/icp_bench_modes_4_6_7.json 2> $OUT/icp_bench.err
 bash tools/build_variant.sh momi4 -DHOP_ICP_MOMI_W=4 > $OUT/build_momi4.log 2>&1 && HOP_LIB=tools/_tmp/momi4/libhop.so python tools/icp_bench.py --reps 3 --icp-modes 7 --lcp-modes 3 > $OUT/icp_bench_mode7_4waves.json 2>> $OUT/icp_bench.err
 tail -15 $OUT/gputest.log
 tail -2 $OUT/smoke.log
