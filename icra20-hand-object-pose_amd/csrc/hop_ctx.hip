@@ -1362,6 +1362,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
   const bool cells = o->nn_mode >= 2;
   bool lm_mode = o->nn_mode == 5;   // the reference's Levenberg-Marquardt minimiser (csrc/hop_icp_lm.hip), float-faithful, one pass per evaluation
   bool lm6_mode = o->nn_mode == 6;  // the same minimiser from the moment matrix of the correspondences: one pass per ICP iteration
+  bool icp_mfma = true;
   bool lm7_mode = o->nn_mode == 7;  // the moment form with integer-exact sums and IEEE operations only: the bits the oracle's minimiser 7 returns
   if (o->nn_mode < 0 || o->nn_mode > 7) return HOP_E_INVALID;
   const size_t per_h = cells ? sizeof(int) * (size_t)S.n : sizeof(float) * 6 * (size_t)S.n;
@@ -1417,6 +1418,9 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
       HIPCHK(c, c->icp_lm.ensure(sizeof(LmDev) * (size_t)HB + 64));
       a.lm = c->icp_lm.as<LmDev>();
     }
+    // nn_mode 7: the moment sums on the matrix cores (k_icp_fusedq_momm) unless HOP_ICP_MFMA=0 (k_icp_fusedq_momi, v_dot2 on the vector units): same integers
+    // (read at every call: a test or a tool may switch between two refinements of one process)
+    icp_mfma = !(getenv("HOP_ICP_MFMA") != nullptr && atoi(getenv("HOP_ICP_MFMA")) == 0);
     static const bool icp_split = getenv("HOP_ICP_SPLIT") != nullptr && atoi(getenv("HOP_ICP_SPLIT")) != 0;
     if (lm6_mode && icp_split) {
       HIPCHK(c, c->icp_corr16.ensure(sizeof(unsigned short) * (size_t)S.n * HB + 64));
@@ -1495,7 +1499,8 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
         a.iter = it;
         {
           SpanGuard sg(c, T_ICP_NN);
-          if (lm7_mode) launch_icp_fusedq_momi(a, hb, c->stream);
+          if (lm7_mode && icp_mfma) launch_icp_fusedq_momm(a, hb, c->stream);
+          else if (lm7_mode) launch_icp_fusedq_momi(a, hb, c->stream);
           else if (a.corr16) launch_icp_scan_accum(a, hb, c->stream);
           else launch_icp_fusedq_mom(a, hb, c->stream);
         }
@@ -2232,6 +2237,32 @@ int hop_debug_ppf_matrix(hop_ctx* c, unsigned long long* out, size_t cap_words, 
     std::memcpy(out, c->ppf_matrix_cached, sizeof(unsigned long long) * (size_t)N * W);
   }
   return HOP_OK;
+}
+
+// development aid, not part of the ABI: the gfx950-specific primitives of the ICP kernels on caller-given operands (k_dev_selftest_*)
+//   what = 0: n elements; in = x[n] y[n] (float) ia[n] ib[n] ic[n] (int32) consecutively, out = 9 x n uint32
+//   what = 1: n tiles of one v_mfma_i32_16x16x64_i8; in = a, b, c as [n][64][4] int32 consecutively, out = d [n][64][4] int32
+int hop_debug_selftest(hop_ctx* c, int what, int n, const void* in, void* out) {
+  if (!c || !in || !out || n <= 0 || what < 0 || what > 1) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t in_bytes = what == 0 ? sizeof(int) * 5 * (size_t)n : sizeof(int) * 3 * 256 * (size_t)n;
+  const size_t out_bytes = what == 0 ? sizeof(int) * 9 * (size_t)n : sizeof(int) * 256 * (size_t)n;
+  DevBuf din, dout;
+  const auto run = [&]() -> int {
+    HIPCHK(c, din.ensure(in_bytes));
+    HIPCHK(c, dout.ensure(out_bytes));
+    HIPCHK(c, hop_ctx_h2d(c, din.p, in, in_bytes));
+    const int* ip = din.as<int>();
+    if (what == 0) hop::launch_dev_selftest_scalar(n, din.as<float>(), din.as<float>() + n, ip + 2 * (size_t)n, ip + 3 * (size_t)n, ip + 4 * (size_t)n, dout.as<unsigned>(), c->stream);
+    else hop::launch_dev_selftest_mfma(n, ip, ip + 256 * (size_t)n, ip + 512 * (size_t)n, dout.as<int>(), c->stream);
+    HIPCHK(c, hop_ctx_d2h(c, out, dout.p, out_bytes));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HOP_OK;
+  };
+  const int rc = run();
+  (void)hipStreamSynchronize(c->stream);
+  din.release(), dout.release();
+  return rc;
 }
 
 int hop_timing_get(hop_ctx* c, hop_timing* out) {

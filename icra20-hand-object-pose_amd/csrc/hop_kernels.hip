@@ -2026,13 +2026,9 @@ template __global__ void k_icp_fused<ICP_ACCUM_R>(IcpArgs);
 // quantisation error q_eq of a candidate position added to `tol`).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
-#if defined(HOP_EMU)  // (tests/emu: the kernel text compiled for the CPU model -- no gfx950 instruction there)
-  return max(min(a, b), min(max(a, b), c));
-#else
   unsigned r;
   asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
-#endif
 }
 __device__ __forceinline__ V3 m4_point_fma(const float* T, V3 p) {
   return v3(__builtin_fmaf(T[0], p.x, __builtin_fmaf(T[1], p.y, __builtin_fmaf(T[2], p.z, T[3]))),
@@ -2072,12 +2068,8 @@ struct Q3 {
 __device__ __forceinline__ unsigned q_rank(Q3 l, unsigned lo, unsigned hi) {
   const int dx = l.x - (int)(lo & 0xffffu), dy = l.y - (int)(lo >> 16), dz = l.z - (int)(hi & 0xffffu);
   unsigned d = (unsigned)__mul24(dz, dz);
-#if defined(HOP_EMU)
-  d += (unsigned)__mul24(dy, dy) + (unsigned)__mul24(dx, dx);
-#else
   asm("v_mad_i32_i24 %0, %1, %1, %0" : "+v"(d) : "v"(dy));  // (the compiler prefers three multiplies and v_add3)
   asm("v_mad_i32_i24 %0, %1, %1, %0" : "+v"(d) : "v"(dx));
-#endif
   return d;
 }
 #define Q_L(v) (int)(v)
@@ -2615,18 +2607,11 @@ __device__ __forceinline__ int momi_qp(float x, float y, int lim) {  // nearest 
   return min(max(v, -lim), lim);
 }
 // two signed 16-bit integers in one register / the sum of the two products of the halves added to c
-#if defined(HOP_EMU)  // (tests/emu: the kernel text compiled for the CPU model -- no gfx950 builtins there)
-__device__ __forceinline__ unsigned momi_pack(int a, int b) { return ((unsigned)a & 0xffffu) | ((unsigned)b << 16); }
-__device__ __forceinline__ int momi_dot2(unsigned a, unsigned b, int c) {
-  return c + (int)(short)(a & 0xffffu) * (int)(short)(b & 0xffffu) + (int)(short)(a >> 16) * (int)(short)(b >> 16);
-}
-#else
-typedef short momi_v2i16 __attribute__((ext_vector_type(2)));
+typedef short momi_v2i16 __attribute__((vector_size(4)));
 __device__ __forceinline__ unsigned momi_pack(int a, int b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(a, b)); }  // (|a|, |b| <= 4096: no saturation)
 __device__ __forceinline__ int momi_dot2(unsigned a, unsigned b, int c) {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(momi_v2i16, a), __builtin_bit_cast(momi_v2i16, b), c, false);
 }
-#endif
 // one source point of a hypothesis: lookup, PCL's two gates, and -- if accepted -- its gridded u in U[13] and its gridded squared distance in dq
 // (both left untouched otherwise: the caller zeroes them)
 template <bool DEFER>
@@ -2775,6 +2760,247 @@ void launch_icp_fusedq_momi(const IcpArgs& a, int hb, hipStream_t s) {
   const int R = (a.ns + 256 * nb - 1) / (256 * nb);
   static_assert(2 * ICP_ACCUM_R * (1 << (2 * ICP_MOM_BITS)) < (1ll << 31), "a lane's 32-bit sums cannot overflow");
   hipLaunchKernelGGL(k_icp_fusedq_momi, dim3(nb, hb), dim3(256), 0, s, a, R);
+}
+
+// ------------------------------------------------------------------------------------------------
+// nn_mode 7 with the moment matrix ON THE MATRIX CORES (k_icp_fusedq_momm; hop_icp_refine takes it unless HOP_ICP_MFMA=0): the same integers as
+// k_icp_fusedq_momi -- M = sum U U^T is a contraction over the correspondences (PCL's TransformationEstimationPointToPlane, Utils.cpp:201-202,
+// in the moment form), and with 13-bit integer operands it is an exact one for v_mfma_i32_16x16x64_i8: K = 64 correspondences per
+// instruction, the 13 components fill 13 of the 16 rows.
+//   * the split.  U = 256 H + L with L in [-128, 127], H = (U + 128) >> 8 in [-16, 16]: both signed bytes.  The gridding fma adds the 128 with
+//     its magic constant: t = fma(x, y, 1.5 2^23 + 128) is rounded ONCE to a float of unit 1 (the same nearest-even integer of the exact
+//     product as momi_qp: the constant is even), v_med3_f32 clamps it to +-2^12 about the constant, and then the low 16 bits of t's encoding
+//     are W = U + 128 -- its high byte IS H, its low byte L + 128 = L ^ 0x80.  Two instructions per component, no integer arithmetic.
+//   * the transposition.  The MFMA wants, in lane (i, kb), component i of 16 correspondences; the lookups produce one correspondence per
+//     lane.  Each accepted lane writes its 13 half-words to the wavefront's own ring in LDS, component-major (13 ds_write_b16), at a slot
+//     counted by ballot -- the ring packs the ACCEPTED correspondences densely, whatever trips or deferred batches they come from (the sums
+//     are integers: any order).  Whenever 64 slots are complete every lane reads its component's 16 half-words (2 ds_read_b128),
+//     de-interleaves them with 8 v_perm_b32 + 4 v_xor into the H and L operands, and three MFMAs add H H^T, H L^T and L L^T.
+//   * the sums.  |H| <= 16, |L| <= 128: a wavefront may add 2^31 / 2^14 = 131 072 correspondences per tile entry in 32 bits (it adds at most
+//     64 ICP_ACCUM_R = 2 048).  12 accumulator registers replace momi's 92 per-lane sums and their block transposition; the workgroup adds its
+//     four wavefronts' tiles and recombines M = 65536 HH + 256 (HL + HL^T) + LL in 64 bits, into the layout k_icp_lm7_solve reads.
+// Per accepted correspondence: 3 scalings + 13 x (fma, med3) + 13 LDS writes; per 64 of them: 2 LDS reads, 12 VALU, 3 MFMA (the form above:
+// 94 VALU each).  The deferred lookups are drained in the loop as dense batches of 64 (queue of 128 instead of 64 R entries per wavefront).
+// ------------------------------------------------------------------------------------------------
+typedef int momm_i32x4 __attribute__((vector_size(16)));
+constexpr int MOMM_ROW = 144;  // half-words per component row of a wavefront's ring: 128 slots + 16 (row stride 72 words: the 32-byte reads of the 16 rows spread over the banks)
+constexpr float MOMM_MAGIC = 12583040.0f;                                  // 1.5 * 2^23 + 128
+constexpr float MOMM_LO = MOMM_MAGIC - (float)(1 << ICP_MOM_BITS), MOMM_HI = MOMM_MAGIC + (float)(1 << ICP_MOM_BITS);
+constexpr unsigned short MOMM_ZERO = 0x0080;                               // U = 0 in the ring: low byte L + 128, high byte H
+static_assert(ICP_MOM_BITS == 12, "the byte split U = 256 H + L, |H| <= 16, is written for 13-bit integers");
+struct MommLds {
+  unsigned short ring[4][13][MOMM_ROW];  // (after the last flush: the four wavefronts' three tiles, 4 x 3 x 256 ints)
+  unsigned short defer_i[4][128];
+  long long dsum[4];
+  int n_cnt[4];
+};
+static_assert(sizeof(unsigned short) * 4 * 13 * MOMM_ROW >= sizeof(int) * 4 * 3 * 256, "the tiles fit the rings");
+struct MommTab {
+  unsigned char u[ICP_NMOMI - 1], v[ICP_NMOMI - 1];  // entry k of the packed lower triangle is M[u][v]
+  constexpr MommTab() : u{}, v{} {
+    int k = 0;
+    for (int a = 0; a < 13; ++a)
+      for (int b = 0; b <= a; ++b) u[k] = (unsigned char)a, v[k] = (unsigned char)b, ++k;
+  }
+};
+__constant__ MommTab c_momm_tab = MommTab();
+__device__ __forceinline__ float momm_qp(float x, float y) {  // the float whose low 16 encoding bits are rint(x y) (clamped to +-2^12) + 128
+  return __builtin_amdgcn_fmed3f(__builtin_fmaf(x, y, MOMM_MAGIC), MOMM_LO, MOMM_HI);
+}
+// lookup, PCL's two gates and -- if accepted -- the gridded u as 13 floats in the magic form, the gridded squared distance in dq
+template <bool DEFER>
+__device__ __forceinline__ int icp_fusedq_point_momm(const IcpArgs& a, int i, const float* __restrict__ pose, const float* __restrict__ sTi,
+                                                      const float* __restrict__ F, V3 ctr, float (&T)[13], int& dq) {
+  const float4 p4 = a.s_pts4[i];
+  V3 q = v3(p4.x, p4.y, p4.z);
+  if (a.iter > 0) q = m4_point_fma(F, q);
+  float d2 = 3.0e38f;
+  int j = -1;
+  V3 tq;
+  if (cells_nnq<DEFER>(a.cells, m4_point_fma(sTi, q), pose, q, d2, j, tq)) return ICP_PT_DEFERRED;
+  if (j < 0 || !(d2 <= a.max_d2)) return ICP_PT_REJECTED;
+  const float4 tn = a.cells.nrm_idx[j];
+  const float4 n4 = a.s_nrm4[i];
+  V3 qn = v3(n4.x, n4.y, n4.z);
+  if (a.iter > 0) qn = m4_dir_fma(F, qn);
+  const V3 nt = m4_dir(pose, v3(tn.x, tn.y, tn.z));
+  if (!(((qn.x * nt.x + qn.y * nt.y) + qn.z * nt.z) > a.cos_thr)) return ICP_PT_REJECTED;
+  const V3 pc = q - ctr;
+  const float r0 = vdot(q - tq, nt);
+  const float ps[3] = {pc.x * a.mom_s_np, pc.y * a.mom_s_np, pc.z * a.mom_s_np};  // (powers of two: exact)
+  const float nv[3] = {nt.x, nt.y, nt.z};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) T[3 * c + b] = momm_qp(nv[c], ps[b]);
+    T[9 + c] = momm_qp(nv[c], a.mom_s_n);
+  }
+  T[12] = momm_qp(r0, a.mom_s_r);
+  dq = momi_q(d2, a.mom_s_d, a.mom_lim_d);
+  return ICP_PT_ACCEPTED;
+}
+// 64 complete slots of the ring (half 0 or 1) -> operands -> three MFMAs.  Every lane of the wavefront is here (v_mfma ignores EXEC).
+__device__ __forceinline__ void momm_flush(const unsigned short (*__restrict__ ring)[MOMM_ROW], int lane, int half, momm_i32x4& HH, momm_i32x4& HL,
+                                           momm_i32x4& LL) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int row = min(lane & 15, 12);  // (tile rows 13..15 are never read back: those lanes repeat row 12)
+  const uint4* __restrict__ p = reinterpret_cast<const uint4*>(&ring[row][half * 64 + (lane >> 4) * 16]);
+  const uint4 w0 = p[0], w1 = p[1];  // 16 half-words (L ^ 0x80 | H << 8) = this component of 16 correspondences
+  momm_i32x4 Hv, Lv;
+  Hv[0] = (int)__builtin_amdgcn_perm(w0.y, w0.x, 0x07050301u), Lv[0] = (int)(__builtin_amdgcn_perm(w0.y, w0.x, 0x06040200u) ^ 0x80808080u);
+  Hv[1] = (int)__builtin_amdgcn_perm(w0.w, w0.z, 0x07050301u), Lv[1] = (int)(__builtin_amdgcn_perm(w0.w, w0.z, 0x06040200u) ^ 0x80808080u);
+  Hv[2] = (int)__builtin_amdgcn_perm(w1.y, w1.x, 0x07050301u), Lv[2] = (int)(__builtin_amdgcn_perm(w1.y, w1.x, 0x06040200u) ^ 0x80808080u);
+  Hv[3] = (int)__builtin_amdgcn_perm(w1.w, w1.z, 0x07050301u), Lv[3] = (int)(__builtin_amdgcn_perm(w1.w, w1.z, 0x06040200u) ^ 0x80808080u);
+  HH = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hv, Hv, HH, 0, 0, 0);
+  HL = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hv, Lv, HL, 0, 0, 0);
+  LL = __builtin_amdgcn_mfma_i32_16x16x64_i8(Lv, Lv, LL, 0, 0, 0);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (later writes to this half stay behind these reads)
+  __builtin_amdgcn_wave_barrier();
+}
+// the accepted lanes of one batch of lookups appended to the ring (fill: slots in use, 0..127, wave-uniform); a half that becomes complete is flushed
+__device__ __forceinline__ void momm_push(unsigned short (*__restrict__ ring)[MOMM_ROW], int lane, bool ok, const float (&T)[13], int& fill, momm_i32x4& HH,
+                                          momm_i32x4& HL, momm_i32x4& LL) {
+  const unsigned long long m = __ballot(ok);
+  if (m == 0ull) return;
+  if (ok) {
+    const int pos = (fill + __popcll(m & ((1ull << lane) - 1ull))) & 127;
+#pragma unroll
+    for (int c = 0; c < 13; ++c) ring[c][pos] = (unsigned short)__float_as_uint(T[c]);
+  }
+  const int nf = fill + __popcll(m);
+  if ((fill ^ nf) & 64) momm_flush(ring, lane, (fill >> 6) & 1, HH, HL, LL);
+  fill = nf & 127;
+}
+#ifndef HOP_ICP_MOMM_W
+#define HOP_ICP_MOMM_W 5
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOMM_W))) void k_icp_fusedq_momm(IcpArgs a, int R) {
+  __shared__ __attribute__((aligned(16))) MommLds L;
+  const int hl = blockIdx.y, h = a.h0 + hl;
+  const IcpState& st = a.state[hl];
+  if (!st.active) return;
+  const float* __restrict__ pose = a.pose + (size_t)h * 16;
+  const float* __restrict__ sTi = a.pose_inv + (size_t)h * 12;
+  const float* __restrict__ F = st.final_tf;
+  const V3 ctr = v3(pose[3], pose[7], pose[11]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned short(*__restrict__ ring)[MOMM_ROW] = L.ring[wave];
+  unsigned short* __restrict__ defer_i = L.defer_i[wave];
+  momm_i32x4 HH = {0, 0, 0, 0}, HL = {0, 0, 0, 0}, LL = {0, 0, 0, 0};
+  int dsum = 0, n_wave = 0, n_def = 0, fill = 0;
+  const int base = blockIdx.x * (256 * R);
+  // every lane of the wavefront makes every trip (a point past the end of the cloud counts as rejected): ballots, pushes and MFMAs see all 64 lanes
+  for (int r = 0; r < R; ++r) {
+    const int li = r * 256 + threadIdx.x, i = base + li;
+    float T[13];
+    int dq = 0;
+    const int res = i < a.ns ? icp_fusedq_point_momm<true>(a, i, pose, sTi, F, ctr, T, dq) : ICP_PT_REJECTED;
+    const unsigned long long dm = __ballot(res == ICP_PT_DEFERRED);
+    if (res == ICP_PT_DEFERRED) defer_i[n_def + __popcll(dm & ((1ull << lane) - 1ull))] = (unsigned short)li;
+    n_def += __popcll(dm);
+    n_wave += __popcll(__ballot(res == ICP_PT_ACCEPTED));
+    dsum += dq;
+    momm_push(ring, lane, res == ICP_PT_ACCEPTED, T, fill, HH, HL, LL);
+    while (n_def >= 64 || (r == R - 1 && n_def > 0)) {  // a dense batch of the queued lookups (wave-uniform condition; the queue never holds 128)
+      const int take = n_def < 64 ? n_def : 64;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int mine = lane < take ? (int)defer_i[lane] : -1;
+      const int rest = lane + 64 < n_def ? (int)defer_i[lane + 64] : -1;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (rest >= 0) defer_i[lane] = (unsigned short)rest;
+      n_def -= take;
+      float T2[13];
+      int dq2 = 0;
+      const int res2 = mine >= 0 ? icp_fusedq_point_momm<false>(a, base + mine, pose, sTi, F, ctr, T2, dq2) : ICP_PT_REJECTED;
+      n_wave += __popcll(__ballot(res2 == ICP_PT_ACCEPTED));
+      dsum += dq2;
+      momm_push(ring, lane, res2 == ICP_PT_ACCEPTED, T2, fill, HH, HL, LL);
+    }
+  }
+  if (fill & 63) {  // the incomplete half: its free slots as zeros
+    const int half = (fill >> 6) & 1;
+    if (lane >= (fill & 63)) {
+#pragma unroll
+      for (int c = 0; c < 13; ++c) ring[c][half * 64 + lane] = MOMM_ZERO;
+    }
+    momm_flush(ring, lane, half, HH, HL, LL);
+  }
+  // the squared distances of the MSE stop rule: a lane added <= R + its share of the deferred batches (each <= 2^24) in 32 bits
+  long long dw = (long long)dsum;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) dw += __shfl_xor(dw, o);
+  __syncthreads();  // every wavefront is done with its ring: the tiles take their place
+  int* __restrict__ tile = reinterpret_cast<int*>(&L.ring[0][0][0]);
+  // tile entry (row, col) sits in lane col + 16 (row / 4), register row % 4
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = ((lane >> 4) * 4 + k) * 16 + (lane & 15);
+    tile[(wave * 3 + 0) * 256 + e] = HH[k], tile[(wave * 3 + 1) * 256 + e] = HL[k], tile[(wave * 3 + 2) * 256 + e] = LL[k];
+  }
+  if (lane == 0) L.dsum[wave] = dw, L.n_cnt[wave] = n_wave;
+  __syncthreads();
+  long long* __restrict__ out = reinterpret_cast<long long*>(a.partial) + ((size_t)hl * gridDim.x + blockIdx.x) * ICP_NMOMI_STRIDE;
+  const int t = threadIdx.x;
+  if (t < ICP_NMOMI - 1) {
+    const int e = (int)c_momm_tab.u[t] * 16 + (int)c_momm_tab.v[t], et = (int)c_momm_tab.v[t] * 16 + (int)c_momm_tab.u[t];
+    long long hh = 0, hl2 = 0, ll = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      hh += (long long)tile[(w * 3 + 0) * 256 + e];
+      hl2 += (long long)tile[(w * 3 + 1) * 256 + e] + (long long)tile[(w * 3 + 1) * 256 + et];
+      ll += (long long)tile[(w * 3 + 2) * 256 + e];
+    }
+    out[t] = hh * 65536 + hl2 * 256 + ll;
+  } else if (t == ICP_NMOMI - 1) {
+    out[t] = (L.dsum[0] + L.dsum[1]) + (L.dsum[2] + L.dsum[3]);
+  } else if (t == ICP_NMOMI) {
+    out[t] = (long long)((L.n_cnt[0] + L.n_cnt[1]) + (L.n_cnt[2] + L.n_cnt[3]));
+  }
+}
+void launch_icp_fusedq_momm(const IcpArgs& a, int hb, hipStream_t s) {
+  const int nb = icp_blocks_per_hyp(a.ns, true);
+  const int R = (a.ns + 256 * nb - 1) / (256 * nb);
+  hipLaunchKernelGGL(k_icp_fusedq_momm, dim3(nb, hb), dim3(256), 0, s, a, R);
+}
+
+// development aid (hop_debug_selftest, tests/test_gpu_dev_selftest.py): the gfx950-specific primitives of the packed lookups and of the two
+// moment kernels on caller-given operands, one element per thread -- what the instructions return on a device is compared with their
+// documented semantics restated in numpy (the CPU model of tests/emu states them a third time).
+//   out[0] momi_qp(x, y, 2^12)   [1] encoding of momm_qp(x, y)   [2] momi_pack(ia, ib)   [3] momi_dot2(ia, ib, ic)   [4] umed3(ia, ib, ic)
+//   [5] q_rank({ia & 0xffff, ia >> 16, ic & 0xffff}, ib, ic)   [6] v_perm_b32(ia, ib, 0x07050301)   [7] v_perm_b32(ia, ib, 0x06040200)
+//   [8] momi_q(x, y, 2^24)
+__global__ void k_dev_selftest_scalar(int n, const float* __restrict__ x, const float* __restrict__ y, const int* __restrict__ ia, const int* __restrict__ ib,
+                                      const int* __restrict__ ic, unsigned* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned ua = (unsigned)ia[i], ub = (unsigned)ib[i], uc = (unsigned)ic[i];
+  out[0 * (size_t)n + i] = (unsigned)momi_qp(x[i], y[i], 1 << ICP_MOM_BITS);
+  out[1 * (size_t)n + i] = __float_as_uint(momm_qp(x[i], y[i]));
+  out[2 * (size_t)n + i] = momi_pack(ia[i], ib[i]);
+  out[3 * (size_t)n + i] = (unsigned)momi_dot2(ua, ub, ic[i]);
+  out[4 * (size_t)n + i] = umed3(ua, ub, uc);
+  out[5 * (size_t)n + i] = q_rank(Q3{(int)(ua & 0xffffu), (int)(ua >> 16), (int)(uc & 0xffffu)}, ub, uc);
+  out[6 * (size_t)n + i] = __builtin_amdgcn_perm(ua, ub, 0x07050301u);
+  out[7 * (size_t)n + i] = __builtin_amdgcn_perm(ua, ub, 0x06040200u);
+  out[8 * (size_t)n + i] = (unsigned)momi_q(x[i], y[i], 16777216.0f);
+}
+// one v_mfma_i32_16x16x64_i8 per wavefront: a, b, c, d as [tiles][64 lanes][4 registers]
+__global__ __launch_bounds__(64) void k_dev_selftest_mfma(const int* __restrict__ a, const int* __restrict__ b, const int* __restrict__ c, int* __restrict__ d) {
+  const size_t o = ((size_t)blockIdx.x * 64 + threadIdx.x) * 4;
+  const momm_i32x4 A = {a[o], a[o + 1], a[o + 2], a[o + 3]}, B = {b[o], b[o + 1], b[o + 2], b[o + 3]}, Cc = {c[o], c[o + 1], c[o + 2], c[o + 3]};
+  const momm_i32x4 D = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, Cc, 0, 0, 0);
+  d[o] = D[0], d[o + 1] = D[1], d[o + 2] = D[2], d[o + 3] = D[3];
+}
+void launch_dev_selftest_scalar(int n, const float* x, const float* y, const int* ia, const int* ib, const int* ic, unsigned* out, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_dev_selftest_scalar, dim3((n + 255) / 256), dim3(256), 0, s, n, x, y, ia, ib, ic, out);
+}
+void launch_dev_selftest_mfma(int tiles, const int* a, const int* b, const int* c, int* d, hipStream_t s) {
+  if (tiles > 0) hipLaunchKernelGGL(k_dev_selftest_mfma, dim3(tiles), dim3(64), 0, s, a, b, c, d);
 }
 
 // nn_mode 6 in two kernels (HOP_ICP_SPLIT, see hop_icp_refine): k_icp_scan does the lookups and PCL's two gates of k_icp_fusedq_mom and

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """tests/emu/chevrons.py -- TEST INFRASTRUCTURE: g++ does not parse `kernel<<<grid, block, shmem, stream>>>(args)`; this rewrites the launches
-of a .hip source into the equivalent hipLaunchKernelGGL(...) calls (which the product also uses) for the CPU model's build.  Nothing else in
-the text changes.   chevrons.py in.hip out.cpp"""
+of a .hip source into the equivalent hipLaunchKernelGGL(...) calls (which the product also uses) for the CPU model's build.  The other thing g++ cannot take is
+gfx950 inline assembly: a statement  asm("v_xxx %0, %1, ..." : "=v"(d) : "v"(a), ...);  becomes a call  emu_asm::v_xxx(d, a, ...)  of the
+instruction's functional model in hip/hip_runtime.h, operands in the order of the template (so the PRODUCT text carries no test conditional).
+Nothing else in the text changes.   chevrons.py in.hip out.cpp"""
+import re
 import sys
 
 
@@ -69,6 +72,31 @@ def rewrite(text):
     return "".join(out)
 
 
+ASM_RE = re.compile(r'asm\(\s*"(v_[a-z0-9_]+)\s+([^"]*)"\s*:([^;]*?)\)\s*;')
+
+
+def rewrite_asm(text):
+    """single-instruction VALU asm statements -> emu_asm::<mnemonic>(operands in template order); the first operand is the destination"""
+    def one(m):
+        mnem, templ, rest = m.group(1), m.group(2), m.group(3)
+        exprs = []
+        for part in rest.split(":"):                      # outputs, then inputs; each a list of "constraint"(expr)
+            for c in split_top(part):
+                c = c.strip()
+                if not c:
+                    continue
+                mm = re.match(r'"[^"]*"\s*\((.*)\)$', c, re.S)
+                if not mm:
+                    raise SystemExit("chevrons.py: cannot read asm operand %r" % c)
+                exprs.append(mm.group(1).strip())
+        ops = [exprs[int(t)] for t in re.findall(r"%(\d+)", templ)]
+        return "emu_asm::%s(%s);" % (mnem, ", ".join(ops))
+    out = ASM_RE.sub(one, text)
+    if re.search(r"\basm\s*(volatile)?\s*\(", out):
+        raise SystemExit("chevrons.py: an asm statement was not understood")
+    return out
+
+
 if __name__ == "__main__":
     src = open(sys.argv[1]).read()
-    open(sys.argv[2], "w").write('#line 1 "%s"\n' % sys.argv[1] + rewrite(src))
+    open(sys.argv[2], "w").write('#line 1 "%s"\n' % sys.argv[1] + rewrite_asm(rewrite(src)))

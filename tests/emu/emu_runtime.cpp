@@ -150,6 +150,18 @@ static bool resolve_wave(int t0, int t1) {
       if (first < 0) first = t;
     }
   }
+  if (kind == K_MFMA_I8_16X16X64) {
+    if (t1 - t0 != 64 || mask != ~0ull) die("v_mfma issued with inactive lanes (the instruction ignores EXEC: every lane's registers take part)", t1);
+    emu_mfma_regs* R[64];
+    for (int l = 0; l < 64; ++l) R[l] = reinterpret_cast<emu_mfma_regs*>((uintptr_t)g_fibers[t0 + l].payload);
+    auto byte_of = [](const emu_v4i32& v, int k) { return (int)(signed char)(((unsigned)v[k >> 2] >> (8 * (k & 3))) & 0xFFu); };
+    for (int i = 0; i < 16; ++i)
+      for (int j = 0; j < 16; ++j) {
+        unsigned acc = (unsigned)R[j + 16 * (i / 4)]->c[i % 4];
+        for (int k = 0; k < 64; ++k) acc += (unsigned)(byte_of(R[i + 16 * (k / 16)]->a, k % 16) * byte_of(R[j + 16 * (k / 16)]->b, k % 16));
+        R[j + 16 * (i / 4)]->d[i % 4] = (int)acc;
+      }
+  }
   unsigned long long ballot = 0;
   if (kind == K_BALLOT)
     for (int t = t0; t < t1; ++t)

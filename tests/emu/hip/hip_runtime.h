@@ -93,7 +93,7 @@ EMU_VEC4(unsigned char, uchar4, 4)
 
 // ---- the scheduler's side of the collectives (tests/emu/emu_runtime.cpp) ------------------------------------------------------------------
 namespace emu {
-enum Kind { K_NONE = 0, K_SYNC, K_BALLOT, K_SHFL, K_WAVE_BARRIER, K_FIRSTLANE };
+enum Kind { K_NONE = 0, K_SYNC, K_BALLOT, K_SHFL, K_WAVE_BARRIER, K_FIRSTLANE, K_MFMA_I8_16X16X64 };
 // blocks the calling work-item until the operation has been resolved; payload in / result out through 8 bytes
 unsigned long long collective(Kind kind, int site, unsigned long long payload, int arg, int arg2);
 int site_of(const char* file, int line);  // call sites ordered by (file registration order, line)
@@ -142,6 +142,65 @@ inline T emu_readfirstlane(int site, T v) {
 // ---- scalar builtins ------------------------------------------------------------------------------------------------------------------------
 inline float emu_fmed3(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }
 #define __builtin_amdgcn_fmed3f(a, b, c) emu_fmed3((a), (b), (c))
+// ---- gfx950 instructions the product names (builtins, and inline asm through chevrons.py -> emu_asm::) ----------------------------------------
+// Functional models from the instruction descriptions of the CDNA ISA; tests/test_gpu_dev_selftest.py runs the same inputs through the real
+// instructions on a device (hop_dev_selftest) and compares with these semantics restated in numpy.
+typedef short emu_v2i16 __attribute__((vector_size(4)));
+typedef int emu_v4i32 __attribute__((vector_size(16)));
+inline emu_v2i16 emu_cvt_pk_i16(int a, int b) {  // v_cvt_pk_i16_i32: each source saturated to 16 bits
+  auto sat = [](int v) { return (short)std::min(32767, std::max(-32768, v)); };
+  return emu_v2i16{sat(a), sat(b)};
+}
+#define __builtin_amdgcn_cvt_pk_i16(a, b) emu_cvt_pk_i16((a), (b))
+inline int emu_sdot2(emu_v2i16 a, emu_v2i16 b, int c, bool clamp) {  // v_dot2_i32_i16: c + a.x b.x + a.y b.y (wrapping unless clamp)
+  const long long r = (long long)c + (long long)a[0] * b[0] + (long long)a[1] * b[1];
+  if (clamp) return (int)std::min<long long>(2147483647ll, std::max<long long>(-2147483648ll, r));
+  return (int)(unsigned)(unsigned long long)r;
+}
+#define __builtin_amdgcn_sdot2(a, b, c, clamp) emu_sdot2((a), (b), (c), (clamp))
+// v_perm_b32 D, S0, S1, S2: byte k of D = byte sel_k of the pool {S0 (bytes 7..4), S1 (bytes 3..0)}; selectors 8..11 replicate a sign bit
+// (of S1's halves / S0's halves ...), 12 = 0x00, >= 13 = 0xFF.  The product uses selectors 0..7 only; the others abort here.
+inline unsigned emu_perm(unsigned s0, unsigned s1, unsigned sel) {
+  const unsigned long long pool = ((unsigned long long)s0 << 32) | s1;
+  unsigned d = 0;
+  for (int k = 0; k < 4; ++k) {
+    const unsigned c = (sel >> (8 * k)) & 0xFFu;
+    unsigned b;
+    if (c <= 7) b = (unsigned)(pool >> (8 * c)) & 0xFFu;
+    else if (c == 12) b = 0;
+    else if (c >= 13) b = 0xFFu;
+    else {
+      std::fprintf(stderr, "emu: v_perm_b32 selector %u is not modelled\n", c);
+      std::abort();
+    }
+    d |= b << (8 * k);
+  }
+  return d;
+}
+#define __builtin_amdgcn_perm(s0, s1, sel) emu_perm((s0), (s1), (sel))
+namespace emu_asm {
+inline void v_med3_u32(unsigned& d, unsigned a, unsigned b, unsigned c) { d = std::max(std::min(a, b), std::min(std::max(a, b), c)); }
+inline int sext24(int a) { return (int)((unsigned)a << 8) >> 8; }
+template <class D, class A, class B, class Cc>
+inline void v_mad_i32_i24(D& d, A a, B b, Cc c) {  // D = sext24(a) * sext24(b) + c, low 32 bits
+  d = (D)((unsigned)sext24((int)a) * (unsigned)sext24((int)b) + (unsigned)c);
+}
+}  // namespace emu_asm
+// v_mfma_i32_16x16x64_i8: D[16][16] = C + A[16][64] B[64][16], 8-bit signed inputs, 32-bit wrapping sums.  Operand layout (CDNA3/4 MFMA
+// register maps; K = 64 laid out as four blocks of 16 consecutive k, one block per 16-lane group, 16 bytes = 4 VGPRs per lane):
+//   A[i][k]: lane (i + 16 (k / 16)), byte k % 16        B[k][j]: lane (j + 16 (k / 16)), byte k % 16
+//   C / D[i][j]: lane (j + 16 (i / 4)), register i % 4
+// The instruction ignores EXEC; the model insists that all 64 lanes arrive together (a kernel that issues it under divergence is wrong).
+struct emu_mfma_regs {
+  emu_v4i32 a, b, c, d;
+};
+inline emu_v4i32 emu_mfma_i32_16x16x64_i8(int site, emu_v4i32 a, emu_v4i32 b, emu_v4i32 c) {
+  emu_mfma_regs r{a, b, c, c};
+  (void)emu::collective(emu::K_MFMA_I8_16X16X64, site, (unsigned long long)(uintptr_t)&r, 0, 0);
+  return r.d;
+}
+#define __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, cbsz, abid, blgp) emu_mfma_i32_16x16x64_i8(EMU_SITE(), (a), (b), (c))
+
 #define __builtin_amdgcn_sqrtf(x) (std::sqrt((float)(x)))          // (hardware: 1 ulp estimate; modelled as correctly rounded)
 #define __builtin_amdgcn_rsqf(x) (1.0f / std::sqrt((float)(x)))
 #define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt((double)(x)))

@@ -80,11 +80,20 @@ def test_render_and_normals_kernels_on_the_model(emu_lib):
 
 
 def test_icp_with_the_references_minimiser_on_the_model(emu_lib):
-    """k_icp_fusedq_momi + k_icp_lm7_solve (nn_mode 7, what the mirrors run): refined poses, iteration counts and convergence flags equal to the
-    oracle's BIT FOR BIT, hypotheses that do not converge included; the C1 frame's 100 hypotheses (a trial step outside the quaternion's unit
-    ball among them) too"""
+    """k_icp_fusedq_momm (the moment sums on the matrix cores: round 5) + k_icp_lm7_solve (nn_mode 7, what the mirrors run): refined poses,
+    iteration counts and convergence flags equal to the oracle's BIT FOR BIT, hypotheses that do not converge included; the C1 frame's 100
+    hypotheses (a trial step outside the quaternion's unit ball among them) too -- and once more through k_icp_fusedq_momi (HOP_ICP_MFMA=0:
+    v_dot2 on the vector units), the other way to the same integers"""
     sel = [os.path.join("tests", "test_gpu_icp_canon.py")]
     assert _child_pytest(sel, "not_converged or c1_depth7_bits", timeout=1500) == 2
+    assert _child_pytest(sel, "not_converged", env={"HOP_ICP_MFMA": "0"}, timeout=1500) == 1
+
+
+def test_gfx950_primitives_as_the_model_states_them(emu_lib):
+    """tests/test_gpu_dev_selftest.py on the model: the stand-ins of tests/emu/hip/hip_runtime.h for v_med3_u32, v_mad_i32_i24, v_cvt_pk_i16_i32,
+    v_dot2_i32_i16, v_perm_b32, v_med3_f32 and v_mfma_i32_16x16x64_i8 against the numpy statement of the same instructions, and the two moment
+    kernels against each other (on a device the same file checks the instructions themselves)"""
+    assert _child_pytest([os.path.join("tests", "test_gpu_dev_selftest.py")]) == 3
 
 
 def _emu_env(emu_lib, **extra):
