@@ -26,6 +26,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <numeric>
 #include <random>
 #include <string>
@@ -1345,6 +1347,49 @@ int hop_hypos_keep_topk(hop_ctx* c, int k) {
 }
 
 // ---------------------------------------------------------------------------------------------- ICP
+// k_icp_fusedq_momm rests on the operand layout of v_mfma_i32_16x16x64_i8 (rows / columns = lane & 15, the four 16-lane groups = the four
+// K blocks, C / D: column lane & 15, rows 4 (lane >> 4) + register).  That layout is documented, but this code was written without a
+// device to run it on: the first nn_mode-7 refinement on a device issues ONE instruction on known operands (k_dev_selftest_mfma) and
+// compares with the product computed here.  A device that answers differently gets the vector-unit kernel (k_icp_fusedq_momi: the same
+// integers from v_dot2_i32_i16) and one line on stderr -- never a wrong moment matrix.
+int hop_debug_selftest(hop_ctx* c, int what, int n, const void* in, void* out);
+static bool mfma_i8_layout_ok(hop_ctx* c) {
+  static std::mutex mu;
+  static std::map<int, bool> verdict;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = verdict.find(c->device);
+  if (it != verdict.end()) return it->second;
+  // three batches of 64 vectors, the second accepted on 41 lanes only: a full half, a half completed across two pushes, a partial last half
+  constexpr int NB = 3;
+  std::vector<int> in(NB * 64 * 13 + NB * 2), out(3 * 256, 0);
+  const unsigned long long masks[NB] = {~0ull, 0x0000F0F3FFFF1F7Full, ~0ull};
+  unsigned lcg = 12345u;
+  long long M[13][13] = {};
+  for (int b = 0; b < NB; ++b)
+    for (int l = 0; l < 64; ++l) {
+      int* u = &in[((size_t)b * 64 + l) * 13];
+      for (int k = 0; k < 13; ++k) {
+        lcg = lcg * 1664525u + 1013904223u;
+        u[k] = (int)((lcg >> 8) % 8193u) - 4096;
+      }
+      if (b == 0 && l < 4) u[l] = l & 1 ? 4096 : -4096;  // the ends of the range
+      if ((masks[b] >> l) & 1ull)
+        for (int i = 0; i < 13; ++i)
+          for (int j = 0; j < 13; ++j) M[i][j] += (long long)u[i] * u[j];
+    }
+  std::memcpy(&in[NB * 64 * 13], masks, sizeof(masks));
+  const bool ran = hop_debug_selftest(c, 2, NB, in.data(), out.data()) == HOP_OK;
+  bool ok = ran;
+  auto tile = [&](int t, int i, int j) { return (long long)out[(t * 64 + j + 16 * (i / 4)) * 4 + i % 4]; };  // entry (row i, column j)
+  for (int i = 0; i < 13 && ok; ++i)
+    for (int j = 0; j < 13 && ok; ++j) ok = tile(0, i, j) * 65536 + (tile(1, i, j) + tile(1, j, i)) * 256 + tile(2, i, j) == M[i][j];
+  if (!ok)
+    std::fprintf(stderr, "libhop: the matrix-core read-out of k_icp_fusedq_momm %s on device %d; nn_mode 7 adds its moment sums on the vector units "
+                 "(k_icp_fusedq_momi: the same integers)\n", ran ? "does not reproduce sum U U^T (v_mfma_i32_16x16x64_i8 operand layout / v_perm_b32 selectors)" : "could not be checked", c->device);
+  verdict[c->device] = ok;
+  return ok;
+}
+
 int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* converged_out) {
   if (!c || !o || o->max_iter <= 0) return HOP_E_INVALID;
   if (c->scene_d.n <= 0 || c->model_d[HOP_MODEL_5MM].n <= 0) return HOP_E_STATE;
@@ -1366,7 +1411,8 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
   bool lm7_mode = o->nn_mode == 7;  // the moment form with integer-exact sums and IEEE operations only: the bits the oracle's minimiser 7 returns
   if (o->nn_mode < 0 || o->nn_mode > 7) return HOP_E_INVALID;
   const size_t per_h = cells ? sizeof(int) * (size_t)S.n : sizeof(float) * 6 * (size_t)S.n;
-  const size_t ws_cap = cells ? ((size_t)4 << 30) : ((size_t)1 << 30);
+  size_t ws_cap = cells ? ((size_t)4 << 30) : ((size_t)1 << 30);
+  if (const char* e = getenv("HOP_ICP_WS_CAP_MB")) ws_cap = (size_t)std::max(1, atoi(e)) << 20;  // (tests: several hypothesis batches at small sizes)
   const int HB = (int)std::max<size_t>(1, std::min<size_t>((size_t)H, ws_cap / per_h));
   if (!cells) HIPCHK(c, c->icp_moved.ensure(per_h * HB));
   HIPCHK(c, c->icp_partial.ensure(sizeof(double) * (size_t)std::max(std::max(ICP_NACC, ICP_NMOM_STRIDE), ICP_NMOMI_STRIDE) * (size_t)nb * HB));
@@ -1421,6 +1467,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     // nn_mode 7: the moment sums on the matrix cores (k_icp_fusedq_momm) unless HOP_ICP_MFMA=0 (k_icp_fusedq_momi, v_dot2 on the vector units): same integers
     // (read at every call: a test or a tool may switch between two refinements of one process)
     icp_mfma = !(getenv("HOP_ICP_MFMA") != nullptr && atoi(getenv("HOP_ICP_MFMA")) == 0);
+    if (lm7_mode && icp_mfma) icp_mfma = mfma_i8_layout_ok(c);
     static const bool icp_split = getenv("HOP_ICP_SPLIT") != nullptr && atoi(getenv("HOP_ICP_SPLIT")) != 0;
     if (lm6_mode && icp_split) {
       HIPCHK(c, c->icp_corr16.ensure(sizeof(unsigned short) * (size_t)S.n * HB + 64));
@@ -2242,11 +2289,13 @@ int hop_debug_ppf_matrix(hop_ctx* c, unsigned long long* out, size_t cap_words, 
 // development aid, not part of the ABI: the gfx950-specific primitives of the ICP kernels on caller-given operands (k_dev_selftest_*)
 //   what = 0: n elements; in = x[n] y[n] (float) ia[n] ib[n] ic[n] (int32) consecutively, out = 9 x n uint32
 //   what = 1: n tiles of one v_mfma_i32_16x16x64_i8; in = a, b, c as [n][64][4] int32 consecutively, out = d [n][64][4] int32
+//   what = 2: the read-out path of k_icp_fusedq_momm on one wavefront (k_dev_selftest_momm): n batches; in = U [n][64][13] int32 then the
+//             accepted-lane masks [n] uint64; out = the tiles HH, HL, LL as [3][64][4] int32
 int hop_debug_selftest(hop_ctx* c, int what, int n, const void* in, void* out) {
-  if (!c || !in || !out || n <= 0 || what < 0 || what > 1) return HOP_E_INVALID;
+  if (!c || !in || !out || n <= 0 || what < 0 || what > 2) return HOP_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
-  const size_t in_bytes = what == 0 ? sizeof(int) * 5 * (size_t)n : sizeof(int) * 3 * 256 * (size_t)n;
-  const size_t out_bytes = what == 0 ? sizeof(int) * 9 * (size_t)n : sizeof(int) * 256 * (size_t)n;
+  const size_t in_bytes = what == 0 ? sizeof(int) * 5 * (size_t)n : what == 1 ? sizeof(int) * 3 * 256 * (size_t)n : (sizeof(int) * 64 * 13 + 8) * (size_t)n;
+  const size_t out_bytes = what == 0 ? sizeof(int) * 9 * (size_t)n : what == 1 ? sizeof(int) * 256 * (size_t)n : sizeof(int) * 3 * 256;
   DevBuf din, dout;
   const auto run = [&]() -> int {
     HIPCHK(c, din.ensure(in_bytes));
@@ -2254,7 +2303,8 @@ int hop_debug_selftest(hop_ctx* c, int what, int n, const void* in, void* out) {
     HIPCHK(c, hop_ctx_h2d(c, din.p, in, in_bytes));
     const int* ip = din.as<int>();
     if (what == 0) hop::launch_dev_selftest_scalar(n, din.as<float>(), din.as<float>() + n, ip + 2 * (size_t)n, ip + 3 * (size_t)n, ip + 4 * (size_t)n, dout.as<unsigned>(), c->stream);
-    else hop::launch_dev_selftest_mfma(n, ip, ip + 256 * (size_t)n, ip + 512 * (size_t)n, dout.as<int>(), c->stream);
+    else if (what == 1) hop::launch_dev_selftest_mfma(n, ip, ip + 256 * (size_t)n, ip + 512 * (size_t)n, dout.as<int>(), c->stream);
+    else hop::launch_dev_selftest_momm(n, ip, reinterpret_cast<const unsigned long long*>(ip + 64 * 13 * (size_t)n), dout.as<int>(), c->stream);
     HIPCHK(c, hop_ctx_d2h(c, out, dout.p, out_bytes));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HOP_OK;

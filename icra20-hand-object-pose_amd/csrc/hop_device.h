@@ -353,6 +353,7 @@ void launch_icp_fusedq_momi(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_fusedq_momm(const IcpArgs& a, int hb, hipStream_t s);  // the same sums on the matrix cores
 void launch_dev_selftest_scalar(int n, const float* x, const float* y, const int* ia, const int* ib, const int* ic, unsigned* out, hipStream_t s);
 void launch_dev_selftest_mfma(int tiles, const int* a, const int* b, const int* c, int* d, hipStream_t s);
+void launch_dev_selftest_momm(int batches, const int* U, const unsigned long long* mask, int* out, hipStream_t s);
 void launch_icp_lm7_solve(const IcpArgs& a, int hb, int nblocks, hipStream_t s);
 void launch_icp_scan_accum(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_fusedq_mom(const IcpArgs& a, int hb, hipStream_t s);

@@ -2775,7 +2775,7 @@ void launch_icp_fusedq_momi(const IcpArgs& a, int hb, hipStream_t s) {
 //     lane.  Each accepted lane writes its 13 half-words to the wavefront's own ring in LDS, component-major (13 ds_write_b16), at a slot
 //     counted by ballot -- the ring packs the ACCEPTED correspondences densely, whatever trips or deferred batches they come from (the sums
 //     are integers: any order).  Whenever 64 slots are complete every lane reads its component's 16 half-words (2 ds_read_b128),
-//     de-interleaves them with 8 v_perm_b32 + 4 v_xor into the H and L operands, and three MFMAs add H H^T, H L^T and L L^T.
+//     de-interleaves them (8 byte gathers: v_perm_b32, + 4 v_xor) into the H and L operands, and three MFMAs add H H^T, H L^T and L L^T.
 //   * the sums.  |H| <= 16, |L| <= 128: a wavefront may add 2^31 / 2^14 = 131 072 correspondences per tile entry in 32 bits (it adds at most
 //     64 ICP_ACCUM_R = 2 048).  12 accumulator registers replace momi's 92 per-lane sums and their block transposition; the workgroup adds its
 //     four wavefronts' tiles and recombines M = 65536 HH + 256 (HL + HL^T) + LL in 64 bits, into the layout k_icp_lm7_solve reads.
@@ -2839,6 +2839,14 @@ __device__ __forceinline__ int icp_fusedq_point_momm(const IcpArgs& a, int i, co
   dq = momi_q(d2, a.mom_s_d, a.mom_lim_d);
   return ICP_PT_ACCEPTED;
 }
+// bytes ODD, ODD + 2 of `lo` then of `hi` as one word: the H (ODD = 1) or L ^ 0x80 (ODD = 0) bytes of four consecutive ring half-words.
+// One v_perm_b32 (selector bytes 0..3 address S1 = lo, 4..7 address S0 = hi); the shift-and-mask statement of the same costs 5 instructions,
+// and the read-out runs once per 64 accepted correspondences of every wavefront.  hop_icp_refine checks the whole read-out -- ring layout,
+// these gathers, the MFMA operand layout, the tile map -- on the device before it first uses this kernel (k_dev_selftest_momm).
+template <int ODD>
+__device__ __forceinline__ unsigned momm_bytes(unsigned lo, unsigned hi) {
+  return __builtin_amdgcn_perm(hi, lo, ODD ? 0x07050301u : 0x06040200u);
+}
 // 64 complete slots of the ring (half 0 or 1) -> operands -> three MFMAs.  Every lane of the wavefront is here (v_mfma ignores EXEC).
 __device__ __forceinline__ void momm_flush(const unsigned short (*__restrict__ ring)[MOMM_ROW], int lane, int half, momm_i32x4& HH, momm_i32x4& HL,
                                            momm_i32x4& LL) {
@@ -2849,10 +2857,10 @@ __device__ __forceinline__ void momm_flush(const unsigned short (*__restrict__ r
   const uint4* __restrict__ p = reinterpret_cast<const uint4*>(&ring[row][half * 64 + (lane >> 4) * 16]);
   const uint4 w0 = p[0], w1 = p[1];  // 16 half-words (L ^ 0x80 | H << 8) = this component of 16 correspondences
   momm_i32x4 Hv, Lv;
-  Hv[0] = (int)__builtin_amdgcn_perm(w0.y, w0.x, 0x07050301u), Lv[0] = (int)(__builtin_amdgcn_perm(w0.y, w0.x, 0x06040200u) ^ 0x80808080u);
-  Hv[1] = (int)__builtin_amdgcn_perm(w0.w, w0.z, 0x07050301u), Lv[1] = (int)(__builtin_amdgcn_perm(w0.w, w0.z, 0x06040200u) ^ 0x80808080u);
-  Hv[2] = (int)__builtin_amdgcn_perm(w1.y, w1.x, 0x07050301u), Lv[2] = (int)(__builtin_amdgcn_perm(w1.y, w1.x, 0x06040200u) ^ 0x80808080u);
-  Hv[3] = (int)__builtin_amdgcn_perm(w1.w, w1.z, 0x07050301u), Lv[3] = (int)(__builtin_amdgcn_perm(w1.w, w1.z, 0x06040200u) ^ 0x80808080u);
+  Hv[0] = (int)momm_bytes<1>(w0.x, w0.y), Lv[0] = (int)(momm_bytes<0>(w0.x, w0.y) ^ 0x80808080u);
+  Hv[1] = (int)momm_bytes<1>(w0.z, w0.w), Lv[1] = (int)(momm_bytes<0>(w0.z, w0.w) ^ 0x80808080u);
+  Hv[2] = (int)momm_bytes<1>(w1.x, w1.y), Lv[2] = (int)(momm_bytes<0>(w1.x, w1.y) ^ 0x80808080u);
+  Hv[3] = (int)momm_bytes<1>(w1.z, w1.w), Lv[3] = (int)(momm_bytes<0>(w1.z, w1.w) ^ 0x80808080u);
   HH = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hv, Hv, HH, 0, 0, 0);
   HL = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hv, Lv, HL, 0, 0, 0);
   LL = __builtin_amdgcn_mfma_i32_16x16x64_i8(Lv, Lv, LL, 0, 0, 0);
@@ -2972,7 +2980,7 @@ void launch_icp_fusedq_momm(const IcpArgs& a, int hb, hipStream_t s) {
 // moment kernels on caller-given operands, one element per thread -- what the instructions return on a device is compared with their
 // documented semantics restated in numpy (the CPU model of tests/emu states them a third time).
 //   out[0] momi_qp(x, y, 2^12)   [1] encoding of momm_qp(x, y)   [2] momi_pack(ia, ib)   [3] momi_dot2(ia, ib, ic)   [4] umed3(ia, ib, ic)
-//   [5] q_rank({ia & 0xffff, ia >> 16, ic & 0xffff}, ib, ic)   [6] v_perm_b32(ia, ib, 0x07050301)   [7] v_perm_b32(ia, ib, 0x06040200)
+//   [5] q_rank({ia & 0xffff, ia >> 16, ic & 0xffff}, ib, ic)   [6] momm_bytes<1>(ib, ia)   [7] momm_bytes<0>(ib, ia)
 //   [8] momi_q(x, y, 2^24)
 __global__ void k_dev_selftest_scalar(int n, const float* __restrict__ x, const float* __restrict__ y, const int* __restrict__ ia, const int* __restrict__ ib,
                                       const int* __restrict__ ic, unsigned* __restrict__ out) {
@@ -2985,8 +2993,8 @@ __global__ void k_dev_selftest_scalar(int n, const float* __restrict__ x, const 
   out[3 * (size_t)n + i] = (unsigned)momi_dot2(ua, ub, ic[i]);
   out[4 * (size_t)n + i] = umed3(ua, ub, uc);
   out[5 * (size_t)n + i] = q_rank(Q3{(int)(ua & 0xffffu), (int)(ua >> 16), (int)(uc & 0xffffu)}, ub, uc);
-  out[6 * (size_t)n + i] = __builtin_amdgcn_perm(ua, ub, 0x07050301u);
-  out[7 * (size_t)n + i] = __builtin_amdgcn_perm(ua, ub, 0x06040200u);
+  out[6 * (size_t)n + i] = momm_bytes<1>(ub, ua);
+  out[7 * (size_t)n + i] = momm_bytes<0>(ub, ua);
   out[8 * (size_t)n + i] = (unsigned)momi_q(x[i], y[i], 16777216.0f);
 }
 // one v_mfma_i32_16x16x64_i8 per wavefront: a, b, c, d as [tiles][64 lanes][4 registers]
@@ -2995,6 +3003,34 @@ __global__ __launch_bounds__(64) void k_dev_selftest_mfma(const int* __restrict_
   const momm_i32x4 A = {a[o], a[o + 1], a[o + 2], a[o + 3]}, B = {b[o], b[o + 1], b[o + 2], b[o + 3]}, Cc = {c[o], c[o + 1], c[o + 2], c[o + 3]};
   const momm_i32x4 D = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, Cc, 0, 0, 0);
   d[o] = D[0], d[o + 1] = D[1], d[o + 2] = D[2], d[o + 3] = D[3];
+}
+// the read-out path of k_icp_fusedq_momm end to end on one wavefront: `batches` x 64 gridded vectors (13 integers each, |U| <= 2^12; batch b
+// is accepted on the lanes of mask[b]) go through momm_qp-encoded floats -> momm_push -> ring -> momm_flush -> tiles; out = the three tiles
+// [3][64 lanes][4 registers].  The caller recombines M = 65536 HH + 256 (HL + HL^T) + LL and compares with the sum of U U^T.
+__global__ __launch_bounds__(64) void k_dev_selftest_momm(int batches, const int* __restrict__ U, const unsigned long long* __restrict__ mask, int* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) unsigned short ring[13][MOMM_ROW];
+  const int lane = threadIdx.x;
+  momm_i32x4 HH = {0, 0, 0, 0}, HL = {0, 0, 0, 0}, LL = {0, 0, 0, 0};
+  int fill = 0;
+  for (int b = 0; b < batches; ++b) {
+    float T[13];
+#pragma unroll
+    for (int c = 0; c < 13; ++c) T[c] = momm_qp((float)U[((size_t)b * 64 + lane) * 13 + c], 1.0f);
+    momm_push(ring, lane, ((mask[b] >> lane) & 1ull) != 0ull, T, fill, HH, HL, LL);
+  }
+  if (fill & 63) {
+    const int half = (fill >> 6) & 1;
+    if (lane >= (fill & 63)) {
+#pragma unroll
+      for (int c = 0; c < 13; ++c) ring[c][half * 64 + lane] = MOMM_ZERO;
+    }
+    momm_flush(ring, lane, half, HH, HL, LL);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[(0 * 64 + lane) * 4 + k] = HH[k], out[(1 * 64 + lane) * 4 + k] = HL[k], out[(2 * 64 + lane) * 4 + k] = LL[k];
+}
+void launch_dev_selftest_momm(int batches, const int* U, const unsigned long long* mask, int* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_dev_selftest_momm, dim3(1), dim3(64), 0, s, batches, U, mask, out);
 }
 void launch_dev_selftest_scalar(int n, const float* x, const float* y, const int* ia, const int* ib, const int* ic, unsigned* out, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_dev_selftest_scalar, dim3((n + 255) / 256), dim3(256), 0, s, n, x, y, ia, ib, ic, out);

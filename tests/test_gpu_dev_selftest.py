@@ -1,7 +1,7 @@
 """The gfx950-specific instructions the ICP kernels lean on, one by one, against their documented semantics restated in numpy -- `pytest -m gpu`.
 
 ADVICE r04 / VERDICT r04 "what the CPU model cannot vouch for": the model of tests/emu runs C stand-ins for `v_med3_u32`, `v_mad_i32_i24`,
-`v_cvt_pk_i16_i32`, `v_dot2_i32_i16` -- and now `v_perm_b32`, `v_med3_f32` on the magic-constant form and `v_mfma_i32_16x16x64_i8` (operand
+`v_cvt_pk_i16_i32`, `v_dot2_i32_i16` -- and now the byte gathers of the ring read-out, `v_med3_f32` on the magic-constant form and `v_mfma_i32_16x16x64_i8` (operand
 layout!).  `hop_debug_selftest` (csrc/hop_kernels.hip k_dev_selftest_*) evaluates the product's own device functions on caller-given
 operands; here they meet a third, independent statement.  On a device this decides whether the instructions do what the kernels assume;
 on the model it decides whether the model's stand-ins do.
@@ -97,7 +97,7 @@ def test_scalar_primitives_match_their_documented_semantics(ctx):
     dx, dy, dz = lx - (ub & 0xFFFF), ly - (ub >> 16), lz - (uc & 0xFFFF)
     rank = (_sext(dz, 24) ** 2 + _sext(dy, 24) ** 2 + _sext(dx, 24) ** 2) & 0xFFFFFFFF
     assert np.array_equal(out[5].astype(np.int64), rank)
-    # [6], [7] v_perm_b32 D, S0 = ia, S1 = ib: selector byte c picks byte c of {S0 : S1} (0..3 from S1, 4..7 from S0)
+    # [6], [7] momm_bytes<ODD>(lo = ib, hi = ia): bytes ODD, ODD + 2 of lo, then of hi (the compiler's v_perm_b32 / bit-field sequence)
     pool = (ua << 32) | ub
     for row, sel in ((6, (1, 3, 5, 7)), (7, (0, 2, 4, 6))):
         want = sum(((pool >> (8 * c)) & 0xFF) << (8 * k) for k, c in enumerate(sel))
@@ -141,6 +141,33 @@ def test_mfma_i32_16x16x64_i8_is_the_contraction_the_moment_kernel_assumes(ctx):
     inp2 = np.concatenate([a_regs[:, :, perm].reshape(-1).view(np.uint32), b_regs[:, :, perm].reshape(-1).view(np.uint32), c_regs.reshape(-1).view(np.uint32)])
     d2 = _selftest(ctx, 1, tiles, inp2, tiles * 256).view(np.int32).reshape(tiles, 64, 4)
     assert np.array_equal(d2, d)
+
+
+def test_ring_read_out_of_the_matrix_core_kernel_reproduces_the_moment_sums(ctx):
+    """k_dev_selftest_momm: gridded vectors -> momm_qp encoding -> momm_push (ballot-counted slots of the wavefront's ring, component-major
+    half-words) -> momm_flush (two 16-byte reads per lane, byte gathers, three MFMAs) -> tiles.  M = 65536 HH + 256 (HL + HL^T) + LL must be
+    the sum of U U^T over the accepted lanes, whatever the batches' masks: full halves, a half completed across pushes, empty batches, a
+    partial last half.  (hop_icp_refine runs a small version of this on the device before it first takes the matrix-core kernel.)"""
+    rng = np.random.default_rng(3)
+    for case in range(4):
+        nb = [1, 3, 9, 40][case]
+        U = rng.integers(-4096, 4097, (nb, 64, 13)).astype(np.int32)
+        U[0, :2, :] = [[4096] * 13, [-4096] * 13]
+        masks = rng.integers(0, 2 ** 63, nb, dtype=np.uint64) | (rng.integers(0, 2, nb, dtype=np.uint64) << np.uint64(63))
+        masks[rng.integers(0, nb, max(1, nb // 4))] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        if nb > 2:
+            masks[1] = np.uint64(0)                       # a batch without an accepted lane
+        inp = np.concatenate([U.reshape(-1).view(np.uint32), masks.view(np.uint32)])
+        t = _selftest(ctx, 2, nb, inp, 3 * 256).view(np.int32).reshape(3, 64, 4).astype(np.int64)
+        tiles = np.zeros((3, 16, 16), np.int64)
+        for lane in range(64):
+            for r in range(4):
+                tiles[:, 4 * (lane >> 4) + r, lane & 15] = t[:, lane, r]
+        M = tiles[0] * 65536 + (tiles[1] + tiles[1].T) * 256 + tiles[2]
+        acc = np.array([[(int(masks[b]) >> l) & 1 for l in range(64)] for b in range(nb)], np.int64)
+        Uw = U.astype(np.int64) * acc[:, :, None]
+        want = np.einsum("bli,blj->ij", Uw, U.astype(np.int64))
+        assert np.array_equal(M[:13, :13], want), case
 
 
 def test_the_two_moment_kernels_return_the_same_integers(ctx, hop, orc, monkeypatch):

@@ -52,7 +52,8 @@ def main():
     bytes_per_hyp = 24 * (N + args.model) + 72
     res = {}
     for name in args.icp_modes.split(","):
-        mode = int(name.replace("old", ""))
+        mode = int(name.replace("old", "").replace("dot2", ""))
+        os.environ["HOP_ICP_MFMA"] = "0" if name.endswith("dot2") else "1"   # "7dot2": nn_mode 7 with the moment sums on the vector units (k_icp_fusedq_momi)
         if name.startswith("old"):
             os.environ["HOP_ICP_OLD_FUSED"] = "1"
         else:
