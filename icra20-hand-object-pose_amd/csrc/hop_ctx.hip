@@ -143,7 +143,7 @@ struct hop_ctx {
   int n_hyp = 0;
 
   // scoring workspaces
-  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv, icp_corr_idx, icp_corr16, icp_hist, icp_lm, pose_inv, topk_rows;
+  DevBuf lcp_rev_idx, lcp_rev_d2, lcp_terms, icp_moved, icp_partial, icp_state, icp_iters, icp_conv, icp_corr_idx, icp_hist, icp_lm, pose_inv, topk_rows;
 
   // hand
   CloudDevice hand_scene_d, hand_lookup_d, hand_swivel_d, hand_model_d;
@@ -362,8 +362,8 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
   HIPCHK(c, hipStreamSynchronize(c->stream));
   cs.c.pts_idx = cs.pts_idx_d.as<float4>();
   cs.packed = false, cs.pack_requested = packed, cs.c.rec = nullptr, cs.c.qlist = nullptr;
-  // (the empty-slot convention of cells_nnq needs the cell well below the gating distance: cell < 0.42 (max_dist + margin);
-  // its 32-bit integer squared distances need every coordinate difference below 37 800 steps: cell < 0.3 max_dist)
+  // (the empty-slot convention of cells_nnq -- coordinates 0xFFFF: per axis the 16-bit difference to a query wraps to >= 28 000 steps, a key above
+  // that of any real member of the list -- needs the cell well below the gating distance: cell < 0.3 max_dist)
   if (packed && h.n < 0xFFFF && cell < 0.3f * max_dist) {
     std::vector<float4> hp(std::max<size_t>(total, 1));
     HIPCHK(c, hop_ctx_d2h(c, hp.data(), cs.pts_d.p, sizeof(float4) * total));
@@ -371,7 +371,9 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
     // per-cell quantisation frame: every list member lies within max_dist + margin of the cell's box on every axis
     // (cell_list_thr2), so [corner - R, corner + cell + R] holds it
     const double R = (double)max_dist + 2.0 * (double)a.margin;
-    const double step = ((double)cell + 2.0 * R) / 65535.0, qcs = (double)cell / step, qrs = R / step;
+    // step: the largest difference between a query (inside the cell) and a list member, cell + R, is 32 767 steps -- q_rank subtracts and
+    // squares in 16 bits (v_pk_sub_i16 / v_dot2_i32_i16) -- which leaves the frame [0, cell + 2 R] below 65 535 steps as well
+    const double step = ((double)cell + R) / 32767.0, qcs = (double)cell / step, qrs = R / step;
     bool in_range = true;
     // The exact point and normal of a winner are fetched by index; neighbouring queries win neighbouring points, so the two
     // arrays are stored in Morton order of the cloud and the entries carry the Morton rank (a wavefront's fetch then touches a
@@ -453,6 +455,11 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
     cs.c.q_cs = (float)qcs, cs.c.q_rs = (float)(qrs + 0.5), cs.c.q_step2 = (float)(step * step);  // + 0.5: the lookup truncates
     // sqrt(3)/2 of a step for the entry, as much for the query (rounded to whole steps too), the float evaluation of its local coordinate
     cs.c.q_eq = (float)(step * 1.8);
+    {
+      const double cc = (double)max_dist / 3.0;
+      cs.c.q_sa = (float)(0.5 / cc * 1.000001), cs.c.q_sb = (float)(0.5 * cc * 1.000001);   // (rounded up: S stays an upper bound)
+      cs.c.q_tk = 4.2f * cs.c.q_eq, cs.c.q_t0 = 2.1f * cs.c.q_eq * cs.c.q_eq + 2.f * cs.c.q_step2;
+    }
     cs.packed = true;
     if (getenv("HOP_PROFILE_SELECT")) std::printf("packed lists: %.1f MB records + %.1f MB chunks, step %.3g m\n", rec.size() * 4e-6, ql.size() * 4e-6, step);
   }
@@ -767,7 +774,7 @@ void hop_ctx_destroy(hop_ctx* c) {
                     &c->pairs2_d, &c->cnt_d, &c->elems_d, &c->queries_d, &c->cands_d, &c->cand_counts_d, &c->counters_d, &c->hyp_pose,
                     &c->hyp_score, &c->hyp_id, &c->hyp_key, &c->hyp_inv, &c->tmp_pose, &c->tmp_score, &c->tmp_id, &c->sort_keys_alt,
                     &c->sort_vals, &c->sort_vals_alt, &c->sort_tmp, &c->lcp_rev_idx, &c->lcp_rev_d2, &c->lcp_terms, &c->icp_moved,
-                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->icp_corr_idx, &c->icp_corr16, &c->icp_hist, &c->icp_lm, &c->pose_inv, &c->topk_rows, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
+                    &c->icp_partial, &c->icp_state, &c->icp_iters, &c->icp_conv, &c->icp_corr_idx, &c->icp_hist, &c->icp_lm, &c->pose_inv, &c->topk_rows, &c->hand_scene_d.buf, &c->hand_lookup_d.buf,
                     &c->hand_swivel_d.buf, &c->hand_model_d.buf, &c->finger_hist_d, &c->pso_particles_d, &c->pso_match_d,
                     &c->pso_terms_d, &c->pso_sum_d, &c->pso_cnt_d};
   for (DevBuf* b : bufs) b->release();
@@ -1468,11 +1475,6 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     // (read at every call: a test or a tool may switch between two refinements of one process)
     icp_mfma = !(getenv("HOP_ICP_MFMA") != nullptr && atoi(getenv("HOP_ICP_MFMA")) == 0);
     if (lm7_mode && icp_mfma) icp_mfma = mfma_i8_layout_ok(c);
-    static const bool icp_split = getenv("HOP_ICP_SPLIT") != nullptr && atoi(getenv("HOP_ICP_SPLIT")) != 0;
-    if (lm6_mode && icp_split) {
-      HIPCHK(c, c->icp_corr16.ensure(sizeof(unsigned short) * (size_t)S.n * HB + 64));
-      a.corr16 = c->icp_corr16.as<unsigned short>();
-    }
     if (lm7_mode) {
       // the grid of the moment form (oracle: mom_spec): powers of two from the model's radius about its origin and the gate
       const CloudHost& mh = c->gen.model_h[HOP_MODEL_5MM];
@@ -1508,7 +1510,6 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     a.sx = Q.plane(0), a.sy = Q.plane(1), a.sz = Q.plane(2), a.snx = Q.plane(3), a.sny = Q.plane(4), a.snz = Q.plane(5);
     a.s_pts4 = c->scene_sorted_aos_d.as<float4>(), a.s_nrm4 = a.s_pts4 + std::max(S.n, 1);
   }
-  const bool old_fused = getenv("HOP_ICP_OLD_FUSED") != nullptr;  // experiment switch: the round-1 kernel
   for (int h0 = 0; h0 < H; h0 += HB) {
     const int hb = std::min(HB, H - h0);
     a.h0 = h0;
@@ -1548,7 +1549,6 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
           SpanGuard sg(c, T_ICP_NN);
           if (lm7_mode && icp_mfma) launch_icp_fusedq_momm(a, hb, c->stream);
           else if (lm7_mode) launch_icp_fusedq_momi(a, hb, c->stream);
-          else if (a.corr16) launch_icp_scan_accum(a, hb, c->stream);
           else launch_icp_fusedq_mom(a, hb, c->stream);
         }
         {
@@ -1566,7 +1566,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
       {
         SpanGuard sg(c, T_ICP_NN);
         if (o->nn_mode >= 3) {
-          if ((old_fused && o->nn_mode == 3) || !a.cells.rec) launch_icp_fused(a, hb, c->stream);  // (models of >= 65535 points: unpacked lists)
+          if (!a.cells.rec) launch_icp_fused(a, hb, c->stream);  // (models of >= 65535 points: unpacked lists)
           else launch_icp_fusedq(a, hb, o->nn_mode == 4, c->stream);
         } else if (cells) {
           launch_icp_corr_cells(a, hb, c->stream);

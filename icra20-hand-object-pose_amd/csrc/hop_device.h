@@ -146,6 +146,8 @@ struct CellListDev {
   float q_cs, q_rs;        // local query coordinate in whole steps = (int)fma(fraction of the grid coordinate, q_cs, q_rs)
   float q_step2;           // step^2: squared step-unit distances -> m^2
   float q_eq;              // bound of the position error of a dequantised entry + that of the rounded query (metres)
+  float q_sa, q_sb;        // S = f2 q_sa + q_sb >= sqrt(f2): the root-free bound in cells_nnq's tolerance (q_sa = 1 / (2 c), q_sb = c / 2)
+  float q_tk, q_t0;        // 4.2 q_eq and 2.1 q_eq^2 + 2 step^2 of that tolerance
 };
 constexpr unsigned Q_EMPTY_HI = 0xFFFF0000u;  // high word >= this: empty slot
 
@@ -246,7 +248,6 @@ struct IcpArgs {
   const float* pose_inv;  // nn_mode 2: [H][12] inverse of the input poses
   const float4 *s_pts4, *s_nrm4;  // nn_mode 3/4: the Morton-ordered source as AoS float4 (two 16-byte loads per point)
   LmDev* lm;                      // nn_mode 5: [hb]
-  unsigned short* corr16;         // nn_mode 6, split form: [hb][ns] list position of the accepted correspondence (0xFFFF: none)
   // nn_mode 7: the grid of the moment form -- powers of two (as floats, and their exponents) that scale n_a p'_b, n_a, r0 and the squared
   // correspondence distance to integers, and the clamps (oracle: mom_spec)
   float mom_s_np, mom_s_n, mom_s_r, mom_s_d, mom_lim, mom_lim_d;
@@ -355,7 +356,6 @@ void launch_dev_selftest_scalar(int n, const float* x, const float* y, const int
 void launch_dev_selftest_mfma(int tiles, const int* a, const int* b, const int* c, int* d, hipStream_t s);
 void launch_dev_selftest_momm(int batches, const int* U, const unsigned long long* mask, int* out, hipStream_t s);
 void launch_icp_lm7_solve(const IcpArgs& a, int hb, int nblocks, hipStream_t s);
-void launch_icp_scan_accum(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_fusedq_mom(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_lm6_solve(const IcpArgs& a, int hb, int nblocks, hipStream_t s);
 void launch_icp_lm_begin(const IcpArgs& a, int hb, hipStream_t s);

@@ -228,120 +228,6 @@ __global__ __launch_bounds__(256) void k_ppf_matrix_sym(PpfMatrixArgs a) {
   if (both && jvalid) a.out[(size_t)j * a.words + ib] = rev;
 }
 
-// k_ppf_matrix_sym wrote its words where they fell: a row's forward word as one 8-byte store per wavefront, the reverse words as 64
-// scattered 8-byte stores -- 172 MB of HBM writes for the 50 MB matrix (profiles/r02_pmc_hbm.txt).  The tiled form computes an
-// PPF_TW x PPF_TW-word tile per block, stages the forward words and the transposed reverse words in LDS and writes both as
-// row segments of PPF_TW words.  Same evaluations, same bits (tests/test_gpu_parity.py compares the kernels).
-#ifndef HOP_PPF_TW
-#define HOP_PPF_TW 4
-#endif
-constexpr int PPF_TW = HOP_PPF_TW;  // words per tile edge (4: 32-byte segments, 16 KB of LDS; 8: 64-byte segments, 64 KB -- too few waves per SIMD)
-constexpr int PPF_WQ = PPF_TW / 4;  // column words per wavefront
-__global__ __launch_bounds__(256) void k_ppf_matrix_tile(PpfMatrixArgs a) {
-  __shared__ float rows[PPF_ROWS][8];
-  __shared__ float sthr[32];
-  __shared__ unsigned long long tfw[PPF_TW * 64][PPF_TW];  // forward: [row in tile][column word]
-  __shared__ unsigned long long trv[PPF_TW * 64][PPF_TW];  // reverse: [column in tile = output row][row word]
-  const int TI = blockIdx.y, TJ = blockIdx.x;
-  if (TJ < TI) return;
-  const bool diag = TI == TJ;
-  if (threadIdx.x < 32) sthr[threadIdx.x] = a.angle_thr[threadIdx.x];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int t = threadIdx.x; t < PPF_TW * 64 * PPF_TW; t += 256) (&tfw[0][0])[t] = 0ull, (&trv[0][0])[t] = 0ull;
-  auto member = [&](int d, int a1, int a2, int a3) -> bool {
-    const unsigned bit = ((unsigned)(d * 19 + a1) * 19u + (unsigned)a2) * 19u + (unsigned)a3;
-    return (a.bitmap[bit >> 5] >> (bit & 31)) & 1u;
-  };
-  // the two column words of this wavefront
-  V3 pj[PPF_WQ], nj[PPF_WQ];
-  bool jvalid[PPF_WQ];
-  int jcol[PPF_WQ];
-#pragma unroll
-  for (int q = 0; q < PPF_WQ; ++q) {
-    const int jb = TJ * PPF_TW + wave + 4 * q, j = jb * 64 + lane;
-    jcol[q] = j;
-    jvalid[q] = jb < a.words && j < a.n;
-    pj[q] = v3(0, 0, 0), nj[q] = v3(0, 0, 1);
-    if (jvalid[q]) pj[q] = v3(a.x[j], a.y[j], a.z[j]), nj[q] = v3(a.nx[j], a.ny[j], a.nz[j]);
-  }
-  for (int ibl = 0; ibl < PPF_TW; ++ibl) {
-    const int ib = TI * PPF_TW + ibl, i0 = ib * 64;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      const int i = i0 + threadIdx.x;
-      if (i < a.n) {
-        rows[threadIdx.x][0] = a.x[i], rows[threadIdx.x][1] = a.y[i], rows[threadIdx.x][2] = a.z[i];
-        rows[threadIdx.x][3] = a.nx[i], rows[threadIdx.x][4] = a.ny[i], rows[threadIdx.x][5] = a.nz[i];
-      }
-    }
-    __syncthreads();
-    const int rmax = min(64, a.n - i0);
-    if (rmax <= 0) continue;
-#pragma unroll
-    for (int q = 0; q < PPF_WQ; ++q) {
-      const int jbl = wave + 4 * q, jb = TJ * PPF_TW + jbl;
-      if (jb >= a.words || jb < ib) continue;  // (below the diagonal: produced as the reverse words of the mirrored pair)
-      const bool both = jb != ib;
-      unsigned long long rev = 0ull;
-      for (int r = 0; r < rmax; ++r) {
-        const V3 pi = v3(rows[r][0], rows[r][1], rows[r][2]);
-        const V3 ni = v3(rows[r][3], rows[r][4], rows[r][5]);
-        bool fwd = false, bwd = false;
-        if (jvalid[q] && (i0 + r) != jcol[q]) {
-          const float nrm = vnorm(pi - pj[q]) * 1000.f;
-          if (nrm < 2147483648.0f) {
-            const int k0 = ppf_closest_bin((int)nrm, 5);
-            const V3 dir = vnormalized(pj[q] - pi);
-            const float s1 = vdot(ni, dir), s2 = vdot(nj[q], dir), s3 = vdot(ni, nj[q]);
-            int b1, b2, b3;
-            if (ppf_angle_bin_thr(s1, sthr, &b1) && ppf_angle_bin_thr(s2, sthr, &b2) && ppf_angle_bin_thr(s3, sthr, &b3)) {
-              const int d = k0 / 5, a3 = b3 / 10;
-              if (k0 >= 0 && d < a.dist_bins) {
-                fwd = member(d, b1 / 10, b2 / 10, a3);
-                if (both) {
-                  int c1, c2;
-                  (void)ppf_angle_bin_thr(-s2, sthr, &c1), (void)ppf_angle_bin_thr(-s1, sthr, &c2);
-                  bwd = member(d, c1 / 10, c2 / 10, a3);
-                }
-              }
-            }
-          }
-        }
-        const unsigned long long word = __ballot(fwd);
-        if (lane == 0) tfw[ibl * 64 + r][jbl] = word;
-        rev |= (unsigned long long)bwd << r;
-      }
-      if (both) trv[jbl * 64 + lane][ibl] = rev;
-    }
-  }
-  __syncthreads();
-  // write-out: 64-byte row segments (16 bytes per thread and step)
-  const int row0_f = TI * PPF_TW * 64, col0_f = TJ * PPF_TW;  // forward tile: rows of TI, column words of TJ
-  const int row0_r = TJ * PPF_TW * 64, col0_r = TI * PPF_TW;  // reverse tile: rows of TJ, column words of TI
-  for (int t = threadIdx.x; t < PPF_TW * 64 * (PPF_TW / 2); t += 256) {
-    const int rl = t / (PPF_TW / 2), c2 = (t % (PPF_TW / 2)) * 2;
-    if (diag) {
-      // one output tile: column words at or right of the row's own word come from the forward pass, the others are reverse words
-      const int row = row0_f + rl, rw = rl >> 6;
-      if (row < a.n) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int c = c2 + u;
-          if (col0_f + c < a.words) a.out[(size_t)row * a.words + col0_f + c] = c >= rw ? tfw[rl][c] : trv[rl][c];
-        }
-      }
-    } else {
-      const int rowf = row0_f + rl, rowr = row0_r + rl;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int c = c2 + u;
-        if (rowf < a.n && col0_f + c < a.words) a.out[(size_t)rowf * a.words + col0_f + c] = tfw[rl][c];
-        if (rowr < a.n && col0_r + c < a.words) a.out[(size_t)rowr * a.words + col0_r + c] = trv[rl][c];
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // K3a: pair extraction for a batch of bases (FunctorSuper4PCS::ExtractPairs + PairCreationFunctor::process
 // + AdaptivePointFilter, FunctorSuper4pcs.h:79-116, pairCreationFunctor.h:189-214, PointPairFilter.h:88-172)
@@ -2059,25 +1945,29 @@ void icp_counters_read(unsigned long long* out8, bool reset) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_icp_count), z, sizeof(z));
   }
 }
-// squared distance (whole steps) of the local query l (rounded to whole steps) to a packed entry (lo = x | y << 16,
-// hi = z | index << 16): three word-select subtractions and 24-bit integer multiply-adds.  Every difference is below 2^15.2
-// steps (cell < 0.3 gate, see build_cell_lists), so the sum stays below 2^32.
+// squared distance (whole steps) of the local query l (rounded to whole steps) to a packed entry (lo = x | y << 16, hi = z | index << 16).
+// Every coordinate difference fits a signed 16-bit integer (the step of the cell frame is chosen for that, build_cell_lists), so the x and y
+// differences are ONE v_pk_sub, their squares ONE v_dot2_i32_i16, the z difference the low half of a second v_pk_sub (its high half, minus
+// the index, is never read) and its square a v_mad_i32_i16: 4 instructions per candidate (the three field extractions, three subtractions
+// and three 24-bit multiply-adds of the 32-bit form: 9).  The sum stays below 3 * 2^30 < 2^32.
+typedef unsigned short q_v2u16 __attribute__((vector_size(4)));
+typedef short q_v2i16 __attribute__((vector_size(4)));
 struct Q3 {
-  int x, y, z;
+  unsigned xy, z;  // x | y << 16, z
 };
 __device__ __forceinline__ unsigned q_rank(Q3 l, unsigned lo, unsigned hi) {
-  const int dx = l.x - (int)(lo & 0xffffu), dy = l.y - (int)(lo >> 16), dz = l.z - (int)(hi & 0xffffu);
-  unsigned d = (unsigned)__mul24(dz, dz);
-  asm("v_mad_i32_i24 %0, %1, %1, %0" : "+v"(d) : "v"(dy));  // (the compiler prefers three multiplies and v_add3)
-  asm("v_mad_i32_i24 %0, %1, %1, %0" : "+v"(d) : "v"(dx));
+  const q_v2u16 dxy = __builtin_bit_cast(q_v2u16, l.xy) - __builtin_bit_cast(q_v2u16, lo);
+  const unsigned dzw = __builtin_bit_cast(unsigned, __builtin_bit_cast(q_v2u16, l.z) - __builtin_bit_cast(q_v2u16, hi));
+  unsigned d = (unsigned)__builtin_amdgcn_sdot2(__builtin_bit_cast(q_v2i16, dxy), __builtin_bit_cast(q_v2i16, dxy), 0, false);
+  asm("v_mad_i32_i16 %0, %1, %1, %0" : "+v"(d) : "v"(dzw));
   return d;
 }
 #define Q_L(v) (int)(v)
 #define Q_KEYF(k) (float)(k)
 #define Q_INF 0xFFFFFFFFu
 // one chunk of two entries: keys = squared distance with the lowest bit replaced by the slot.
-// Empty slots carry coordinates 0xFFFF (>= 30 000 steps from any query on every axis, farther than any real entry of
-// a list can be: those lie within gate + margin + the cell diagonal), so they need no test here.
+// Empty slots carry coordinates 0xFFFF: on every axis the 16-bit difference to a query (28 000 .. 32 767 steps into the frame) wraps to
+// >= 28 000 steps, farther than any real entry of a list can be (those lie within gate + margin + the cell diagonal), so they need no test here.
 __device__ __forceinline__ void q_chunk(Q3 l, const uint4& ch, unsigned& b1, unsigned& b2, unsigned& why, unsigned& whw) {
   const unsigned k0 = q_rank(l, ch.x, ch.y) & ~1u, k1 = q_rank(l, ch.z, ch.w) | 1u;
   const unsigned prev = b1;
@@ -2118,7 +2008,8 @@ __device__ __forceinline__ bool cells_nnq(const CellListDev& c, V3 qg, const flo
   ICP_COUNT(0, 1);
   if (nch == 0) return false;
   // local coordinate in whole steps (q_rs carries the + 0.5 of the rounding)
-  const Q3 l = {Q_L(__builtin_fmaf(hx - gx, c.q_cs, c.q_rs)), Q_L(__builtin_fmaf(hy - gy, c.q_cs, c.q_rs)), Q_L(__builtin_fmaf(hz - gz, c.q_cs, c.q_rs))};
+  const Q3 l = {(unsigned)Q_L(__builtin_fmaf(hx - gx, c.q_cs, c.q_rs)) | ((unsigned)Q_L(__builtin_fmaf(hy - gy, c.q_cs, c.q_rs)) << 16),
+                (unsigned)Q_L(__builtin_fmaf(hz - gz, c.q_cs, c.q_rs))};
   unsigned b1 = Q_INF, b2 = Q_INF;
   unsigned why = 0xFFFFFFFFu, whw = 0xFFFFFFFFu;  // high words (index) of the chunk that holds the winner
   const uint4* __restrict__ lp = c.qlist + r.x;
@@ -2143,10 +2034,14 @@ __device__ __forceinline__ bool cells_nnq(const CellListDev& c, V3 qg, const flo
   bidx = widx;
   const float mag = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), 0.25f));
   const float delta = mag * 2.0e-6f;
-  const float s1 = __builtin_amdgcn_sqrtf(f1), s2 = __builtin_amdgcn_sqrtf(fminf(f2, 1.0e30f));
   // transform rounding as in cells_nn (1.02e-4 also covers the conversion of the keys to float) + the quantisation of the
-  // query and of the two candidate positions being compared (q_eq bounds their sum) + the key bit each of them gave up
-  const float tol = 2.002f * s1 * delta + 1.02e-4f * f1 + delta * delta + 2.1f * c.q_eq * (s1 + s2) + 2.1f * c.q_eq * c.q_eq + 2.f * c.q_step2;
+  // query and of the two candidate positions being compared (q_eq bounds their sum) + the key bit each of them gave up:
+  //   2.002 s1 delta + 1.02e-4 f1 + delta^2 + 2.1 q_eq (s1 + s2) + 2.1 q_eq^2 + 2 step^2,   s1 = sqrt(f1) <= s2 = sqrt(f2).
+  // Only an upper bound is needed (a larger tol defers a few more lookups to the exact scan, it never changes an answer): both roots are
+  // bounded by S = f2 / (2 c) + c / 2 >= sqrt(f2) for any c > 0 (c = a third of the gate: exact at the typical runner-up distance) -- five
+  // multiply-adds instead of two square roots (quarter-rate instructions) and eight operations.
+  const float S = __builtin_fmaf(f2, c.q_sa, c.q_sb);
+  const float tol = __builtin_fmaf(S, __builtin_fmaf(2.002f, delta, c.q_tk), __builtin_fmaf(1.02e-4f, f1, __builtin_fmaf(delta, delta, c.q_t0)));
   if (f2 - f1 <= tol) {
     if (DEFER) return true;
     ICP_COUNT(4, 1);
@@ -2361,10 +2256,6 @@ __device__ __forceinline__ int icp_fusedq_point_mom(const IcpArgs& a, int i, con
   if (!(((qn.x * nt.x + qn.y * nt.y) + qn.z * nt.z) > a.cos_thr)) return ICP_PT_REJECTED;
   const V3 pc = q - ctr;
   const float r0 = vdot(q - tq, nt);
-#ifdef HOP_ICP_MOM_NOACC  // experiment: the lookups and gates alone
-  acc[0] += (r0 + d2) + (nt.x + pc.x);
-  return ICP_PT_ACCEPTED;
-#endif
   const float nn[6] = {nt.x * nt.x, nt.x * nt.y, nt.x * nt.z, nt.y * nt.y, nt.y * nt.z, nt.z * nt.z};
   const float pp[6] = {pc.x * pc.x, pc.x * pc.y, pc.x * pc.z, pc.y * pc.y, pc.y * pc.z, pc.z * pc.z};
   const float pv[3] = {pc.x, pc.y, pc.z}, nv[3] = {nt.x, nt.y, nt.z};
@@ -2387,7 +2278,6 @@ __device__ __forceinline__ int icp_fusedq_point_mom(const IcpArgs& a, int i, con
   acc[73] += d2;
   return ICP_PT_ACCEPTED;
 }
-#ifndef HOP_ICP_MOM_MFMA
 #ifndef HOP_ICP_MOM_W
 #define HOP_ICP_MOM_W 4
 #endif
@@ -2426,159 +2316,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM
   block_sum_floats<ICP_NMOM>(acc, bs, out);  // (its barriers order n_cnt as well)
   if (threadIdx.x == 0) out[ICP_NMOM] = (double)((n_cnt[0] + n_cnt[1]) + (n_cnt[2] + n_cnt[3]));
 }
-#else
-// EXPERIMENT (tools/build_variant.sh mfma -DHOP_ICP_MOM_MFMA; measured SLOWER): the moment matrix on the
-// matrix cores.  M = sum_i u_i u_i^T is a rank-1-update GEMM: v_mfma_f32_16x16x4_f32 (exact f32,
-// bitwise an fmaf chain: MI355X_MICROARCH.md) takes four points per instruction, A[c][k] = B[k][c] = component c of point k.
-// u (15 of 16 rows used) = (n_a p'_b [9], n_a [3], r0, d2, 1): M[13][14] = sum of squared correspondence distances,
-// M[14][14] = the number of accepted correspondences.  Per batch of 64 lookups a wavefront
-//   * writes the accepted lanes' u (zeros for the others) to its 4 KB of LDS, point-major: 4 x ds_write_b128 per lane, the 16-byte
-//     groups XOR-swizzled by (point >> 2) & 3 so that the 16 lanes of a write phase cover the 64 banks;
-//   * reads them back component-major for instruction t = points 4t .. 4t+3: lane l needs component l & 15 of point 4t + (l >> 4),
-//     which is word 64 t + l up to the swizzle inside its 16-word group: one conflict-free ds_read_b32 per instruction;
-//   * issues 16 MFMAs into two accumulators (even / odd t: no back-to-back dependency), then adds them to 4 doubles per lane.
-// The wavefront's 256 entries of M therefore cost 4 + 8 accumulator registers instead of 74 (and no cross-lane reduction at the
-// end), the kernel fits 8 waves per SIMD instead of 4, and the matrix pipe works while other wavefronts scan their lists.
-// Sums: 64 terms per batch in float inside the MFMAs (the same 1e-6 relative as 30 terms per lane before), batches / waves / blocks
-// in double.  The deferred lookups (see k_icp_fusedq) are queued per wavefront and run as dense batches of 64.
-typedef float mom_f32x4 __attribute__((ext_vector_type(4)));
-struct MomTab {
-  unsigned char at[ICP_NMOM + 1];  // entry (row * 16 + col) of the 16 x 16 tile that holds sum k of the solver's layout
-  constexpr MomTab() : at{} {
-    const int pa[6] = {0, 0, 0, 1, 1, 2}, pc[6] = {0, 1, 2, 1, 2, 2};
-    for (int u = 0; u < 6; ++u) {
-      for (int v = 0; v < 6; ++v) at[u * 6 + v] = (unsigned char)((pa[u] * 3 + pa[v]) * 16 + pc[u] * 3 + pc[v]);  // sum n_a n_c p_b p_d
-      for (int b = 0; b < 3; ++b) at[36 + u * 3 + b] = (unsigned char)((pa[u] * 3 + b) * 16 + 9 + pc[u]);          // sum n_a n_c p_b
-      at[54 + u] = (unsigned char)((9 + pa[u]) * 16 + 9 + pc[u]);                                                 // sum n_a n_c
-    }
-    for (int c = 0; c < 3; ++c) {
-      for (int b = 0; b < 3; ++b) at[60 + c * 3 + b] = (unsigned char)((c * 3 + b) * 16 + 12);  // sum n_c r0 p_b
-      at[69 + c] = (unsigned char)((9 + c) * 16 + 12);                                          // sum n_c r0
-    }
-    at[72] = 12 * 16 + 12;        // sum r0^2
-    at[73] = 13 * 16 + 14;        // sum d2
-    at[ICP_NMOM] = 14 * 16 + 14;  // count
-  }
-};
-__constant__ MomTab c_mom_tab = MomTab();
-#ifndef HOP_ICP_MOM_W
-#define HOP_ICP_MOM_W 7  // (72 VGPRs; 8 spills)
-#endif
-#ifndef HOP_ICP_MOM_FLUSH
-#define HOP_ICP_MOM_FLUSH 1  // batches of 64 lookups between two additions of the float tile to the double sums
-#endif
-// lookup + gates of one source point; on acceptance the ingredients of u
-template <bool DEFER>
-__device__ __forceinline__ int icp_mom_point(const IcpArgs& a, int i, const float* __restrict__ pose, const float* __restrict__ sTi,
-                                              const float* __restrict__ F, V3 ctr, V3& nt, V3& pc, float& r0, float& d2) {
-  const float4 p4 = a.s_pts4[i];
-  V3 q = v3(p4.x, p4.y, p4.z);
-  if (a.iter > 0) q = m4_point_fma(F, q);
-  float best = 3.0e38f;
-  int j = -1;
-  V3 tq;
-  if (cells_nnq<DEFER>(a.cells, m4_point_fma(sTi, q), pose, q, best, j, tq)) return ICP_PT_DEFERRED;
-  if (j < 0 || !(best <= a.max_d2)) return ICP_PT_REJECTED;
-  const float4 tn = a.cells.nrm_idx[j];
-  const float4 n4 = a.s_nrm4[i];
-  V3 qn = v3(n4.x, n4.y, n4.z);
-  if (a.iter > 0) qn = m4_dir_fma(F, qn);
-  const V3 n = m4_dir(pose, v3(tn.x, tn.y, tn.z));
-  if (!(((qn.x * n.x + qn.y * n.y) + qn.z * n.z) > a.cos_thr)) return ICP_PT_REJECTED;
-  nt = n, pc = q - ctr, r0 = vdot(q - tq, n), d2 = best;
-  return ICP_PT_ACCEPTED;
-}
-// one batch: the wavefront's accepted lanes (mask ok != 0) -> LDS -> 16 MFMAs
-__device__ __forceinline__ void icp_mom_batch(float* __restrict__ stage, int lane, bool ok, V3 nt, V3 pc, float r0, float d2, mom_f32x4& C0,
-                                              mom_f32x4& C1) {
-  const float one = ok ? 1.f : 0.f;  // (nt, pc, r0, d2 are zero on the lanes that were not accepted)
-  char* __restrict__ wp = (char*)stage + lane * 64;
-  const unsigned sx = ((unsigned)(lane >> 2) & 3u) << 4;
-  *(float4*)(wp + (0x00u ^ sx)) = make_float4(nt.x * pc.x, nt.x * pc.y, nt.x * pc.z, nt.y * pc.x);
-  *(float4*)(wp + (0x10u ^ sx)) = make_float4(nt.y * pc.y, nt.y * pc.z, nt.z * pc.x, nt.z * pc.y);
-  *(float4*)(wp + (0x20u ^ sx)) = make_float4(nt.z * pc.z, nt.x, nt.y, nt.z);
-  *(float4*)(wp + (0x30u ^ sx)) = make_float4(r0, d2, one, 0.f);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const unsigned c = (unsigned)lane & 15u, grp = (unsigned)lane & 48u;  // word offset of the lane's 16-word group inside an instruction's 64
-  float v[16];
-#pragma unroll
-  for (int t = 0; t < 16; ++t) v[t] = stage[64 * t + grp + ((((c >> 2) ^ (unsigned)(t & 3)) << 2) | (c & 3u))];
-#pragma unroll
-  for (int t = 0; t < 16; t += 2) {
-    C0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t], v[t], C0, 0, 0, 0);
-    C1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t + 1], v[t + 1], C1, 0, 0, 0);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next batch's writes stay behind these reads)
-  __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ void icp_mom_flush(double (&cd)[4], mom_f32x4& C0, mom_f32x4& C1) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) cd[k] += (double)C0[k] + (double)C1[k];
-  C0 = C1 = mom_f32x4{0.f, 0.f, 0.f, 0.f};
-}
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM_W))) void k_icp_fusedq_mom(IcpArgs a, int R) {
-  __shared__ __attribute__((aligned(16))) float stage[4][64 * 16];  // (the cross-wave sum reuses it: 4 x 256 doubles)
-  __shared__ unsigned short defer_i[4][128];
-  const int hl = blockIdx.y, h = a.h0 + hl;
-  const IcpState& st = a.state[hl];
-  if (!st.active) return;
-  const float* __restrict__ pose = a.pose + (size_t)h * 16;
-  const float* __restrict__ sTi = a.pose_inv + (size_t)h * 12;
-  const float* __restrict__ F = st.final_tf;
-  const V3 ctr = v3(pose[3], pose[7], pose[11]);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  mom_f32x4 C0 = {0.f, 0.f, 0.f, 0.f}, C1 = {0.f, 0.f, 0.f, 0.f};
-  double cd[4] = {0.0, 0.0, 0.0, 0.0};
-  int n_def = 0, pending = 0;
-  const int base = blockIdx.x * (256 * R);
-  for (int r = 0; r < R; ++r) {
-    const int li = r * 256 + threadIdx.x, i = base + li;
-    V3 nt = v3(0.f, 0.f, 0.f), pc = v3(0.f, 0.f, 0.f);
-    float r0 = 0.f, d2 = 0.f;
-    const int res = i < a.ns ? icp_mom_point<true>(a, i, pose, sTi, F, ctr, nt, pc, r0, d2) : ICP_PT_REJECTED;
-    const unsigned long long dm = __ballot(res == ICP_PT_DEFERRED);
-    if (res == ICP_PT_DEFERRED) defer_i[wave][n_def + __popcll(dm & ((1ull << lane) - 1ull))] = (unsigned short)li;
-    n_def += __popcll(dm);
-    if (__ballot(res == ICP_PT_ACCEPTED) != 0ull) {
-      icp_mom_batch(stage[wave], lane, res == ICP_PT_ACCEPTED, nt, pc, r0, d2, C0, C1);
-      if (++pending == HOP_ICP_MOM_FLUSH) icp_mom_flush(cd, C0, C1), pending = 0;
-    }
-    while (n_def >= 64 || (r == R - 1 && n_def > 0)) {  // a dense batch of the queued lookups (wave-uniform condition)
-      const int take = n_def < 64 ? n_def : 64;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int mine = lane < take ? (int)defer_i[wave][lane] : -1;
-      const int rest = lane + 64 < n_def ? (int)defer_i[wave][lane + 64] : -1;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (rest >= 0) defer_i[wave][lane] = (unsigned short)rest;
-      n_def -= take;
-      V3 nt2 = v3(0.f, 0.f, 0.f), pc2 = v3(0.f, 0.f, 0.f);
-      float r02 = 0.f, d22 = 0.f;
-      const int res2 = mine >= 0 ? icp_mom_point<false>(a, base + mine, pose, sTi, F, ctr, nt2, pc2, r02, d22) : ICP_PT_REJECTED;
-      if (__ballot(res2 == ICP_PT_ACCEPTED) != 0ull) {
-        icp_mom_batch(stage[wave], lane, res2 == ICP_PT_ACCEPTED, nt2, pc2, r02, d22, C0, C1);
-        if (++pending == HOP_ICP_MOM_FLUSH) icp_mom_flush(cd, C0, C1), pending = 0;
-      }
-    }
-  }
-  if (pending) icp_mom_flush(cd, C0, C1);
-  // tile entry (row, col): lane (row / 4) * 16 + col, register row % 4
-  __syncthreads();
-  double* __restrict__ red = (double*)&stage[0][0];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) red[wave * 256 + ((lane >> 4) * 4 + k) * 16 + (lane & 15)] = cd[k];
-  __syncthreads();
-  if (threadIdx.x <= ICP_NMOM) {
-    const int e = c_mom_tab.at[threadIdx.x];
-    const double s = (red[e] + red[256 + e]) + (red[512 + e] + red[768 + e]);
-    a.partial[((size_t)hl * gridDim.x + blockIdx.x) * ICP_NMOM_STRIDE + threadIdx.x] = s;
-  }
-}
-#endif
 // ------------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------------
 // nn_mode 7: the moment form with INTEGER-EXACT sums -- the result no longer depends on which lane, wavefront or workgroup adds which
@@ -2980,7 +2717,7 @@ void launch_icp_fusedq_momm(const IcpArgs& a, int hb, hipStream_t s) {
 // moment kernels on caller-given operands, one element per thread -- what the instructions return on a device is compared with their
 // documented semantics restated in numpy (the CPU model of tests/emu states them a third time).
 //   out[0] momi_qp(x, y, 2^12)   [1] encoding of momm_qp(x, y)   [2] momi_pack(ia, ib)   [3] momi_dot2(ia, ib, ic)   [4] umed3(ia, ib, ic)
-//   [5] q_rank({ia & 0xffff, ia >> 16, ic & 0xffff}, ib, ic)   [6] momm_bytes<1>(ib, ia)   [7] momm_bytes<0>(ib, ia)
+//   [5] q_rank({xy = ia, z = ic >> 16}, lo = ib, hi = ic)   [6] momm_bytes<1>(ib, ia)   [7] momm_bytes<0>(ib, ia)
 //   [8] momi_q(x, y, 2^24)
 __global__ void k_dev_selftest_scalar(int n, const float* __restrict__ x, const float* __restrict__ y, const int* __restrict__ ia, const int* __restrict__ ib,
                                       const int* __restrict__ ic, unsigned* __restrict__ out) {
@@ -2992,7 +2729,7 @@ __global__ void k_dev_selftest_scalar(int n, const float* __restrict__ x, const 
   out[2 * (size_t)n + i] = momi_pack(ia[i], ib[i]);
   out[3 * (size_t)n + i] = (unsigned)momi_dot2(ua, ub, ic[i]);
   out[4 * (size_t)n + i] = umed3(ua, ub, uc);
-  out[5 * (size_t)n + i] = q_rank(Q3{(int)(ua & 0xffffu), (int)(ua >> 16), (int)(uc & 0xffffu)}, ub, uc);
+  out[5 * (size_t)n + i] = q_rank(Q3{ua, ia[i] < 0 ? (uc >> 16) : ((uc >> 16) | 0xABCD0000u)}, ub, uc);   // (the high half of l.z must not matter)
   out[6 * (size_t)n + i] = momm_bytes<1>(ub, ua);
   out[7 * (size_t)n + i] = momm_bytes<0>(ub, ua);
   out[8 * (size_t)n + i] = (unsigned)momi_q(x[i], y[i], 16777216.0f);
@@ -3039,144 +2776,6 @@ void launch_dev_selftest_mfma(int tiles, const int* a, const int* b, const int* 
   if (tiles > 0) hipLaunchKernelGGL(k_dev_selftest_mfma, dim3(tiles), dim3(64), 0, s, a, b, c, d);
 }
 
-// nn_mode 6 in two kernels (HOP_ICP_SPLIT, see hop_icp_refine): k_icp_scan does the lookups and PCL's two gates of k_icp_fusedq_mom and
-// writes the accepted correspondence of every (hypothesis, source point) as a 16-bit list position (0xFFFF: none) -- no accumulators,
-// so it runs at twice the occupancy --; k_icp_mom_accum walks the same (block, lane, r) partition, rebuilds the operands from that index
-// with the same float expressions and adds the 74 sums.  2 B per point and hypothesis of extra traffic (132 MB per launch at C2).
-// ------------------------------------------------------------------------------------------------
-template <bool DEFER>
-__device__ __forceinline__ int icp_scan_point(const IcpArgs& a, int i, const float* __restrict__ pose, const float* __restrict__ sTi,
-                                               const float* __restrict__ F, int& jout) {
-  const float4 p4 = a.s_pts4[i];
-  V3 q = v3(p4.x, p4.y, p4.z);
-  if (a.iter > 0) q = m4_point_fma(F, q);
-  float d2 = 3.0e38f;
-  int j = -1;
-  V3 tq;
-  if (cells_nnq<DEFER>(a.cells, m4_point_fma(sTi, q), pose, q, d2, j, tq)) return ICP_PT_DEFERRED;
-  if (j < 0 || !(d2 <= a.max_d2)) return ICP_PT_REJECTED;
-  const float4 tn = a.cells.nrm_idx[j];
-  const float4 n4 = a.s_nrm4[i];
-  V3 qn = v3(n4.x, n4.y, n4.z);
-  if (a.iter > 0) qn = m4_dir_fma(F, qn);
-  const V3 nt = m4_dir(pose, v3(tn.x, tn.y, tn.z));
-  if (!(((qn.x * nt.x + qn.y * nt.y) + qn.z * nt.z) > a.cos_thr)) return ICP_PT_REJECTED;
-  jout = j;
-  return ICP_PT_ACCEPTED;
-}
-#ifndef HOP_ICP_SCAN_W
-#define HOP_ICP_SCAN_W 8
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_SCAN_W))) void k_icp_scan(IcpArgs a, int R) {
-  __shared__ unsigned short defer_i[4][64 * ICP_ACCUM_R];
-  const int hl = blockIdx.y, h = a.h0 + hl;
-  const IcpState& st = a.state[hl];
-  if (!st.active) return;
-  const float* __restrict__ pose = a.pose + (size_t)h * 16;
-  const float* __restrict__ sTi = a.pose_inv + (size_t)h * 12;
-  const float* __restrict__ F = st.final_tf;
-  unsigned short* __restrict__ corr = a.corr16 + (size_t)hl * a.ns;
-  int n_def = 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int base = blockIdx.x * (256 * R);
-  for (int r = 0; r < R; ++r) {
-    const int li = r * 256 + threadIdx.x, i = base + li;
-    int j = 0xFFFF;
-    const int res = i < a.ns ? icp_scan_point<true>(a, i, pose, sTi, F, j) : ICP_PT_REJECTED;
-    const unsigned long long dm = __ballot(res == ICP_PT_DEFERRED);
-    if (res == ICP_PT_DEFERRED) defer_i[wave][n_def + __popcll(dm & ((1ull << lane) - 1ull))] = (unsigned short)li;
-    else if (i < a.ns) corr[i] = (unsigned short)(res == ICP_PT_ACCEPTED ? j : 0xFFFF);
-    n_def += __popcll(dm);
-  }
-  const int nd = __builtin_amdgcn_readfirstlane(n_def);
-  for (int t = lane; t < nd; t += 64) {
-    const int i = base + defer_i[wave][t];
-    int j = 0xFFFF;
-    const int res = icp_scan_point<false>(a, i, pose, sTi, F, j);
-    corr[i] = (unsigned short)(res == ICP_PT_ACCEPTED ? j : 0xFFFF);
-  }
-}
-#ifndef HOP_ICP_ACC_U
-#define HOP_ICP_ACC_U 4
-#endif
-__global__ __launch_bounds__(256) void k_icp_mom_accum(IcpArgs a, int R) {
-  __shared__ BlockSumLds bs;
-  __shared__ int n_cnt[4];
-  const int hl = blockIdx.y, h = a.h0 + hl;
-  const IcpState& st = a.state[hl];
-  if (!st.active) return;
-  const float* __restrict__ pose = a.pose + (size_t)h * 16;
-  const float* __restrict__ F = st.final_tf;
-  const unsigned short* __restrict__ corr = a.corr16 + (size_t)hl * a.ns;
-  const V3 ctr = v3(pose[3], pose[7], pose[11]);
-  float acc[ICP_NMOM];
-#pragma unroll
-  for (int k = 0; k < ICP_NMOM; ++k) acc[k] = 0.f;
-  int n_wave = 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int base = blockIdx.x * (256 * R);
-  // branch-free over HOP_ICP_ACC_U points per trip: the index, then the three gathers of every point of the trip are in flight together
-  // (a lane without a correspondence reads entry 0 and adds zeros: fma(0, x, s) and s + 0 leave s as it is)
-  for (int r0i = 0; r0i < R; r0i += HOP_ICP_ACC_U) {
-    int jj[HOP_ICP_ACC_U];
-    bool okk[HOP_ICP_ACC_U];
-#pragma unroll
-    for (int u = 0; u < HOP_ICP_ACC_U; ++u) {
-      const int i = base + (r0i + u) * 256 + threadIdx.x;
-      const int j = (r0i + u < R && i < a.ns) ? (int)corr[i] : 0xFFFF;
-      okk[u] = j != 0xFFFF, jj[u] = okk[u] ? j : 0;
-    }
-    float4 p4[HOP_ICP_ACC_U], w4[HOP_ICP_ACC_U], t4[HOP_ICP_ACC_U];
-#pragma unroll
-    for (int u = 0; u < HOP_ICP_ACC_U; ++u) {
-      const int i = min(base + (r0i + u) * 256 + (int)threadIdx.x, a.ns - 1);
-      p4[u] = a.s_pts4[i], w4[u] = a.cells.pts_idx[jj[u]], t4[u] = a.cells.nrm_idx[jj[u]];
-    }
-#pragma unroll
-    for (int u = 0; u < HOP_ICP_ACC_U; ++u) {
-      const bool ok = okk[u];
-      n_wave += __popcll(__ballot(ok));
-      V3 q = v3(p4[u].x, p4[u].y, p4[u].z);
-      if (a.iter > 0) q = m4_point_fma(F, q);
-      const V3 tq = m4_point(pose, v3(w4[u].x, w4[u].y, w4[u].z));
-      const float d2 = ok ? sqdist_flann(q, tq) : 0.f;
-      V3 nt = m4_dir(pose, v3(t4[u].x, t4[u].y, t4[u].z));
-      nt = ok ? nt : v3(0.f, 0.f, 0.f);
-      const V3 pc = q - ctr;
-      const float r0 = vdot(q - tq, nt);
-      const float nn[6] = {nt.x * nt.x, nt.x * nt.y, nt.x * nt.z, nt.y * nt.y, nt.y * nt.z, nt.z * nt.z};
-      const float pp[6] = {pc.x * pc.x, pc.x * pc.y, pc.x * pc.z, pc.y * pc.y, pc.y * pc.z, pc.z * pc.z};
-      const float pv[3] = {pc.x, pc.y, pc.z}, nv[3] = {nt.x, nt.y, nt.z};
-#pragma unroll
-      for (int x = 0; x < 6; ++x) {
-#pragma unroll
-        for (int v = 0; v < 6; ++v) acc[x * 6 + v] = __builtin_fmaf(nn[x], pp[v], acc[x * 6 + v]);
-#pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2) acc[36 + x * 3 + b2] = __builtin_fmaf(nn[x], pv[b2], acc[36 + x * 3 + b2]);
-        acc[54 + x] += nn[x];
-      }
-#pragma unroll
-      for (int c2 = 0; c2 < 3; ++c2) {
-        const float nr = nv[c2] * r0;
-#pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2) acc[60 + c2 * 3 + b2] = __builtin_fmaf(nr, pv[b2], acc[60 + c2 * 3 + b2]);
-        acc[69 + c2] += nr;
-      }
-      acc[72] = __builtin_fmaf(r0, r0, acc[72]);
-      acc[73] += d2;
-    }
-  }
-  double* __restrict__ out = a.partial + ((size_t)hl * gridDim.x + blockIdx.x) * ICP_NMOM_STRIDE;
-  if (lane == 0) n_cnt[wave] = n_wave;
-  block_sum_floats<ICP_NMOM>(acc, bs, out);
-  if (threadIdx.x == 0) out[ICP_NMOM] = (double)((n_cnt[0] + n_cnt[1]) + (n_cnt[2] + n_cnt[3]));
-}
-void launch_icp_scan_accum(const IcpArgs& a, int hb, hipStream_t s) {
-  const int nb = icp_blocks_per_hyp(a.ns, true);
-  const int R = (a.ns + 256 * nb - 1) / (256 * nb);
-  hipLaunchKernelGGL(k_icp_scan, dim3(nb, hb), dim3(256), 0, s, a, R);
-  hipLaunchKernelGGL(k_icp_mom_accum, dim3(nb, hb), dim3(256), 0, s, a, R);
-}
 void launch_icp_fusedq_mom(const IcpArgs& a, int hb, hipStream_t s) {
   const int nb = icp_blocks_per_hyp(a.ns, true);
   const int R = (a.ns + 256 * nb - 1) / (256 * nb);
@@ -3744,12 +3343,9 @@ __global__ void k_grid_cell_ids(const float* __restrict__ x, const float* __rest
 void launch_ppf_matrix(const PpfMatrixArgs& a, hipStream_t s) {
   dim3 grid((a.words + 3) / 4, (a.n + PPF_ROWS - 1) / PPF_ROWS);
   const bool sym = !getenv("HOP_PPF_NO_SYM");  // (tests compare the kernels)
-  // measured (C2, N = 20 000): the tiled form halves the HBM writes (172 -> 88 MB) and is SLOWER, 1.48 vs 1.18 ms (8 x 8 words: 2.9 ms) --
-  // the kernel is bound by its vector instructions and the bitmap probes, not by its stores; it stays an experiment switch
-  if (a.angle_thr && sym && getenv("HOP_PPF_TILE")) {
-    const int tiles = (a.words + PPF_TW - 1) / PPF_TW;
-    hipLaunchKernelGGL(k_ppf_matrix_tile, dim3(tiles, tiles), dim3(256), 0, s, a);
-  } else if (a.angle_thr && sym) hipLaunchKernelGGL(k_ppf_matrix_sym, grid, dim3(256), 0, s, a);
+  // (a tiled form that staged the reverse words in LDS and halved the HBM writes, 172 -> 88 MB, was SLOWER at C2, 1.48 vs 1.18 ms: the kernel is
+  // bound by its vector instructions and the bitmap probes, not by its stores -- profiles/HISTORY.md)
+  if (a.angle_thr && sym) hipLaunchKernelGGL(k_ppf_matrix_sym, grid, dim3(256), 0, s, a);
   else if (a.angle_thr) hipLaunchKernelGGL(k_ppf_matrix<true>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(k_ppf_matrix<false>, grid, dim3(256), 0, s, a);
 }

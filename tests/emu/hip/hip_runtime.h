@@ -185,6 +185,10 @@ template <class D, class A, class B, class Cc>
 inline void v_mad_i32_i24(D& d, A a, B b, Cc c) {  // D = sext24(a) * sext24(b) + c, low 32 bits
   d = (D)((unsigned)sext24((int)a) * (unsigned)sext24((int)b) + (unsigned)c);
 }
+template <class D, class A, class B, class Cc>
+inline void v_mad_i32_i16(D& d, A a, B b, Cc c) {  // D = sext16(a) * sext16(b) + c (low halves of the sources), low 32 bits
+  d = (D)((unsigned)((int)(short)(unsigned short)(unsigned)a * (int)(short)(unsigned short)(unsigned)b) + (unsigned)c);
+}
 }  // namespace emu_asm
 // v_mfma_i32_16x16x64_i8: D[16][16] = C + A[16][64] B[64][16], 8-bit signed inputs, 32-bit wrapping sums.  Operand layout (CDNA3/4 MFMA
 // register maps; K = 64 laid out as four blocks of 16 consecutive k, one block per 16-lane group, 16 bytes = 4 VGPRs per lane):
@@ -201,6 +205,11 @@ inline emu_v4i32 emu_mfma_i32_16x16x64_i8(int site, emu_v4i32 a, emu_v4i32 b, em
 }
 #define __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, cbsz, abid, blgp) emu_mfma_i32_16x16x64_i8(EMU_SITE(), (a), (b), (c))
 
+// (only the -DHOP_ICP_COUNT statistics build names these: "the first active lane" is modelled as lane 0 of the wavefront)
+#define __builtin_amdgcn_read_exec_lo() 0u
+#define __builtin_amdgcn_read_exec_hi() 0u
+#define __builtin_amdgcn_mbcnt_lo(mask, v) ((unsigned)(threadIdx.x & 63u))
+#define __builtin_amdgcn_mbcnt_hi(mask, v) (v)
 #define __builtin_amdgcn_sqrtf(x) (std::sqrt((float)(x)))          // (hardware: 1 ulp estimate; modelled as correctly rounded)
 #define __builtin_amdgcn_rsqf(x) (1.0f / std::sqrt((float)(x)))
 #define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt((double)(x)))

@@ -92,10 +92,12 @@ def test_scalar_primitives_match_their_documented_semantics(ctx):
     # [4] v_med3_u32
     ua, ub, uc = (v.view(np.uint32).astype(np.int64) for v in (ia, ib, ic))
     assert np.array_equal(out[4].astype(np.int64), np.median(np.stack([ua, ub, uc]), axis=0).astype(np.int64))
-    # [5] q_rank: three differences of 16-bit fields, squares by v_mad_i32_i24 (24-bit signed operands), 32-bit wrapping sum
-    lx, ly, lz = ua & 0xFFFF, ua >> 16, uc & 0xFFFF
-    dx, dy, dz = lx - (ub & 0xFFFF), ly - (ub >> 16), lz - (uc & 0xFFFF)
-    rank = (_sext(dz, 24) ** 2 + _sext(dy, 24) ** 2 + _sext(dx, 24) ** 2) & 0xFFFFFFFF
+    # [5] q_rank({xy = ia, z = ic >> 16}, lo = ib, hi = ic): 16-bit differences (v_pk_sub), x and y squares by v_dot2_i32_i16, the z square by
+    # v_mad_i32_i16 on the low half of the second difference; 32-bit wrapping sum
+    dx = _sext((ua & 0xFFFF) - (ub & 0xFFFF), 16)
+    dy = _sext((ua >> 16) - (ub >> 16), 16)
+    dz = _sext((uc >> 16) - (uc & 0xFFFF), 16)
+    rank = (dx * dx + dy * dy + dz * dz) & 0xFFFFFFFF
     assert np.array_equal(out[5].astype(np.int64), rank)
     # [6], [7] momm_bytes<ODD>(lo = ib, hi = ia): bytes ODD, ODD + 2 of lo, then of hi (the compiler's v_perm_b32 / bit-field sequence)
     pool = (ua << 32) | ub

@@ -5,8 +5,8 @@ starting poses with HIP events (hop_timing_get) and compare the results between 
 
     python tools/icp_bench.py [--reps 3] [--scene 20000] [--hyps 10240]
 
-Variants: ICP nn_mode 2 (split kernels), 3 (fused, chained increments), 3 with HOP_ICP_OLD_FUSED=1 (the round-1 kernel),
-4 (fused, composed increments); computeLCP nn_mode 2 (ordered sum over a term table), 3 (in-wave partial sums).
+Variants: ICP nn_mode 2 (split kernels), 3 (fused, chained increments), 4 (fused, composed increments), 6 (float moment sums), 7 (integer moment
+sums on the matrix cores), 7dot2 (the same on the vector units); computeLCP nn_mode 2 (ordered sum over a term table), 3 (in-wave partial sums).
 """
 import argparse
 import json
@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--bases", type=int, default=2048)
     ap.add_argument("--hyps", type=int, default=10240)
     ap.add_argument("--lcp-modes", default="2,3")
-    ap.add_argument("--icp-modes", default="old3,3,4")
+    ap.add_argument("--icp-modes", default="4,6,7,7dot2")
     args = ap.parse_args()
     import hop_loader
     hop = hop_loader.load()
@@ -52,12 +52,8 @@ def main():
     bytes_per_hyp = 24 * (N + args.model) + 72
     res = {}
     for name in args.icp_modes.split(","):
-        mode = int(name.replace("old", "").replace("dot2", ""))
+        mode = int(name.replace("dot2", ""))
         os.environ["HOP_ICP_MFMA"] = "0" if name.endswith("dot2") else "1"   # "7dot2": nn_mode 7 with the moment sums on the vector units (k_icp_fusedq_momi)
-        if name.startswith("old"):
-            os.environ["HOP_ICP_OLD_FUSED"] = "1"
-        else:
-            os.environ.pop("HOP_ICP_OLD_FUSED", None)
         ms, nl, ms_all = [], [], []
         for rep in range(args.reps + 1):
             c.hypos_upload(poses0, scores0)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""The experiment behind the 12-bit grid of nn_mode 7's moment form (VERDICT r04 "has no committed artifact").
+"""The experiment behind the 12-bit grid of nn_mode 7's moment form (DESIGN.md section 4 "ICP, nn_mode 7"; VERDICT r04 "has no committed artifact").
 
 For grids of 9 .. 20 bits (|U| <= 2^bits) the oracle's minimiser 7 refines the hypotheses of the as-shipped chain (generate -> cluster -> the
 first 100) on a few frames; every width is compared
