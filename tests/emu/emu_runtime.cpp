@@ -253,6 +253,27 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 struct emu_stream {
   int id;
 };
+namespace {
+struct PendingCopy {
+  emu_stream* s;
+  void* dst;
+  const void* src;
+  size_t bytes;
+};
+std::mutex g_pending_lock;
+std::vector<PendingCopy> g_pending;  // in enqueue order (all streams)
+const bool g_async = !(getenv("EMU_ASYNC") && std::atoi(getenv("EMU_ASYNC")) == 0);
+}  // namespace
+extern "C" void emu_stream_flush(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_pending_lock);
+  size_t w = 0;
+  for (size_t r = 0; r < g_pending.size(); ++r) {
+    PendingCopy& c = g_pending[r];
+    if (s == nullptr || c.s == s || c.s == nullptr) std::memmove(c.dst, c.src, c.bytes);  // (the null stream orders with every stream)
+    else g_pending[w++] = c;
+  }
+  g_pending.resize(w);
+}
 struct emu_event {
   std::chrono::steady_clock::time_point t;
 };
@@ -271,41 +292,86 @@ hipError_t hipGetDevice(int* d) {
   *d = g_device;
   return hipSuccess;
 }
-hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipDeviceSynchronize() {
+  emu_stream_flush(nullptr);
+  return hipSuccess;
+}
 hipError_t hipGetLastError() { return hipSuccess; }
-hipError_t emu_malloc(void** p, size_t bytes) {
-  *p = std::aligned_alloc(256, (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255);
+namespace {
+std::mutex g_range_lock;
+std::map<uintptr_t, std::pair<size_t, int>> g_ranges;  // start -> (bytes, kind: 0 device, 1 pinned host)
+void range_add(void* p, size_t bytes, int kind) {
+  std::lock_guard<std::mutex> lk(g_range_lock);
+  g_ranges[(uintptr_t)p] = {bytes, kind};
+}
+void range_del(void* p) {
+  std::lock_guard<std::mutex> lk(g_range_lock);
+  g_ranges.erase((uintptr_t)p);
+}
+bool is_pageable_host(const void* p) {  // neither device memory nor pinned host memory
+  std::lock_guard<std::mutex> lk(g_range_lock);
+  auto it = g_ranges.upper_bound((uintptr_t)p);
+  if (it == g_ranges.begin()) return true;
+  --it;
+  return !((uintptr_t)p < it->first + it->second.first);
+}
+}  // namespace
+hipError_t emu_malloc(void** p, size_t bytes, int kind) {
+  const size_t sz = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+  *p = std::aligned_alloc(256, sz);
   if (!*p) return hipErrorOutOfMemory;
   std::memset(*p, 0xCD, std::min<size_t>(bytes, 1 << 20));  // (device memory is not zeroed: make reads of unwritten memory visible)
+  range_add(*p, sz, kind);
   return hipSuccess;
 }
 hipError_t hipFree(void* p) {
+  emu_stream_flush(nullptr);  // (hipFree synchronises the device)
+  range_del(p);
   std::free(p);
   return hipSuccess;
 }
 hipError_t hipHostFree(void* p) {
+  emu_stream_flush(nullptr);
+  range_del(p);
   std::free(p);
   return hipSuccess;
 }
-hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
-hipError_t hipHostUnregister(void*) { return hipSuccess; }
+hipError_t hipHostRegister(void* p, size_t bytes, unsigned) {
+  range_add(p, bytes, 1);
+  return hipSuccess;
+}
+hipError_t hipHostUnregister(void* p) {
+  emu_stream_flush(nullptr);
+  range_del(p);
+  return hipSuccess;
+}
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) {
+  emu_stream_flush(nullptr);  // (a synchronous copy on the null stream waits for the blocking streams; the model orders it after everything)
   std::memmove(dst, src, bytes);
   return hipSuccess;
 }
-hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind, hipStream_t) {
-  std::memmove(dst, src, bytes);
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind, hipStream_t s) {
+  if (!g_async || is_pageable_host(src) || is_pageable_host(dst)) {  // pageable host memory: staged / waited for inside the call
+    emu_stream_flush(s);
+    std::memmove(dst, src, bytes);
+    return hipSuccess;
+  }
+  std::lock_guard<std::mutex> lk(g_pending_lock);
+  if (bytes) g_pending.push_back(PendingCopy{s, dst, src, bytes});
   return hipSuccess;
 }
-hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t) {
+hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t s) {
+  emu_stream_flush(s);
   std::memset(dst, value, bytes);
   return hipSuccess;
 }
 hipError_t hipMemset(void* dst, int value, size_t bytes) {
+  emu_stream_flush(nullptr);
   std::memset(dst, value, bytes);
   return hipSuccess;
 }
-hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int value, size_t count, hipStream_t) {
+hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int value, size_t count, hipStream_t s) {
+  emu_stream_flush(s);
   int* p = static_cast<int*>(dst);
   for (size_t i = 0; i < count; ++i) p[i] = value;
   return hipSuccess;
@@ -316,10 +382,14 @@ hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
 }
 hipError_t hipStreamCreate(hipStream_t* s) { return hipStreamCreateWithFlags(s, 0); }
 hipError_t hipStreamDestroy(hipStream_t s) {
+  emu_stream_flush(s);
   delete s;
   return hipSuccess;
 }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s) {
+  emu_stream_flush(s);
+  return hipSuccess;
+}
 hipError_t hipEventCreate(hipEvent_t* e) {
   *e = new emu_event{std::chrono::steady_clock::now()};
   return hipSuccess;
@@ -328,7 +398,8 @@ hipError_t hipEventDestroy(hipEvent_t e) {
   delete e;
   return hipSuccess;
 }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+  emu_stream_flush(s);
   e->t = std::chrono::steady_clock::now();
   return hipSuccess;
 }

@@ -4,6 +4,7 @@
 // C++ dataset driver's end-of-shard gather -- runs with MORE THAN ONE RANK where no GPU (let alone two) is available.  "Device" buffers
 // are host memory in the model, so a collective is a file written per rank and read by the others.  Not RCCL: no topology, no streams, no
 // performance; the call sequence, the buffer arithmetic and the rank bookkeeping of the caller are what it exercises.
+#include <dlfcn.h>
 #include <dirent.h>
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -87,7 +88,9 @@ int ncclCommCount(void* comm, int* n) {
   *n = static_cast<Comm*>(comm)->nranks;
   return 0;
 }
-int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* comm, void* /*stream*/) {
+int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* comm, void* stream) {
+  // the collective is ordered on `stream`: copies the model still holds queued there (tests/emu/emu_runtime.cpp) happen first
+  if (auto flush = reinterpret_cast<void (*)(void*)>(dlsym(RTLD_DEFAULT, "emu_stream_flush"))) flush(stream);
   Comm* c = static_cast<Comm*>(comm);
   const size_t bytes = count * type_bytes(dtype);
   const std::string base = c->dir + "/ag" + std::to_string(++c->seq) + ".r";

@@ -210,10 +210,40 @@ inline emu_v4i32 emu_mfma_i32_16x16x64_i8(int site, emu_v4i32 a, emu_v4i32 b, em
 #define __builtin_amdgcn_read_exec_hi() 0u
 #define __builtin_amdgcn_mbcnt_lo(mask, v) ((unsigned)(threadIdx.x & 63u))
 #define __builtin_amdgcn_mbcnt_hi(mask, v) (v)
-#define __builtin_amdgcn_sqrtf(x) (std::sqrt((float)(x)))          // (hardware: 1 ulp estimate; modelled as correctly rounded)
-#define __builtin_amdgcn_rsqf(x) (1.0f / std::sqrt((float)(x)))
-#define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt((double)(x)))
-#define __builtin_amdgcn_rcp(x) (1.0 / (double)(x))
+// The hardware's square-root / reciprocal instructions are ESTIMATES (v_sqrt_f32 / v_rsq_f32: 1 ulp; v_rsq_f64 / v_rcp_f64: about single
+// precision).  Modelled as correctly rounded by default; EMU_ULP=<k> perturbs every result -- f32 by an integer in [-k, k] units in the last
+// place, f64 by up to k 2^-24 relative, both a fixed function of the operand's bits -- so that a kernel which silently relies on a correctly
+// rounded estimate changes its answers (the kernels that use estimates re-decide near-ties with exact operations, or refine them).
+inline int emu_ulp_k() {
+  static const int k = std::getenv("EMU_ULP") ? std::atoi(std::getenv("EMU_ULP")) : 0;
+  return k;
+}
+inline unsigned emu_mix(unsigned long long v) {
+  v ^= v >> 33, v *= 0xff51afd7ed558ccdull, v ^= v >> 33, v *= 0xc4ceb9fe1a85ec53ull, v ^= v >> 33;
+  return (unsigned)v;
+}
+inline float emu_est_f32(float exact, float operand) {
+  const int k = emu_ulp_k();
+  if (k == 0 || !std::isfinite(exact) || exact == 0.f) return exact;
+  unsigned ob, eb;
+  std::memcpy(&ob, &operand, 4), std::memcpy(&eb, &exact, 4);
+  eb += (unsigned)((int)(emu_mix(ob) % (unsigned)(2 * k + 1)) - k);
+  float r;
+  std::memcpy(&r, &eb, 4);
+  return std::isfinite(r) ? r : exact;
+}
+inline double emu_est_f64(double exact, double operand) {
+  const int k = emu_ulp_k();
+  if (k == 0 || !std::isfinite(exact) || exact == 0.0) return exact;
+  unsigned long long ob;
+  std::memcpy(&ob, &operand, 8);
+  const double u = (double)(emu_mix(ob) % 2001u) / 1000.0 - 1.0;  // [-1, 1]
+  return exact * (1.0 + u * (double)k * 5.9604644775390625e-08);
+}
+#define __builtin_amdgcn_sqrtf(x) emu_est_f32(std::sqrt((float)(x)), (float)(x))
+#define __builtin_amdgcn_rsqf(x) emu_est_f32(1.0f / std::sqrt((float)(x)), (float)(x))
+#define __builtin_amdgcn_rsq(x) emu_est_f64(1.0 / std::sqrt((double)(x)), (double)(x))
+#define __builtin_amdgcn_rcp(x) emu_est_f64(1.0 / (double)(x), (double)(x))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 inline int __float_as_int(float f) {
   int i;
@@ -316,14 +346,14 @@ hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int* d);
 hipError_t hipDeviceSynchronize();
 hipError_t hipGetLastError();
-hipError_t emu_malloc(void** p, size_t bytes);
+hipError_t emu_malloc(void** p, size_t bytes, int kind);  // kind 0: device memory, 1: pinned host memory
 template <class T>
 inline hipError_t hipMalloc(T** p, size_t bytes) {
-  return emu_malloc(reinterpret_cast<void**>(p), bytes);
+  return emu_malloc(reinterpret_cast<void**>(p), bytes, 0);
 }
 template <class T>
 inline hipError_t hipHostMalloc(T** p, size_t bytes, unsigned = 0) {
-  return emu_malloc(reinterpret_cast<void**>(p), bytes);
+  return emu_malloc(reinterpret_cast<void**>(p), bytes, 1);
 }
 hipError_t hipFree(void* p);
 hipError_t hipHostFree(void* p);
@@ -352,6 +382,14 @@ inline hipError_t hipMemcpyFromSymbol(void* dst, const void* sym, size_t bytes, 
   std::memcpy(dst, static_cast<const char*>(sym) + off, bytes);
   return hipSuccess;
 }
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu::launch(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })
+// Streams are in order, but NOT synchronous: a hipMemcpyAsync is queued and performed as LATE as the stream order allows (before the next
+// kernel / memset / event / synchronisation of its stream, or any device-wide synchronisation) -- the worst schedule a device may legally
+// choose.  A caller that reuses a staging buffer before its stream was synchronised therefore corrupts its own data here, visibly.
+// Only copies between device memory and PINNED host memory (hipHostMalloc / hipHostRegister) are queued: with pageable host memory the runtime
+// stages the data before the call returns (a caller may reuse such a buffer at once), and the model copies at the call, after the stream's
+// queued copies.  EMU_ASYNC=0: every copy happens at the call (round 4's model).
+extern "C" void emu_stream_flush(hipStream_t s);  // performs the queued copies of s (nullptr: of every stream); also used by tests/emu/fake_rccl.cpp
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  (emu_stream_flush(stream), emu::launch(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); }))
 
 #endif  // HOP_EMU_HIP_RUNTIME_H_

@@ -96,6 +96,21 @@ def test_gfx950_primitives_as_the_model_states_them(emu_lib):
     assert _child_pytest([os.path.join("tests", "test_gpu_dev_selftest.py")]) == 4
 
 
+def test_the_model_sees_a_staging_slot_reused_before_its_stream_was_synchronised(emu_lib, tmp_path):
+    """round 4's model ran every hipMemcpyAsync at the call, so the pinned-staging ring of hop_ctx_h2d -- reuse of a slot
+    before hipStreamSynchronize -- was invisible to it.  The model now performs a queued copy as LATE as the stream order allows (the worst
+    schedule a device may choose); tests/cpp/emu_async_check.cpp shows that it answers "corrupted" to the premature reuse, "ok" to the legal
+    sequences (synchronise first; pageable source), and that EMU_ASYNC=0 is the old behaviour.  Every other test of this file ran with it."""
+    exe = str(tmp_path / "emu_async_check")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I" + EMU_DIR, os.path.join(ROOT, "tests", "cpp", "emu_async_check.cpp"),
+                        os.path.join(EMU_DIR, "_build", "emu_runtime.o"), "-lpthread", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = subprocess.run([exe], capture_output=True, text=True, env={k: v for k, v in os.environ.items() if k != "EMU_ASYNC"}).stdout.split()
+    assert out == ["staged_then_synced", "ok", "reused_before_sync", "corrupted", "pageable_source", "ok"], out
+    old = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, EMU_ASYNC="0")).stdout.split()
+    assert old == ["staged_then_synced", "ok", "reused_before_sync", "ok", "pageable_source", "ok"], old
+
+
 def _emu_env(emu_lib, **extra):
     """children that find the model under the name libhop.so and the file-based stand-in for RCCL (tests/emu/fake_rccl.cpp) under librccl.so"""
     e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HOP_FORCE", "HOP_COMM_ID_FILE", "HOP_GATHER")}
