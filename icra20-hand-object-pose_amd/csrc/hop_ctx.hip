@@ -53,17 +53,18 @@ struct GridStore {
 };
 
 struct CellListStore {
-  DevBuf start_d, pts_d, nrm_d, u2_d, count_d, work_d, keep_d, range_d, nrm_idx_d, pts_idx_d, rec_d, qlist_d;
+  DevBuf start_d, pts_d, nrm_d, u2_d, count_d, work_d, keep_d, range_d, nrm_idx_d, pts_idx_d, rec_d, qlist_d, head_d;
   hop::CellListDev c{};
   bool valid = false;
   float cell = 0, max_dist = 0, coord_mag = 0;
   bool packed = false, pack_requested = false;
   int sub = 1;  // per-frame lists: subdivision of the ring grid they were built with
   float avg_len = 0;  // entries per voxel with candidates at the last build (chooses the lanes per voxel of the next one)
+  size_t total_entries = 0;  // length of pts at the last build
   void release() {
     start_d.release(), pts_d.release(), nrm_d.release(), u2_d.release(), count_d.release(), work_d.release(), keep_d.release(), range_d.release();
-    nrm_idx_d.release(), pts_idx_d.release(), rec_d.release(), qlist_d.release();
-    valid = false;
+    nrm_idx_d.release(), pts_idx_d.release(), rec_d.release(), qlist_d.release(), head_d.release();
+    valid = false, c.head = nullptr;
   }
 };
 
@@ -306,7 +307,7 @@ int build_grid(hop_ctx* c, GridStore& gs, const float* x, const float* y, const 
 int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const CloudDevice& d, float max_dist, float cell, bool packed = false) {
   // nothing of a previous build may be taken for valid while this one overwrites its geometry and buffers (a failed build must not
   // leave the old cell / max_dist next to new arrays)
-  cs.valid = false, cs.packed = false, cs.c.rec = nullptr, cs.c.qlist = nullptr;
+  cs.valid = false, cs.packed = false, cs.c.rec = nullptr, cs.c.qlist = nullptr, cs.c.head = nullptr;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (int i = 0; i < h.n; ++i) {
     mn[0] = std::min(mn[0], h.x[i]), mn[1] = std::min(mn[1], h.y[i]), mn[2] = std::min(mn[2], h.z[i]);
@@ -442,7 +443,7 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
     if (!in_range) {
       // a list does not fit the 16-bit local frame: the plain lists built above are complete and exact on their own -- the callers
       // fall back to them (launch_icp_fused) when rec is null; pts_idx / nrm_idx are read by the packed kernels only
-      cs.valid = true, cs.cell = cell, cs.max_dist = max_dist, cs.coord_mag = c->coord_mag;
+      cs.valid = true, cs.cell = cell, cs.max_dist = max_dist, cs.coord_mag = c->coord_mag, cs.total_entries = total;
       return HOP_OK;
     }
     if (ql.empty()) ql.assign(4, 0xFFFFFFFFu);
@@ -463,7 +464,7 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
     cs.packed = true;
     if (getenv("HOP_PROFILE_SELECT")) std::printf("packed lists: %.1f MB records + %.1f MB chunks, step %.3g m\n", rec.size() * 4e-6, ql.size() * 4e-6, step);
   }
-  cs.valid = true, cs.cell = cell, cs.max_dist = max_dist, cs.coord_mag = c->coord_mag;
+  cs.valid = true, cs.cell = cell, cs.max_dist = max_dist, cs.coord_mag = c->coord_mag, cs.total_entries = total;
   if (getenv("HOP_PROFILE_SELECT")) std::printf("cell lists: %zu cells, %zu entries (%.1f per cell), cell %.4f\n", ncell, total, (double)total / (double)ncell, cell);
   return HOP_OK;
 }
@@ -475,6 +476,7 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   const GridDev& g = gs.g;
   CellListBuildArgs a{};
   a.margin = 4 * GRID_MARGIN;
+  cs.c.head = nullptr;  // (belongs to the lists this call replaces; cell_list_heads rebuilds it on demand)
   if (!(g.cell > 0) || sub < 1) return HOP_E_STATE;
   // the list grid is the ring grid padded by enough ring cells to reach max_dist beyond the cloud's box, subdivided
   const int pad = (int)std::ceil((max_dist + a.margin + 1.0e-6f) / g.cell);
@@ -531,7 +533,7 @@ int build_cell_lists_local(hop_ctx* c, CellListStore& cs, const GridStore& gs, c
   HIPCHK(c, cs.range_d.ensure(sizeof(int2) * ncell));
   launch_cell_ranges(cs.c.start, (int)ncell, cs.range_d.as<int2>(), c->stream);
   cs.c.range = cs.range_d.as<int2>();
-  cs.valid = true, cs.cell = a.cell, cs.max_dist = max_dist, cs.coord_mag = c->coord_mag;
+  cs.valid = true, cs.cell = a.cell, cs.max_dist = max_dist, cs.coord_mag = c->coord_mag, cs.total_entries = (size_t)std::max(total, 0);
   if (getenv("HOP_PROFILE_SELECT")) {
     std::vector<int> cnt(ncell);
     (void)hipMemcpy(cnt.data(), a.count, sizeof(int) * ncell, hipMemcpyDeviceToHost);
@@ -1591,6 +1593,19 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
   return HOP_OK;
 }
 
+// the inline-head records of a list store (CellListDev::head), built on demand for computeLCP's reduced-sum kernel: one small kernel over the
+// cells.  Stores with more than 2^23 cells or 2^24 entries keep head = null (the kernel then reads range records as before).
+static int cell_list_heads(hop_ctx* c, CellListStore& cs) {
+  if (cs.c.head || !cs.valid) return HOP_OK;
+  const size_t ncell = (size_t)cs.c.dx * cs.c.dy * cs.c.dz;
+  if (ncell == 0 || ncell > ((size_t)1 << 23)) return HOP_OK;
+  if (cs.total_entries >= ((size_t)1 << 24)) return HOP_OK;
+  HIPCHK(c, cs.head_d.ensure(sizeof(uint4) * ncell));
+  launch_cell_heads(cs.c.range, cs.c.pts, (int)ncell, cs.head_d.as<uint4>(), c->stream);
+  cs.c.head = cs.head_d.as<uint4>();
+  return HOP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- LCP
 int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_out, float* best_score_out, int* best_index_out) {
   if (!c || !o || !(o->dist > 0)) return HOP_E_INVALID;
@@ -1670,6 +1685,12 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
         const int rc = build_cell_lists_local(c, c->scene_cells, c->scene_grid, &c->scene_unit_d, o->dist, sub, 0);
         if (rc) return rc;
         c->scene_cells.sub = sub;
+      }
+      if (nn_mode == 3 && !getenv("HOP_LCP_NO_HEAD")) {  // (HOP_LCP_NO_HEAD=1: the range-record lookups of rounds 2-4, for A/B runs)
+        int rc = cell_list_heads(c, c->model_cells[HOP_MODEL_1MM]);
+        if (!rc) rc = cell_list_heads(c, c->scene_cells);
+        if (rc) return rc;
+        a.model_cells = c->model_cells[HOP_MODEL_1MM].c;
       }
       a.scene_cells = c->scene_cells.c;
     }
@@ -2283,6 +2304,15 @@ int hop_debug_ppf_matrix(hop_ctx* c, unsigned long long* out, size_t cap_words, 
     if (cap_words < (size_t)N * W) return HOP_E_CAPACITY;
     std::memcpy(out, c->ppf_matrix_cached, sizeof(unsigned long long) * (size_t)N * W);
   }
+  return HOP_OK;
+}
+
+// development aid, not part of the ABI: list gathers of k_lcp_cells_fast per lookup (zero unless built with -DHOP_LCP_COUNT; tools/lcp_counters.py)
+int hop_debug_lcp_counters(hop_ctx* c, unsigned long long* out4, int reset) {
+  if (!c || !out4) return HOP_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hop::lcp_counters_read(out4, reset != 0);
   return HOP_OK;
 }
 

@@ -134,6 +134,10 @@ struct CellListDev {
   const int2* range;  // dx*dy*dz: (start[c], start[c+1]) side by side -- what the lookups read
   const float4* pts;  // concatenated lists; .w = original index (int bits)
   const float4* nrm;  // normals of the same entries (or null)
+  // head[cell] (computeLCP's reduced-sum kernel; or null) = the list's FIRST entry inline: x, y, z as float bits and
+  // (list position | min(length, 255) << 24): a list of one entry -- most of the 1 mm lists -- costs one 16-byte access instead of the
+  // range record plus the entry (cell_list_heads, k_cell_heads)
+  const uint4* head;
   float gox, goy, goz;     // -origin * inv_cell: grid coordinate = fma(q, inv_cell, go)
   const float4* nrm_idx;   // normals of the cloud by ORIGINAL index (AoS copy; 16 B per point, cache resident)
   const float4* pts_idx;   // points of the cloud by original index (AoS copy)
@@ -352,6 +356,8 @@ int lcp_cells_row_stride(int hb);
 int icp_blocks_per_hyp(int ns, bool cells);
 void launch_icp_fusedq_momi(const IcpArgs& a, int hb, hipStream_t s);
 void launch_icp_fusedq_momm(const IcpArgs& a, int hb, hipStream_t s);  // the same sums on the matrix cores
+void launch_cell_heads(const int2* range, const float4* pts, int ncell, uint4* head, hipStream_t s);
+void lcp_counters_read(unsigned long long* out4, bool reset);
 void launch_dev_selftest_scalar(int n, const float* x, const float* y, const int* ia, const int* ib, const int* ic, unsigned* out, hipStream_t s);
 void launch_dev_selftest_mfma(int tiles, const int* a, const int* b, const int* c, int* d, hipStream_t s);
 void launch_dev_selftest_momm(int batches, const int* U, const unsigned long long* mask, int* out, hipStream_t s);

@@ -1469,6 +1469,20 @@ __device__ __forceinline__ void cells_nn(const CellListDev& c, V3 qg, const floa
   }
 }
 
+// -DHOP_LCP_COUNT (tools/lcp_counters.py): gathers (per-lane 8 / 16-byte loads from the lists) of k_lcp_cells_fast per lookup
+__device__ unsigned long long g_lcp_count[4];  // [0] (point, hypothesis) lookups  [1] gathers of the forward lookups  [2] of the reciprocal lookups  [3] reciprocal lookups
+#ifdef HOP_LCP_COUNT
+#define LCP_COUNT(slot, v) atomicAdd(&g_lcp_count[slot], (unsigned long long)(v))
+#else
+#define LCP_COUNT(slot, v) do { } while (0)
+#endif
+void lcp_counters_read(unsigned long long* out4, bool reset) {
+  (void)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_lcp_count), sizeof(unsigned long long) * 4);
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lcp_count), z, sizeof(z));
+  }
+}
 // exact scan of a cell list whose entries are already in the query's frame (no transform): the distance expression
 // is the reference's, ties go to the lower original index
 __device__ __forceinline__ void cells_nn_plain(const CellListDev& c, V3 q, float& best, int& bpos) {
@@ -1476,10 +1490,12 @@ __device__ __forceinline__ void cells_nn_plain(const CellListDev& c, V3 q, float
   if (!(fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)c.dx && fy < (float)c.dy && fz < (float)c.dz)) return;
   const int cidx = ((int)fz * c.dy + (int)fy) * c.dx + (int)fx;
   const int2 rg = c.range[cidx];
+  LCP_COUNT(2, 1);
   const int beg = rg.x, end = rg.y;
   int bj = 0x7fffffff;
   for (int k = beg; k < end; ++k) {
     const float4 t = c.pts[k];
+    LCP_COUNT(2, 1);
     const float d2 = sqdist_flann(q, v3(t.x, t.y, t.z));
     const int j = __float_as_int(t.w);
     if (d2 < best || (d2 == best && j < bj)) best = d2, bj = j, bpos = k;
@@ -2544,10 +2560,23 @@ __constant__ MommTab c_momm_tab = MommTab();
 __device__ __forceinline__ float momm_qp(float x, float y) {  // the float whose low 16 encoding bits are rint(x y) (clamped to +-2^12) + 128
   return __builtin_amdgcn_fmed3f(__builtin_fmaf(x, y, MOMM_MAGIC), MOMM_LO, MOMM_HI);
 }
-// lookup, PCL's two gates and -- if accepted -- the gridded u as 13 floats in the magic form, the gridded squared distance in dq
+// lookup, PCL's two gates and -- if accepted -- the ingredients of u (target normal, scaled p', residual: momm_push grids the 13 components on
+// their way to the ring, no 13-register vector is ever live) and the gridded squared distance in dq
+struct MommU {
+  V3 n, ps;
+  float r0, s_n, s_r;
+  // component C of the gridded vector in the magic form (momm_qp): C = 3 a + b -> n_a p'_b, 9 + a -> n_a, 12 -> r0
+  template <int C>
+  __device__ __forceinline__ float get() const {
+    const float nv[3] = {n.x, n.y, n.z}, pv[3] = {ps.x, ps.y, ps.z};
+    if (C < 9) return momm_qp(nv[C / 3], pv[C % 3]);
+    if (C < 12) return momm_qp(nv[C - 9 < 0 ? 0 : C - 9], s_n);
+    return momm_qp(r0, s_r);
+  }
+};
 template <bool DEFER>
 __device__ __forceinline__ int icp_fusedq_point_momm(const IcpArgs& a, int i, const float* __restrict__ pose, const float* __restrict__ sTi,
-                                                      const float* __restrict__ F, V3 ctr, float (&T)[13], int& dq) {
+                                                      const float* __restrict__ F, V3 ctr, MommU& u, int& dq) {
   const float4 p4 = a.s_pts4[i];
   V3 q = v3(p4.x, p4.y, p4.z);
   if (a.iter > 0) q = m4_point_fma(F, q);
@@ -2564,17 +2593,14 @@ __device__ __forceinline__ int icp_fusedq_point_momm(const IcpArgs& a, int i, co
   if (!(((qn.x * nt.x + qn.y * nt.y) + qn.z * nt.z) > a.cos_thr)) return ICP_PT_REJECTED;
   const V3 pc = q - ctr;
   const float r0 = vdot(q - tq, nt);
-  const float ps[3] = {pc.x * a.mom_s_np, pc.y * a.mom_s_np, pc.z * a.mom_s_np};  // (powers of two: exact)
-  const float nv[3] = {nt.x, nt.y, nt.z};
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-#pragma unroll
-    for (int b = 0; b < 3; ++b) T[3 * c + b] = momm_qp(nv[c], ps[b]);
-    T[9 + c] = momm_qp(nv[c], a.mom_s_n);
-  }
-  T[12] = momm_qp(r0, a.mom_s_r);
+  u.n = nt, u.ps = v3(pc.x * a.mom_s_np, pc.y * a.mom_s_np, pc.z * a.mom_s_np), u.r0 = r0, u.s_n = a.mom_s_n, u.s_r = a.mom_s_r;  // (powers of two: exact)
   dq = momi_q(d2, a.mom_s_d, a.mom_lim_d);
   return ICP_PT_ACCEPTED;
+}
+template <int C, class UT>
+__device__ __forceinline__ void momm_store(unsigned short (*__restrict__ ring)[MOMM_ROW], int pos, const UT& u) {
+  ring[C][pos] = (unsigned short)__float_as_uint(u.template get<C>());
+  if constexpr (C + 1 < 13) momm_store<C + 1>(ring, pos, u);
 }
 // bytes ODD, ODD + 2 of `lo` then of `hi` as one word: the H (ODD = 1) or L ^ 0x80 (ODD = 0) bytes of four consecutive ring half-words.
 // One v_perm_b32 (selector bytes 0..3 address S1 = lo, 4..7 address S0 = hi); the shift-and-mask statement of the same costs 5 instructions,
@@ -2605,15 +2631,12 @@ __device__ __forceinline__ void momm_flush(const unsigned short (*__restrict__ r
   __builtin_amdgcn_wave_barrier();
 }
 // the accepted lanes of one batch of lookups appended to the ring (fill: slots in use, 0..127, wave-uniform); a half that becomes complete is flushed
-__device__ __forceinline__ void momm_push(unsigned short (*__restrict__ ring)[MOMM_ROW], int lane, bool ok, const float (&T)[13], int& fill, momm_i32x4& HH,
+template <class UT>
+__device__ __forceinline__ void momm_push(unsigned short (*__restrict__ ring)[MOMM_ROW], int lane, bool ok, const UT& u, int& fill, momm_i32x4& HH,
                                           momm_i32x4& HL, momm_i32x4& LL) {
   const unsigned long long m = __ballot(ok);
   if (m == 0ull) return;
-  if (ok) {
-    const int pos = (fill + __popcll(m & ((1ull << lane) - 1ull))) & 127;
-#pragma unroll
-    for (int c = 0; c < 13; ++c) ring[c][pos] = (unsigned short)__float_as_uint(T[c]);
-  }
+  if (ok) momm_store<0>(ring, (fill + __popcll(m & ((1ull << lane) - 1ull))) & 127, u);
   const int nf = fill + __popcll(m);
   if ((fill ^ nf) & 64) momm_flush(ring, lane, (fill >> 6) & 1, HH, HL, LL);
   fill = nf & 127;
@@ -2639,15 +2662,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM
   // every lane of the wavefront makes every trip (a point past the end of the cloud counts as rejected): ballots, pushes and MFMAs see all 64 lanes
   for (int r = 0; r < R; ++r) {
     const int li = r * 256 + threadIdx.x, i = base + li;
-    float T[13];
+    MommU u;
     int dq = 0;
-    const int res = i < a.ns ? icp_fusedq_point_momm<true>(a, i, pose, sTi, F, ctr, T, dq) : ICP_PT_REJECTED;
+    const int res = i < a.ns ? icp_fusedq_point_momm<true>(a, i, pose, sTi, F, ctr, u, dq) : ICP_PT_REJECTED;
     const unsigned long long dm = __ballot(res == ICP_PT_DEFERRED);
     if (res == ICP_PT_DEFERRED) defer_i[n_def + __popcll(dm & ((1ull << lane) - 1ull))] = (unsigned short)li;
     n_def += __popcll(dm);
     n_wave += __popcll(__ballot(res == ICP_PT_ACCEPTED));
     dsum += dq;
-    momm_push(ring, lane, res == ICP_PT_ACCEPTED, T, fill, HH, HL, LL);
+    momm_push(ring, lane, res == ICP_PT_ACCEPTED, u, fill, HH, HL, LL);
     while (n_def >= 64 || (r == R - 1 && n_def > 0)) {  // a dense batch of the queued lookups (wave-uniform condition; the queue never holds 128)
       const int take = n_def < 64 ? n_def : 64;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2659,12 +2682,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM
       __builtin_amdgcn_wave_barrier();
       if (rest >= 0) defer_i[lane] = (unsigned short)rest;
       n_def -= take;
-      float T2[13];
+      MommU u2;
       int dq2 = 0;
-      const int res2 = mine >= 0 ? icp_fusedq_point_momm<false>(a, base + mine, pose, sTi, F, ctr, T2, dq2) : ICP_PT_REJECTED;
+      const int res2 = mine >= 0 ? icp_fusedq_point_momm<false>(a, base + mine, pose, sTi, F, ctr, u2, dq2) : ICP_PT_REJECTED;
       n_wave += __popcll(__ballot(res2 == ICP_PT_ACCEPTED));
       dsum += dq2;
-      momm_push(ring, lane, res2 == ICP_PT_ACCEPTED, T2, fill, HH, HL, LL);
+      momm_push(ring, lane, res2 == ICP_PT_ACCEPTED, u2, fill, HH, HL, LL);
     }
   }
   if (fill & 63) {  // the incomplete half: its free slots as zeros
@@ -2744,16 +2767,23 @@ __global__ __launch_bounds__(64) void k_dev_selftest_mfma(const int* __restrict_
 // the read-out path of k_icp_fusedq_momm end to end on one wavefront: `batches` x 64 gridded vectors (13 integers each, |U| <= 2^12; batch b
 // is accepted on the lanes of mask[b]) go through momm_qp-encoded floats -> momm_push -> ring -> momm_flush -> tiles; out = the three tiles
 // [3][64 lanes][4 registers].  The caller recombines M = 65536 HH + 256 (HL + HL^T) + LL and compares with the sum of U U^T.
+struct MommTestU {  // (13 given integers as the gridded vector)
+  float v[13];
+  template <int C>
+  __device__ __forceinline__ float get() const {
+    return momm_qp(v[C], 1.0f);
+  }
+};
 __global__ __launch_bounds__(64) void k_dev_selftest_momm(int batches, const int* __restrict__ U, const unsigned long long* __restrict__ mask, int* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) unsigned short ring[13][MOMM_ROW];
   const int lane = threadIdx.x;
   momm_i32x4 HH = {0, 0, 0, 0}, HL = {0, 0, 0, 0}, LL = {0, 0, 0, 0};
   int fill = 0;
   for (int b = 0; b < batches; ++b) {
-    float T[13];
+    MommTestU t;
 #pragma unroll
-    for (int c = 0; c < 13; ++c) T[c] = momm_qp((float)U[((size_t)b * 64 + lane) * 13 + c], 1.0f);
-    momm_push(ring, lane, ((mask[b] >> lane) & 1ull) != 0ull, T, fill, HH, HL, LL);
+    for (int c = 0; c < 13; ++c) t.v[c] = (float)U[((size_t)b * 64 + lane) * 13 + c];
+    momm_push(ring, lane, ((mask[b] >> lane) & 1ull) != 0ull, t, fill, HH, HL, LL);
   }
   if (fill & 63) {
     const int half = (fill >> 6) & 1;
@@ -2947,6 +2977,7 @@ __device__ __forceinline__ void cells_nn1f(const CellListDev& c, V3 qg, const fl
   const int ix = (int)gx, iy = (int)gy, iz = (int)gz;
   if ((unsigned)ix >= (unsigned)c.dx || (unsigned)iy >= (unsigned)c.dy || (unsigned)iz >= (unsigned)c.dz) return;
   const int2 rg = c.range[(iz * c.dy + iy) * c.dx + ix];
+  LCP_COUNT(1, 1);
   const int beg = rg.x, end = rg.y;
   if (beg >= end) return;
   float b1 = 3.0e38f, b2 = 3.0e38f;
@@ -2954,6 +2985,7 @@ __device__ __forceinline__ void cells_nn1f(const CellListDev& c, V3 qg, const fl
   float wx = 0.f, wy = 0.f, wz = 0.f;
   for (int k = beg; k < end; ++k) {
     const float4 t = c.pts[k];
+    LCP_COUNT(1, 1);
     const float d = rank_d2(qg, t);
     b2 = __builtin_amdgcn_fmed3f(b1, b2, d);
     const bool better = d < b1;
@@ -2982,6 +3014,95 @@ __device__ __forceinline__ void cells_nn1f(const CellListDev& c, V3 qg, const fl
   }
 }
 
+// cells_nn1f / cells_nn_plain through the inline-head records (CellListDev::head): the same candidates in the same order with the same
+// expressions and tie rules -- the same bits -- but a one-entry list is ONE access (the head) instead of two (range record + entry).
+__device__ __forceinline__ void cells_nn1f_head(const CellListDev& c, V3 qg, const float* T, V3 q, float& best, int& bpos, V3& moved) {
+  const float gx = floorf(__builtin_fmaf(qg.x, c.inv_cell, c.gox)), gy = floorf(__builtin_fmaf(qg.y, c.inv_cell, c.goy)),
+              gz = floorf(__builtin_fmaf(qg.z, c.inv_cell, c.goz));
+  const int ix = (int)gx, iy = (int)gy, iz = (int)gz;
+  if ((unsigned)ix >= (unsigned)c.dx || (unsigned)iy >= (unsigned)c.dy || (unsigned)iz >= (unsigned)c.dz) return;
+  const int cidx = (iz * c.dy + iy) * c.dx + ix;
+  const uint4 hd = c.head[cidx];
+  LCP_COUNT(1, 1);
+  const int n = (int)(hd.w >> 24);
+  if (n == 0) return;
+  const int beg = (int)(hd.w & 0xFFFFFFu);
+  float wx = __uint_as_float(hd.x), wy = __uint_as_float(hd.y), wz = __uint_as_float(hd.z);
+  float b1 = rank_d2(qg, make_float4(wx, wy, wz, 0.f)), b2 = 3.0e38f;
+  int k1 = beg, end = beg + n;
+  if (n > 1) {
+    if (n == 255) {
+      end = c.range[cidx].y;
+      LCP_COUNT(1, 1);
+    }
+    for (int k = beg + 1; k < end; ++k) {
+      const float4 t = c.pts[k];
+      LCP_COUNT(1, 1);
+      const float d = rank_d2(qg, t);
+      b2 = __builtin_amdgcn_fmed3f(b1, b2, d);
+      const bool better = d < b1;
+      k1 = better ? k : k1;
+      wx = better ? t.x : wx, wy = better ? t.y : wy, wz = better ? t.z : wz;
+      b1 = fminf(b1, d);
+    }
+  }
+  const float mag = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), 0.25f));
+  const float delta = mag * 2.0e-6f;
+  const float tol = 2.002f * __builtin_amdgcn_sqrtf(b1) * delta + 1.0e-4f * b1 + delta * delta;
+  moved = m4_point(T, v3(wx, wy, wz));
+  best = sqdist_flann(q, moved);
+  bpos = k1;
+  if (b2 - b1 <= tol) {
+    int bj = __float_as_int(c.pts[k1].w);
+    const float lim = b1 + tol;
+    for (int k = beg; k < end; ++k) {
+      if (k == k1) continue;
+      const float4 t = c.pts[k];
+      if (!(rank_d2(qg, t) <= lim)) continue;
+      const V3 tm = m4_point(T, v3(t.x, t.y, t.z));
+      const float d2 = sqdist_flann(q, tm);
+      const int j = __float_as_int(t.w);
+      if (d2 < best || (d2 == best && j < bj)) best = d2, bj = j, bpos = k, moved = tm;
+    }
+  }
+}
+__device__ __forceinline__ void cells_nn_plain_head(const CellListDev& c, V3 q, float& best, int& bpos) {
+  const float fx = (q.x - c.ox) * c.inv_cell, fy = (q.y - c.oy) * c.inv_cell, fz = (q.z - c.oz) * c.inv_cell;
+  if (!(fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)c.dx && fy < (float)c.dy && fz < (float)c.dz)) return;
+  const int cidx = ((int)fz * c.dy + (int)fy) * c.dx + (int)fx;
+  const uint4 hd = c.head[cidx];
+  LCP_COUNT(2, 1);
+  const int n = (int)(hd.w >> 24);
+  if (n == 0) return;
+  const int beg = (int)(hd.w & 0xFFFFFFu);
+  // entry 0 from the head; its original index (the tie rule) is fetched only if another entry ties with it exactly
+  const float d0 = sqdist_flann(q, v3(__uint_as_float(hd.x), __uint_as_float(hd.y), __uint_as_float(hd.z)));
+  int bj = -1;  // -1: entry 0 is the best so far and its index has not been read
+  if (d0 < best) best = d0, bpos = beg;
+  else return cells_nn_plain(c, q, best, bpos);  // (callers pass best = 3e38: not taken; kept so that the function is right for any caller)
+  if (n > 1) {
+    int end = beg + n;
+    if (n == 255) {
+      end = c.range[cidx].y;
+      LCP_COUNT(2, 1);
+    }
+    for (int k = beg + 1; k < end; ++k) {
+      const float4 t = c.pts[k];
+      LCP_COUNT(2, 1);
+      const float d2 = sqdist_flann(q, v3(t.x, t.y, t.z));
+      const int j = __float_as_int(t.w);
+      if (d2 < best) best = d2, bj = j, bpos = k;
+      else if (d2 == best) {
+        if (bj < 0) {
+          bj = __float_as_int(c.pts[beg].w);
+          LCP_COUNT(2, 1);
+        }
+        if (j < bj) bj = j, bpos = k;
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -2991,6 +3112,7 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // hypotheses per block of the reduced-sum kernel: 4 = one per wavefront (4 / 8 / 16 / 32: 3.29 / 3.62 / 3.75 / 3.91 ms at C2 --
 // the blocks of an XCD walk neighbouring point tiles of the same few hypotheses and share more of the model's lines)
 constexpr int LCP_FTH = 4;
+template <bool HEAD>
 __global__ __launch_bounds__(256) void k_lcp_cells_fast(LcpArgs a, int hb, int hs, int npt) {
   // XCD-aware mapping: workgroups go to the 8 XCDs round-robin (blockIdx.x & 7) and each XCD has its own 4 MB L2; the
   // scene lists + model lists (~18 MB at C2) do not fit one L2, an eighth of the Morton-ordered scene with the model
@@ -3016,12 +3138,16 @@ __global__ __launch_bounds__(256) void k_lcp_cells_fast(LcpArgs a, int hb, int h
       float best = 3.0e38f;
       int pos = -1;
       V3 pm;
-      cells_nn1f(a.model_cells, m4_point_fma(Ti, s), T, s, best, pos, pm);
+      LCP_COUNT(0, 1);
+      if (HEAD) cells_nn1f_head(a.model_cells, m4_point_fma(Ti, s), T, s, best, pos, pm);
+      else cells_nn1f(a.model_cells, m4_point_fma(Ti, s), T, s, best, pos, pm);
       if (pos >= 0 && best < a.dist * a.dist) {
         // this mode's contract is 1e-4 relative on the score: the normalisation and the (1 - d / dist) factor use the hardware's
         // reciprocal square root / square root (1 ulp) instead of the IEEE division and square-root sequences (~100 of the ~590 vector
         // instructions of a lookup, profiles/r03_pmc_sq.txt); nn_mode 2 keeps the reference's operations
         const float4 mnr = a.model_cells.nrm[pos];
+        LCP_COUNT(1, 1);
+        LCP_COUNT(3, 1);
         const V3 nraw = m4_dir(T, v3(mnr.x, mnr.y, mnr.z));
         V3 nmod = nraw * __builtin_amdgcn_rsqf(vsqn(nraw));
         float d1 = vdot(sn, nmod);
@@ -3031,9 +3157,11 @@ __global__ __launch_bounds__(256) void k_lcp_cells_fast(LcpArgs a, int hb, int h
         if (d1 > a.cos_thres) v = d1 * (1.f - __builtin_amdgcn_sqrtf(best) * inv_dist);
         float rbest = 3.0e38f;
         int rk = -1;
-        cells_nn_plain(a.scene_cells, pm, rbest, rk);
+        if (HEAD) cells_nn_plain_head(a.scene_cells, pm, rbest, rk);
+        else cells_nn_plain(a.scene_cells, pm, rbest, rk);
         if (rk >= 0) {
           const float4 rn = a.scene_cells.nrm[rk];
+          LCP_COUNT(2, 1);
           float d2r = vdot(nmod, v3(rn.x, rn.y, rn.z));
           if (fabsf(d2r - a.cos_thres) < 2.0e-6f) d2r = vdot(vnormalized(nraw), v3(rn.x, rn.y, rn.z));
           if (d2r > a.cos_thres) v += d2r * (1.f - __builtin_amdgcn_sqrtf(rbest) * inv_dist);
@@ -3055,7 +3183,9 @@ __global__ __launch_bounds__(64) void k_lcp_sum_partial(LcpArgs a, int hb, int h
 void launch_lcp_cells_fast(const LcpArgs& a, int hb, hipStream_t s) {
   const int npt = (a.ns + 63) / 64, nht = (hb + LCP_FTH - 1) / LCP_FTH;
   const int hs = ((hb + LCP_FTH - 1) / LCP_FTH) * LCP_FTH;
-  hipLaunchKernelGGL(k_lcp_cells_fast, dim3((unsigned)(8 * ((npt + 7) / 8) * nht)), dim3(256), 0, s, a, hb, hs, npt);
+  const dim3 grid((unsigned)(8 * ((npt + 7) / 8) * nht));
+  if (a.model_cells.head && a.scene_cells.head) hipLaunchKernelGGL(k_lcp_cells_fast<true>, grid, dim3(256), 0, s, a, hb, hs, npt);
+  else hipLaunchKernelGGL(k_lcp_cells_fast<false>, grid, dim3(256), 0, s, a, hb, hs, npt);
 }
 void launch_lcp_sum_partial(const LcpArgs& a, int hb, hipStream_t s) {
   const int npt = (a.ns + 63) / 64;
@@ -3465,6 +3595,21 @@ int cell_list_local_keep() { return LOCAL_KEEP; }
 __global__ __launch_bounds__(256) void k_cell_ranges(const int* __restrict__ start, int ncell, int2* __restrict__ range) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < ncell) range[c] = make_int2(start[c], start[c + 1]);
+}
+__global__ __launch_bounds__(256) void k_cell_heads(const int2* __restrict__ range, const float4* __restrict__ pts, int ncell, uint4* __restrict__ head) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const int2 r = range[c];
+  const int n = r.y - r.x;
+  uint4 h = make_uint4(0u, 0u, 0u, 0u);
+  if (n > 0) {
+    const float4 t = pts[r.x];
+    h = make_uint4(__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), (unsigned)r.x | ((unsigned)min(n, 255) << 24));
+  }
+  head[c] = h;
+}
+void launch_cell_heads(const int2* range, const float4* pts, int ncell, uint4* head, hipStream_t s) {
+  hipLaunchKernelGGL(k_cell_heads, dim3((ncell + 255) / 256), dim3(256), 0, s, range, pts, ncell, head);
 }
 void launch_cell_ranges(const int* start, int ncell, int2* range, hipStream_t s) {
   hipLaunchKernelGGL(k_cell_ranges, dim3((ncell + 255) / 256), dim3(256), 0, s, start, ncell, range);

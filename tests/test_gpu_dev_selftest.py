@@ -192,3 +192,33 @@ def test_the_two_moment_kernels_return_the_same_integers(ctx, hop, orc, monkeypa
     assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1])
     assert np.array_equal(res["1"][2].view(np.int32), res["0"][2].view(np.int32))
     assert res["1"][0].max() > 1 and (res["1"][1] != 0).any()
+
+
+def test_compute_lcp_through_inline_head_records_returns_the_same_bits(ctx, hop, monkeypatch):
+    """k_lcp_cells_fast<true> reads a list's first entry from the cell's 16-byte head record (one access for a one-entry list instead of range
+    record + entry); candidates, their order, the distance expressions and the tie rule are those of the range-record form: the reduced-sum
+    scores (lcp nn_mode 3) must be bit-equal between the two, on refined poses (short lists) and on wide perturbations (long lists, empty cells)."""
+    from hop_amd import api
+    synth = hop.synth
+    mx, mn = synth.ellipsoid_model(5000)
+    import os
+    ns, nh = (2500, 12) if os.environ.get("HOP_TEST_EMU") else (6000, 48)     # (the CPU model runs this inside the CPU suite)
+    sc = synth.make_scene(ns, seed=9)
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8)
+    ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
+    ctx.set_model(api.HOP_MODEL_1MM, mx, mn)
+    near = synth.replay_poses(sc.gt_pose, nh, seed=2, max_rot_deg=0.6, max_trans=0.0004)
+    wide = synth.replay_poses(sc.gt_pose, nh, seed=3, max_rot_deg=25.0, max_trans=0.012)
+    poses = np.concatenate([near, wide])
+    out = {}
+    for label, env in (("head", None), ("range", "1")):
+        if env:
+            monkeypatch.setenv("HOP_LCP_NO_HEAD", env)
+        else:
+            monkeypatch.delenv("HOP_LCP_NO_HEAD", raising=False)
+        ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8)      # (a new frame: the scene lists and their heads are rebuilt)
+        ctx.hypos_upload(poses)
+        best, score, idx = ctx.lcp_select_best(0.001, 10.0, 3)
+        out[label] = (ctx.hypos_download()[1].copy(), idx, score)
+    assert np.array_equal(out["head"][0].view(np.int32), out["range"][0].view(np.int32))
+    assert out["head"][1] == out["range"][1] and out["head"][0][:nh].min() > 0.02 * ns

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""List gathers per lookup of computeLCP's reduced-sum kernel (k_lcp_cells_fast), with the inline-head records and with the range records
+(HOP_LCP_NO_HEAD=1), from a library built with -DHOP_LCP_COUNT.
+
+    python tools/lcp_counters.py <libhop_built_with_HOP_LCP_COUNT.so> [--scene 20000] [--hyps 256]
+On the CPU model (no device at hand):
+    make -C tests/emu OUT=/tmp/lcpcnt CXXFLAGS="$(make -s -C tests/emu print-cxxflags) -DHOP_LCP_COUNT" /tmp/lcpcnt/libhop_emu.so
+Counts per-lane loads from the lists (head / range record, entries, normals): what the TCP counts as accesses for divergent gathers.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("lib")
+    ap.add_argument("--scene", type=int, default=20000)
+    ap.add_argument("--hyps", type=int, default=256)
+    args = ap.parse_args()
+    import hop_loader
+    hop = hop_loader.load()
+    from hop_amd import api
+    api.LIB_PATH, api._lib = args.lib, None
+    synth = hop.synth
+    sc = synth.make_scene(args.scene, seed=7)
+    mx, mn = synth.ellipsoid_model(5000)
+    c = api.Context(0)
+    c.set_model(api.HOP_MODEL_5MM, mx, mn)
+    c.set_model(api.HOP_MODEL_1MM, mx, mn)
+    # poses as they reach computeLCP: refined (ICP, nn_mode 7) from the bench's perturbation
+    c.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8)
+    c.hypos_upload(synth.replay_poses(sc.gt_pose, args.hyps, seed=11, max_rot_deg=30.0, max_trans=0.015))
+    c.icp_refine(10, 45.0, 0.01, nn_mode=7)
+    refined = c.hypos_download()[0].copy()
+    fn = c.L.hop_debug_lcp_counters
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+    out = {"scene_points": int(c.L.hop_scene_size(c.h)), "hypotheses": args.hyps}
+    for label, env in (("inline_head_records", None), ("range_records", "1")):
+        if env:
+            os.environ["HOP_LCP_NO_HEAD"] = env
+        else:
+            os.environ.pop("HOP_LCP_NO_HEAD", None)
+        c.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8)
+        c.hypos_upload(refined)
+        cnt = (C.c_ulonglong * 4)()
+        fn(c.h, cnt, 1)
+        c.lcp_select_best(0.001, 10.0, 3)
+        fn(c.h, cnt, 1)
+        v = [int(x) for x in cnt]
+        q = max(v[0], 1)
+        out[label] = {"lookups": v[0], "forward_gathers_per_lookup": v[1] / q, "reciprocal_gathers_per_lookup": v[2] / q,
+                      "lookups_within_the_gate": v[3] / q, "list_gathers_per_lookup": (v[1] + v[2]) / q}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
