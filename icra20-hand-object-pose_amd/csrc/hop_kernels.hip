@@ -1963,8 +1963,8 @@ void icp_counters_read(unsigned long long* out8, bool reset) {
 }
 // squared distance (whole steps) of the local query l (rounded to whole steps) to a packed entry (lo = x | y << 16, hi = z | index << 16).
 // Every coordinate difference fits a signed 16-bit integer (the step of the cell frame is chosen for that, build_cell_lists), so the x and y
-// differences are ONE v_pk_sub, their squares ONE v_dot2_i32_i16, the z difference the low half of a second v_pk_sub (its high half, minus
-// the index, is never read) and its square a v_mad_i32_i16: 4 instructions per candidate (the three field extractions, three subtractions
+// differences are ONE v_pk_sub, the z difference the low half of a second v_pk_sub (its high half, minus the index, is never read), its
+// square a v_mad_i32_i16 and the x, y squares ONE v_dot2_i32_i16 added to it: 4 instructions per candidate (the three field extractions, three subtractions
 // and three 24-bit multiply-adds of the 32-bit form: 9).  The sum stays below 3 * 2^30 < 2^32.
 typedef unsigned short q_v2u16 __attribute__((vector_size(4)));
 typedef short q_v2i16 __attribute__((vector_size(4)));
@@ -1974,9 +1974,9 @@ struct Q3 {
 __device__ __forceinline__ unsigned q_rank(Q3 l, unsigned lo, unsigned hi) {
   const q_v2u16 dxy = __builtin_bit_cast(q_v2u16, l.xy) - __builtin_bit_cast(q_v2u16, lo);
   const unsigned dzw = __builtin_bit_cast(unsigned, __builtin_bit_cast(q_v2u16, l.z) - __builtin_bit_cast(q_v2u16, hi));
-  unsigned d = (unsigned)__builtin_amdgcn_sdot2(__builtin_bit_cast(q_v2i16, dxy), __builtin_bit_cast(q_v2i16, dxy), 0, false);
-  asm("v_mad_i32_i16 %0, %1, %1, %0" : "+v"(d) : "v"(dzw));
-  return d;
+  int dz2;
+  asm("v_mad_i32_i16 %0, %1, %1, 0" : "=v"(dz2) : "v"(dzw));  // (first: v_dot2c accumulates into its destination, which then needs no zero)
+  return (unsigned)__builtin_amdgcn_sdot2(__builtin_bit_cast(q_v2i16, dxy), __builtin_bit_cast(q_v2i16, dxy), dz2, false);
 }
 #define Q_L(v) (int)(v)
 #define Q_KEYF(k) (float)(k)

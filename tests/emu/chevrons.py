@@ -89,7 +89,11 @@ def rewrite_asm(text):
                 if not mm:
                     raise SystemExit("chevrons.py: cannot read asm operand %r" % c)
                 exprs.append(mm.group(1).strip())
-        ops = [exprs[int(t)] for t in re.findall(r"%(\d+)", templ)]
+        ops = []
+        for tok in templ.split(","):                      # operands in template order: %N, or an inline constant passed through
+            tok = tok.strip()
+            mm = re.match(r"%(\d+)$", tok)
+            ops.append(exprs[int(mm.group(1))] if mm else tok)
         return "emu_asm::%s(%s);" % (mnem, ", ".join(ops))
     out = ASM_RE.sub(one, text)
     if re.search(r"\basm\s*(volatile)?\s*\(", out):
