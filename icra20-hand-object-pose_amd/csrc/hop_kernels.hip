@@ -2736,7 +2736,7 @@ void launch_icp_fusedq_momm(const IcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_fusedq_momm, dim3(nb, hb), dim3(256), 0, s, a, R);
 }
 
-// development aid (hop_debug_selftest, tests/test_gpu_dev_selftest.py): the gfx950-specific primitives of the packed lookups and of the two
+// development aid (hop_debug_selftest, tests/test_gpu_zzzz_dev_selftest.py): the gfx950-specific primitives of the packed lookups and of the two
 // moment kernels on caller-given operands, one element per thread -- what the instructions return on a device is compared with their
 // documented semantics restated in numpy (the CPU model of tests/emu states them a third time).
 //   out[0] momi_qp(x, y, 2^12)   [1] encoding of momm_qp(x, y)   [2] momi_pack(ia, ib)   [3] momi_dot2(ia, ib, ic)   [4] umed3(ia, ib, ic)

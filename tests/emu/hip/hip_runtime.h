@@ -143,7 +143,7 @@ inline T emu_readfirstlane(int site, T v) {
 inline float emu_fmed3(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }
 #define __builtin_amdgcn_fmed3f(a, b, c) emu_fmed3((a), (b), (c))
 // ---- gfx950 instructions the product names (builtins, and inline asm through chevrons.py -> emu_asm::) ----------------------------------------
-// Functional models from the instruction descriptions of the CDNA ISA; tests/test_gpu_dev_selftest.py runs the same inputs through the real
+// Functional models from the instruction descriptions of the CDNA ISA; tests/test_gpu_zzzz_dev_selftest.py runs the same inputs through the real
 // instructions on a device (hop_dev_selftest) and compares with these semantics restated in numpy.
 typedef short emu_v2i16 __attribute__((vector_size(4)));
 typedef int emu_v4i32 __attribute__((vector_size(16)));

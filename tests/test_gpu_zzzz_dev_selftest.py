@@ -1,4 +1,5 @@
 """The gfx950-specific instructions the ICP kernels lean on, one by one, against their documented semantics restated in numpy -- `pytest -m gpu`.
+(Last in file order on purpose, like tests/test_gpu_zzz_variants.py: what has never run on hardware must not stop `-x` before the rest was seen.)
 
 ADVICE r04 / VERDICT r04 "what the CPU model cannot vouch for": the model of tests/emu runs C stand-ins for `v_med3_u32`, `v_mad_i32_i24`,
 `v_cvt_pk_i16_i32`, `v_dot2_i32_i16` -- and now the byte gathers of the ring read-out, `v_med3_f32` on the magic-constant form and `v_mfma_i32_16x16x64_i8` (operand
@@ -59,8 +60,8 @@ def _operands(n, seed):
     # small values as the kernels produce them: |a|, |b| <= 4096 for the packs
     ia[:n // 2] = rng.integers(-4096, 4097, n // 2)
     ib[:n // 2] = rng.integers(-4096, 4097, n // 2)
-    ia[:8] = [4096, -4096, 32767, -32768, 40000, -40000, 0, 1]          # (saturation of v_cvt_pk_i16_i32 beyond 16 bits)
-    ib[:8] = [-4096, 4096, -32768, 32767, -40000, 40000, 0, -1]
+    ia[:8] = [4096, -4096, 32767, -32768, 1, -1, 0, 1]                  # (the ends of the 16-bit range; the kernels pack |values| <= 4096)
+    ib[:8] = [-4096, 4096, -32768, 32767, -1, 1, 0, -1]
     return x, y, ia.astype(np.int32), ib.astype(np.int32), ic.astype(np.int32)
 
 
@@ -82,13 +83,16 @@ def test_scalar_primitives_match_their_documented_semantics(ctx):
     w = (enc & 0xFFFF)
     assert np.array_equal(_sext(w >> 8, 8)[big] * 256 + (_sext((w & 0xFF) ^ 0x80, 8))[big], u[big]), "U = 256 H + L from the two bytes"
     assert np.abs(_sext(w >> 8, 8)[big]).max() <= 16
-    # [2] v_cvt_pk_i16_i32: two saturated 16-bit halves
-    sa, sb = np.clip(ia.astype(np.int64), -32768, 32767), np.clip(ib.astype(np.int64), -32768, 32767)
-    assert np.array_equal(out[2].astype(np.int64), (sa & 0xFFFF) | ((sb & 0xFFFF) << 16))
-    # [3] v_dot2_i32_i16: c + a.lo b.lo + a.hi b.hi, wrapping
+    # [2] v_cvt_pk_i16_i32 on operands inside the 16-bit range (what happens beyond it is not the kernels' business: they pack |values| <= 4096)
+    fits = (np.abs(ia.astype(np.int64)) <= 32767) & (np.abs(ib.astype(np.int64)) <= 32767)
+    assert fits.sum() > n // 4
+    assert np.array_equal(out[2].astype(np.int64)[fits], ((ia.astype(np.int64) & 0xFFFF) | ((ib.astype(np.int64) & 0xFFFF) << 16))[fits])
+    # [3] v_dot2_i32_i16: c + a.lo b.lo + a.hi b.hi -- compared where the exact sum fits 32 bits (momi adds <= 64 products of <= 2^24)
     a64, b64 = ia.astype(np.int64), ib.astype(np.int64)
     dot = ic.astype(np.int64) + _sext(a64, 16) * _sext(b64, 16) + _sext(a64 >> 16, 16) * _sext(b64 >> 16, 16)
-    assert np.array_equal(out[3].astype(np.int64), dot & 0xFFFFFFFF)
+    inr = np.abs(dot) < 2 ** 31
+    assert inr.sum() > n // 2
+    assert np.array_equal(out[3].view(np.int32).astype(np.int64)[inr], dot[inr])
     # [4] v_med3_u32
     ua, ub, uc = (v.view(np.uint32).astype(np.int64) for v in (ia, ib, ic))
     assert np.array_equal(out[4].astype(np.int64), np.median(np.stack([ua, ub, uc]), axis=0).astype(np.int64))
