@@ -713,7 +713,9 @@ def main():
                 kern.pop("k_icp_accum")
             elif args.nn_mode >= 3:
                 # nn_mode 6 / 7: lookups + the 13 x 13 moment sums in one kernel, then the whole Levenberg-Marquardt run per hypothesis
-                momi = "k_icp_fusedq_momi" if os.environ.get("HOP_ICP_MFMA", "1") == "0" else "k_icp_fusedq_momm"   # (csrc/hop_ctx.hip hop_icp_refine: the same switch)
+                # which of the two moment kernels ran: the library says (HOP_ICP_MFMA=0, or a device that failed the read-out check, take the vector units)
+                eng = w.ctx.L.hop_debug_icp_engine(w.ctx.h) if hasattr(w.ctx.L, "hop_debug_icp_engine") else -1
+                momi = "k_icp_fusedq_momi" if (eng == 0 or (eng < 0 and os.environ.get("HOP_ICP_MFMA", "1") == "0")) else "k_icp_fusedq_momm"
                 kern[{6: "k_icp_fusedq_mom", 7: momi}.get(args.nn_mode, "k_icp_fusedq")] = kern.pop("k_icp_corr_cells")
                 kern.pop("k_icp_accum")
                 if args.nn_mode >= 5:

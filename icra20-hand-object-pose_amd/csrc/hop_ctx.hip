@@ -156,6 +156,7 @@ struct hop_ctx {
   PinnedBuf pso_particles_h, pso_out_h;
   PinnedBuf stage_up, stage_down;  // hop_ctx_h2d / hop_ctx_d2h
   size_t stage_cur = 0;
+  int icp_last_engine = -1;  // nn_mode 7's moment kernel of the last hop_icp_refine: 1 matrix cores (k_icp_fusedq_momm), 0 vector units (k_icp_fusedq_momi)
   bool have_finger = false, have_hand_scene = false;
 
   // row modules (hop_physics.hip)
@@ -1477,6 +1478,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     // (read at every call: a test or a tool may switch between two refinements of one process)
     icp_mfma = !(getenv("HOP_ICP_MFMA") != nullptr && atoi(getenv("HOP_ICP_MFMA")) == 0);
     if (lm7_mode && icp_mfma) icp_mfma = mfma_i8_layout_ok(c);
+    if (lm7_mode) c->icp_last_engine = icp_mfma ? 1 : 0;
     if (lm7_mode) {
       // the grid of the moment form (oracle: mom_spec): powers of two from the model's radius about its origin and the gate
       const CloudHost& mh = c->gen.model_h[HOP_MODEL_5MM];
@@ -2306,6 +2308,10 @@ int hop_debug_ppf_matrix(hop_ctx* c, unsigned long long* out, size_t cap_words, 
   }
   return HOP_OK;
 }
+
+// development aid, not part of the ABI: which moment kernel the last nn_mode-7 refinement of this context ran (1 k_icp_fusedq_momm on the
+// matrix cores, 0 k_icp_fusedq_momi on the vector units -- HOP_ICP_MFMA=0, or a device that failed the read-out check --, -1 none yet)
+int hop_debug_icp_engine(hop_ctx* c) { return c ? c->icp_last_engine : -1; }
 
 // development aid, not part of the ABI: list gathers of k_lcp_cells_fast per lookup (zero unless built with -DHOP_LCP_COUNT; tools/lcp_counters.py)
 int hop_debug_lcp_counters(hop_ctx* c, unsigned long long* out4, int reset) {

@@ -193,6 +193,8 @@ def test_the_two_moment_kernels_return_the_same_integers(ctx, hop, orc, monkeypa
         it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=7, want_stats=True)
         p, _, _ = ctx.hypos_download()
         res[mfma] = (it.copy(), cv.copy(), p.copy())
+        # the library says which kernel ran: the matrix-core one only where the device passed its read-out check (mfma_i8_layout_ok)
+        assert api.lib().hop_debug_icp_engine(ctx.h) == int(mfma), "the device failed the read-out check of k_icp_fusedq_momm: see stderr"
     assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1])
     assert np.array_equal(res["1"][2].view(np.int32), res["0"][2].view(np.int32))
     assert res["1"][0].max() > 1 and (res["1"][1] != 0).any()
