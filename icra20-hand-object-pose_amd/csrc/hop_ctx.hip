@@ -1695,6 +1695,7 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
         a.model_cells = c->model_cells[HOP_MODEL_1MM].c;
       }
       a.scene_cells = c->scene_cells.c;
+      if (nn_mode != 3 || getenv("HOP_LCP_NO_HEAD")) a.model_cells.head = a.scene_cells.head = nullptr;  // (records an earlier call may have left in the stores)
     }
     const CloudDevice& Q = c->scene_sorted_d;
     a.qx = Q.plane(0), a.qy = Q.plane(1), a.qz = Q.plane(2), a.qnx = Q.plane(3), a.qny = Q.plane(4), a.qnz = Q.plane(5);
