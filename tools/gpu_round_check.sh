@@ -22,6 +22,10 @@ HOP_ICP_MFMA=0 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-c
 # the ICP stage alone (one frame at a time, HIP events): nn_mode 4 / 6 / 7 on the matrix cores / 7 on the vector units, and k_icp_fusedq_momm built for
 # 6 and 8 waves per SIMD (default 5: 92 VGPRs, no scratch; 6: 80 VGPRs + 7 dwords of scratch; 8: 64 + 29)
 timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 4,6,7,7dot2 --lcp-modes 3 > $OUT/icp_bench_modes_4_6_7.json 2> $OUT/icp_bench.err
+# computeLCP's reduced-sum kernel: range records instead of the inline-head records (round 5), and the scene lists at subdivision 3 (shorter lists,
+# which the head records make cheaper; more cells to build) -- lcp.3.ms_cells of the three files is the comparison
+HOP_LCP_NO_HEAD=1 timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 7 --lcp-modes 3 > $OUT/icp_bench_lcp_range_records.json 2>> $OUT/icp_bench.err
+HOP_LCP_SCENE_SUB=3 timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 7 --lcp-modes 3 > $OUT/icp_bench_lcp_scene_sub3.json 2>> $OUT/icp_bench.err
 for W in 6 8; do
   bash tools/build_variant.sh momm$W -DHOP_ICP_MOMM_W=$W > $OUT/build_momm$W.log 2>&1 && HOP_LIB=tools/_tmp/momm$W/libhop.so timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 7 --lcp-modes 3 > $OUT/icp_bench_mode7_${W}waves.json 2>> $OUT/icp_bench.err
 done
