@@ -111,6 +111,34 @@ def test_the_model_sees_a_staging_slot_reused_before_its_stream_was_synchronised
     assert old == ["staged_then_synced", "ok", "reused_before_sync", "ok", "pageable_source", "ok"], old
 
 
+def test_the_models_v_perm_b32_is_the_compilers(emu_lib, tmp_path):
+    """k_icp_fusedq_momm's ring read-out gathers bytes with v_perm_b32; which operand the selector bytes 0..3 / 4..7 address is the kind of thing
+    a model gets wrong together with the kernel.  LLVM folds __builtin_amdgcn_perm on constants: hipcc's own statement of the instruction, read
+    from the gfx950 assembly, must equal the model's (tests/emu/hip/hip_runtime.h emu_perm) for the two selectors the kernel uses."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = tmp_path / "p.hip"
+    src.write_text("#include <hip/hip_runtime.h>\n__global__ void kperm(unsigned* o) {\n"
+                   "  o[0] = __builtin_amdgcn_perm(0x44434241u, 0x14131211u, 0x07050301u);\n"
+                   "  o[1] = __builtin_amdgcn_perm(0x44434241u, 0x14131211u, 0x06040200u);\n}\n")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", str(src), "-o", str(tmp_path / "p.s")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = (tmp_path / "p.s").read_text()
+    if "v_perm_b32" in asm:
+        pytest.skip("this compiler does not fold the builtin")
+    prog = tmp_path / "m.cpp"
+    prog.write_text('#include "hip/hip_runtime.h"\nint main() { std::printf("0x%08x 0x%08x\\n", __builtin_amdgcn_perm(0x44434241u, 0x14131211u, 0x07050301u), '
+                    '__builtin_amdgcn_perm(0x44434241u, 0x14131211u, 0x06040200u)); }\n')
+    exe = str(tmp_path / "m")
+    r = subprocess.run(["g++", "-std=c++17", "-I" + EMU_DIR, str(prog), os.path.join(EMU_DIR, "_build", "emu_runtime.o"), "-lpthread", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    model = subprocess.run([exe], capture_output=True, text=True).stdout.split()
+    assert model == ["0x44421412", "0x43411311"], model
+    for lit in model:
+        assert lit in asm, (lit, [ln for ln in asm.splitlines() if "v_mov_b32" in ln])
+
+
 def _emu_env(emu_lib, **extra):
     """children that find the model under the name libhop.so and the file-based stand-in for RCCL (tests/emu/fake_rccl.cpp) under librccl.so"""
     e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HOP_FORCE", "HOP_COMM_ID_FILE", "HOP_GATHER")}
