@@ -13,20 +13,38 @@ hop = hop_loader.load()
 from hop_amd import api  # noqa: E402
 
 synth = hop.synth
+EMU = bool(os.environ.get("HOP_TEST_EMU"))
+if EMU:
+    # TEST INFRASTRUCTURE (tests/emu): the CPU model of the kernels and its file-based stand-in for RCCL (the parent test put the stand-in on
+    # LD_LIBRARY_PATH); "device memory" is host memory there
+    api.LIB_PATH = os.environ.get("HOP_TEST_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "_build", "libhop_emu.so")
+    api._lib = None
 api.lib()
 ctx = api.Context(0)
-hip = C.CDLL("libamdhip64.so")     # a 9 KB device buffer without PyTorch (whose bundled HIP / RCCL must not mix with the system's here)
-hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-hip.hipFree.argtypes = [C.c_void_p]
-dbuf = C.c_void_p()
-assert hip.hipMalloc(C.byref(dbuf), 128 * api.TOPK_ROW_FLOATS * 4) == 0
+if EMU:
+    _host_rows = np.zeros((128, api.TOPK_ROW_FLOATS), np.float32)
+    dbuf = C.c_void_p(_host_rows.ctypes.data)
 
+    class hip:  # noqa: N801
+        @staticmethod
+        def hipFree(_):
+            return 0
 
-def dev_rows():
-    out = np.zeros((128, api.TOPK_ROW_FLOATS), np.float32)
-    assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), dbuf, out.nbytes, 2) == 0   # hipMemcpyDeviceToHost
-    return out
+    def dev_rows():
+        ctx.synchronize()
+        return _host_rows.copy()
+else:
+    hip = C.CDLL("libamdhip64.so")     # a 9 KB device buffer without PyTorch (whose bundled HIP / RCCL must not mix with the system's here)
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    dbuf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dbuf), 128 * api.TOPK_ROW_FLOATS * 4) == 0
+
+    def dev_rows():
+        out = np.zeros((128, api.TOPK_ROW_FLOATS), np.float32)
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), dbuf, out.nbytes, 2) == 0   # hipMemcpyDeviceToHost
+        return out
 
 
 sc = synth.make_scene(2000, seed=7)

@@ -341,7 +341,11 @@ def test_device_resident_topk_exchange_and_frame_gather_single_rank():
     ROCm it loads never meets the HIP runtime PyTorch bundles (pytest imports torch while collecting the CPU tests)."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "exchange_child.py")], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ)
+    if env.get("HOP_TEST_EMU"):   # (tests/emu: the child finds the model's stand-in for RCCL under the name librccl.so)
+        emu_lib = env.get("HOP_TEST_EMU_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "_build", "libhop_emu.so")
+        env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(emu_lib), "as_libhop") + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "exchange_child.py")], capture_output=True, text=True, timeout=300, env=env)
     if "SKIP" in r.stdout:
         pytest.skip(r.stdout.strip().splitlines()[-1])
     assert r.returncode == 0 and "EXCHANGE OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
