@@ -154,7 +154,9 @@ def test_c5_full_size_8192_hypotheses_50k_scene(ctx, api, synth):
     s2 = ctx.hypos_download()[1].copy()
     big = s2 > 1.0
     assert np.all(np.abs(s3[big] - s2[big]) <= 1e-4 * s2[big])
-    assert int(np.argmax(s2)) == idx
+    # (8 192 starts converge to the same pose: hundreds of scores agree to 1e-5, and the arg-max of the reduced sums may be another member of
+    # that tie than the arg-max of the ordered sums -- its ordered-sum score is within 1e-4 of the maximum)
+    assert s2[idx] >= (1 - 1e-4) * s2.max()
     # the winner is the ground truth (modulo the ellipsoid's 180 degree symmetries)
     gt = sc.gt_pose.astype(np.float64)
     flips = [np.diag(v) for v in ([1, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1])]
