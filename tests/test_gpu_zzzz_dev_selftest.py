@@ -182,8 +182,10 @@ def test_the_two_moment_kernels_return_the_same_integers(ctx, hop, orc, monkeypa
     from hop_amd import api
     synth = hop.synth
     mx5, mn5 = synth.ellipsoid_model_spacing(0.005)
-    sc = synth.make_scene(3000, seed=21)
-    poses = synth.replay_poses(sc.gt_pose, 96, seed=4, max_rot_deg=25.0, max_trans=0.012)
+    import os
+    ns, nh = (1200, 24) if os.environ.get("HOP_TEST_EMU") else (3000, 96)     # (the CPU model runs this inside the CPU suite)
+    sc = synth.make_scene(ns, seed=21)
+    poses = synth.replay_poses(sc.gt_pose, nh, seed=4, max_rot_deg=25.0, max_trans=0.012)
     res = {}
     for mfma in ("1", "0"):
         monkeypatch.setenv("HOP_ICP_MFMA", mfma)
@@ -206,9 +208,9 @@ def test_compute_lcp_through_inline_head_records_returns_the_same_bits(ctx, hop,
     scores (lcp nn_mode 3) must be bit-equal between the two, on refined poses (short lists) and on wide perturbations (long lists, empty cells)."""
     from hop_amd import api
     synth = hop.synth
-    mx, mn = synth.ellipsoid_model(5000)
     import os
-    ns, nh = (2500, 12) if os.environ.get("HOP_TEST_EMU") else (6000, 48)     # (the CPU model runs this inside the CPU suite)
+    ns, nh = (1500, 6) if os.environ.get("HOP_TEST_EMU") else (6000, 48)     # (the CPU model runs this inside the CPU suite)
+    mx, mn = synth.ellipsoid_model(1000 if os.environ.get("HOP_TEST_EMU") else 5000)
     sc = synth.make_scene(ns, seed=9)
     ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8)
     ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
