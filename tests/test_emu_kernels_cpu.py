@@ -83,7 +83,7 @@ def test_icp_with_the_references_minimiser_on_the_model(emu_lib):
     """k_icp_fusedq_momm (the moment sums on the matrix cores: round 5) + k_icp_lm7_solve (nn_mode 7, what the mirrors run): refined poses,
     iteration counts and convergence flags equal to the oracle's BIT FOR BIT, hypotheses that do not converge included; the C1 frame's 100
     hypotheses (a trial step outside the quaternion's unit ball among them) too"""
-    sel = [os.path.join("tests", "test_gpu_icp_canon.py")]
+    sel = [os.path.join("tests", "test_gpu_zy_icp_canon.py")]
     assert _child_pytest(sel, "not_converged or c1_depth7_bits", timeout=1500) == 2
     # (the vector-unit kernel, HOP_ICP_MFMA=0: test_the_two_moment_kernels_return_the_same_integers of the selection below)
 

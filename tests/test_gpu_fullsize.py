@@ -181,48 +181,6 @@ def test_c5_full_size_8192_hypotheses_50k_scene(ctx, api, synth):
     assert np.array_equal(s0, s2[sub])     # ordered sums: cell lists == brute force, bit for bit
 
 
-@pytest.mark.parametrize("config", ["C2", "C5"])
-def test_shipped_icp_mode_at_the_bench_sizes(ctx, api, orc, synth, config, monkeypatch):
-    """nn_mode 7 (what the mirrors and the bench run) at the sizes the bench runs it at -- C2: 10 240 hypotheses x the
-    20 000-point scene, C5: one GPU's share, 8 192 x 50 000.  The WHOLE set: two runs return the same bits, the same hypotheses in another
-    order return the same bits (integer sums: no dependence on the launch), hypothesis batches of another size (HOP_ICP_WS_CAP_MB: h0 > 0)
-    return the same bits; the ORACLE's bits on a 256-hypothesis subsample spread over the whole set.  (On the CPU model of tests/emu the
-    set is 384 hypotheses: the sizes are the point of this test on a device only.)"""
-    emu = bool(os.environ.get("HOP_TEST_EMU"))
-    ns, H, seed = (20000, 10240, 7) if config == "C2" else (50000, 8192, 13)
-    if emu:
-        ns, H = ns // 10, 384
-    sc = synth.make_scene(ns, seed=seed)
-    mx, mn = synth.ellipsoid_model(5000)
-    thr = 0.8 if config == "C2" else 0.0
-    poses = synth.replay_poses(sc.gt_pose, H, seed=seed, max_rot_deg=30.0, max_trans=0.015)
-    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, thr)
-    ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
-
-    def run(p):
-        ctx.hypos_upload(p)
-        it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=7, want_stats=True)
-        return ctx.hypos_download()[0].copy(), it.copy(), cv.copy()
-    p1, it1, cv1 = run(poses)
-    assert cv1.mean() > 0.9 and it1.max() <= 10 and np.isfinite(p1).all()
-    p2, it2, cv2 = run(poses)
-    assert np.array_equal(p1.view(np.int32), p2.view(np.int32)) and np.array_equal(it1, it2) and np.array_equal(cv1, cv2)
-    o = np.random.default_rng(3).permutation(H)
-    p3, it3, cv3 = run(poses[o])
-    assert np.array_equal(p3.view(np.int32), p1[o].view(np.int32)) and np.array_equal(it3, it1[o]) and np.array_equal(cv3, cv1[o])
-    # batches of ~H / 5 hypotheses (4 bytes per scene point and hypothesis of workspace): the state of batch h0 > 0, the last batch short
-    monkeypatch.setenv("HOP_ICP_WS_CAP_MB", str(max(1, (4 * ns * H // 5) >> 20)))
-    p4, it4, cv4 = run(poses)
-    monkeypatch.delenv("HOP_ICP_WS_CAP_MB")
-    assert np.array_equal(p4.view(np.int32), p1.view(np.int32)) and np.array_equal(it4, it1) and np.array_equal(cv4, cv1)
-    # the oracle (kd-tree NN, minimiser 7) on a subsample drawn across the whole set
-    sub = np.unique(np.linspace(0, H - 1, 64 if emu else 256).astype(int))
-    keep = sc.conf >= thr
-    po, ito, cvo = orc.icp_refine_batch_lm(sc.xyz[keep], sc.nrm[keep], mx, mn, np.ascontiguousarray(poses[sub]), 10, 45.0, 0.01, moment=True)
-    assert np.array_equal(it1[sub], ito) and np.array_equal(cv1[sub], cvo)
-    assert np.array_equal(p1[sub].view(np.int32), np.ascontiguousarray(po, np.float32).view(np.int32))
-
-
 def test_c5_subsample_against_the_oracle_at_size(ctx, api, orc, synth):
     """BASELINE.json configs[4] against the ORACLE (not only against the GPU's own brute-force kernels): 64 of the C5 replay
     hypotheses x the 50 000-point scene through refineByICP and computeLCP, oracle with its kd-tree (Utils.cpp:188-229, 372-444):
@@ -250,13 +208,7 @@ def test_c5_subsample_against_the_oracle_at_size(ctx, api, orc, synth):
     assert np.median(d6) < 2e-6 and np.percentile(d6, 90) < 5e-5
     for a, b in zip(p6, ref6):
         assert np.linalg.norm(a[:3, 3] - b[:3, 3]) < 1e-3 and _rot_err_deg(a[:3, :3], b[:3, :3]) < 1.0
-    # nn_mode 7 (what the mirrors and the bench run): the oracle's bits at this size too
-    ref7, rit7, rcv7 = orc.icp_refine_batch_lm(sc.xyz, sc.nrm, mx, mn, poses, 10, 45.0, 0.01, moment=True)
-    ctx.hypos_upload(poses)
-    it7, cv7 = ctx.icp_refine(10, 45.0, 0.01, nn_mode=7, want_stats=True)
-    p7 = ctx.hypos_download()[0].copy()
-    assert np.array_equal(cv7, rcv7) and np.array_equal(it7, rit7)
-    assert np.array_equal(p7.view(np.int32), np.ascontiguousarray(ref7, np.float32).view(np.int32))
+    # (nn_mode 7 at this size: tests/test_gpu_zy_icp_canon.py::test_shipped_icp_mode_at_the_bench_sizes -- later in file order: it has never met hardware)
     sref = orc.compute_lcp_batch(sc.xyz, sc.nrm, mx, mn, ref, 0.001, 10.0, use_tree=True)
     ctx.hypos_upload(ref)
     _, _, i2 = ctx.lcp_select_best(0.001, 10.0, 2)

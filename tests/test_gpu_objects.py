@@ -108,7 +108,7 @@ def test_as_shipped_chain_per_object_against_oracle_and_ground_truth(ctx, api, o
     k1 = orc.cluster_poses(op, ol, np.arange(len(ol)), 30.0, 0.015, sym)
     assert len(k1) == n1          # the symmetry folding keeps the same cluster heads
     p1, l1 = op[k1][:100], ol[k1][:100]
-    p2, _, _ = orc.icp_refine_batch_lm(sc.xyz, sc.nrm, mx5, mn5, p1, 10, 45.0, 0.01, moment=True)   # (the mirrors' nn_mode 7: same bits, tests/test_gpu_icp_canon.py)
+    p2, _, _ = orc.icp_refine_batch_lm(sc.xyz, sc.nrm, mx5, mn5, p1, 10, 45.0, 0.01, moment=True)   # (the mirrors' nn_mode 7: same bits, tests/test_gpu_zy_icp_canon.py)
     k2 = orc.cluster_poses(p2, l1, np.arange(len(l1)), 5.0, 0.003, sym)
     p3 = p2[k2]
     s3 = orc.compute_lcp_batch(sc.xyz, sc.nrm, mx1, mn1, p3, 0.001, 10.0)

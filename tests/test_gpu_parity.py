@@ -414,7 +414,7 @@ def test_full_chain_pose_within_1mm_1deg_of_oracle(ctx, api, orc, synth):
     (minus the two rejectBy* steps, which are 'next' rows): GPU chain vs oracle chain on the same inputs -- with ICP nn_mode 0, the
     ONE-GAUSS-NEWTON-STEP variant of rounds 1-2 against the oracle's variant of the same (NOT the reference's minimiser: a faster option the
     library keeps).  The chain with the minimiser the reference runs and the mirrors ship (nn_mode 7) is asserted bit for bit in
-    tests/test_gpu_icp_canon.py (this scene: test_ellipse_chain_returns_the_oracle_chains_pose_and_the_truth)."""
+    tests/test_gpu_zy_icp_canon.py (this scene: test_ellipse_chain_returns_the_oracle_chains_pose_and_the_truth)."""
     mx5, mn5 = synth.ellipsoid_model_spacing(0.005)
     mx1, mn1 = synth.ellipsoid_model(4000)
     keys = synth.ppf_key_table()
@@ -550,7 +550,7 @@ def test_c1_depth7_full_chain_within_1mm_1deg_of_oracle(ctx, api, orc, synth, go
     with the as-shipped option values and the synthetic ellipse.  The north star's criterion: the pose returned by the
     GPU chain within 1 mm / 1 degree of the CPU restatement's on the same frame -- here with ICP nn_mode 3 (ONE GAUSS-NEWTON STEP per
     iteration, the variant of rounds 1-2, against the oracle's variant of the same; NOT the reference's minimiser).  With the minimiser the
-    reference runs (nn_mode 7, what the mirrors ship) the same frame is asserted bit for bit in tests/test_gpu_icp_canon.py
+    reference runs (nn_mode 7, what the mirrors ship) the same frame is asserted bit for bit in tests/test_gpu_zy_icp_canon.py
     (test_c1_depth7_chain_returns_the_oracle_chains_pose), which also says what can and cannot be expected of C1 against Eigen's own run."""
     g = np.load(os.path.join(golden_dir, "depth7_hand_region.npz"))
     xyz, nrm = g["xyz"], g["nrm"]

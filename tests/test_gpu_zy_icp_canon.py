@@ -14,6 +14,8 @@ Asserted here:
     ellipse at 1 200 points;
   * against Eigen's own float run (golden vectors): as close to the reference's default build as its -march=native build is.
 nn_mode 5 / 6 (the float-faithful pin and the fast float moment form) keep their own tests in tests/test_gpu_icp_lm.py.
+(Late in file order on purpose -- "zy": after every file whose kernels have run on hardware, before the variants and the instruction
+self-test: `pytest -x` must not stop on code that has never met a device before the rest was seen.)
 """
 import math
 import os
@@ -194,6 +196,49 @@ def test_ellipse_chain_returns_the_oracle_chains_pose_and_the_truth(ctx, api, or
     a = mx1 @ best[:3, :3].T + best[:3, 3]
     b = mx1 @ sc.gt_pose[:3, :3].T + sc.gt_pose[:3, 3]
     assert cKDTree(b).query(a)[0].mean() < 0.005
+
+
+@pytest.mark.parametrize("config", ["C2", "C5"])
+def test_shipped_icp_mode_at_the_bench_sizes(ctx, api, orc, hop, config, monkeypatch):
+    """nn_mode 7 (what the mirrors and the bench run) at the sizes the bench runs it at -- C2: 10 240 hypotheses x the
+    20 000-point scene, C5: one GPU's share, 8 192 x 50 000.  The WHOLE set: two runs return the same bits, the same hypotheses in another
+    order return the same bits (integer sums: no dependence on the launch), hypothesis batches of another size (HOP_ICP_WS_CAP_MB: h0 > 0)
+    return the same bits; the ORACLE's bits on a 256-hypothesis subsample spread over the whole set.  (On the CPU model of tests/emu the
+    set is 384 hypotheses: the sizes are the point of this test on a device only.)"""
+    synth = hop.synth
+    emu = bool(os.environ.get("HOP_TEST_EMU"))
+    ns, H, seed = (20000, 10240, 7) if config == "C2" else (50000, 8192, 13)
+    if emu:
+        ns, H = ns // 10, 384
+    sc = synth.make_scene(ns, seed=seed)
+    mx, mn = synth.ellipsoid_model(5000)
+    thr = 0.8 if config == "C2" else 0.0
+    poses = synth.replay_poses(sc.gt_pose, H, seed=seed, max_rot_deg=30.0, max_trans=0.015)
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, thr)
+    ctx.set_model(api.HOP_MODEL_5MM, mx, mn)
+
+    def run(p):
+        ctx.hypos_upload(p)
+        it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=7, want_stats=True)
+        return ctx.hypos_download()[0].copy(), it.copy(), cv.copy()
+    p1, it1, cv1 = run(poses)
+    assert cv1.mean() > 0.9 and it1.max() <= 10 and np.isfinite(p1).all()
+    p2, it2, cv2 = run(poses)
+    assert np.array_equal(p1.view(np.int32), p2.view(np.int32)) and np.array_equal(it1, it2) and np.array_equal(cv1, cv2)
+    o = np.random.default_rng(3).permutation(H)
+    p3, it3, cv3 = run(poses[o])
+    assert np.array_equal(p3.view(np.int32), p1[o].view(np.int32)) and np.array_equal(it3, it1[o]) and np.array_equal(cv3, cv1[o])
+    # batches of ~H / 5 hypotheses (4 bytes per scene point and hypothesis of workspace): the state of batch h0 > 0, the last batch short
+    monkeypatch.setenv("HOP_ICP_WS_CAP_MB", str(max(1, (4 * ns * H // 5) >> 20)))
+    p4, it4, cv4 = run(poses)
+    monkeypatch.delenv("HOP_ICP_WS_CAP_MB")
+    assert np.array_equal(p4.view(np.int32), p1.view(np.int32)) and np.array_equal(it4, it1) and np.array_equal(cv4, cv1)
+    # the oracle (kd-tree NN, minimiser 7) on a subsample drawn across the whole set
+    sub = np.unique(np.linspace(0, H - 1, 64 if emu else 256).astype(int))
+    keep = sc.conf >= thr
+    po, ito, cvo = orc.icp_refine_batch_lm(sc.xyz[keep], sc.nrm[keep], mx, mn, np.ascontiguousarray(poses[sub]), 10, 45.0, 0.01, moment=True)
+    assert np.array_equal(it1[sub], ito) and np.array_equal(cv1[sub], cvo)
+    assert np.array_equal(p1[sub].view(np.int32), np.ascontiguousarray(po, np.float32).view(np.int32))
 
 
 def test_stage_min_switch_has_an_effect(api, hop, orc):

@@ -178,7 +178,7 @@ def test_ring_read_out_of_the_matrix_core_kernel_reproduces_the_moment_sums(ctx)
 
 def test_the_two_moment_kernels_return_the_same_integers(ctx, hop, orc, monkeypatch):
     """k_icp_fusedq_momm (matrix cores) and k_icp_fusedq_momi (v_dot2 on the vector units) are two ways to the same exact sums: refined poses,
-    iteration counts and flags of nn_mode 7 are bit-equal between them (and to the oracle: tests/test_gpu_icp_canon.py runs the default)."""
+    iteration counts and flags of nn_mode 7 are bit-equal between them (and to the oracle: tests/test_gpu_zy_icp_canon.py runs the default)."""
     from hop_amd import api
     synth = hop.synth
     mx5, mn5 = synth.ellipsoid_model_spacing(0.005)
