@@ -151,7 +151,9 @@ typedef struct {
                       * reference's float forward differences), the moment matrix is their exact integer sum (any order of the
                       * lanes / wavefronts / workgroups gives the same 64-bit integers), and the solve uses IEEE + - * / sqrt fma in
                       * a fixed order: the CPU statement of the algorithm (oracle minimiser 7) returns the same bits, so the chain
-                      * above it returns the same pose.  As close to the reference's run as mode 6.
+                      * above it returns the same pose.  As close to the reference's run as mode 6.  The sums run on the matrix cores
+                      * (v_mfma_i32_16x16x64_i8 on a byte split of the 13-bit operands: k_icp_fusedq_momm) once the device has passed a check
+                      * of the operand layout, else -- or with HOP_ICP_MFMA=0 -- on the vector units (k_icp_fusedq_momi): the same integers.
                       * Modes 6 and 7 walk the packed (8-byte) cell lists, which exist for a HOP_MODEL_5MM of < 65535 points whose
                       * lists fit the 16-bit cell frame.  Without them mode 6 runs as mode 5 (same minimiser, float per-pass form);
                       * mode 7 returns HOP_E_STATE (hop_last_error says why) rather than bits other than the ones it promises. */
