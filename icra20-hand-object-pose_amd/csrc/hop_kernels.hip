@@ -3112,29 +3112,31 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // hypotheses per block of the reduced-sum kernel: 4 = one per wavefront (4 / 8 / 16 / 32: 3.29 / 3.62 / 3.75 / 3.91 ms at C2 --
 // the blocks of an XCD walk neighbouring point tiles of the same few hypotheses and share more of the model's lines)
 constexpr int LCP_FTH = 4;
+// K = 64-point tiles per wavefront and hypothesis (lcp_tiles_per_wave): with many hypotheses a wavefront walks K consecutive tiles of the
+// Morton-ordered scene for its hypothesis, adds a lane's terms in a register and reduces ONCE -- the pose and inverse pose (28 scalar loads), the
+// wavefront reduction and the partial-sum store are paid per 64 K lookups instead of per 64.
 template <bool HEAD>
-__global__ __launch_bounds__(256) void k_lcp_cells_fast(LcpArgs a, int hb, int hs, int npt) {
+__global__ __launch_bounds__(256) void k_lcp_cells_fast(LcpArgs a, int hb, int hs, int npt, int K) {
   // XCD-aware mapping: workgroups go to the 8 XCDs round-robin (blockIdx.x & 7) and each XCD has its own 4 MB L2; the
   // scene lists + model lists (~18 MB at C2) do not fit one L2, an eighth of the Morton-ordered scene with the model
-  // region it meets does.  XCD k walks the point tiles [k * per, (k + 1) * per) for every hypothesis tile.
+  // region it meets does.  XCD k walks the point tiles [k * per, (k + 1) * per) for every hypothesis tile.  (npt: tiles of 64 K points)
   const int per = (npt + 7) >> 3;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int pt = xcd * per + j % per, ht = j / per;
   if (pt >= npt) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int k = pt * 64 + lane;
-  const bool kin = k < a.ns;
   const float inv_dist = 1.f / a.dist;
-  V3 s = v3(0, 0, 0), sn = v3(0, 0, 0);
-  if (kin) s = v3(a.qx[k], a.qy[k], a.qz[k]), sn = v3(a.qnx[k], a.qny[k], a.qnz[k]);
   for (int j = 0; j < LCP_FTH / 4; ++j) {
     const int hh = wave * (LCP_FTH / 4) + j, hl = ht * LCP_FTH + hh;
     if (hl >= hb) break;  // wave-uniform
+    const float* __restrict__ T = a.pose + (size_t)(a.h0 + hl) * 16;
+    const float* __restrict__ Ti = a.pose_inv + (size_t)(a.h0 + hl) * 12;
     float v = 0.f;
-    if (kin) {
-      const float* __restrict__ T = a.pose + (size_t)(a.h0 + hl) * 16;
-      const float* __restrict__ Ti = a.pose_inv + (size_t)(a.h0 + hl) * 12;
+    for (int u = 0; u < K; ++u) {
+      const int k = (pt * K + u) * 64 + lane;
+      if (k >= a.ns) continue;
+      const V3 s = v3(a.qx[k], a.qy[k], a.qz[k]), sn = v3(a.qnx[k], a.qny[k], a.qnz[k]);
       float best = 3.0e38f;
       int pos = -1;
       V3 pm;
@@ -3154,7 +3156,7 @@ __global__ __launch_bounds__(256) void k_lcp_cells_fast(LcpArgs a, int hb, int h
         // a dot product within 2e-6 of the threshold is decided by the reference's own operations (the fast value is within 3e-7 of it):
         // which terms enter the sum is exactly the reference's choice
         if (fabsf(d1 - a.cos_thres) < 2.0e-6f) nmod = vnormalized(nraw), d1 = vdot(sn, nmod);
-        if (d1 > a.cos_thres) v = d1 * (1.f - __builtin_amdgcn_sqrtf(best) * inv_dist);
+        if (d1 > a.cos_thres) v += d1 * (1.f - __builtin_amdgcn_sqrtf(best) * inv_dist);
         float rbest = 3.0e38f;
         int rk = -1;
         if (HEAD) cells_nn_plain_head(a.scene_cells, pm, rbest, rk);
@@ -3180,15 +3182,24 @@ __global__ __launch_bounds__(64) void k_lcp_sum_partial(LcpArgs a, int hb, int h
   for (int t = 0; t < npt; ++t) cp += (double)a.terms[(size_t)t * hs + hl];
   a.score[a.h0 + hl] = (float)cp;
 }
+// 64-point tiles per wavefront of k_lcp_cells_fast: 4 when that still leaves >= 16 workgroups per CU (C2: 69 x 2560), else 1 (the as-shipped
+// sizes -- 100 hypotheses x 2 000 points -- need every workgroup they can get).  HOP_LCP_TILES=<k> overrides (A/B runs).
+int lcp_tiles_per_wave(int ns, int hb) {
+  if (const char* e = getenv("HOP_LCP_TILES")) return std::max(1, std::min(16, atoi(e)));
+  const long long blocks1 = (long long)((ns + 63) / 64) * ((hb + LCP_FTH - 1) / LCP_FTH);
+  return blocks1 >= 4 * 4096 ? 4 : 1;
+}
 void launch_lcp_cells_fast(const LcpArgs& a, int hb, hipStream_t s) {
-  const int npt = (a.ns + 63) / 64, nht = (hb + LCP_FTH - 1) / LCP_FTH;
+  const int K = lcp_tiles_per_wave(a.ns, hb);
+  const int npt = (a.ns + 64 * K - 1) / (64 * K), nht = (hb + LCP_FTH - 1) / LCP_FTH;
   const int hs = ((hb + LCP_FTH - 1) / LCP_FTH) * LCP_FTH;
   const dim3 grid((unsigned)(8 * ((npt + 7) / 8) * nht));
-  if (a.model_cells.head && a.scene_cells.head) hipLaunchKernelGGL(k_lcp_cells_fast<true>, grid, dim3(256), 0, s, a, hb, hs, npt);
-  else hipLaunchKernelGGL(k_lcp_cells_fast<false>, grid, dim3(256), 0, s, a, hb, hs, npt);
+  if (a.model_cells.head && a.scene_cells.head) hipLaunchKernelGGL(k_lcp_cells_fast<true>, grid, dim3(256), 0, s, a, hb, hs, npt, K);
+  else hipLaunchKernelGGL(k_lcp_cells_fast<false>, grid, dim3(256), 0, s, a, hb, hs, npt, K);
 }
 void launch_lcp_sum_partial(const LcpArgs& a, int hb, hipStream_t s) {
-  const int npt = (a.ns + 63) / 64;
+  const int K = lcp_tiles_per_wave(a.ns, hb);
+  const int npt = (a.ns + 64 * K - 1) / (64 * K);
   const int hs = ((hb + LCP_FTH - 1) / LCP_FTH) * LCP_FTH;
   hipLaunchKernelGGL(k_lcp_sum_partial, dim3((hb + 63) / 64), dim3(64), 0, s, a, hb, hs, npt);
 }

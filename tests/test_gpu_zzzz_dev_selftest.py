@@ -229,4 +229,16 @@ def test_compute_lcp_through_inline_head_records_returns_the_same_bits(ctx, hop,
         best, score, idx = ctx.lcp_select_best(0.001, 10.0, 3)
         out[label] = (ctx.hypos_download()[1].copy(), idx, score)
     assert np.array_equal(out["head"][0].view(np.int32), out["range"][0].view(np.int32))
+    # several 64-point tiles per wavefront and hypothesis (what large hypothesis sets select; HOP_LCP_TILES forces it here): a lane adds its
+    # tiles' terms before the wavefront reduction -- the same terms in another association: scores to float rounding, the same winner
+    monkeypatch.delenv("HOP_LCP_NO_HEAD", raising=False)
+    monkeypatch.setenv("HOP_LCP_TILES", "4")
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8)
+    ctx.hypos_upload(poses)
+    _, _, idx4 = ctx.lcp_select_best(0.001, 10.0, 3)
+    s4 = ctx.hypos_download()[1].copy()
+    monkeypatch.delenv("HOP_LCP_TILES")
+    s1 = out["head"][0]
+    assert np.all(np.abs(s4 - s1) <= 2e-6 * np.maximum(np.abs(s1), 1.0)) and idx4 == out["head"][1]
+    assert not np.array_equal(s4, np.zeros_like(s4))
     assert out["head"][1] == out["range"][1] and out["head"][0][:nh].min() > 0.02 * ns

@@ -25,6 +25,7 @@ timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 4,6,7,7dot2 --lcp-mod
 # computeLCP's reduced-sum kernel: range records instead of the inline-head records (round 5), and the scene lists at subdivision 3 (shorter lists,
 # which the head records make cheaper; more cells to build) -- lcp.3.ms_cells of the three files is the comparison
 HOP_LCP_NO_HEAD=1 timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 7 --lcp-modes 3 > $OUT/icp_bench_lcp_range_records.json 2>> $OUT/icp_bench.err
+HOP_LCP_TILES=1 timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 7 --lcp-modes 3 > $OUT/icp_bench_lcp_one_tile_per_wave.json 2>> $OUT/icp_bench.err
 HOP_LCP_SCENE_SUB=3 timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 7 --lcp-modes 3 > $OUT/icp_bench_lcp_scene_sub3.json 2>> $OUT/icp_bench.err
 for W in 6 8; do
   bash tools/build_variant.sh momm$W -DHOP_ICP_MOMM_W=$W > $OUT/build_momm$W.log 2>&1 && HOP_LIB=tools/_tmp/momm$W/libhop.so timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 7 --lcp-modes 3 > $OUT/icp_bench_mode7_${W}waves.json 2>> $OUT/icp_bench.err
