@@ -4,7 +4,8 @@
 
     python tools/lcp_counters.py <libhop_built_with_HOP_LCP_COUNT.so> [--scene 20000] [--hyps 256]
 On the CPU model (no device at hand):
-    make -C tests/emu OUT=/tmp/lcpcnt CXXFLAGS="$(make -s -C tests/emu print-cxxflags) -DHOP_LCP_COUNT" /tmp/lcpcnt/libhop_emu.so
+    make -C tests/emu OUT=/tmp/lcpcnt /tmp/lcpcnt/libhop_emu.so CXXFLAGS="-x c++ -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -fno-strict-aliasing \
+         -Wno-attributes -Wno-unknown-pragmas -DHOP_EMU -DHOP_LCP_COUNT -I. -I../../icra20-hand-object-pose_amd/csrc"
 Counts per-lane loads from the lists (head / range record, entries, normals): what the TCP counts as accesses for divergent gathers.
 """
 import argparse
