@@ -81,10 +81,11 @@ def test_render_and_normals_kernels_on_the_model(emu_lib):
 
 def test_icp_with_the_references_minimiser_on_the_model(emu_lib):
     """k_icp_fusedq_momm (the moment sums on the matrix cores: round 5) + k_icp_lm7_solve (nn_mode 7, what the mirrors run): refined poses,
-    iteration counts and convergence flags equal to the oracle's BIT FOR BIT, hypotheses that do not converge included; the C1 frame's 100
-    hypotheses (a trial step outside the quaternion's unit ball among them) too"""
+    iteration counts and convergence flags equal to the oracle's BIT FOR BIT, hypotheses that do not converge included"""
     sel = [os.path.join("tests", "test_gpu_zy_icp_canon.py")]
-    assert _child_pytest(sel, "not_converged or c1_depth7_bits", timeout=1500) == 2
+    assert _child_pytest(sel, "not_converged", timeout=1500) == 1
+    # (the C1 frame's 100 hypotheses -- test_nn_mode7_c1_depth7_bits_and_distance_to_eigens_run -- and the rest of that file: the whole-suite run
+    # on the model, profiles/r05_emu_gpu_suite.txt; kept out of the CPU suite for its minute)
     # (the vector-unit kernel, HOP_ICP_MFMA=0: test_the_two_moment_kernels_return_the_same_integers of the selection below)
 
 
