@@ -1358,10 +1358,11 @@ int hop_hypos_keep_topk(hop_ctx* c, int k) {
 
 // ---------------------------------------------------------------------------------------------- ICP
 // k_icp_fusedq_momm rests on the operand layout of v_mfma_i32_16x16x64_i8 (rows / columns = lane & 15, the four 16-lane groups = the four
-// K blocks, C / D: column lane & 15, rows 4 (lane >> 4) + register).  That layout is documented, but this code was written without a
-// device to run it on: the first nn_mode-7 refinement on a device issues ONE instruction on known operands (k_dev_selftest_mfma) and
-// compares with the product computed here.  A device that answers differently gets the vector-unit kernel (k_icp_fusedq_momi: the same
-// integers from v_dot2_i32_i16) and one line on stderr -- never a wrong moment matrix.
+// K blocks, C / D: column lane & 15, rows 4 (lane >> 4) + register) and on v_perm_b32's selector convention.  Both are documented, but this
+// code was written without a device to run it on: the first nn_mode-7 refinement on a device sends known vectors through the kernel's own
+// read-out path (k_dev_selftest_momm: momm_push -> ring -> momm_flush -> tiles) and compares the recombined matrix with sum U U^T computed
+// here.  A device that answers differently gets the vector-unit kernel (k_icp_fusedq_momi: the same integers from v_dot2_i32_i16) and one
+// line on stderr -- never a wrong moment matrix.
 int hop_debug_selftest(hop_ctx* c, int what, int n, const void* in, void* out);
 static bool mfma_i8_layout_ok(hop_ctx* c) {
   static std::mutex mu;
@@ -1369,7 +1370,7 @@ static bool mfma_i8_layout_ok(hop_ctx* c) {
   std::lock_guard<std::mutex> lk(mu);
   auto it = verdict.find(c->device);
   if (it != verdict.end()) return it->second;
-  // three batches of 64 vectors, the second accepted on 41 lanes only: a full half, a half completed across two pushes, a partial last half
+  // three batches of 64 vectors, the second accepted on 38 lanes only: a full half, a half completed across two pushes, a partial last half
   constexpr int NB = 3;
   std::vector<int> in(NB * 64 * 13 + NB * 2), out(3 * 256, 0);
   const unsigned long long masks[NB] = {~0ull, 0x0000F0F3FFFF1F7Full, ~0ull};
