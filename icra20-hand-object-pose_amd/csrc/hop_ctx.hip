@@ -355,6 +355,10 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
   HIPCHK(c, hipStreamSynchronize(c->stream));
   cs.c.range = cs.range_d.as<int2>();
   cs.c.gox = -a.ox * cs.c.inv_cell, cs.c.goy = -a.oy * cs.c.inv_cell, cs.c.goz = -a.oz * cs.c.inv_cell;
+  {  // sqrt(d2) <= d2 q_sa + q_sb for every d2 >= 0 (exact at d = max_dist / 2): the root-free tolerance of cells_nn1f; the packed lists set their own
+    const double cc = (double)max_dist / 2.0;
+    cs.c.q_sa = (float)(0.5 / cc * 1.000001), cs.c.q_sb = (float)(0.5 * cc * 1.000001);
+  }
   HIPCHK(c, cs.nrm_idx_d.ensure(sizeof(float4) * (size_t)std::max(h.n, 1)));
   launch_soa_to_aos4(d.plane(3), d.plane(4), d.plane(5), h.n, cs.nrm_idx_d.as<float4>(), c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -2995,7 +2995,9 @@ __device__ __forceinline__ void cells_nn1f(const CellListDev& c, V3 qg, const fl
   }
   const float mag = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), 0.25f));
   const float delta = mag * 2.0e-6f;
-  const float tol = 2.002f * __builtin_amdgcn_sqrtf(b1) * delta + 1.0e-4f * b1 + delta * delta;
+  // (an upper bound of cells_nn's tolerance without the square root: sqrt(b1) <= b1 q_sa + q_sb, see cells_nnq; a larger tol only sends a few
+  // more lookups through the exact scan below)
+  const float tol = __builtin_fmaf(2.002f * __builtin_fmaf(b1, c.q_sa, c.q_sb), delta, __builtin_fmaf(1.0e-4f, b1, delta * delta));
   moved = m4_point(T, v3(wx, wy, wz));
   best = sqdist_flann(q, moved);
   bpos = k1;
@@ -3048,7 +3050,9 @@ __device__ __forceinline__ void cells_nn1f_head(const CellListDev& c, V3 qg, con
   }
   const float mag = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), 0.25f));
   const float delta = mag * 2.0e-6f;
-  const float tol = 2.002f * __builtin_amdgcn_sqrtf(b1) * delta + 1.0e-4f * b1 + delta * delta;
+  // (an upper bound of cells_nn's tolerance without the square root: sqrt(b1) <= b1 q_sa + q_sb, see cells_nnq; a larger tol only sends a few
+  // more lookups through the exact scan below)
+  const float tol = __builtin_fmaf(2.002f * __builtin_fmaf(b1, c.q_sa, c.q_sb), delta, __builtin_fmaf(1.0e-4f, b1, delta * delta));
   moved = m4_point(T, v3(wx, wy, wz));
   best = sqdist_flann(q, moved);
   bpos = k1;
