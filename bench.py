@@ -738,15 +738,37 @@ def main():
         kern = kernel_table(tm, infos)
         dom = max(kern, key=lambda k: kern[k][0])
         roof = roofline_of(kern, dom, infos)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        # HBM traffic and the issue-side utilisation of the dominant kernel come from SEPARATE rocprofv3 --pmc passes (tools/gpu_profile.sh ->
+        # profiles/pmc_latest.json, profiles/pmc_sq_latest.json), never from this run.  A kernel those files do not hold is said to be
+        # unmeasured -- with its predecessor's figures beside it, labelled as such -- instead of a bare null.
+        PREDECESSOR = {"k_icp_fusedq_momm": "k_icp_fusedq_mom", "k_icp_fusedq_momi": "k_icp_fusedq_mom"}
+
+        def pmc_lookup(fname):
             try:
-                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                return json.load(open(os.path.join(ROOT, "profiles", fname)))
             except Exception:
-                traffic = None
+                return {}
+        pmc_hbm, pmc_sq = pmc_lookup("pmc_latest.json"), pmc_lookup("pmc_sq_latest.json")
+        traffic = pmc_hbm.get(dom, {}).get("hbm_bytes_per_launch")
+        pmc_extra = {"traffic_of": dom if traffic is not None else None}
+        if traffic is None:
+            pre = PREDECESSOR.get(dom)
+            pmc_extra["traffic_status"] = f"unmeasured for {dom} (no --pmc pass has run since it was written)"
+            if pre and pre in pmc_hbm:
+                pmc_extra["traffic_predecessor"] = {"kernel": pre, "hbm_bytes_per_launch": pmc_hbm[pre].get("hbm_bytes_per_launch"),
+                                                    "note": "the kernel this one replaced, same lookups and lists; NOT this kernel's traffic"}
+        sq = pmc_sq.get(dom)
+        sq_of = dom
+        if sq is None and PREDECESSOR.get(dom) in pmc_sq:
+            sq_of = PREDECESSOR[dom] + " (predecessor; " + dom + " unmeasured)"
+            sq = pmc_sq[PREDECESSOR[dom]]
+        # the roof that actually binds the cell-list kernels is vector issue and L1 tag rate (a VALU-side fraction is mandatory)
+        pmc_extra["valu_busy"] = sq.get("valu_busy") if sq else None
+        pmc_extra["l1_accesses_per_clk_cu"] = sq.get("l1_accesses_per_clk_cu") if sq else None
+        pmc_extra["issue_counters_of"] = sq_of if sq else f"unmeasured for {dom}"
+        pmc_extra["issue_counters_source"] = pmc_sq.get("_source")
         roof["frac_timed_region"] = roof["frac"]
-        roof = {"bound": "hbm", **roof, "traffic": traffic,
+        roof = {"bound": "hbm", **roof, "traffic": traffic, **pmc_extra,
                 "traffic_source": "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command taken separately "
                                   "(MI355X_MICROARCH.md corrections applied by tools/pmc_summary.py), per launch; not measured in this run",
                 "definition": "achieved = algorithmic bytes per launch (SURVEY.md 8(d): 24*(N+M)+72 B per hypothesis and NN pass, x the "
@@ -798,6 +820,14 @@ def main():
             "best_lcp_score": infos[-1]["score"],
             "alt_modes": alt,
         }
+        try:
+            # which moment kernel nn_mode 7 ran, and what the library's first-use checks of the gfx950-specific instructions said on this device
+            # (False = the library substituted a kernel and said so on stderr: a finding about the part, not a pass)
+            chk = w.ctx.selfcheck(force=False)
+            out["icp_engine"] = chk["icp_engine"] if args.nn_mode == 7 else None
+            out["device_selfcheck"] = {"packed_ranking_q_rank": chk["qrank"], "matrix_core_read_out": chk["mfma"]}
+        except Exception as e:
+            out["device_selfcheck"] = {"error": f"{type(e).__name__}: {e}"}
         if not strong:
             # the returned pose of every timed frame against the frame's ground truth, modulo the ellipsoid's symmetry (north_star: 1 mm / 1 deg
             # is asked of the pose against the CPU reference -- parity_sample below; this is the absolute error the chain ends with)

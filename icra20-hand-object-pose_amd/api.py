@@ -13,6 +13,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -55,7 +56,23 @@ HOP_ABI_VERSION = 2
 # hop_icp_opts.nn_mode of the mirrors: 7 = the reference's Levenberg-Marquardt on (t, quaternion) to its stopping rule per ICP iteration, from
 # integer-exact moment sums with an IEEE-only solve: the poses the CPU oracle (minimiser 7) returns, bit for bit.  HOP_ICP_NN_MODE overrides it
 # without a rebuild (host/PoseEstimator.h icp_nn_mode_reference: e.g. 6, the float-sum form round 3 measured on hardware).
-ICP_NN_MODE_REFERENCE = int(os.environ.get("HOP_ICP_NN_MODE", "7"))
+def _icp_nn_mode_reference():
+    """HOP_ICP_NN_MODE as host/PoseEstimator.h icp_nn_mode_reference reads it: an integer in 0..7, anything else (empty, text, out of range) is
+    the default 7 with a line on stderr -- never an exception at import, never an out-of-range mode passed through."""
+    e = os.environ.get("HOP_ICP_NN_MODE")
+    if e is None or e == "":
+        return 7
+    try:
+        m = int(e.strip())
+    except ValueError:
+        m = -1
+    if not 0 <= m <= 7:
+        sys.stderr.write(f"hop: HOP_ICP_NN_MODE={e!r} is not an integer in 0..7; using 7\n")
+        return 7
+    return m
+
+
+ICP_NN_MODE_REFERENCE = _icp_nn_mode_reference()
 ICP_NN_MODE_GN = 4         # one Gauss-Newton step per ICP iteration (faster; not what PCL computes)
 
 
@@ -594,6 +611,32 @@ class Context:
             return it[:n], cv[:n]
         self._chk(self.L.hop_icp_refine(self.h, C.byref(o), None, None), "hop_icp_refine")
 
+    def selfcheck(self, force=True):
+        """What the library's first-use checks of the gfx950-specific instructions said on this device (hop_debug_selfcheck; a development
+        aid outside include/hop.h).  Returns {"qrank": True | False | None, "mfma": ..., "icp_engine": "momm" | "momi" | None}: None = not
+        checked yet.  False means the library runs a substitute kernel on this device (and has said so on stderr)."""
+        L = self.L
+        fn = L.hop_debug_selfcheck
+        fn.restype, fn.argtypes = C.c_int, [_vp, C.c_int]
+        bits = fn(self.h, 1 if force else 0)
+        eng_fn = L.hop_debug_icp_engine
+        eng_fn.restype, eng_fn.argtypes = C.c_int, [_vp]
+        eng = eng_fn(self.h)
+        return {"qrank": (bool(bits & 2) if bits & 1 else None), "mfma": (bool(bits & 8) if bits & 4 else None),
+                "icp_engine": {1: "momm", 0: "momi"}.get(eng)}
+
+    def icp_refine_reference(self, max_iter, angle_deg, max_corr_dist, max_hypotheses=0, want_stats=False):
+        """The mirrors' refinement (host/PoseEstimator.h icp_refine_reference): ICP_NN_MODE_REFERENCE, and where nn_mode 7 refuses for want of
+        packed model lists (HOP_E_STATE: a 5 mm model of >= 65535 points, a list outside the 16-bit cell frame) one retry with nn_mode 5 -- the
+        same minimiser in its per-evaluation float form -- announced on stderr."""
+        try:
+            return self.icp_refine(max_iter, angle_deg, max_corr_dist, max_hypotheses, ICP_NN_MODE_REFERENCE, want_stats)
+        except HopError as e:
+            if e.status != -5 or ICP_NN_MODE_REFERENCE != 7:
+                raise
+            sys.stderr.write(f"hop: {e} -- retrying with nn_mode 5 (per-evaluation float form of the same minimiser)\n")
+            return self.icp_refine(max_iter, angle_deg, max_corr_dist, max_hypotheses, 5, want_stats)
+
     def lcp_select_best(self, dist=0.001, angle_deg=10.0, nn_mode=0):
         o = LcpOpts(dist, angle_deg, nn_mode)
         pose = np.zeros(16, np.float32)
@@ -960,7 +1003,7 @@ class PoseEstimator:
 
     def refineByICP(self):
         # nn_mode 7: the reference's minimiser (PCL's point-to-plane estimator = Eigen's Levenberg-Marquardt, Utils.cpp:200-216)
-        self.ctx.icp_refine(10, float(self.cfg["icp_angle_thres"]), float(self.cfg["icp_dist_thres"]), max_hypotheses=100, nn_mode=ICP_NN_MODE_REFERENCE)
+        self.ctx.icp_refine_reference(10, float(self.cfg["icp_angle_thres"]), float(self.cfg["icp_dist_thres"]), max_hypotheses=100)
 
     def selectBest(self):
         pose, score, idx = self.ctx.lcp_select_best(float(self.cfg["lcp"]["dist"]), float(self.cfg["lcp"]["normal_angle"]), -1)
@@ -1075,7 +1118,7 @@ class HandT42:
                 ci.set_model(HOP_MODEL_5MM, bx, bn)
                 ci.model_owner = self.hand                       # (a PoseEstimator on this context uploads its models again)
             ci.hypos_upload(np.eye(4, dtype=np.float32)[None])
-            ci.icp_refine(50, 30.0, 0.03, nn_mode=ICP_NN_MODE_REFERENCE)
+            ci.icp_refine_reference(50, 30.0, 0.03)
             pose, _, _ = ci.hypos_download()
             offset = np.linalg.inv(pose[0].astype(np.float64)).astype(np.float32)  # source -> target
         translation = float(np.linalg.norm(offset[:3, 3]))

@@ -380,7 +380,12 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
     // step: the largest difference between a query (inside the cell) and a list member, cell + R, is 32 767 steps -- q_rank subtracts and
     // squares in 16 bits (v_pk_sub_i16 / v_dot2_i32_i16) -- which leaves the frame [0, cell + 2 R] below 65 535 steps as well
     const double step = ((double)cell + R) / 32767.0, qcs = (double)cell / step, qrs = R / step;
-    bool in_range = true;
+    // q_rank's invariant, stated where the lists are made: a query's local coordinate is a whole number in [qrs - 0.5, qrs + qcs + 0.5] with
+    // qrs + qcs = 32 767, and every member coordinate w of a list must differ from every such query by at most 32 767 steps (a signed 16-bit
+    // difference): 0 <= w <= qrs + 32 766.  A member beyond that would wrap to a SMALL difference and win the ranking silently, so the guard
+    // below tests exactly this bound (not just the 16-bit field), and a list that breaks it sends the store to the plain lists.
+    bool in_range = qrs + qcs <= 32767.0 + 1.0e-6;
+    const double w_max = std::min(65534.0, std::floor(qrs) + 32766.0);
     // The exact point and normal of a winner are fetched by index; neighbouring queries win neighbouring points, so the two
     // arrays are stored in Morton order of the cloud and the entries carry the Morton rank (a wavefront's fetch then touches a
     // handful of 128-byte lines instead of up to 64: tools/ubench/l1_rate.hip).  .w of a point = its original index (ties).
@@ -436,7 +441,7 @@ int build_cell_lists(hop_ctx* c, CellListStore& cs, const CloudHost& h, const Cl
           uint32_t u[3], idx;
           for (int ax = 0; ax < 3; ++ax) {
             const double w = std::nearbyint((((double)v[ax] - (double)org[ax]) / (double)cell - (double)ic[ax]) * qcs + qrs);
-            if (w < 0.0 || w > 65534.0) in_range = false;
+            if (w < 0.0 || w > w_max) in_range = false;
             u[ax] = (uint32_t)std::min(65534.0, std::max(0.0, w));
           }
           memcpy(&idx, &t.w, 4);
@@ -1368,12 +1373,62 @@ int hop_hypos_keep_topk(hop_ctx* c, int k) {
 // here.  A device that answers differently gets the vector-unit kernel (k_icp_fusedq_momi: the same integers from v_dot2_i32_i16) and one
 // line on stderr -- never a wrong moment matrix.
 int hop_debug_selftest(hop_ctx* c, int what, int n, const void* in, void* out);
+// The packed lookups (cells_nnq, every ICP mode >= 3) rank candidates with q_rank: v_pk_sub_i16, an inline-asm v_mad_i32_i16 and v_dot2_i32_i16
+// -- written, like the matrix-core read-out below, without a device to run them on.  A wrong ranking would return a wrong neighbour that the
+// exact re-scan (bounded by the same keys) cannot catch, so the first packed lookup on a device is preceded by this check of q_rank and
+// v_med3_u32 against their scalar statements on operands that cover the field boundaries.  A device that disagrees gets NO packed lists
+// (the callers then take the plain-list kernels: nn_mode 3 / 4 -> k_icp_fused, 6 -> the per-evaluation form, 7 refuses and the mirrors retry
+// with 5), one line on stderr, and the verdict in hop_debug_selfcheck -- never a silently wrong correspondence.
+static std::mutex g_selfcheck_mu;
+static std::map<int, int> g_selfcheck;  // device -> bits of hop_debug_selfcheck
+static unsigned qrank_scalar(unsigned lxy, unsigned lz, unsigned lo, unsigned hi) {
+  const int dx = (int)(int16_t)(uint16_t)((lxy & 0xFFFFu) - (lo & 0xFFFFu)), dy = (int)(int16_t)(uint16_t)((lxy >> 16) - (lo >> 16));
+  const int dz = (int)(int16_t)(uint16_t)((lz & 0xFFFFu) - (hi & 0xFFFFu));
+  return (unsigned)(dx * dx) + (unsigned)(dy * dy) + (unsigned)(dz * dz);
+}
+static bool qrank_ok(hop_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_selfcheck_mu);
+  int& bits = g_selfcheck[c->device];
+  if (bits & 1) return (bits & 2) != 0;
+  constexpr int N = 1024;
+  std::vector<int> in(5 * N);
+  std::vector<unsigned> out(9 * N, 0u);
+  float* xf = reinterpret_cast<float*>(in.data());
+  unsigned lcg = 2463534242u;
+  auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return lcg >> 8; };
+  for (int i = 0; i < N; ++i) {
+    xf[i] = 0.25f, xf[N + i] = 1.0f;  // (operands of the moment primitives: not judged here)
+    // queries 28 000 .. 32 767 steps into the frame, members anywhere in [0, 65 534], empty slots 0xFFFF: every sign of every difference
+    unsigned q[3], w[3];
+    for (int ax = 0; ax < 3; ++ax) {
+      q[ax] = 28000u + rnd() % 4768u;
+      const unsigned lo_w = q[ax] > 32767u ? q[ax] - 32767u : 0u, hi_w = std::min(65534u, q[ax] + 32767u);
+      w[ax] = (i & 7) == 7 ? 0xFFFFu : lo_w + rnd() % (hi_w - lo_w + 1u);
+      if (i < 6 && (i >> 1) == ax) w[ax] = (i & 1) ? hi_w : lo_w;  // the extreme differences +-32 767 on each axis
+    }
+    in[2 * N + i] = (int)(q[0] | (q[1] << 16));                         // ia: l.xy (bit 31 decides what garbage the kernel puts above l.z)
+    in[3 * N + i] = (int)(w[0] | (w[1] << 16));                         // ib: lo
+    in[4 * N + i] = (int)(w[2] | (q[2] << 16));                         // ic: hi = member z | (what k_dev_selftest_scalar takes for l.z) << 16
+  }
+  const bool ran = hop_debug_selftest(c, 0, N, in.data(), out.data()) == HOP_OK;
+  bool ok = ran;
+  for (int i = 0; i < N && ok; ++i) {
+    const unsigned ua = (unsigned)in[2 * N + i], ub = (unsigned)in[3 * N + i], uc = (unsigned)in[4 * N + i];
+    ok = out[5 * (size_t)N + i] == qrank_scalar(ua, uc >> 16, ub, uc);
+    const unsigned lo3 = std::min(ua, std::min(ub, uc)), hi3 = std::max(ua, std::max(ub, uc));
+    ok = ok && out[4 * (size_t)N + i] == (unsigned)((unsigned long long)ua + ub + uc - lo3 - hi3);  // v_med3_u32
+  }
+  if (!ok)
+    std::fprintf(stderr, "libhop: the 16-bit packed ranking of the ICP lookups (q_rank: v_pk_sub_i16 / v_mad_i32_i16 / v_dot2_i32_i16, v_med3_u32) %s on device %d; "
+                 "the packed cell lists are NOT used (plain-list kernels instead; nn_mode 7 refuses, the mirrors retry with nn_mode 5)\n",
+                 ran ? "does not reproduce its scalar statement" : "could not be checked", c->device);
+  bits |= 1 | (ok ? 2 : 0);
+  return ok;
+}
 static bool mfma_i8_layout_ok(hop_ctx* c) {
-  static std::mutex mu;
-  static std::map<int, bool> verdict;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = verdict.find(c->device);
-  if (it != verdict.end()) return it->second;
+  std::lock_guard<std::mutex> lk(g_selfcheck_mu);
+  int& bits = g_selfcheck[c->device];
+  if (bits & 4) return (bits & 8) != 0;
   // three batches of 64 vectors, the second accepted on 38 lanes only: a full half, a half completed across two pushes, a partial last half
   constexpr int NB = 3;
   std::vector<int> in(NB * 64 * 13 + NB * 2), out(3 * 256, 0);
@@ -1401,7 +1456,7 @@ static bool mfma_i8_layout_ok(hop_ctx* c) {
   if (!ok)
     std::fprintf(stderr, "libhop: the matrix-core read-out of k_icp_fusedq_momm %s on device %d; nn_mode 7 adds its moment sums on the vector units "
                  "(k_icp_fusedq_momi: the same integers)\n", ran ? "does not reproduce sum U U^T (v_mfma_i32_16x16x64_i8 operand layout / v_perm_b32 selectors)" : "could not be checked", c->device);
-  verdict[c->device] = ok;
+  bits |= 4 | (ok ? 8 : 0);
   return ok;
 }
 
@@ -1460,7 +1515,7 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     float cell = o->max_corr_dist / (packed_mode ? 7.f : 6.f);
     if (const char* e = getenv("HOP_ICP_CELL_DIV")) cell = o->max_corr_dist / (float)atof(e);
     CellListStore& cs = c->model_cells[HOP_MODEL_5MM];
-    const bool want_packed = packed_mode && c->gen.model_h[HOP_MODEL_5MM].n < 0xFFFF;
+    const bool want_packed = packed_mode && c->gen.model_h[HOP_MODEL_5MM].n < 0xFFFF && qrank_ok(c);  // (a device that fails the ranking check gets the plain lists)
     if (!cs.valid || cs.cell != cell || cs.max_dist != o->max_corr_dist || cs.coord_mag < c->coord_mag || (want_packed && !cs.pack_requested)) {
       const int rc = build_cell_lists(c, cs, c->gen.model_h[HOP_MODEL_5MM], c->model_d[HOP_MODEL_5MM], o->max_corr_dist, cell, want_packed);
       if (rc) return rc;
@@ -1643,6 +1698,7 @@ int hop_lcp_select_best(hop_ctx* c, const hop_lcp_opts* o, float* best_pose16_ou
   a.cos_thres = (float)std::cos((double)(o->angle_deg / 180.0f) * M_PI);
   a.rev_idx = c->lcp_rev_idx.as<int>(), a.rev_d2 = c->lcp_rev_d2.as<float>(), a.terms = c->lcp_terms.as<float>();
   a.score = c->hyp_score.as<float>();
+  a.tiles_per_wave = nn_mode == 3 ? lcp_tiles_per_wave(S.n, H) : 1;  // from the whole set, not from a batch: one association per call
   if (lcp_grid) {
     const float cell = o->dist + GRID_MARGIN * 8;
     GridStore& gm = c->model_grid[HOP_MODEL_1MM];
@@ -2318,6 +2374,23 @@ int hop_debug_ppf_matrix(hop_ctx* c, unsigned long long* out, size_t cap_words, 
 // development aid, not part of the ABI: which moment kernel the last nn_mode-7 refinement of this context ran (1 k_icp_fusedq_momm on the
 // matrix cores, 0 k_icp_fusedq_momi on the vector units -- HOP_ICP_MFMA=0, or a device that failed the read-out check --, -1 none yet)
 int hop_debug_icp_engine(hop_ctx* c) { return c ? c->icp_last_engine : -1; }
+
+// development aid, not part of the ABI: what the first-use checks of the gfx950-specific instructions said on this context's device.
+//   bit 0: the packed ranking (q_rank, v_med3_u32) has been checked, bit 1: it reproduced its scalar statement;
+//   bit 2: the matrix-core read-out of k_icp_fusedq_momm has been checked, bit 3: it reproduced sum U U^T.
+// force != 0 runs the checks now (smoke(), bench.py and the tests ask before they time or judge anything); a checked-and-failed bit pair
+// (01 / 0100) means the library is running a substitute kernel on this device and has said so on stderr.
+int hop_debug_selfcheck(hop_ctx* c, int force) {
+  if (!c) return 0;
+  if (force) {
+    if (hipSetDevice(c->device) != hipSuccess) return 0;
+    (void)qrank_ok(c);
+    (void)mfma_i8_layout_ok(c);
+  }
+  std::lock_guard<std::mutex> lk(g_selfcheck_mu);
+  auto it = g_selfcheck.find(c->device);
+  return it == g_selfcheck.end() ? 0 : it->second;
+}
 
 // development aid, not part of the ABI: list gathers of k_lcp_cells_fast per lookup (zero unless built with -DHOP_LCP_COUNT; tools/lcp_counters.py)
 int hop_debug_lcp_counters(hop_ctx* c, unsigned long long* out4, int reset) {

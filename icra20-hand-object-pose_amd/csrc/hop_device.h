@@ -210,6 +210,7 @@ struct LcpArgs {
   const int* perm;
   const float* pose_inv;  // [H][12] inverse poses (cell-list path)
   const int* inv_perm;  // caller index -> sorted position (cell-list path: the term table is indexed by sorted position)
+  int tiles_per_wave;   // nn_mode 3: 64-point tiles a wavefront adds before it reduces (lcp_tiles_per_wave), ONE value for every batch of a call
 };
 
 struct IcpState {
@@ -339,6 +340,7 @@ void launch_lcp_grid(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_cells(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_sum_t(const LcpArgs& a, int hb, hipStream_t s);
 int lcp_cells_row_stride(int hb);
+int lcp_tiles_per_wave(int ns, int H);
 void launch_lcp_cells_fast(const LcpArgs& a, int hb, hipStream_t s);
 void launch_lcp_sum_partial(const LcpArgs& a, int hb, hipStream_t s);
 void launch_cell_list_local_flag(const CellListBuildArgs& a, const GridDev& g, int* flag, hipStream_t s);

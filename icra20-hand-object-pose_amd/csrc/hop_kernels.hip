@@ -3188,13 +3188,15 @@ __global__ __launch_bounds__(64) void k_lcp_sum_partial(LcpArgs a, int hb, int h
 }
 // 64-point tiles per wavefront of k_lcp_cells_fast: 4 when that still leaves >= 16 workgroups per CU (C2: 69 x 2560), else 1 (the as-shipped
 // sizes -- 100 hypotheses x 2 000 points -- need every workgroup they can get).  HOP_LCP_TILES=<k> overrides (A/B runs).
-int lcp_tiles_per_wave(int ns, int hb) {
+// Decided ONCE per hop_lcp_select_best call from the whole set's H (LcpArgs::tiles_per_wave), never per batch: K fixes the association of a
+// hypothesis' float sum, and a score must not depend on which batch of a call its hypothesis fell into.
+int lcp_tiles_per_wave(int ns, int H) {
   if (const char* e = getenv("HOP_LCP_TILES")) return std::max(1, std::min(16, atoi(e)));
-  const long long blocks1 = (long long)((ns + 63) / 64) * ((hb + LCP_FTH - 1) / LCP_FTH);
+  const long long blocks1 = (long long)((ns + 63) / 64) * ((H + LCP_FTH - 1) / LCP_FTH);
   return blocks1 >= 4 * 4096 ? 4 : 1;
 }
 void launch_lcp_cells_fast(const LcpArgs& a, int hb, hipStream_t s) {
-  const int K = lcp_tiles_per_wave(a.ns, hb);
+  const int K = std::max(1, a.tiles_per_wave);
   const int npt = (a.ns + 64 * K - 1) / (64 * K), nht = (hb + LCP_FTH - 1) / LCP_FTH;
   const int hs = ((hb + LCP_FTH - 1) / LCP_FTH) * LCP_FTH;
   const dim3 grid((unsigned)(8 * ((npt + 7) / 8) * nht));
@@ -3202,7 +3204,7 @@ void launch_lcp_cells_fast(const LcpArgs& a, int hb, hipStream_t s) {
   else hipLaunchKernelGGL(k_lcp_cells_fast<false>, grid, dim3(256), 0, s, a, hb, hs, npt, K);
 }
 void launch_lcp_sum_partial(const LcpArgs& a, int hb, hipStream_t s) {
-  const int K = lcp_tiles_per_wave(a.ns, hb);
+  const int K = std::max(1, a.tiles_per_wave);
   const int npt = (a.ns + 64 * K - 1) / (64 * K);
   const int hs = ((hb + LCP_FTH - 1) / LCP_FTH) * LCP_FTH;
   hipLaunchKernelGGL(k_lcp_sum_partial, dim3((hb + 63) / 64), dim3(64), 0, s, a, hb, hs, npt);

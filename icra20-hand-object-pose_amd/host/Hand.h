@@ -253,7 +253,7 @@ class Hand {
       const Mat4 I = Mat4::Identity();
       hop::check(hop_hypos_upload(ic, I.m, nullptr, 1), ic, "hop_hypos_upload");
       hop_icp_opts o{50, 30.f, 0.03f, 0, hop::icp_nn_mode_reference()};  // nn_mode 7: Utils::runICP's own minimiser (Levenberg-Marquardt), the oracle's bits
-      hop::check(hop_icp_refine(ic, &o, nullptr, nullptr), ic, "hop_icp_refine");
+      hop::icp_refine_reference(ic, o, "hop_icp_refine(handbaseICP)");
       Mat4 pose;
       int got = 0;
       hop::check(hop_hypos_download(ic, pose.m, nullptr, nullptr, 1, &got), ic, "hop_hypos_download");

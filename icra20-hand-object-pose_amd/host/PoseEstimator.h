@@ -32,11 +32,30 @@ struct Mesh {             // what igl::readOBJ / pcl::PolygonMesh hold: vertices
 // form that round 3 measured on hardware, should a device disagree with nn_mode 7's CPU-verified bits.
 inline int icp_nn_mode_reference() {
   const char* e = std::getenv("HOP_ICP_NN_MODE");
-  const int m = e ? std::atoi(e) : 7;
-  return (m < 0 || m > 7) ? 7 : m;
+  if (!e || !*e) return 7;
+  char* end = nullptr;
+  const long m = std::strtol(e, &end, 10);
+  while (end && (*end == ' ' || *end == '\t' || *end == '\n')) ++end;
+  if (end == e || (end && *end) || m < 0 || m > 7) {  // empty, trailing text or out of range: the default, and a line that says so
+    std::fprintf(stderr, "hop: HOP_ICP_NN_MODE='%s' is not an integer in 0..7; using 7\n", e);
+    return 7;
+  }
+  return (int)m;
 }
 inline void check(int rc, hop_ctx* c, const char* where) {
   if (rc != HOP_OK) throw std::runtime_error(std::string(where) + ": " + hop_strerror(rc) + " " + (c ? hop_last_error(c) : ""));
+}
+// The mirrors' refinement call.  nn_mode 7 needs the packed model lists (a 5 mm model of < 65535 points inside the 16-bit cell frame) and
+// refuses with HOP_E_STATE without them; the reference refines any model, so the mirrors retry once with nn_mode 5 (the same minimiser in its
+// per-evaluation float form on the plain lists) and say so on stderr -- a different arithmetic is never taken silently.
+inline void icp_refine_reference(hop_ctx* c, hop_icp_opts o, const char* where) {
+  int rc = hop_icp_refine(c, &o, nullptr, nullptr);
+  if (rc == HOP_E_STATE && o.nn_mode == 7) {
+    std::fprintf(stderr, "hop: %s: %s -- retrying with nn_mode 5 (per-evaluation float form of the same minimiser)\n", where, hop_last_error(c));
+    o.nn_mode = 5;
+    rc = hop_icp_refine(c, &o, nullptr, nullptr);
+  }
+  check(rc, c, where);
 }
 }  // namespace hop
 
@@ -119,7 +138,7 @@ class PoseEstimator {
     // nn_mode 7: the reference's minimiser (PCL's TransformationEstimationPointToPlane = Eigen's Levenberg-Marquardt, Utils.cpp:200-216) from
     // integer-exact moment sums with an IEEE-only solve: the refined poses are the CPU oracle's, bit for bit
     hop_icp_opts o{10, cfg->getf("icp_angle_thres"), cfg->getf("icp_dist_thres"), 100, hop::icp_nn_mode_reference()};
-    hop::check(hop_icp_refine(ctx_, &o, nullptr, nullptr), ctx_, "hop_icp_refine");
+    hop::icp_refine_reference(ctx_, o, "hop_icp_refine");
   }
 
   // registerMesh (PoseEstimator.cpp:505-508 -> SDFchecker::registerMesh, SDFchecker.cpp:36-78)

@@ -71,7 +71,7 @@ def estimate_frame(ctx, xyz, nrm, conf, sym):
     if st.n_hypotheses == 0:
         return np.eye(4, dtype=np.float32)   # "No pose found": the reference writes the identity (main :189-196)
     ctx.cluster_poses(30.0, 0.015, sym, True)
-    ctx.icp_refine(10, 45.0, 0.01, max_hypotheses=100, nn_mode=api.ICP_NN_MODE_REFERENCE)
+    ctx.icp_refine_reference(10, 45.0, 0.01, max_hypotheses=100)
     ctx.cluster_poses(5.0, 0.003, sym, False)
     best, _, _ = ctx.lcp_select_best(0.001, 10.0, -1)
     return best

@@ -23,6 +23,7 @@ python tools/rocprof_summary.py $OUT/stats_default/b_results.db $OUT/kernel_stat
 python tools/rocprof_summary.py $OUT/stats_serial/b_results.db $OUT/kernel_stats_serial_inflight1.txt "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-next-rows --inflight 1 --steps 8 --warmup 2" > /dev/null
 python tools/pmc_summary.py $OUT/pmc_fetch/b_results.db $OUT/pmc_write/b_results.db $OUT/pmc_latest.json > $OUT/pmc_hbm.txt
 python tools/pmc_sq_summary.py $OUT/pmc_sq.txt "rocprofv3 --kernel-trace --pmc <set> -- python bench.py --no-cpu-baseline --no-next-rows --inflight 1 --steps 2 --warmup 1 (three passes: SQ x2, TCP/TCC)" $OUT/pmc_sq1/b_results.db $OUT/pmc_sq2/b_results.db $OUT/pmc_tcp/b_results.db > /dev/null
+cp $OUT/pmc_sq.json $OUT/pmc_sq_latest.json 2>/dev/null   # (copy both *_latest.json into profiles/ to have bench.py quote them)
 find $OUT -name "*.db" -delete
 find $OUT -type d -empty -delete
 ls -la $OUT

@@ -38,6 +38,7 @@ def main():
             c[0] += 1
             c[1] += float(value)
             c[2] += float(dur)
+    derived = {}
     lines = [f"# rocprofv3 --kernel-trace --pmc ... per-kernel counter summary (values per launch; avg_us under PMC)", f"# command: {cmd}"]
     order = sorted(per, key=lambda k: -max(c[2] for c in per[k].values()))
     for k in order:
@@ -57,6 +58,17 @@ def main():
             d.append(f"parked (s_waitcnt) share {v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']:.3f}")
         if "SQ_WAIT_INST_ANY" in v and "SQ_WAVE_CYCLES" in v and v["SQ_WAVE_CYCLES"] > 0:
             d.append(f"issue-stall share {v['SQ_WAIT_INST_ANY'] / v['SQ_WAVE_CYCLES']:.3f}")
+        dj = derived.setdefault(k, {"launches": n, "avg_us_under_pmc": avg_us})
+        if "SQ_ACTIVE_INST_VALU" in v and avg_us > 0:
+            dj["valu_busy"] = v["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * avg_us * 1e-6 * 2.4e9)
+        if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v and v["SQ_WAVES"] > 0:
+            dj["valu_insts_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in v and avg_us > 0:
+            dj["l1_accesses_per_clk_cu"] = v["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256 * avg_us * 1e-6 * 2.4e9)
+            if "TCP_TCC_READ_REQ_sum" in v and v["TCP_TOTAL_CACHE_ACCESSES_sum"] > 0:
+                dj["l1_hit"] = 1 - v["TCP_TCC_READ_REQ_sum"] / v["TCP_TOTAL_CACHE_ACCESSES_sum"]
+        if "TCC_HIT_sum" in v and "TCC_MISS_sum" in v and v["TCC_HIT_sum"] + v["TCC_MISS_sum"] > 0:
+            dj["l2_hit"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
         if "SQ_ACTIVE_INST_VALU" in v and avg_us > 0:
             # quad-cycles of VALU issue, 1024 SIMDs; clock taken as 2.4 GHz
             d.append(f"SIMD VALU busy {v['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * avg_us * 1e-6 * 2.4e9):.3f} (4 cyc/quad, 1024 SIMDs, 2.4 GHz)")
@@ -70,6 +82,10 @@ def main():
         for x in d:
             lines.append("    -> " + x)
     open(out, "w").write("\n".join(lines) + "\n")
+    # the derived figures per kernel as JSON next to the text (bench.py puts them into the line's roofline object: profiles/pmc_sq_latest.json)
+    import json
+    import os
+    json.dump({"_source": cmd, **derived}, open(os.path.splitext(out)[0] + ".json", "w"), indent=1)
     print("\n".join(lines[:120]))
 
 
