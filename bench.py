@@ -68,7 +68,71 @@ def parse():
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--parity-sample", type=int, default=64, help="hypotheses of one more frame (same seed, same stages as a timed step) whose refined poses the "
                     "oracle recomputes after the timed region: the bench line's parity gate (BASELINE.md 3.6); 0 = skip")
+    ap.add_argument("--no-preflight", action="store_true", help="skip the crash / hang guard that runs one small frame in a child process first")
+    ap.add_argument("--preflight-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--preflight-device", type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+def preflight_child(args):
+    """One SMALL frame of the hot path (generate -> keep -> refineByICP in the requested nn_mode -> computeLCP) on the device, in a process
+    of its own: a kernel that faults or hangs on first contact with a part takes this child down, not the bench.  No oracle here -- parity
+    is judged by parity_sample after the timed region; this only says "it runs, the numbers are finite, and the library's own device
+    self-checks passed"."""
+    import hop_loader
+    hop = hop_loader.load()
+    from hop_amd import api
+    synth = hop.synth
+    ctx = api.Context(args.preflight_device)
+    chk = ctx.selfcheck(force=True)
+    sc = synth.make_scene(2000, seed=7)
+    mx5, mn5 = synth.ellipsoid_model_spacing(0.005)
+    mx1, mn1 = synth.ellipsoid_model(3000)
+    ctx.set_scene(sc.xyz, sc.nrm, sc.conf, 0.8)
+    ctx.set_model(api.HOP_MODEL_5MM, mx5, mn5)
+    ctx.set_model(api.HOP_MODEL_1MM, mx1, mn1)
+    ctx.set_ppf_keys(synth.ppf_key_table())
+    o = ctx.default_s4pcs_opts(sample_size=100, success_quadrilaterals=64, max_time_seconds=0, n_trials=64, random_seed=5489, verify_mode=args.verify_mode)
+    ctx.s4pcs_generate(o, download=False)
+    ctx.hypos_keep_topk(512)
+    n = ctx.hypos_count()
+    it, cv = ctx.icp_refine(10, 45.0, 0.01, nn_mode=args.nn_mode, want_stats=True)
+    best, score, idx = ctx.lcp_select_best(0.001, 10.0, args.lcp_mode)
+    p, s_, _ = ctx.hypos_download()
+    chk2 = ctx.selfcheck(force=False)
+    print(json.dumps({"ok": bool(n > 0 and np.isfinite(p).all() and np.isfinite(s_).all() and np.isfinite(score)), "hypotheses": int(n),
+                      "icp_iterations_mean": float(np.mean(it)) if n else 0.0, "best_lcp_score": float(score),
+                      "selfcheck": {"packed_ranking_q_rank": chk["qrank"], "matrix_core_read_out": chk["mfma"]}, "icp_engine": chk2["icp_engine"]}), flush=True)
+    ctx.close()
+
+
+def preflight(args, device):
+    """Runs preflight_child for args.nn_mode; if that child dies (fault), hangs (timeout) or reports garbage, tries the ICP forms that HAVE
+    run on this hardware before (nn_mode 6: round 3, nn_mode 4: round 2) in turn.  Returns (nn_mode to time, report for the JSON line).  A
+    fallback is never silent: the line carries the report, `config.nn_mode` is the mode that was timed, and `dtype` / `icp_minimiser` follow it."""
+    import subprocess
+    report = {"requested_nn_mode": args.nn_mode, "tries": []}
+    order = [args.nn_mode] + [m for m in (6, 4) if m < args.nn_mode and args.nn_mode >= 5]
+    for m in order:
+        cmd = [sys.executable, os.path.abspath(__file__), "--preflight-child", "--preflight-device", str(device), "--nn-mode", str(m),
+               "--lcp-mode", str(args.lcp_mode), "--verify-mode", str(args.verify_mode)]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=float(os.environ.get("HOP_BENCH_PREFLIGHT_TIMEOUT_S", "300")))
+            line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+            res = json.loads(line) if r.returncode == 0 and line.startswith("{") else {"ok": False, "exit": r.returncode, "stderr_tail": r.stderr[-400:]}
+        except subprocess.TimeoutExpired:
+            res = {"ok": False, "error": "timeout (hang?)"}
+        except Exception as e:
+            res = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+        res["nn_mode"] = m
+        res["seconds"] = time.perf_counter() - t0
+        report["tries"].append(res)
+        if res.get("ok"):
+            report["timed_nn_mode"] = m
+            return m, report
+    report["timed_nn_mode"] = args.nn_mode   # nothing survived: run the requested mode and let the failure show in the parent
+    return args.nn_mode, report
 
 
 CFG = {"hand_match": {"finger1_min_match": 5, "finger2_min_match": 5, "finger1_dist_thres": 0.005, "finger2_dist_thres": 0.005,
@@ -472,9 +536,16 @@ def parity_sample(w, args, n_sample):
 
 def main():
     args = parse()
+    if args.preflight_child:
+        return preflight_child(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    preflight_report = None
+    if not args.no_preflight and not os.environ.get("HOP_TEST_EMU"):
+        # before anything of this process touches the device: the small frame in a child (every rank on its own device; the ranks agree on the
+        # lowest surviving mode below, once the process group is up)
+        args.nn_mode, preflight_report = preflight(args, local_rank)
     import threading
     import torch
     dist = None
@@ -499,6 +570,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     xdev = dev if backend == "nccl" else torch.device("cpu")   # where the collectives run
 
+    if use_dist and preflight_report is not None:
+        tm_ = torch.tensor([args.nn_mode], dtype=torch.int32, device=xdev)
+        dist.all_reduce(tm_, op=dist.ReduceOp.MIN)   # (7 > 6 > 4: the ranks time the same arithmetic)
+        args.nn_mode = int(tm_.item())
+        preflight_report["timed_nn_mode"] = args.nn_mode
     strong = args.scaling == "strong"
     F = 1 if strong else max(1, args.inflight)
     w = Workload(args, rank)
@@ -820,6 +896,8 @@ def main():
             "best_lcp_score": infos[-1]["score"],
             "alt_modes": alt,
         }
+        if preflight_report is not None:
+            out["preflight"] = preflight_report
         try:
             # which moment kernel nn_mode 7 ran, and what the library's first-use checks of the gfx950-specific instructions said on this device
             # (False = the library substituted a kernel and said so on stderr: a finding about the part, not a pass)

@@ -1,5 +1,6 @@
 import os
 import sys
+import time
 
 import pytest
 
@@ -10,6 +11,20 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+# The driver's `pytest -m gpu` step has a wall-clock limit (1200 s) and the suite's time on a real box has not been observed since round 2
+# (102 tests then, 201 now; the heavy ones run the CPU oracle beside the device).  A run killed at the limit reports nothing; a run that stops
+# STARTING tests shortly before it reports every result it has.  So: once HOP_GPU_SUITE_BUDGET_S (default 1000) seconds of the session have
+# passed, the remaining `gpu` tests are skipped with a reason that says so -- a skip is not a pass, and the file order (cheap and
+# hardware-proven files first, the never-run kernels of nn_mode 7 last) decides what gets its result first.
+_SESSION_T0 = time.time()
+GPU_SUITE_BUDGET_S = float(os.environ.get("HOP_GPU_SUITE_BUDGET_S", "1000"))
+
+
+def pytest_runtest_setup(item):
+    if "gpu" in item.keywords and not os.environ.get("HOP_TEST_EMU") and time.time() - _SESSION_T0 > GPU_SUITE_BUDGET_S:
+        pytest.skip(f"NOT RUN: the GPU suite's time budget ({GPU_SUITE_BUDGET_S:.0f} s, HOP_GPU_SUITE_BUDGET_S) was used up before this test")
 
 
 EMU_LIB = os.environ.get("HOP_TEST_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "_build", "libhop_emu.so")   # (override: e.g. an AddressSanitizer build of the model)
