@@ -27,6 +27,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of the GPU boxes supports dmabuf IPC only: without this RCCL's cross-process buffer sharing fails with
+# `hipIpcGetMemHandle: invalid argument`.  Exported by the image already; kept here for any launcher that builds its own environment
+# (must be in place before the HSA runtime starts, i.e. before torch / libhop.so are loaded).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak, same guide

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The short form of tools/gpu_round_check.sh for a box that is only available for a few minutes: smoke(), the instruction self-test, the driver's
 # bench command, the nn_mode 7 bit tests at small sizes -- logs under gpurun_out/<tag>/.
-TAG=${1:-r05q}
+TAG=${1:-r06q}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1

@@ -8,7 +8,7 @@
 #     bench_*.json     the same with nn_mode 6 (round 3's default), with nn_mode 7's sums on the vector units (HOP_ICP_MFMA=0), with k_quads_hash
 #     icp_bench_*.json the ICP stage alone: nn_mode 4 / 6 / 7 (matrix cores) / 7dot2 (vector units), and nn_mode 7 built for 6 and 8 waves per SIMD
 # Profiles (rocprofv3 kernel stats, PMC passes) are a second call: tools/gpu_profile.sh <tag>.
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
