@@ -1927,6 +1927,14 @@ template __global__ void k_icp_fused<ICP_ACCUM_R>(IcpArgs);
 // The result is the same correspondence the linear scan finds (same argument as cells_nn above, with the
 // quantisation error q_eq of a candidate position added to `tol`).
 // ------------------------------------------------------------------------------------------------
+// One gather instead of two.  A lookup reads a small record, tests one field (an empty cell ends the lookup) and only then uses the others; left alone,
+// the compiler loads the tested field, branches, and fetches the rest in a SECOND load behind the branch -- two passes of the L1 tag pipe over the
+// very same lines (a wavefront's gather costs 64.5 cycles of that pipe whatever its width: profiles/r02_l1_load_rates.txt; seen in the gfx950
+// assembly of the packed ICP lookups' cell record and of computeLCP's head records).  Declaring every field live right after the load keeps it ONE
+// 8- / 16-byte load.  The asm statement is empty: no instruction is emitted, no value changes.  (Not `volatile`: that would count as a store to
+// unknown memory and turn every later uniform load -- the poses of computeLCP -- from a scalar load into a vector one.)
+__device__ __forceinline__ void keep_whole(uint2& r) { asm("" : "+v"(r.x), "+v"(r.y)); }
+__device__ __forceinline__ void keep_whole(uint4& r) { asm("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
 __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
   unsigned r;
   asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -2013,13 +2021,17 @@ __device__ __forceinline__ void q_chunk_exact(const CellListDev& c, Q3 l, const 
 
 // DEFER: a lookup whose two best keys the ranking cannot separate is not re-scanned here; the caller is told (true) and
 // repeats it later with DEFER = false (k_icp_fusedq<true> collects such lookups per block and runs them densely packed).
-template <bool DEFER>
+// ONE_GATHER: the cell record as one 8-byte load (keep_whole).  Only k_icp_fusedq_momm asks for it: the kernels that have run on hardware (nn_mode 4
+// at 7 waves, nn_mode 6 at 4 -- the forms bench.py falls back to) have no registers for the longer life of r.x (72 VGPRs + 84 B of scratch, 128 + 48 B
+// with it) and are to compile to the assembly that ran.
+template <bool DEFER, bool ONE_GATHER = false>
 __device__ __forceinline__ bool cells_nnq(const CellListDev& c, V3 qg, const float* T, V3 q, float& best, int& bidx, V3& moved) {
   const float hx = __builtin_fmaf(qg.x, c.inv_cell, c.gox), hy = __builtin_fmaf(qg.y, c.inv_cell, c.goy), hz = __builtin_fmaf(qg.z, c.inv_cell, c.goz);
   const float gx = floorf(hx), gy = floorf(hy), gz = floorf(hz);
   const int ix = (int)gx, iy = (int)gy, iz = (int)gz;
   if ((unsigned)ix >= (unsigned)c.dx || (unsigned)iy >= (unsigned)c.dy || (unsigned)iz >= (unsigned)c.dz) return false;
-  const uint2 r = c.rec[(iz * c.dy + iy) * c.dx + ix];
+  uint2 r = c.rec[(iz * c.dy + iy) * c.dx + ix];
+  if constexpr (ONE_GATHER) keep_whole(r);
   const int nch = (int)r.y;
   ICP_COUNT(0, 1);
   if (nch == 0) return false;
@@ -2546,6 +2558,7 @@ struct MommLds {
   unsigned short defer_i[4][128];
   long long dsum[4];
   int n_cnt[4];
+  __attribute__((aligned(16))) float tf[3][12];  // pose, inverse pose, accumulated ICP transform of the workgroup's hypothesis (rows of 4)
 };
 static_assert(sizeof(unsigned short) * 4 * 13 * MOMM_ROW >= sizeof(int) * 4 * 3 * 256, "the tiles fit the rings");
 struct MommTab {
@@ -2583,7 +2596,7 @@ __device__ __forceinline__ int icp_fusedq_point_momm(const IcpArgs& a, int i, co
   float d2 = 3.0e38f;
   int j = -1;
   V3 tq;
-  if (cells_nnq<DEFER>(a.cells, m4_point_fma(sTi, q), pose, q, d2, j, tq)) return ICP_PT_DEFERRED;
+  if (cells_nnq<DEFER, true>(a.cells, m4_point_fma(sTi, q), pose, q, d2, j, tq)) return ICP_PT_DEFERRED;
   if (j < 0 || !(d2 <= a.max_d2)) return ICP_PT_REJECTED;
   const float4 tn = a.cells.nrm_idx[j];
   const float4 n4 = a.s_nrm4[i];
@@ -2649,9 +2662,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM
   const int hl = blockIdx.y, h = a.h0 + hl;
   const IcpState& st = a.state[hl];
   if (!st.active) return;
-  const float* __restrict__ pose = a.pose + (size_t)h * 16;
-  const float* __restrict__ sTi = a.pose_inv + (size_t)h * 12;
-  const float* __restrict__ F = st.final_tf;
+  // the three 3 x 4 transforms of this workgroup's hypothesis, staged in LDS once: every lane of every trip reads the same 48-byte rows, and the
+  // fences of the ring and of the deferred queue make the compiler re-load them from global memory at each use (15 uniform vector loads per trip
+  // through the L1 tag pipe, next to the trip's gathers); a uniform ds_read_b128 is a broadcast and leaves the tags alone
+  if (threadIdx.x < 36) {
+    const int m = threadIdx.x / 12, k = threadIdx.x % 12;
+    L.tf[m][k] = m == 0 ? a.pose[(size_t)h * 16 + k] : m == 1 ? a.pose_inv[(size_t)h * 12 + k] : st.final_tf[k];
+  }
+  __syncthreads();
+  const float* __restrict__ pose = L.tf[0];
+  const float* __restrict__ sTi = L.tf[1];
+  const float* __restrict__ F = L.tf[2];
   const V3 ctr = v3(pose[3], pose[7], pose[11]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned short(*__restrict__ ring)[MOMM_ROW] = L.ring[wave];
@@ -3024,7 +3045,8 @@ __device__ __forceinline__ void cells_nn1f_head(const CellListDev& c, V3 qg, con
   const int ix = (int)gx, iy = (int)gy, iz = (int)gz;
   if ((unsigned)ix >= (unsigned)c.dx || (unsigned)iy >= (unsigned)c.dy || (unsigned)iz >= (unsigned)c.dz) return;
   const int cidx = (iz * c.dy + iy) * c.dx + ix;
-  const uint4 hd = c.head[cidx];
+  uint4 hd = c.head[cidx];
+  keep_whole(hd);
   LCP_COUNT(1, 1);
   const int n = (int)(hd.w >> 24);
   if (n == 0) return;
@@ -3074,7 +3096,8 @@ __device__ __forceinline__ void cells_nn_plain_head(const CellListDev& c, V3 q, 
   const float fx = (q.x - c.ox) * c.inv_cell, fy = (q.y - c.oy) * c.inv_cell, fz = (q.z - c.oz) * c.inv_cell;
   if (!(fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)c.dx && fy < (float)c.dy && fz < (float)c.dz)) return;
   const int cidx = ((int)fz * c.dy + (int)fy) * c.dx + (int)fx;
-  const uint4 hd = c.head[cidx];
+  uint4 hd = c.head[cidx];
+  keep_whole(hd);
   LCP_COUNT(2, 1);
   const int n = (int)(hd.w >> 24);
   if (n == 0) return;

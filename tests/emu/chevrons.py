@@ -96,6 +96,8 @@ def rewrite_asm(text):
             ops.append(exprs[int(mm.group(1))] if mm else tok)
         return "emu_asm::%s(%s);" % (mnem, ", ".join(ops))
     out = ASM_RE.sub(one, text)
+    # an asm statement with an EMPTY template emits no instruction (a liveness hint to the device compiler: csrc keep_whole): dropped
+    out = re.sub(r'asm\s*(volatile)?\s*\(\s*""\s*:[^;]*?\)\s*;', "", out)
     if re.search(r"\basm\s*(volatile)?\s*\(", out):
         raise SystemExit("chevrons.py: an asm statement was not understood")
     return out
