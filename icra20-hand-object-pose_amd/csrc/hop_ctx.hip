@@ -1525,7 +1525,8 @@ int hop_icp_refine(hop_ctx* c, const hop_icp_opts* o, int* iterations_out, int* 
     // same minimiser in its per-evaluation form on the plain lists (nn_mode 5: the float results of that form); nn_mode 7 promises the
     // oracle's bits and has no other form that returns them: it refuses instead of answering with another arithmetic.
     if (lm7_mode && !cs.c.rec) {
-      hop_ctx_set_error(c, "hop_icp_refine: nn_mode 7 needs the packed cell lists (HOP_MODEL_5MM of < 65535 points, lists inside the 16-bit cell frame); use nn_mode 5");
+      hop_ctx_set_error(c, qrank_ok(c) ? "hop_icp_refine: nn_mode 7 needs the packed cell lists (HOP_MODEL_5MM of < 65535 points, lists inside the 16-bit cell frame); use nn_mode 5"
+                                          : "hop_icp_refine: nn_mode 7 needs the packed cell lists, and this device failed the check of their 16-bit ranking (q_rank; see stderr, hop_debug_selfcheck); use nn_mode 5");
       return HOP_E_STATE;
     }
     if (lm6_mode && !cs.c.rec) lm6_mode = false, lm_mode = true;
