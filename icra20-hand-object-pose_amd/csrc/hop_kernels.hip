@@ -3118,8 +3118,11 @@ __device__ __forceinline__ void cells_nn_plain_head(const CellListDev& c, V3 q, 
       LCP_COUNT(2, 1);
       const float d2 = sqdist_flann(q, v3(t.x, t.y, t.z));
       const int j = __float_as_int(t.w);
-      if (d2 < best) best = d2, bj = j, bpos = k;
-      else if (d2 == best) {
+      // (selects on the common path; the exact tie -- two scene points at one float distance from the query -- is the only branch)
+      const float b0 = best;
+      const bool lt = d2 < b0;
+      best = lt ? d2 : best, bj = lt ? j : bj, bpos = lt ? k : bpos;
+      if (d2 == b0) {
         if (bj < 0) {
           bj = __float_as_int(c.pts[beg].w);
           LCP_COUNT(2, 1);
