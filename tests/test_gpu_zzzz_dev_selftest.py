@@ -242,3 +242,14 @@ def test_compute_lcp_through_inline_head_records_returns_the_same_bits(ctx, hop,
     assert np.all(np.abs(s4 - s1) <= 2e-6 * np.maximum(np.abs(s1), 1.0)) and idx4 == out["head"][1]
     assert not np.array_equal(s4, np.zeros_like(s4))
     assert out["head"][1] == out["range"][1] and out["head"][0][:nh].min() > 0.02 * ns
+
+
+def test_the_librarys_own_first_use_checks_pass_on_this_device(ctx):
+    """Round 6: before its first packed lookup / matrix-core read-out on a device the library checks the instruction sequences itself
+    (hop_ctx.hip qrank_ok, mfma_i8_layout_ok) and, on a mismatch, disables the path that depends on them.  This test is where such a
+    substitution becomes a red result instead of a line on stderr: both checks must have run and passed, and nn_mode 7 must then run on the
+    matrix cores."""
+    chk = ctx.selfcheck(force=True)
+    assert chk["qrank"] is True, "q_rank (v_pk_sub_i16 / v_mad_i32_i16 / v_dot2_i32_i16) or v_med3_u32 does not reproduce its scalar statement on this device"
+    assert chk["mfma"] is True, "the ring -> v_perm_b32 -> v_mfma_i32_16x16x64_i8 read-out does not reproduce sum U U^T on this device"
+    assert ctx.selfcheck(force=False) == ctx.selfcheck(force=True)   # a verdict is per device and does not change
