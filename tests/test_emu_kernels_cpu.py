@@ -93,7 +93,7 @@ def test_gfx950_primitives_as_the_model_states_them(emu_lib):
     """tests/test_gpu_zzzz_dev_selftest.py on the model: the stand-ins of tests/emu/hip/hip_runtime.h for v_med3_u32, v_mad_i32_i24, v_cvt_pk_i16_i32,
     v_dot2_i32_i16, v_perm_b32, v_med3_f32 and v_mfma_i32_16x16x64_i8 against the numpy statement of the same instructions, and the two moment
     kernels against each other (on a device the same file checks the instructions themselves)"""
-    assert _child_pytest([os.path.join("tests", "test_gpu_zzzz_dev_selftest.py")], timeout=1500) == 5
+    assert _child_pytest([os.path.join("tests", "test_gpu_zzzz_dev_selftest.py")], timeout=1500) == 6
 
 
 def test_the_model_sees_a_staging_slot_reused_before_its_stream_was_synchronised(emu_lib, tmp_path):
