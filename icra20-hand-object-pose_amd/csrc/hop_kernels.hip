@@ -13,6 +13,21 @@
 #include "../../include/hop.h"
 #include "hop_device.h"
 
+// Packed f32 arithmetic, kernel by kernel.  This unit is compiled with the target feature packed-fp32-ops OFF (csrc/Makefile: -Xclang -target-feature
+// -Xclang -packed-fp32-ops) and every kernel below switches it back ON for itself (HOP_PK_F32) EXCEPT the two lookup kernels of the shipped
+// configuration, k_icp_fusedq_momm and k_lcp_cells_fast.  Why: the compiler pairs independent float operations into v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 -- its cost model has them at twice the scalar rate -- and pays v_mov_b32s to line the operands up in register pairs; on this part a
+// packed f32 operation issues in 5.2 cycles per wavefront against 2.5-2.7 for each of the two scalar ones (profiles/r02_valu_issue_rates.txt, measured
+// on the MI355X), so a pair buys nothing and every move costs 2.3 cycles.  Why this way round: a kernel that switches the feature OFF for itself can no
+// longer inline the HIP header's __syncthreads / __ballot / __shfl_xor (a callee with more target features than its caller is not inlined: tried); a
+// kernel that switches it ON can.  With the attribute a kernel compiles to exactly the assembly it had -- the kernels that have run on hardware stay
+// what ran (checked body by body) -- and the arithmetic is the same IEEE operations either way.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HOP_PK_F32 __attribute__((target("packed-fp32-ops")))
+#else
+#define HOP_PK_F32
+#endif
+
 namespace hop {
 
 // ------------------------------------------------------------------------------------------------
@@ -115,7 +130,7 @@ __device__ __forceinline__ void wave_count_by_key(bool flag, int key, int* __res
 // rows i whose data sits in LDS (broadcast reads); __ballot packs the 64 answers of a row into one word.
 // ------------------------------------------------------------------------------------------------
 template <bool THR>
-__global__ __launch_bounds__(256) void k_ppf_matrix(PpfMatrixArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_ppf_matrix(PpfMatrixArgs a) {
   __shared__ float rows[PPF_ROWS][8];
   __shared__ float sthr[32];
   if (THR && threadIdx.x < 32) sthr[threadIdx.x] = a.angle_thr[threadIdx.x];
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(256) void k_ppf_matrix(PpfMatrixArgs a) {
 // from values already in registers, bit for bit what the direct evaluation gives.  A wave owns the 64 columns jb and walks the 64
 // rows of word ib <= jb: the forward bits of a row go out as one ballot word M[i][jb], the reverse bits accumulate per lane
 // into M[j][ib]; diagonal blocks (ib == jb) hold both orders already.
-__global__ __launch_bounds__(256) void k_ppf_matrix_sym(PpfMatrixArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_ppf_matrix_sym(PpfMatrixArgs a) {
   __shared__ float rows[PPF_ROWS][8];
   __shared__ float sthr[32];
   static_assert(PPF_ROWS == 64, "one matrix word of rows per block");
@@ -253,7 +268,7 @@ __device__ __forceinline__ void wave_append_pair(bool flag, unsigned a, unsigned
   }
 }
 
-__global__ __launch_bounds__(256) void k_pairs(PairArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_pairs(PairArgs a) {
   const int b = blockIdx.y;
   const BaseDev& B = a.bases[b];
   const int n = a.nq;
@@ -284,7 +299,7 @@ __global__ __launch_bounds__(256) void k_pairs(PairArgs a) {
 //   main: the n1 x n2 predicate matrix, fused with the 3-point rigid fit (ComputeRigidTransformation) and
 //         the rms<delta gate of TryCongruentSet (cse.hpp:273-291); survivors become Verify candidates.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_quad_prep(QuadPrepArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_quad_prep(QuadPrepArgs a) {
   const int b = blockIdx.y;
   const BaseDev& B = a.bases[b];
   const int n1 = min(a.cnt1[b], a.cap), n2 = min(a.cnt2[b], a.cap);
@@ -411,7 +426,7 @@ __device__ __forceinline__ void quad_fit_emit(const QuadArgs& a, const BaseDev& 
 // (query) per wave at a time -- wave-uniform, read once -- against all first pairs (elements), 64 per step, read
 // coalesced.  The ~0.2 % that pass go into a device-wide queue (one wave-aggregated atomic per step that has any), so that
 // the long rigid-fit code of stage 2 always runs with full lanes whatever the per-wave yield.
-__global__ __launch_bounds__(256) void k_quads(QuadArgs a, int n1_above) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_quads(QuadArgs a, int n1_above) {
   __shared__ int queue_s[4][2][128];  // per wave: accepted (id1, id2) on their way to the device-wide queue
   const int b = blockIdx.y;
   const int n1 = min(a.cnt1[b], a.cap), n2 = min(a.cnt2[b], a.cap);
@@ -482,7 +497,7 @@ constexpr int QH_MAX = 4096, QH_SLOTS = 4096;
 __device__ __forceinline__ int qh_hash(int cx, int cy, int cz) {
   return (int)(((unsigned)cx * 73856093u) ^ ((unsigned)cy * 19349663u) ^ ((unsigned)cz * 83492791u)) & (QH_SLOTS - 1);
 }
-__global__ __launch_bounds__(256) void k_quads_hash(QuadArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_quads_hash(QuadArgs a) {
   __shared__ int head[QH_SLOTS];
   __shared__ unsigned short nxt[QH_MAX];
   __shared__ uint2 ekey[QH_MAX];
@@ -571,7 +586,7 @@ __global__ __launch_bounds__(256) void k_quads_hash(QuadArgs a) {
 }
 
 // Stage 2: one queued quadrilateral per lane
-__global__ __launch_bounds__(256) void k_quad_fit(QuadArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_quad_fit(QuadArgs a) {
   const int qi = blockIdx.y;
   const int n = min(a.fit_count[qi], a.fit_cap);
   const int stride = gridDim.x * blockDim.x;
@@ -588,7 +603,7 @@ __global__ __launch_bounds__(256) void k_quad_fit(QuadArgs a) {
 // query g = (candidate c, sample s): T_c * Qs[s]; targets: all of P (centred), streamed through LDS.
 // ------------------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(256) void k_verify_brute(VerifyArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_verify_brute(VerifyArgs a) {
   __shared__ float4 tile[NN_TILE];
   const int n_cand = a.n_cand_ptr ? min(*a.n_cand_ptr, a.cand_cap) : a.n_cand;
   const long long total = (long long)n_cand * a.nq;
@@ -628,7 +643,7 @@ template __global__ void k_verify_brute<8>(VerifyArgs);
 
 // Verify on a voxel grid over P (cell >= delta): a transformed sample can only have an inlier partner in
 // the 27 cells around its own.  Same arithmetic for the distance test, hence identical counts.
-__global__ __launch_bounds__(256) void k_verify_grid(VerifyArgs a, GridDev gd) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_verify_grid(VerifyArgs a, GridDev gd) {
   const int n_cand = a.n_cand_ptr ? min(*a.n_cand_ptr, a.cand_cap) : a.n_cand;
   const long long total = (long long)n_cand * a.nq;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ((total + 63) / 64) * 64;
@@ -667,7 +682,7 @@ __global__ __launch_bounds__(256) void k_verify_grid(VerifyArgs a, GridDev gd) {
 
 // Verify on NN cell lists over P built in EXIST mode (verify_mode 2): one cell lookup, then a handful of candidates
 // (one, when every query of the cell is known to hit).  Same distance expression and threshold as the other modes.
-__global__ __launch_bounds__(256) void k_verify_cells(VerifyArgs a, CellListDev cl) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_verify_cells(VerifyArgs a, CellListDev cl) {
   const int n_cand = a.n_cand_ptr ? min(*a.n_cand_ptr, a.cand_cap) : a.n_cand;
   const long long total = (long long)n_cand * a.nq;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ((total + 63) / 64) * 64;
@@ -700,7 +715,7 @@ __global__ __launch_bounds__(256) void k_verify_cells(VerifyArgs a, CellListDev 
 
 // K3c: candidates with at least one inlier become hypotheses (cse.hpp:313-333): the translation is
 // re-expressed for the un-centred clouds, t = c1 + centroid_P - R (c2 + centroid_Q).
-__global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_emit(EmitArgs a) {
   const int n_cand = min(*a.cand_count, a.cand_cap);
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.cand_total, n_cand);
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cand; c += gridDim.x * blockDim.x) {
@@ -728,7 +743,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
 }
 
 // gather of the sorted hypothesis set
-__global__ void k_gather_hypos(const unsigned* __restrict__ perm, int n, const float* __restrict__ pose_in,
+__global__ HOP_PK_F32 void k_gather_hypos(const unsigned* __restrict__ perm, int n, const float* __restrict__ pose_in,
                                const float* __restrict__ score_in, float* __restrict__ pose_out, float* __restrict__ score_out,
                                int* __restrict__ id_out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -742,7 +757,7 @@ __global__ void k_gather_hypos(const unsigned* __restrict__ perm, int n, const f
   }
 }
 // row r of the top-k table (hop.h: score, id, pose[16]) from the r-th entry of the sorted order; rows beyond the set: score -FLT_MAX, id -1
-__global__ void k_topk_pack(const unsigned* __restrict__ order, int H, int k, int id_offset, const float* __restrict__ pose, const float* __restrict__ score,
+__global__ HOP_PK_F32 void k_topk_pack(const unsigned* __restrict__ order, int H, int k, int id_offset, const float* __restrict__ pose, const float* __restrict__ score,
                             const int* __restrict__ ids, float* __restrict__ rows) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = t / HOP_TOPK_ROW_FLOATS, q = t % HOP_TOPK_ROW_FLOATS;
@@ -759,11 +774,11 @@ void launch_topk_pack(const unsigned* order, int H, int k, int id_offset, const 
   const int n = k * HOP_TOPK_ROW_FLOATS;
   hipLaunchKernelGGL(k_topk_pack, dim3((n + 255) / 256), dim3(256), 0, s, order, H, k, id_offset, pose, score, ids, rows);
 }
-__global__ void k_iota(unsigned* p, int n) {
+__global__ HOP_PK_F32 void k_iota(unsigned* p, int n) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) p[t] = (unsigned)t;
 }
-__global__ void k_score_keys(const float* __restrict__ score, const int* __restrict__ ids, int n, unsigned long long* __restrict__ key) {
+__global__ HOP_PK_F32 void k_score_keys(const float* __restrict__ score, const int* __restrict__ ids, int n, unsigned long long* __restrict__ key) {
   // descending score, then ascending id, as one ascending 64-bit key (score_order_key: -0 = +0, NaN below every number -- the
   // same key the host's hop_topk_merge and the device merge of hop_comm.hip order by)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -779,7 +794,7 @@ __global__ void k_score_keys(const float* __restrict__ score, const int* __restr
 // hypothesis repeats exactly that, so scores are bit-equal to the CPU.
 // ------------------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(256) void k_lcp_reverse(LcpArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_lcp_reverse(LcpArgs a) {
   __shared__ float4 tile[NN_TILE];
   const int h = a.h0 + blockIdx.y;
   const float* T = a.pose + (size_t)h * 16;
@@ -827,7 +842,7 @@ __device__ __forceinline__ float lcp_term_unit(V3 u1, V3 u2, float d2, float dis
   if (d > cos_thres) return d * (1 - sqrtf(d2) / dist_thres) * 1.0f;
   return -1.f;
 }
-__global__ __launch_bounds__(256) void k_unit_normals(const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz, int n,
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_unit_normals(const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz, int n,
                                                      float* __restrict__ ux, float* __restrict__ uy, float* __restrict__ uz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -839,7 +854,7 @@ void launch_unit_normals(const float* nx, const float* ny, const float* nz, int 
 }
 
 template <int R>
-__global__ __launch_bounds__(256) void k_lcp_forward(LcpArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_lcp_forward(LcpArgs a) {
   __shared__ float4 tile[NN_TILE];
   const int h = a.h0 + blockIdx.y;
   const float* T = a.pose + (size_t)h * 16;
@@ -882,7 +897,7 @@ __global__ __launch_bounds__(256) void k_lcp_forward(LcpArgs a) {
 }
 template __global__ void k_lcp_forward<4>(LcpArgs);
 
-__global__ __launch_bounds__(64) void k_lcp_sum(LcpArgs a, int hb) {
+__global__ HOP_PK_F32 __launch_bounds__(64) void k_lcp_sum(LcpArgs a, int hb) {
   const int hl = blockIdx.x * blockDim.x + threadIdx.x;
   if (hl >= hb) return;
   // (forward term, reciprocal term) of a scene point: 8-byte pairs -- a hypothesis' row starts at a multiple of 8 bytes whatever ns is (16-byte
@@ -984,7 +999,7 @@ __device__ __forceinline__ void block_pose_and_inverse(const float* pose, float*
 
 // computeLCP on grids: forward NN (scene point -> transformed model) through the model's rest-frame grid,
 // reciprocal NN (transformed model point -> scene) through the scene grid; same terms[] as the brute-force pair.
-__global__ __launch_bounds__(256) void k_lcp_grid(LcpArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_lcp_grid(LcpArgs a) {
   __shared__ float sT[12], sTi[12];
   const int h = a.h0 + blockIdx.y;
   block_pose_and_inverse(a.pose + (size_t)h * 16, sT, sTi);
@@ -1034,7 +1049,7 @@ __device__ __forceinline__ float box_mindist2(const float lo[3], const float hi[
   return dx * dx + dy * dy + dz * dz;
 }
 
-__global__ __launch_bounds__(256) void k_cell_list_bounds(CellListBuildArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_cell_list_bounds(CellListBuildArgs a) {
   __shared__ float red[4];
   const int cidx = blockIdx.x;
   float lo[3], hi[3];
@@ -1070,7 +1085,7 @@ __device__ __forceinline__ bool dominates(const float4& o, const float4& m, cons
 }
 #define CELL_LCAP 1024
 template <bool WRITE>
-__global__ __launch_bounds__(64) void k_cell_list_build(CellListBuildArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(64) void k_cell_list_build(CellListBuildArgs a) {
   __shared__ float4 lp[CELL_LCAP];
   __shared__ unsigned char keep[CELL_LCAP];
   const int cidx = blockIdx.x;
@@ -1174,7 +1189,7 @@ __device__ __forceinline__ void local_ranges(const CellListBuildArgs& a, const G
   y0 = max((int)floorf((lo[1] - R - g.oy) * g.inv_cell), 0), y1 = min((int)floorf((hi[1] + R - g.oy) * g.inv_cell), g.dy - 1);
   z0 = max((int)floorf((lo[2] - R - g.oz) * g.inv_cell), 0), z1 = min((int)floorf((hi[2] + R - g.oz) * g.inv_cell), g.dz - 1);
 }
-__global__ __launch_bounds__(256) void k_cell_list_local_flag(CellListBuildArgs a, GridDev g, int* __restrict__ flag) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_cell_list_local_flag(CellListBuildArgs a, GridDev g, int* __restrict__ flag) {
   const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
   const int ncell = a.dx * a.dy * a.dz;
   if (cidx > ncell) return;
@@ -1198,7 +1213,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local_flag(CellListBuildArgs 
   a.count[cidx] = 0;
 }
 // work[k] = k-th flagged cell (flag_scan = exclusive scan of flag)
-__global__ __launch_bounds__(256) void k_cell_list_local_work(const int* __restrict__ flag, const int* __restrict__ flag_scan, int ncell,
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_cell_list_local_work(const int* __restrict__ flag, const int* __restrict__ flag_scan, int ncell,
                                                               int* __restrict__ work) {
   const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
   if (cidx < ncell && flag[cidx]) work[flag_scan[cidx]] = cidx;
@@ -1211,7 +1226,7 @@ __global__ __launch_bounds__(256) void k_cell_list_local_work(const int* __restr
 // SUB lanes work on one voxel (256 / SUB voxels per workgroup): the candidate rows of a voxel are few (3 x 3 ring cells: 9 rows), so
 // a whole wavefront per voxel left most lanes idle in a latency-bound kernel.
 template <bool WRITE, int SUB>
-__global__ __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, GridDev g, int exist_mode, const int* __restrict__ work, int nwork,
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_cell_list_local(CellListBuildArgs a, GridDev g, int exist_mode, const int* __restrict__ work, int nwork,
                                                          int* __restrict__ keep_buf) {
   __shared__ int list_s[256 / SUB][LOCAL_WCAP];
   const int grp = threadIdx.x / SUB, lane = threadIdx.x % SUB;
@@ -1510,7 +1525,7 @@ __device__ __forceinline__ void cells_nn_plain(const CellListDev& c, V3 q, float
 // order of the rows -- so neither kernel scatters (the hypothesis-major layout cost 4x write amplification plus the
 // read-for-ownership traffic of partial lines: 17 GB of HBM traffic per launch instead of 0.8).
 constexpr int LCP_TH = 16;
-__global__ __launch_bounds__(256) void k_lcp_cells(LcpArgs a, int hb, int hs, int npt) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_lcp_cells(LcpArgs a, int hb, int hs, int npt) {
   __shared__ float2 out[64][LCP_TH + 1];
   const int pt = blockIdx.x % npt, ht = blockIdx.x / npt;
   const int lane = threadIdx.x & 63;
@@ -1561,7 +1576,7 @@ __global__ __launch_bounds__(256) void k_lcp_cells(LcpArgs a, int hb, int hs, in
 
 // ordered sum over the point-major table: lanes = hypotheses, rows visited in the caller's point order (inv[i] = sorted
 // position of caller point i); additions in exactly that order, loads issued 32 rows ahead
-__global__ __launch_bounds__(64) void k_lcp_sum_t(LcpArgs a, int hb, int hs) {
+__global__ HOP_PK_F32 __launch_bounds__(64) void k_lcp_sum_t(LcpArgs a, int hb, int hs) {
   const int hl = blockIdx.x * blockDim.x + threadIdx.x;
   if (hl >= hb) return;
   const float2* tt = reinterpret_cast<const float2*>(a.terms) + hl;
@@ -1598,7 +1613,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 template <int R>
-__global__ __launch_bounds__(256) void k_icp_nn(IcpArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_icp_nn(IcpArgs a) {
   __shared__ float4 tile[NN_TILE];
   __shared__ double red[4][ICP_NACC];
   const int hl = blockIdx.y, h = a.h0 + hl;
@@ -1681,7 +1696,7 @@ __global__ __launch_bounds__(256) void k_icp_nn(IcpArgs a) {
 template __global__ void k_icp_nn<4>(IcpArgs);
 
 template <int R>
-__global__ __launch_bounds__(256) void k_icp_nn_grid(IcpArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_icp_nn_grid(IcpArgs a) {
   __shared__ float sT[12], sTi[12];
   __shared__ double red[4][ICP_NACC];
   const int hl = blockIdx.y, h = a.h0 + hl;
@@ -1778,7 +1793,7 @@ __device__ __forceinline__ void icp_chain_point_normal(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void k_icp_corr_cells(IcpArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_icp_corr_cells(IcpArgs a) {
   const int hl = blockIdx.y, h = a.h0 + hl;
   const IcpState& st = a.state[hl];
   if (!st.active) return;
@@ -1795,7 +1810,7 @@ __global__ __launch_bounds__(256) void k_icp_corr_cells(IcpArgs a) {
   a.corr_idx[(size_t)hl * a.ns + i] = (pos >= 0 && best <= a.max_d2) ? pos : -1;
 }
 
-__global__ __launch_bounds__(256) void k_icp_accum(IcpArgs a, int R) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_icp_accum(IcpArgs a, int R) {
   __shared__ double red[4][ICP_NACC];
   const int hl = blockIdx.y, h = a.h0 + hl;
   const IcpState& st = a.state[hl];
@@ -1852,7 +1867,7 @@ __global__ __launch_bounds__(256) void k_icp_accum(IcpArgs a, int R) {
 // nn_mode 3: correspondence search and accumulation in one launch (no correspondence array in between).  Same
 // arithmetic as the split pair; R points per lane share one block-level reduction of the 32 accumulators.
 template <int R>
-__global__ __launch_bounds__(256) void k_icp_fused(IcpArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_icp_fused(IcpArgs a) {
   __shared__ double red[4][ICP_NACC];
   const int hl = blockIdx.y, h = a.h0 + hl;
   const IcpState& st = a.state[hl];
@@ -2183,7 +2198,7 @@ __device__ __forceinline__ int icp_fusedq_point(const IcpArgs& a, int i, const f
   return ICP_PT_ACCEPTED;
 }
 template <bool COMPOSED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPOSED ? HOP_ICP_W : 4))) void k_icp_fusedq(IcpArgs a, int R) {
+__global__ HOP_PK_F32 __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPOSED ? HOP_ICP_W : 4))) void k_icp_fusedq(IcpArgs a, int R) {
   __shared__ double red[COMPOSED ? 1 : 4][ICP_NACC];
   __shared__ int n_cnt[4];
   // nn_mode 4: lookups that need the exact re-scan (0.6 % of them, but a fifth of the wavefronts held one) are queued per
@@ -2309,7 +2324,7 @@ __device__ __forceinline__ int icp_fusedq_point_mom(const IcpArgs& a, int i, con
 #ifndef HOP_ICP_MOM_W
 #define HOP_ICP_MOM_W 4
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM_W))) void k_icp_fusedq_mom(IcpArgs a, int R) {
+__global__ HOP_PK_F32 __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOM_W))) void k_icp_fusedq_mom(IcpArgs a, int R) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[sizeof(BlockSumLds)];  // the queue, then the tile of the block sum
   __shared__ int n_cnt[4];
   unsigned short(*defer_i)[64 * ICP_ACCUM_R] = reinterpret_cast<unsigned short(*)[64 * ICP_ACCUM_R]>(lds_raw);
@@ -2455,7 +2470,7 @@ __device__ __forceinline__ void block_sum_ints(const int (&acc)[NV], BlockSumLds
 #ifndef HOP_ICP_MOMI_W
 #define HOP_ICP_MOMI_W 3
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOMI_W))) void k_icp_fusedq_momi(IcpArgs a, int R) {
+__global__ HOP_PK_F32 __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOMI_W))) void k_icp_fusedq_momi(IcpArgs a, int R) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[sizeof(BlockSumLds)];  // the queue, then the tile of the block sum
   __shared__ int n_cnt[4];
   unsigned short(*defer_i)[64 * ICP_ACCUM_R] = reinterpret_cast<unsigned short(*)[64 * ICP_ACCUM_R]>(lds_raw);
@@ -2763,7 +2778,7 @@ void launch_icp_fusedq_momm(const IcpArgs& a, int hb, hipStream_t s) {
 //   out[0] momi_qp(x, y, 2^12)   [1] encoding of momm_qp(x, y)   [2] momi_pack(ia, ib)   [3] momi_dot2(ia, ib, ic)   [4] umed3(ia, ib, ic)
 //   [5] q_rank({xy = ia, z = ic >> 16}, lo = ib, hi = ic)   [6] momm_bytes<1>(ib, ia)   [7] momm_bytes<0>(ib, ia)
 //   [8] momi_q(x, y, 2^24)
-__global__ void k_dev_selftest_scalar(int n, const float* __restrict__ x, const float* __restrict__ y, const int* __restrict__ ia, const int* __restrict__ ib,
+__global__ HOP_PK_F32 void k_dev_selftest_scalar(int n, const float* __restrict__ x, const float* __restrict__ y, const int* __restrict__ ia, const int* __restrict__ ib,
                                       const int* __restrict__ ic, unsigned* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -2779,7 +2794,7 @@ __global__ void k_dev_selftest_scalar(int n, const float* __restrict__ x, const 
   out[8 * (size_t)n + i] = (unsigned)momi_q(x[i], y[i], 16777216.0f);
 }
 // one v_mfma_i32_16x16x64_i8 per wavefront: a, b, c, d as [tiles][64 lanes][4 registers]
-__global__ __launch_bounds__(64) void k_dev_selftest_mfma(const int* __restrict__ a, const int* __restrict__ b, const int* __restrict__ c, int* __restrict__ d) {
+__global__ HOP_PK_F32 __launch_bounds__(64) void k_dev_selftest_mfma(const int* __restrict__ a, const int* __restrict__ b, const int* __restrict__ c, int* __restrict__ d) {
   const size_t o = ((size_t)blockIdx.x * 64 + threadIdx.x) * 4;
   const momm_i32x4 A = {a[o], a[o + 1], a[o + 2], a[o + 3]}, B = {b[o], b[o + 1], b[o + 2], b[o + 3]}, Cc = {c[o], c[o + 1], c[o + 2], c[o + 3]};
   const momm_i32x4 D = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, Cc, 0, 0, 0);
@@ -2795,7 +2810,7 @@ struct MommTestU {  // (13 given integers as the gridded vector)
     return momm_qp(v[C], 1.0f);
   }
 };
-__global__ __launch_bounds__(64) void k_dev_selftest_momm(int batches, const int* __restrict__ U, const unsigned long long* __restrict__ mask, int* __restrict__ out) {
+__global__ HOP_PK_F32 __launch_bounds__(64) void k_dev_selftest_momm(int batches, const int* __restrict__ U, const unsigned long long* __restrict__ mask, int* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) unsigned short ring[13][MOMM_ROW];
   const int lane = threadIdx.x;
   momm_i32x4 HH = {0, 0, 0, 0}, HL = {0, 0, 0, 0}, LL = {0, 0, 0, 0};
@@ -2833,7 +2848,7 @@ void launch_icp_fusedq_mom(const IcpArgs& a, int hb, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_fusedq_mom, dim3(nb, hb), dim3(256), 0, s, a, R);
 }
 
-__global__ void k_soa_to_aos4(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n, float4* __restrict__ out) {
+__global__ HOP_PK_F32 void k_soa_to_aos4(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n, float4* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = make_float4(x[i], y[i], z[i], 0.f);
 }
@@ -2869,7 +2884,7 @@ __device__ bool chol6(double A[6][6], const double b[6], double x[6]) {
   return true;
 }
 
-__global__ __launch_bounds__(64) void k_icp_solve(IcpArgs a, int hb, int nblocks) {
+__global__ HOP_PK_F32 __launch_bounds__(64) void k_icp_solve(IcpArgs a, int hb, int nblocks) {
   const int hl = blockIdx.x * blockDim.x + threadIdx.x;
   if (hl >= hb) return;
   IcpState& st = a.state[hl];
@@ -2940,7 +2955,7 @@ __global__ __launch_bounds__(64) void k_icp_solve(IcpArgs a, int hb, int nblocks
 }
 
 // pose <- T_icp^-1 * pose (PoseEstimator.cpp:267), identity if not converged
-__global__ void k_icp_finish(IcpArgs a, int hb, int* iters_out, int* conv_out) {
+__global__ HOP_PK_F32 void k_icp_finish(IcpArgs a, int hb, int* iters_out, int* conv_out) {
   const int hl = blockIdx.x * blockDim.x + threadIdx.x;
   if (hl >= hb) return;
   const IcpState& st = a.state[hl];
@@ -2958,7 +2973,7 @@ __global__ void k_icp_finish(IcpArgs a, int hb, int* iters_out, int* conv_out) {
 
 // inverse of every hypothesis pose (affine), once per stage: the cell-list kernels map queries into the model's rest
 // frame with it and read it through scalar loads instead of inverting per block
-__global__ void k_pose_inverse(const float* __restrict__ pose, int n, float* __restrict__ inv12) {
+__global__ HOP_PK_F32 void k_pose_inverse(const float* __restrict__ pose, int n, float* __restrict__ inv12) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= n) return;
   M4 P;
@@ -2970,7 +2985,7 @@ void launch_pose_inverse(const float* pose, int n, float* inv12, hipStream_t s) 
   if (n > 0) hipLaunchKernelGGL(k_pose_inverse, dim3((n + 63) / 64), dim3(64), 0, s, pose, n, inv12);
 }
 
-__global__ void k_icp_init(IcpState* st, int hb) {
+__global__ HOP_PK_F32 void k_icp_init(IcpState* st, int hb) {
   const int hl = blockIdx.x * blockDim.x + threadIdx.x;
   if (hl >= hb) return;
   IcpState s;
@@ -3205,7 +3220,7 @@ __global__ __launch_bounds__(256) void k_lcp_cells_fast(LcpArgs a, int hb, int h
   }
 }
 
-__global__ __launch_bounds__(64) void k_lcp_sum_partial(LcpArgs a, int hb, int hs, int npt) {
+__global__ HOP_PK_F32 __launch_bounds__(64) void k_lcp_sum_partial(LcpArgs a, int hb, int hs, int npt) {
   const int hl = blockIdx.x * blockDim.x + threadIdx.x;
   if (hl >= hb) return;
   double cp = 0.0;
@@ -3244,7 +3259,7 @@ void launch_lcp_sum_partial(const LcpArgs& a, int hb, hipStream_t s) {
 // The host finishes the scalar part of the objective (gripper gap, penalties), hop_host.cpp.
 // ------------------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(256) void k_pso_match(PsoArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_pso_match(PsoArgs a) {
   __shared__ float4 tile[NN_TILE];
   const int p = blockIdx.y;
   const PsoParticle& pp = a.particles[p];
@@ -3309,7 +3324,7 @@ __global__ __launch_bounds__(256) void k_pso_match(PsoArgs a) {
 }
 template __global__ void k_pso_match<2>(PsoArgs);
 
-__global__ __launch_bounds__(256) void k_pso_outer(PsoArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_pso_outer(PsoArgs a) {
   // lanes = particles (each keeps its inverse transform in registers), the block walks a tile of scene points;
   // terms are stored as float4 groups of four consecutive points per particle, [point/4][particle][point%4], so that
   // this kernel writes and the sequential sum reads 16 bytes per lane, coalesced.
@@ -3339,7 +3354,7 @@ __global__ __launch_bounds__(256) void k_pso_outer(PsoArgs a) {
   }
 }
 
-__global__ __launch_bounds__(64) void k_pso_outer_sum(PsoArgs a, int n_particles) {
+__global__ HOP_PK_F32 __launch_bounds__(64) void k_pso_outer_sum(PsoArgs a, int n_particles) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_particles) return;
   if (a.particles[p].skip) return;
@@ -3377,7 +3392,7 @@ __global__ __launch_bounds__(64) void k_pso_outer_sum(PsoArgs a, int n_particles
 // order: one block per particle, threads stride over the no-swivel scene, float tree reduction in a fixed order
 // (deterministic; equal to the reference's sequential float sum to ~1e-6 relative -- tests/test_gpu_parity.py).  No term
 // table, no 4-wave sequential pass.
-__global__ __launch_bounds__(256) void k_pso_outer_reduce(PsoArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_pso_outer_reduce(PsoArgs a) {
   __shared__ float rs[4];
   __shared__ int rc[4];
   const int p = blockIdx.x;
@@ -3408,7 +3423,7 @@ __global__ __launch_bounds__(256) void k_pso_outer_reduce(PsoArgs a) {
 // N4: the pair loop of the offline computePPF tool (computePPF.cpp:17-38,88-100): key of every pair i < j of the model
 // cloud, collected in the same direct-address bitmap the generator looks keys up in.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_model_ppf_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_model_ppf_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                                                        const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz,
                                                        int n, int dist_bins, unsigned* __restrict__ bitmap, int* __restrict__ overflow) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
@@ -3436,7 +3451,7 @@ void launch_model_ppf_keys(const float* x, const float* y, const float* z, const
 // clouds (a few hundred points each) are scanned by brute force -- every lane of a wave reads the same link point, so
 // a load serves 64 queries.  Links are visited in the reference's map order with its early exit.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hand_surround(SurroundArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_hand_surround(SurroundArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   const V3 p = m4_point(a.cam2hb, v3(a.sx[i], a.sy[i], a.sz[i]));
@@ -3476,7 +3491,7 @@ __global__ __launch_bounds__(256) void k_hand_surround(SurroundArgs a) {
   a.conf[i] = 1 - (float)exp((double)(-231.04906018664843f * min_dist));
   a.keep[i] = keep ? 1 : 0;
 }
-__global__ __launch_bounds__(256) void k_hand_surround_out(SurroundOutArgs a) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_hand_surround_out(SurroundOutArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n || !a.keep[i]) return;
   const size_t n = (size_t)a.n;
@@ -3498,7 +3513,7 @@ void launch_hand_surround_out(const SurroundOutArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // voxel-grid construction over a fixed cloud (counting sort by cell): count, scan on host, fill.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_grid_cell_ids(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
+__global__ HOP_PK_F32 void k_grid_cell_ids(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
                                 GridDev gd, int* __restrict__ cell_of, int* __restrict__ cell_count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -3635,11 +3650,11 @@ void launch_cell_list_local(const CellListBuildArgs& a, const GridDev& g, bool w
   }
 }
 int cell_list_local_keep() { return LOCAL_KEEP; }
-__global__ __launch_bounds__(256) void k_cell_ranges(const int* __restrict__ start, int ncell, int2* __restrict__ range) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_cell_ranges(const int* __restrict__ start, int ncell, int2* __restrict__ range) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < ncell) range[c] = make_int2(start[c], start[c + 1]);
 }
-__global__ __launch_bounds__(256) void k_cell_heads(const int2* __restrict__ range, const float4* __restrict__ pts, int ncell, uint4* __restrict__ head) {
+__global__ HOP_PK_F32 __launch_bounds__(256) void k_cell_heads(const int2* __restrict__ range, const float4* __restrict__ pts, int ncell, uint4* __restrict__ head) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncell) return;
   const int2 r = range[c];

@@ -18,7 +18,8 @@ def isa(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
     d = tmp_path_factory.mktemp("isa")
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c", os.path.join(SRC, "hop_kernels.hip"),
+    kflags = re.search(r"^KERNELS_FLAGS := (.*)$", open(os.path.join(SRC, "Makefile")).read(), re.M).group(1).split()   # the unit's own flags
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", *kflags, "-c", os.path.join(SRC, "hop_kernels.hip"),
                         "-o", str(d / "k.o"), "--save-temps", "-Rpass-analysis=kernel-resource-usage"], cwd=str(d), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     usage, cur = {}, None
@@ -82,3 +83,19 @@ def test_the_poses_stay_scalar_in_compute_lcp_and_leave_the_tag_pipe_in_the_icp_
     # re-loads of pose / inverse pose / accumulated transform are gone (staged in LDS, read by broadcast)
     assert n_uniform <= 8, n_uniform
     assert sum(x.startswith("v_mfma_i32_16x16x64_i8") for x in m) == 9
+
+
+def test_packed_f32_is_off_in_the_two_shipped_lookup_kernels_and_nowhere_else(isa):
+    """The unit is compiled with packed-fp32-ops off and every kernel but k_icp_fusedq_momm / k_lcp_cells_fast switches it back on (HOP_PK_F32): a
+    v_pk_*_f32 pair issues no faster than its two scalar halves on this part and costs v_movs to set up (profiles/r02_valu_issue_rates.txt).  Nothing
+    may have become a CALL by it (a kernel whose target features differ from the HIP header's stops inlining __syncthreads / __ballot)."""
+    _, body = isa
+    pk = re.compile(r"v_pk_(fma|mul|add)_f32")
+    for k in (MOMM, LCP, "_ZN3hop16k_lcp_cells_fastILb0EEEvNS_7LcpArgsEiiii"):
+        b = body(k)
+        assert not any(pk.match(x) for x in b), k
+        assert not any(x.startswith("s_swappc") for x in b), k
+    for k in ("_ZN3hop12k_icp_fusedqILb1EEEvNS_7IcpArgsEi", "_ZN3hop16k_icp_fusedq_momENS_7IcpArgsEi", "_ZN3hop7k_quadsENS_8QuadArgsEi"):
+        b = body(k)
+        assert any(pk.match(x) for x in b), k     # (as they ran on hardware)
+        assert not any(x.startswith("s_swappc") for x in b), k

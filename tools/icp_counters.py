@@ -21,7 +21,8 @@ SRC = os.path.join(ROOT, "icra20-hand-object-pose_amd", "csrc")
 
 def build():
     os.makedirs(OUT, exist_ok=True)
-    flags = "--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DHOP_ICP_COUNT".split()
+    import re
+    flags = ("--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DHOP_ICP_COUNT " + re.search(r"^KERNELS_FLAGS := (.*)$", open(os.path.join(SRC, "Makefile")).read(), re.M).group(1)).split()
     subprocess.check_call(["make", "-C", SRC], stdout=subprocess.DEVNULL)
     o = os.path.join(OUT, "hop_kernels_count.o")
     subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-c", os.path.join(SRC, "hop_kernels.hip"), "-o", o])

@@ -32,7 +32,9 @@ def main():
              "# kernel | VGPRs AGPRs SGPRs | scratch B/lane | LDS B/block | waves/SIMD | instructions: total VALU SALU VMEM LDS MFMA"]
     with tempfile.TemporaryDirectory() as d:
         for unit in ("hop_kernels", "hop_icp_lm", "hop_comm"):
-            r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c", os.path.join(SRC, unit + ".hip"),
+            # (hop_kernels.hip has flags of its own in csrc/Makefile: packed f32 off as the unit's default, back on per kernel)
+            kflags = re.search(r"^KERNELS_FLAGS := (.*)$", open(os.path.join(SRC, "Makefile")).read(), re.M).group(1).split() if unit == "hop_kernels" else []
+            r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", *kflags, "-c", os.path.join(SRC, unit + ".hip"),
                                 "-o", os.path.join(d, unit + ".o"), "--save-temps", "-Rpass-analysis=kernel-resource-usage"], cwd=d, capture_output=True, text=True)
             if r.returncode != 0:
                 sys.exit(r.stderr[-3000:])
