@@ -30,6 +30,9 @@ HOP_LCP_SCENE_SUB=3 timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 7
 for W in 6 8; do
   bash tools/build_variant.sh momm$W -DHOP_ICP_MOMM_W=$W > $OUT/build_momm$W.log 2>&1 && HOP_LIB=tools/_tmp/momm$W/libhop.so timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 7 --lcp-modes 3 > $OUT/icp_bench_mode7_${W}waves.json 2>> $OUT/icp_bench.err
 done
+# round 6's scalar-f32 build of the two lookup kernels against the compiler's packed pairs (the only difference of this variant): lcp.3.ms_cells and the
+# icp.7 figures of the two files are the comparison
+HOP_VARIANT_PACKED_F32=1 bash tools/build_variant.sh pkf32 > $OUT/build_pkf32.log 2>&1 && HOP_LIB=tools/_tmp/pkf32/libhop.so timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 7 --lcp-modes 3 > $OUT/icp_bench_mode7_packed_f32.json 2>> $OUT/icp_bench.err
 tail -15 $OUT/gputest.log
 tail -2 $OUT/smoke.log
 head -c 1500 $OUT/bench.json
