@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--scene", type=int, default=1500)
     ap.add_argument("--only", default="", help="comma-separated frame names (e.g. synthetic_1004,synthetic_1017)")
     ap.add_argument("--out", default="")
+    ap.add_argument("--compact", action="store_true", help="keep the per-frame rows only for frames on which some minimiser leaves 1 mm / 1 deg")
     args = ap.parse_args()
     import hop_loader
     import orc
@@ -131,7 +132,7 @@ def main():
         "lm_moment_off_while_every_reference_build_agrees": [r["frame"] for r in rows if not r["vs_ref"]["lm_moment"]["within"] and not r["reference_builds_off"]],
         "lm_moment_within_OR_a_reference_build_disagrees_too": int(sum(1 for r in rows if r["vs_ref"]["lm_moment"]["within"] or r["reference_builds_off"])),
         "reference_builds": ref_tags,
-        "rows": rows,
+        "rows": [r for r in rows if not args.compact or r["reference_builds_off"] or not r["vs_ref"]["lm_moment"]["within"]],
     }
     s = json.dumps(summary, indent=1)
     print(json.dumps({k: v for k, v in summary.items() if k != "rows"}, indent=1))
