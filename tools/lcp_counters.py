@@ -6,7 +6,9 @@
 On the CPU model (no device at hand):
     make -C tests/emu OUT=/tmp/lcpcnt /tmp/lcpcnt/libhop_emu.so CXXFLAGS="-x c++ -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -fno-strict-aliasing \
          -Wno-attributes -Wno-unknown-pragmas -DHOP_EMU -DHOP_LCP_COUNT -I. -I../../icra20-hand-object-pose_amd/csrc"
-Counts per-lane loads from the lists (head / range record, entries, normals): what the TCP counts as accesses for divergent gathers.
+Counts per-lane loads from the lists (head / range record, entries, normals) IN THE SOURCE: one per record.  Until round 6 the machine code made
+two gathers of every head record (its tested field first, the rest behind the branch: DESIGN section 4 "Round 6") -- the 11.9 this tool reported for
+round 5's kernel was 13.9 in the assembly; with keep_whole() the two agree (tests/test_isa_cpu.py checks the assembly).
 """
 import argparse
 import ctypes as C
