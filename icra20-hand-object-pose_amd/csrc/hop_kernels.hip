@@ -2619,7 +2619,7 @@ __device__ __forceinline__ int icp_fusedq_point_momm(const IcpArgs& a, int i, co
   if (a.iter > 0) qn = m4_dir_fma(F, qn);
   const V3 nt = m4_dir(pose, v3(tn.x, tn.y, tn.z));
   if (!(((qn.x * nt.x + qn.y * nt.y) + qn.z * nt.z) > a.cos_thr)) return ICP_PT_REJECTED;
-  const V3 pc = q - ctr;
+  const V3 pc = q - v3(pose[3], pose[7], pose[11]);  // (= ctr, read from the LDS copy where it is used: three registers less across the lookup -- what lets the kernel run 6 waves per SIMD without scratch)
   const float r0 = vdot(q - tq, nt);
   u.n = nt, u.ps = v3(pc.x * a.mom_s_np, pc.y * a.mom_s_np, pc.z * a.mom_s_np), u.r0 = r0, u.s_n = a.mom_s_n, u.s_r = a.mom_s_r;  // (powers of two: exact)
   dq = momi_q(d2, a.mom_s_d, a.mom_lim_d);
@@ -2670,7 +2670,7 @@ __device__ __forceinline__ void momm_push(unsigned short (*__restrict__ ring)[MO
   fill = nf & 127;
 }
 #ifndef HOP_ICP_MOMM_W
-#define HOP_ICP_MOMM_W 5
+#define HOP_ICP_MOMM_W 6  // 80 VGPRs, no scratch (round 6; 5 waves before: 90-94 VGPRs).  tools/gpu_round_check.sh times 5 and 8 beside it
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOP_ICP_MOMM_W))) void k_icp_fusedq_momm(IcpArgs a, int R) {
   __shared__ __attribute__((aligned(16))) MommLds L;

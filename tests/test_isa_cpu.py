@@ -46,7 +46,7 @@ LCP = "_ZN3hop16k_lcp_cells_fastILb1EEEvNS_7LcpArgsEiiii"
 
 def test_registers_scratch_and_occupancy_of_the_icp_kernels(isa):
     usage, _ = isa
-    want = {MOMM: (96, 5),                                            # the shipped nn_mode 7 kernel: 5 waves per SIMD, nothing in scratch
+    want = {MOMM: (80, 6),                                            # the shipped nn_mode 7 kernel: 6 waves per SIMD, nothing in scratch
             "_ZN3hop12k_icp_fusedqILb1EEEvNS_7IcpArgsEi": (72, 7),    # nn_mode 4 as it ran on hardware in round 2
             "_ZN3hop16k_icp_fusedq_momENS_7IcpArgsEi": (120, 4),      # nn_mode 6 as it ran in round 3
             "_ZN3hop17k_icp_fusedq_momiENS_7IcpArgsEi": (152, 3),     # nn_mode 7 on the vector units
