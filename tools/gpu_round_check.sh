@@ -20,14 +20,14 @@ timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --nn-mode 6 --no-cpu-
 HOP_QUADS_HASH=1 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-next-rows --no-alt-modes > $OUT/bench_quads_hash.json 2> $OUT/bench_quads_hash.err
 HOP_ICP_MFMA=0 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-next-rows --no-alt-modes > $OUT/bench_nn_mode7_dot2.json 2> $OUT/bench_nn_mode7_dot2.err
 # the ICP stage alone (one frame at a time, HIP events): nn_mode 4 / 6 / 7 on the matrix cores / 7 on the vector units, and k_icp_fusedq_momm built for
-# 5 and 8 waves per SIMD (default 6 since round 6: 80 VGPRs, no scratch; 5: 87 VGPRs; 8: 64 VGPRs + scratch)
+# 5, 7 and 8 waves per SIMD (default 6 since round 6: 80 VGPRs, no scratch; 5: 87 VGPRs; 7: 72 + 9 dwords of scratch; 8: 64 + 25)
 timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 4,6,7,7dot2 --lcp-modes 3 > $OUT/icp_bench_modes_4_6_7.json 2> $OUT/icp_bench.err
 # computeLCP's reduced-sum kernel: range records instead of the inline-head records (round 5), and the scene lists at subdivision 3 (shorter lists,
 # which the head records make cheaper; more cells to build) -- lcp.3.ms_cells of the three files is the comparison
 HOP_LCP_NO_HEAD=1 timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 7 --lcp-modes 3 > $OUT/icp_bench_lcp_range_records.json 2>> $OUT/icp_bench.err
 HOP_LCP_TILES=1 timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 7 --lcp-modes 3 > $OUT/icp_bench_lcp_one_tile_per_wave.json 2>> $OUT/icp_bench.err
 HOP_LCP_SCENE_SUB=3 timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 7 --lcp-modes 3 > $OUT/icp_bench_lcp_scene_sub3.json 2>> $OUT/icp_bench.err
-for W in 5 8; do
+for W in 5 7 8; do
   bash tools/build_variant.sh momm$W -DHOP_ICP_MOMM_W=$W > $OUT/build_momm$W.log 2>&1 && HOP_LIB=tools/_tmp/momm$W/libhop.so timeout 600 python tools/icp_bench.py --reps 3 --icp-modes 7 --lcp-modes 3 > $OUT/icp_bench_mode7_${W}waves.json 2>> $OUT/icp_bench.err
 done
 # round 6's scalar-f32 build of the two lookup kernels against the compiler's packed pairs (the only difference of this variant): lcp.3.ms_cells and the
